@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "self-supervised-depth-estimation_amd")
+for p in (REPO, PKG, os.path.join(REPO, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    d = os.path.join(REPO, "tests", "golden")
+    return {name: np.load(os.path.join(d, name + ".npz"), allow_pickle=False)
+            for name in ("layers_ops", "trainer_losses", "decoders")}
