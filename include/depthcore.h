@@ -1,0 +1,177 @@
+/*
+ * depthcore.h -- C ABI of libdepthcore.so: the MI355X (gfx950) native hot path of
+ * self-supervised monocular depth training (Monodepth2-family photometric step).
+ *
+ * Drop-in boundary: the reference is pure Python on PyTorch and
+ * every op below is, in the reference, a chain of stock ATen calls made from
+ * `layers.py` / `trainer.py`.  Each entry point cites the reference code it replaces.
+ * The Python facade (`self-supervised-depth-estimation_amd/layers.py`, `networks/`,
+ * `trainer.py`) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - all tensors fp32, NCHW, contiguous, device memory owned by the caller;
+ *     the library never allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
+ *   - return value: 0 = ok, negative = DC_E* (no exceptions cross the boundary);
+ *   - "frame 0/1" means source frame_id -1 / +1 (`trainer.py:482`);
+ *   - deterministic: no float atomics; partial sums are reduced in fixed order.
+ */
+#ifndef DEPTHCORE_H
+#define DEPTHCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DC_OK 0
+#define DC_EINVAL (-1)      /* bad shape / null pointer / unsupported option */
+#define DC_ELAUNCH (-2)     /* hipLaunch error */
+#define DC_EWORKSPACE (-3)  /* workspace too small */
+
+#define DC_MAX_SCALES 4
+
+/* option flags of the fused photometric loss (`trainer.py:531-622` ablation branches) */
+#define DC_OPT_NO_AUTOMASK 1u   /* opt.disable_automasking */
+#define DC_OPT_AVG_REPROJ 2u    /* opt.avg_reprojection */
+#define DC_OPT_NO_SSIM 4u       /* opt.no_ssim */
+#define DC_OPT_ALIGN_CORNERS 8u /* grid_sample(align_corners=True); default False = installed-torch default */
+
+const char* dc_version(void);
+/* Compiled-for architecture string, e.g. "gfx950". */
+const char* dc_arch(void);
+
+/* ------------------------------------------------------------------ a5 */
+/* layers.py:28-103 transformation_from_parameters (+rot_from_axisangle, get_translation_matrix).
+ * axisangle, translation: (B,3); invert: 0/1; out M: (B,4,4). */
+int dc_pose_matrix_fwd(const float* axisangle, const float* translation, int invert, float* M, int B,
+                       void* stream);
+/* dM (B,4,4) -> d_axisangle (B,3), d_translation (B,3). */
+int dc_pose_matrix_bwd(const float* axisangle, const float* translation, int invert, const float* dM,
+                       float* d_axisangle, float* d_translation, int B, void* stream);
+
+/* ------------------------------------------------------------------ a6 */
+/* layers.py:16-25 disp_to_depth: scaled = 1/max + (1/min-1/max)*disp; depth = 1/scaled. n elements. */
+int dc_disp_to_depth_fwd(const float* disp, float* scaled, float* depth, size_t n, float min_depth,
+                         float max_depth, void* stream);
+/* d_disp = g_scaled*(1/min-1/max) - g_depth*depth^2*(1/min-1/max); g_* nullable. */
+int dc_disp_to_depth_bwd(const float* disp, const float* g_scaled, const float* g_depth, float* d_disp,
+                         size_t n, float min_depth, float max_depth, void* stream);
+
+/* ------------------------------------------------------------------ a7 */
+/* layers.py:139-161: fills pix_coords (B,3,H*W) = [x; y; 1] with x = i mod W, y = i div W (exact). */
+int dc_pix_coords(float* pix_coords, int B, int H, int W, void* stream);
+/* layers.py:163-168 BackprojectDepth.forward: depth (B,1,H,W), inv_K (B,4,4) -> cam (B,4,H*W). */
+int dc_backproject_fwd(const float* depth, const float* inv_K, float* cam, int B, int H, int W, void* stream);
+/* g_cam (B,4,HW) -> d_depth (B,1,H,W). */
+int dc_backproject_bwd(const float* g_cam, const float* inv_K, float* d_depth, int B, int H, int W,
+                       void* stream);
+
+/* ------------------------------------------------------------------ a8 */
+/* layers.py:171-193 Project3D.forward: points (B,4,HW), K,T (B,4,4) -> grid (B,H,W,2). */
+int dc_project3d_fwd(const float* points, const float* K, const float* T, float* grid, int B, int H, int W,
+                     float eps, void* stream);
+/* g_grid (B,H,W,2) -> d_points (B,4,HW) and d_T (B,4,4) (d_T nullable).  `ws` : workspace of
+ * dc_project3d_bwd_workspace(B,H,W) bytes. */
+size_t dc_project3d_bwd_workspace(int B, int H, int W);
+int dc_project3d_bwd(const float* points, const float* K, const float* T, const float* g_grid,
+                     float* d_points, float* d_T, void* ws, int B, int H, int W, float eps, void* stream);
+
+/* ------------------------------------------------------------------ a9 */
+/* F.grid_sample(img, grid, mode=bilinear, padding_mode="border") as called at trainer.py:508-511.
+ * img (B,C,H,W), grid (B,Ho,Wo,2) -> out (B,C,Ho,Wo). */
+int dc_grid_sample_fwd(const float* img, const float* grid, float* out, int B, int C, int H, int W, int Ho,
+                       int Wo, int align_corners, void* stream);
+/* g_out -> d_grid (B,Ho,Wo,2) (images are leaves without grad in the reference). */
+int dc_grid_sample_bwd(const float* img, const float* grid, const float* g_out, float* d_grid, int B, int C,
+                       int H, int W, int Ho, int Wo, int align_corners, void* stream);
+
+/* ------------------------------------------------------------------ a10 */
+/* F.interpolate(x, [Ho,Wo], mode="bilinear", align_corners=False) (trainer.py:474-475), x (B,C,h,w). */
+int dc_upsample_bilinear_fwd(const float* x, float* out, int BC, int h, int w, int Ho, int Wo, void* stream);
+int dc_upsample_bilinear_bwd(const float* g_out, float* d_x, int BC, int h, int w, int Ho, int Wo,
+                             void* stream);
+
+/* ------------------------------------------------------------------ a11 */
+/* layers.py:218-248 SSIM.forward: x,y (B,C,H,W) -> clamp((1-n/d)/2,0,1) (B,C,H,W). */
+int dc_ssim_fwd(const float* x, const float* y, float* out, int BC, int H, int W, void* stream);
+/* g_out -> d_x and d_y (each nullable). */
+int dc_ssim_bwd(const float* x, const float* y, const float* g_out, float* d_x, float* d_y, int BC, int H,
+                int W, void* stream);
+
+/* ------------------------------------------------------------------ a13 */
+/* layers.py:202-215 get_smooth_loss: disp (B,1,h,w), img (B,C,h,w) -> scalar out[0].
+ * ws: dc_smooth_workspace(B,h,w) bytes. */
+size_t dc_smooth_workspace(int B, int h, int w);
+int dc_smooth_fwd(const float* disp, const float* img, float* out, void* ws, int B, int C, int h, int w,
+                  void* stream);
+/* d_disp = g[0] * dL/ddisp. */
+int dc_smooth_bwd(const float* disp, const float* img, const float* g, float* d_disp, int B, int C, int h,
+                  int w, void* stream);
+
+/* ------------------------------------------------------------------ a12/a14/a15 fused */
+/* The fused photometric step: trainer.py:465-515 (generate_images_pred) + 517-529
+ * (compute_reprojection_loss) + 531-622 (compute_losses) in three launches forward and three backward.
+ *
+ * All sizes in one struct so that the ctypes binding stays readable. */
+typedef struct dc_photo_desc {
+    int32_t B, H, W;              /* per-rank batch, full resolution (opt.height, opt.width) */
+    int32_t num_scales;           /* len(opt.scales) <= 4; scale s has size (H>>s, W>>s) */
+    uint32_t flags;               /* DC_OPT_* */
+    float min_depth, max_depth;   /* options.py:117-124 */
+    float smoothness;             /* opt.disparity_smoothness */
+    /* inputs */
+    const float* target;          /* inputs[("color",0,0)]   (B,3,H,W) */
+    const float* source[2];       /* inputs[("color",-1,0)], inputs[("color",+1,0)] */
+    const float* color_s[DC_MAX_SCALES]; /* inputs[("color",0,s)]  (B,3,H>>s,W>>s) */
+    const float* K;               /* inputs[("K",0)]      (B,4,4) */
+    const float* inv_K;           /* inputs[("inv_K",0)]  (B,4,4) */
+    const float* T[2];            /* outputs[("cam_T_cam",0,-1/+1)]  (B,4,4) */
+    const float* disp[DC_MAX_SCALES];    /* outputs[("disp",s)]  (B,1,H>>s,W>>s) */
+    const float* noise[DC_MAX_SCALES];   /* tie-break randn (B,2,H,W) per scale ((B,1,H,W) with
+                                            AVG_REPROJ), trainer.py:594-595; NULL = on-device RNG */
+    uint64_t rng_seed;            /* used when noise[s] == NULL */
+    /* outputs of forward */
+    float* losses;                /* (num_scales+1): loss/0.., loss */
+    uint8_t* argmin[DC_MAX_SCALES];      /* (B,H,W) winning channel of torch.min(combined,1) */
+    /* optional materialised log tensors (trainer.py:480-515); any may be NULL */
+    float* depth[DC_MAX_SCALES];         /* ("depth",0,s)   (B,1,H,W) */
+    float* sample[DC_MAX_SCALES][2];     /* ("sample",f,s)  (B,H,W,2) */
+    float* color[DC_MAX_SCALES][2];      /* ("color",f,s)   (B,3,H,W) */
+    float* identity_selection[DC_MAX_SCALES]; /* "identity_selection/s" (B,H,W) float 0/1 */
+    /* backward */
+    const float* g_losses;        /* (num_scales+1) upstream gradient of `losses` */
+    float* d_disp[DC_MAX_SCALES]; /* (B,1,H>>s,W>>s) */
+    float* d_T[2];                /* (B,4,4) */
+    /* scratch */
+    void* workspace;              /* dc_photo_workspace(desc) bytes, same buffer for fwd and bwd */
+    size_t workspace_bytes;
+} dc_photo_desc;
+
+size_t dc_photo_workspace(const dc_photo_desc* d);
+int dc_photo_fwd(const dc_photo_desc* d, void* stream);
+int dc_photo_bwd(const dc_photo_desc* d, void* stream);
+/* Names and per-launch algorithmic bytes of the two dominant kernels, for bench.py. */
+double dc_photo_algorithmic_bytes(const dc_photo_desc* d, int backward);
+
+/* ------------------------------------------------------------------ a2/a3 decoder blocks */
+/* layers.py:106-136 + 196-199 and networks/depth_decoder.py:50-66:
+ *   y = act( conv3x3( reflect_pad1( cat( up2?(x0), x1 ) ) ) + bias )
+ * x0 (B,C0,h0,w0) optionally nearest-upsampled x2 on the fly (up0=1), x1 (B,C1,H,W) nullable skip;
+ * weight (Co,C0+C1,3,3); act: 0 none, 1 ELU, 2 sigmoid.  Output (B,Co,H,W). */
+int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
+                   const float* bias, float* y, int B, int Co, int H, int W, int act, void* stream);
+/* Backward: gy (B,Co,H,W) is the gradient wrt the *activated* output y (the activation derivative is
+ * applied from y, ELU/sigmoid being invertible from their outputs).  Produces dx0 (pre-upsample shape,
+ * 2x2-summed when up0), dx1, dweight, dbias (each nullable).  ws: dc_conv3x3_bwd_workspace bytes. */
+size_t dc_conv3x3_bwd_workspace(int C0, int C1, int B, int Co, int H, int W);
+int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
+                   const float* y, const float* gy, float* dx0, float* dx1, float* dweight, float* dbias,
+                   void* ws, int B, int Co, int H, int W, int act, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEPTHCORE_H */

@@ -1,0 +1,134 @@
+"""ctypes binding of libdepthcore.so (C ABI: include/depthcore.h).
+
+The library is the product: there is NO fallback.  If the shared object is
+missing or a tensor is not a contiguous fp32 device tensor the call raises.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint32,
+                    c_uint64, c_void_p)
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdepthcore.so")
+MAX_SCALES = 4
+
+OPT_NO_AUTOMASK = 1
+OPT_AVG_REPROJ = 2
+OPT_NO_SSIM = 4
+OPT_ALIGN_CORNERS = 8
+
+_ERR = {-1: "DC_EINVAL (bad shape / null pointer / unsupported option)",
+        -2: "DC_ELAUNCH (hip launch failed)",
+        -3: "DC_EWORKSPACE (workspace too small)"}
+
+
+class DepthcoreError(RuntimeError):
+    pass
+
+
+_F = c_void_p  # raw device pointers travel as void*
+
+
+class PhotoDesc(Structure):
+    """Mirror of `dc_photo_desc` (include/depthcore.h)."""
+    _fields_ = [
+        ("B", c_int32), ("H", c_int32), ("W", c_int32), ("num_scales", c_int32),
+        ("flags", c_uint32), ("min_depth", c_float), ("max_depth", c_float), ("smoothness", c_float),
+        ("target", _F), ("source", _F * 2), ("color_s", _F * MAX_SCALES),
+        ("K", _F), ("inv_K", _F), ("T", _F * 2),
+        ("disp", _F * MAX_SCALES), ("noise", _F * MAX_SCALES), ("rng_seed", c_uint64),
+        ("losses", _F), ("argmin", _F * MAX_SCALES),
+        ("depth", _F * MAX_SCALES), ("sample", (_F * 2) * MAX_SCALES), ("color", (_F * 2) * MAX_SCALES),
+        ("identity_selection", _F * MAX_SCALES),
+        ("g_losses", _F), ("d_disp", _F * MAX_SCALES), ("d_T", _F * 2),
+        ("workspace", _F), ("workspace_bytes", c_size_t),
+    ]
+
+
+_lib = None
+
+
+def _sig(lib):
+    i, f, p, z = c_int, c_float, c_void_p, c_size_t
+    S = {
+        "dc_version": (c_char_p, []),
+        "dc_arch": (c_char_p, []),
+        "dc_pose_matrix_fwd": (i, [p, p, i, p, i, p]),
+        "dc_pose_matrix_bwd": (i, [p, p, i, p, p, p, i, p]),
+        "dc_disp_to_depth_fwd": (i, [p, p, p, z, f, f, p]),
+        "dc_disp_to_depth_bwd": (i, [p, p, p, p, z, f, f, p]),
+        "dc_pix_coords": (i, [p, i, i, i, p]),
+        "dc_backproject_fwd": (i, [p, p, p, i, i, i, p]),
+        "dc_backproject_bwd": (i, [p, p, p, i, i, i, p]),
+        "dc_project3d_fwd": (i, [p, p, p, p, i, i, i, f, p]),
+        "dc_project3d_bwd_workspace": (z, [i, i, i]),
+        "dc_project3d_bwd": (i, [p, p, p, p, p, p, p, i, i, i, f, p]),
+        "dc_grid_sample_fwd": (i, [p, p, p, i, i, i, i, i, i, i, p]),
+        "dc_grid_sample_bwd": (i, [p, p, p, p, i, i, i, i, i, i, i, p]),
+        "dc_upsample_bilinear_fwd": (i, [p, p, i, i, i, i, i, p]),
+        "dc_upsample_bilinear_bwd": (i, [p, p, i, i, i, i, i, p]),
+        "dc_ssim_fwd": (i, [p, p, p, i, i, i, p]),
+        "dc_ssim_bwd": (i, [p, p, p, p, p, i, i, i, p]),
+        "dc_smooth_workspace": (z, [i, i, i]),
+        "dc_smooth_fwd": (i, [p, p, p, p, i, i, i, i, p]),
+        "dc_smooth_bwd": (i, [p, p, p, p, i, i, i, i, p]),
+        "dc_photo_workspace": (z, [POINTER(PhotoDesc)]),
+        "dc_photo_fwd": (i, [POINTER(PhotoDesc), p]),
+        "dc_photo_bwd": (i, [POINTER(PhotoDesc), p]),
+        "dc_photo_algorithmic_bytes": (c_double, [POINTER(PhotoDesc), i]),
+        "dc_conv3x3_fwd": (i, [p, i, i, p, i, p, p, p, i, i, i, i, i, p]),
+        "dc_conv3x3_bwd_workspace": (z, [i, i, i, i, i, i]),
+        "dc_conv3x3_bwd": (i, [p, i, i, p, i, p, p, p, p, p, p, p, p, i, i, i, i, i, p]),
+    }
+    missing = []
+    for name, (res, args) in S.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:           # an op whose symbol is absent fails loudly when called
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    return S, missing
+
+
+EXPORTS = None
+MISSING = None
+
+
+def lib():
+    """Load libdepthcore.so (once).  Raises if it has not been built."""
+    global _lib, EXPORTS, MISSING
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DepthcoreError(
+                "libdepthcore.so not found at %s -- build it with `python __graft_entry__.py` "
+                "(or `make -C self-supervised-depth-estimation_amd/csrc`); there is no fallback path" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        EXPORTS, MISSING = _sig(l)
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DepthcoreError("%s failed: %s" % (what, _ERR.get(rc, rc)))
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA(HIP) tensor, validated; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DepthcoreError("depthcore ops need device tensors (got %s); there is no CPU path" % t.device)
+    if t.dtype != dtype:
+        raise DepthcoreError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise DepthcoreError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
