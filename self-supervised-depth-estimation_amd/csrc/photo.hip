@@ -49,7 +49,7 @@ struct PhotoArgs {
     float* d_disp[DC_MAX_SCALES];
     float* d_T[2];
     // workspace carve
-    float* part_photo;   // [ns][nblk_f][2]
+    float* part_photo;   // [ns][nblk_f]
     float* part_smooth;  // [ns][B][nchunk][3]
     float* stats;        // [ns][B][3]  (mean disp, Sx, Sy)
     float* gdup[DC_MAX_SCALES];   // full-res d(upsampled disp)
@@ -61,90 +61,226 @@ __device__ __forceinline__ float uni(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
-// per-(batch, frame) geometry held in SGPRs
+typedef float f2 __attribute__((ext_vector_type(2)));   // (frame -1, frame +1) -> v_pk_*_f32
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 splat(float a) { return mk2(a, a); }
+__device__ __forceinline__ f2 left2(f2 v) { return mk2(from_left(v.x), from_left(v.y)); }
+__device__ __forceinline__ f2 right2(f2 v) { return mk2(from_right(v.x), from_right(v.y)); }
+__device__ __forceinline__ f2 rcp2(f2 v) { return mk2(frcp(v.x), frcp(v.y)); }
+__device__ __forceinline__ f2 abs2(f2 v) { return mk2(fabsf(v.x), fabsf(v.y)); }
+__device__ __forceinline__ f2 clamp01(f2 v) { return mk2(fminf(fmaxf(v.x, 0.f), 1.f), fminf(fmaxf(v.y, 0.f), 1.f)); }
+
+// ---- buffer resources: one 32-bit byte offset addresses all three channel planes (soffset = channel)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bstore(rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 0);
+}
+
+// per-batch geometry held in SGPRs: inv_K[:3,:3] and P_f = (K @ T_f)[:3,:] for both source frames
 struct Geo {
     float iK[9];
-    float P[12];
+    float P[2][12];
 };
 
-__device__ __forceinline__ void load_geo(Geo& g, const float* K, const float* invK, const float* T, int b) {
-    const float* k = K + b * 16;
-    const float* t = T + b * 16;
-    const float* ik = invK + b * 16;
+__device__ __forceinline__ void load_geo(Geo& g, const PhotoArgs& p, int b) {
+    const float* k = p.K + b * 16;
+    const float* ik = p.invK + b * 16;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) g.iK[i * 3 + j] = uni(ik[i * 4 + j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // torch.matmul(K, T)[:, :3, :]   (layers.py:183)
-            float acc = k[i * 4 + 0] * t[0 * 4 + j];
-            acc = fmaf(k[i * 4 + 1], t[1 * 4 + j], acc);
-            acc = fmaf(k[i * 4 + 2], t[2 * 4 + j], acc);
-            acc = fmaf(k[i * 4 + 3], t[3 * 4 + j], acc);
-            g.P[i * 4 + j] = uni(acc);
-        }
+    for (int f = 0; f < 2; ++f) {
+        const float* t = p.T[f] + b * 16;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // torch.matmul(K, T)[:, :3, :]   (layers.py:183)
+                float acc = k[i * 4 + 0] * t[0 * 4 + j];
+                acc = fmaf(k[i * 4 + 1], t[1 * 4 + j], acc);
+                acc = fmaf(k[i * 4 + 2], t[2 * 4 + j], acc);
+                acc = fmaf(k[i * 4 + 3], t[3 * 4 + j], acc);
+                g.P[f][i * 4 + j] = uni(acc);
+            }
     }
 }
 
-// F.interpolate(disp_s, [H,W], bilinear, align_corners=False) at one pixel (trainer.py:474-475)
-__device__ __forceinline__ float disp_at(const float* d, int hs, int ws, float ry, float rx, int H, int W,
-                                         int x, int y) {
-    if (hs == H && ws == W) return d[y * W + x];
-    LinTap ty = lin_tap(y, ry, hs), tx = lin_tap(x, rx, ws);
-    float a = d[ty.i0 * ws + tx.i0], b = d[ty.i0 * ws + tx.i1];
-    float c = d[ty.i1 * ws + tx.i0], e = d[ty.i1 * ws + tx.i1];
-    float w0 = 1.f - tx.w1, h0 = 1.f - ty.w1;
-    return h0 * (w0 * a + tx.w1 * b) + ty.w1 * (w0 * c + tx.w1 * e);
-}
-
-struct Proj {
-    float depth, ray[3], cam[3], u, v, zi;   // zi = 1/(z+eps)
-    float ix, iy, mx, my;                    // source coords + d(ix)/d(gx) incl. clamp mask
-    float gx, gy;
+struct Ctx {   // per-wave constants (scalar registers)
+    int H, W;
+    unsigned plane4;        // bytes of one channel plane
+    rsrc_t tg, s0, s1;      // target / source -1 / source +1 of this batch element (3 planes each)
+    rsrc_t dp;              // disparity of this (scale, batch element)
+    int hs, ws;
+    float ry, rx;
+    bool full;              // scale 0: the upsample is the identity
+    float min_disp, disp_range, inv_Wm1, inv_Hm1;
+    bool ac;
 };
 
-// disp -> depth -> BackprojectDepth -> Project3D -> grid_sample coordinate (layers.py:21-24,163-192)
-__device__ __forceinline__ void project_pixel(Proj& p, const Geo& g, float disp, float min_disp,
-                                              float disp_range, int x, int y, int H, int W, float inv_Wm1,
-                                              float inv_Hm1, bool ac) {
-    float scaled = min_disp + disp_range * disp;
-    p.depth = 1.0f / scaled;
-    float xf = (float)x, yf = (float)y;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        float r = g.iK[i * 3 + 0] * xf;
-        r = fmaf(g.iK[i * 3 + 1], yf, r);
-        r = r + g.iK[i * 3 + 2];
-        p.ray[i] = r;
-        p.cam[i] = p.depth * r;
-    }
-    float q[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        float a = g.P[i * 4 + 0] * p.cam[0];
-        a = fmaf(g.P[i * 4 + 1], p.cam[1], a);
-        a = fmaf(g.P[i * 4 + 2], p.cam[2], a);
-        q[i] = a + g.P[i * 4 + 3];
-    }
-    p.zi = 1.0f / (q[2] + 1e-7f);
-    p.u = q[0] * p.zi;
-    p.v = q[1] * p.zi;
-    p.gx = (p.u * inv_Wm1 - 0.5f) * 2.f;
-    p.gy = (p.v * inv_Hm1 - 0.5f) * 2.f;
-    p.ix = unnormalize_clip(p.gx, W, ac, p.mx);
-    p.iy = unnormalize_clip(p.gy, H, ac, p.my);
+__device__ __forceinline__ void make_ctx(Ctx& c, const PhotoArgs& p, int b, int s) {
+    c.H = p.H; c.W = p.W;
+    const unsigned plane = (unsigned)(p.H * p.W);
+    c.plane4 = plane * 4u;
+    const size_t img = (size_t)b * 3 * plane;
+    c.tg = make_rsrc(p.target + img, 3u * c.plane4);
+    c.s0 = make_rsrc(p.src[0] + img, 3u * c.plane4);
+    c.s1 = make_rsrc(p.src[1] + img, 3u * c.plane4);
+    c.hs = p.hs[s]; c.ws = p.ws[s];
+    c.ry = p.ry[s]; c.rx = p.rx[s];
+    c.full = (c.hs == p.H && c.ws == p.W);
+    c.dp = make_rsrc(p.disp[s] + (size_t)b * c.hs * c.ws, (unsigned)(c.hs * c.ws) * 4u);
+    c.min_disp = p.min_disp; c.disp_range = p.disp_range;
+    c.inv_Wm1 = p.inv_Wm1; c.inv_Hm1 = p.inv_Hm1;
+    c.ac = p.flags & DC_OPT_ALIGN_CORNERS;
 }
 
-struct HSum {   // horizontal 3-sums of one row, one source frame, three channels
-    float hy[3], hyy[3], hx[3], hxx[3], hxy[3];
+// ---- F.interpolate(disp_s, [H,W], bilinear, align_corners=False) at one pixel (trainer.py:474-475),
+// split into "issue the loads" / "use them" so that the loads of row y+2 fly during row y.
+struct DispTaps {
+    float a, b, c, e, wx1, wy1;
+};
+__device__ __forceinline__ void disp_issue(DispTaps& t, const Ctx& c, int x, int y) {
+    // No scale-0 shortcut on purpose: with ratio 1 the taps are (dst, w1 = 0) and the lerp returns the
+    // pixel bit-exactly, and every wave issues the same number of loads on every path -- a branch here
+    // makes the in-order vmcnt bookkeeping conservative and serialises the whole prefetch.
+    const LinTap ty = lin_tap(y, c.ry, c.hs), tx = lin_tap(x, c.rx, c.ws);
+    t.a = bload(c.dp, (unsigned)(ty.i0 * c.ws + tx.i0) * 4u, 0);
+    t.b = bload(c.dp, (unsigned)(ty.i0 * c.ws + tx.i1) * 4u, 0);
+    t.c = bload(c.dp, (unsigned)(ty.i1 * c.ws + tx.i0) * 4u, 0);
+    t.e = bload(c.dp, (unsigned)(ty.i1 * c.ws + tx.i1) * 4u, 0);
+    t.wx1 = tx.w1;
+    t.wy1 = ty.w1;
+}
+__device__ __forceinline__ float disp_value(const DispTaps& t, const Ctx& c) {
+    const float w0 = 1.f - t.wx1, h0 = 1.f - t.wy1;
+    return h0 * (w0 * t.a + t.wx1 * t.b) + t.wy1 * (w0 * t.c + t.wx1 * t.e);
+}
+
+// ---- one pixel, both source frames: disp -> depth -> BackprojectDepth -> Project3D -> grid_sample
+// coordinates (layers.py:21-24,163-192; trainer.py:508-511), with the 3 + 12 + 12 loads left in flight.
+struct Taps {
+    float t[3];       // target
+    f2 tap[3][4];     // [channel][nw, ne, sw, se] x (frame -1, frame +1)
+    f2 wx1, wy1;      // bilinear weights
+    f2 sx, sy;        // backward only: d(ix)/du, d(iy)/dv incl. the border-clamp zero
+};
+struct RowLog {       // forward, only when the log tensors are requested
+    f2 g0, g1;        // sampling grid (x,y) of frame -1 / +1
+    float depth;
 };
 
-__device__ __forceinline__ void hsum_row(HSum& h, const float t[3], const float w[3]) {
+__device__ __forceinline__ void frame_coords(float u, float v, const Ctx& c, float& ix, float& iy, float& mx,
+                                             float& my, float& gx, float& gy) {
+    gx = (u * c.inv_Wm1 - 0.5f) * 2.f;      // layers.py:190-192
+    gy = (v * c.inv_Hm1 - 0.5f) * 2.f;
+    ix = unnormalize_clip(gx, c.W, c.ac, mx);
+    iy = unnormalize_clip(gy, c.H, c.ac, my);
+}
+
+struct TapOff {
+    unsigned o00, o01, o10, o11;   // byte offsets inside one plane
+    float wx1, wy1;
+};
+__device__ __forceinline__ TapOff tap_offsets(float x, float y, int H, int W) {
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);   // the clamped tap carries weight 0
+    TapOff t;
+    t.wx1 = x - xf;
+    t.wy1 = y - yf;
+    const int r0 = y0 * W, r1 = y1 * W;
+    t.o00 = (unsigned)(r0 + x0) * 4u;
+    t.o01 = (unsigned)(r0 + x1) * 4u;
+    t.o10 = (unsigned)(r1 + x0) * 4u;
+    t.o11 = (unsigned)(r1 + x1) * 4u;
+    return t;
+}
+
+// MODE 0: forward (fills `lg` when LOGS); MODE 1: backward (fills r.sx/sy and parks u,v,zi,depth -- what
+// stage C needs two rows later -- straight into the per-lane LDS slot `park`, stride 64 floats).
+template <int MODE, bool LOGS>
+__device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, float disp, int x, int y, RowLog& lg,
+                                          float* park) {
+    const unsigned o = (unsigned)(y * c.W + x) * 4u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) r.t[ch] = bload(c.tg, o, ch * c.plane4);
+    const float scaled = c.min_disp + c.disp_range * disp;
+    const float depth = frcp(scaled);
+    const float xf = (float)x, yf = (float)y;
+    float cam[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float ray = g.iK[i * 3 + 0] * xf;
+        ray = fmaf(g.iK[i * 3 + 1], yf, ray);
+        ray = ray + g.iK[i * 3 + 2];
+        cam[i] = depth * ray;
+    }
+    f2 q[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        f2 a = mk2(g.P[0][i * 4 + 0], g.P[1][i * 4 + 0]) * cam[0];
+        a = mk2(g.P[0][i * 4 + 1], g.P[1][i * 4 + 1]) * cam[1] + a;
+        a = mk2(g.P[0][i * 4 + 2], g.P[1][i * 4 + 2]) * cam[2] + a;
+        q[i] = a + mk2(g.P[0][i * 4 + 3], g.P[1][i * 4 + 3]);
+    }
+    const f2 zi = rcp2(q[2] + 1e-7f);
+    const f2 u = q[0] * zi, v = q[1] * zi;
+    float ix0, iy0, ix1, iy1, gx0, gy0, gx1, gy1, mx0, my0, mx1, my1;
+    frame_coords(u.x, v.x, c, ix0, iy0, mx0, my0, gx0, gy0);
+    frame_coords(u.y, v.y, c, ix1, iy1, mx1, my1, gx1, gy1);
+    if (MODE == 0) {
+        if (LOGS) { lg.g0 = mk2(gx0, gy0); lg.g1 = mk2(gx1, gy1); lg.depth = depth; }
+    } else {
+        r.sx = mk2(mx0, mx1) * (2.f * c.inv_Wm1);
+        r.sy = mk2(my0, my1) * (2.f * c.inv_Hm1);
+        park[0 * 64] = u.x; park[1 * 64] = u.y; park[2 * 64] = v.x; park[3 * 64] = v.y;
+        park[4 * 64] = zi.x; park[5 * 64] = zi.y; park[6 * 64] = depth;
+    }
+    const TapOff b0 = tap_offsets(ix0, iy0, c.H, c.W), b1 = tap_offsets(ix1, iy1, c.H, c.W);
+    r.wx1 = mk2(b0.wx1, b1.wx1);
+    r.wy1 = mk2(b0.wy1, b1.wy1);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const unsigned so = ch * c.plane4;
+        r.tap[ch][0] = mk2(bload(c.s0, b0.o00, so), bload(c.s1, b1.o00, so));
+        r.tap[ch][1] = mk2(bload(c.s0, b0.o01, so), bload(c.s1, b1.o01, so));
+        r.tap[ch][2] = mk2(bload(c.s0, b0.o10, so), bload(c.s1, b1.o10, so));
+        r.tap[ch][3] = mk2(bload(c.s0, b0.o11, so), bload(c.s1, b1.o11, so));
+    }
+}
+
+struct Center {   // values of one row at the lane's own pixel
+    float t[3];
+    f2 w[3];
+};
+
+__device__ __forceinline__ void blend_row(const Taps& r, Center& o) {
+    const f2 wx0 = 1.f - r.wx1, wy0 = 1.f - r.wy1;
+    const f2 wnw = wx0 * wy0, wne = r.wx1 * wy0, wsw = wx0 * r.wy1, wse = r.wx1 * r.wy1;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        o.w[ch] = r.tap[ch][0] * wnw + r.tap[ch][1] * wne + r.tap[ch][2] * wsw + r.tap[ch][3] * wse;
+        o.t[ch] = r.t[ch];
+    }
+}
+
+struct HSum {   // horizontal 3-sums of one row: target (scalar) and both warped frames (packed)
+    float hy[3], hyy[3];
+    f2 hx[3], hxx[3], hxy[3];
+};
+
+__device__ __forceinline__ void hsum_row(HSum& h, const float t[3], const f2 w[3]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float tl = from_left(t[c]), tr = from_right(t[c]);
-        float wl = from_left(w[c]), wr = from_right(w[c]);
+        const float tl = from_left(t[c]), tr = from_right(t[c]);
+        const f2 wl = left2(w[c]), wr = right2(w[c]);
         h.hy[c] = tl + t[c] + tr;
         h.hyy[c] = tl * tl + t[c] * t[c] + tr * tr;
         h.hx[c] = wl + w[c] + wr;
@@ -154,33 +290,34 @@ __device__ __forceinline__ void hsum_row(HSum& h, const float t[3], const float 
 }
 
 struct SsimTerms {
-    float mu_x, mu_y, n1, n2, d1, d2;
+    f2 mu_x, n1, n2, d1, d2;
+    float mu_y;
 };
 __device__ __forceinline__ SsimTerms ssim_terms(const HSum& a, const HSum& b, const HSum& c, int ch) {
     SsimTerms s;
     s.mu_x = (a.hx[ch] + b.hx[ch] + c.hx[ch]) * k9;
     s.mu_y = (a.hy[ch] + b.hy[ch] + c.hy[ch]) * k9;
-    float sig_x = (a.hxx[ch] + b.hxx[ch] + c.hxx[ch]) * k9 - s.mu_x * s.mu_x;
-    float sig_y = (a.hyy[ch] + b.hyy[ch] + c.hyy[ch]) * k9 - s.mu_y * s.mu_y;
-    float sig_xy = (a.hxy[ch] + b.hxy[ch] + c.hxy[ch]) * k9 - s.mu_x * s.mu_y;
+    const f2 sig_x = (a.hxx[ch] + b.hxx[ch] + c.hxx[ch]) * k9 - s.mu_x * s.mu_x;
+    const float sig_y = (a.hyy[ch] + b.hyy[ch] + c.hyy[ch]) * k9 - s.mu_y * s.mu_y;
+    const f2 sig_xy = (a.hxy[ch] + b.hxy[ch] + c.hxy[ch]) * k9 - s.mu_x * s.mu_y;
     s.n1 = 2.f * s.mu_x * s.mu_y + kC1;
     s.n2 = 2.f * sig_xy + kC2;
-    s.d1 = s.mu_x * s.mu_x + s.mu_y * s.mu_y + kC1;
-    s.d2 = sig_x + sig_y + kC2;
+    s.d1 = s.mu_x * s.mu_x + (s.mu_y * s.mu_y + kC1);
+    s.d2 = sig_x + (sig_y + kC2);
     return s;
 }
 
-// 0.85 * mean_c SSIM + 0.15 * mean_c |t - w|      (trainer.py:517-529)
-__device__ __forceinline__ float reproj_value(const HSum& a, const HSum& b, const HSum& c, const float tc[3],
-                                              const float wc[3], bool no_ssim) {
-    float l1 = (fabsf(tc[0] - wc[0]) + fabsf(tc[1] - wc[1]) + fabsf(tc[2] - wc[2])) * (1.f / 3.f);
+// 0.85 * mean_c SSIM + 0.15 * mean_c |t - w|      (trainer.py:517-529), both frames at once
+__device__ __forceinline__ f2 reproj_value(const HSum& a, const HSum& b, const HSum& c, const Center& ctr,
+                                           bool no_ssim) {
+    const f2 l1 = (abs2(ctr.t[0] - ctr.w[0]) + abs2(ctr.t[1] - ctr.w[1]) + abs2(ctr.t[2] - ctr.w[2])) * (1.f / 3.f);
     if (no_ssim) return l1;
-    float ss = 0.f;
+    f2 ss = splat(0.f);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        SsimTerms s = ssim_terms(a, b, c, ch);
-        float v = (1.f - (s.n1 * s.n2) / (s.d1 * s.d2)) * 0.5f;
-        ss += fminf(fmaxf(v, 0.f), 1.f);
+        const SsimTerms s = ssim_terms(a, b, c, ch);
+        const f2 v = (1.f - (s.n1 * s.n2) * rcp2(s.d1 * s.d2)) * 0.5f;
+        ss += clamp01(v);
     }
     return 0.85f * (ss * (1.f / 3.f)) + 0.15f * l1;
 }
@@ -198,180 +335,182 @@ __device__ __forceinline__ float rng_normal(unsigned long long seed, unsigned id
 
 // ------------------------------------------------------------------------------------------------
 // identity reprojection losses: reprojection_loss(color(f,0), color(0,0)), f = -1,+1  (trainer.py:562-568)
-// one wave = one strip x R rows, both frames.   grid (strips, rowblocks, B), block 64.
+// one wave = one strip x ID_ROWS rows, both frames packed.   grid (strips62, rowblocks_id, B), block 64.
 // ------------------------------------------------------------------------------------------------
+constexpr int ID_ROWS = 8;
+
 __global__ __launch_bounds__(64) void identity_kernel(PhotoArgs p) {
     const int lane = threadIdx.x;
     const int b = blockIdx.z;
     const int x = blockIdx.x * 62 - 1 + lane;
-    const int y0 = blockIdx.y * R_ROWS;
+    const int y0 = blockIdx.y * ID_ROWS;
     const int H = p.H, W = p.W;
     const int xr = reflect_clamp(x, W);
-    const size_t plane = (size_t)H * W;
-    const float* tg = p.target + (size_t)b * 3 * plane;
-    const float* s0 = p.src[0] + (size_t)b * 3 * plane;
-    const float* s1 = p.src[1] + (size_t)b * 3 * plane;
+    Ctx c;
+    make_ctx(c, p, b, 0);
     const bool no_ssim = p.flags & DC_OPT_NO_SSIM;
     const bool avg = p.flags & DC_OPT_AVG_REPROJ;
     const bool lane_ok = lane >= 1 && lane <= 62 && x < W;
+    const rsrc_t idl = make_rsrc(p.idl + (size_t)b * (avg ? 1 : 2) * (c.plane4 / 4), (avg ? 1u : 2u) * c.plane4);
 
-    HSum a0, a1, b0, b1;   // rows yy-2, yy-1 for frame 0 / 1
-    float ct[3], c0[3], c1[3];
-    a0 = a1 = b0 = b1 = HSum{};
-    ct[0] = ct[1] = ct[2] = c0[0] = c0[1] = c0[2] = c1[0] = c1[1] = c1[2] = 0.f;
-#pragma unroll 1
-    for (int i = 0; i < R_ROWS + 2; ++i) {
-        const int yy = y0 - 1 + i;
-        const int yr = reflect_clamp(yy, H);
-        float t[3], w0[3], w1[3];
+    HSum hA = {}, hB = {};
+    Center cA = {}, cB = {};
+    float t[3];
+    f2 w[3];
+    auto load_row = [&](int yy) {
+        const unsigned o = (unsigned)(reflect_clamp(yy, H) * W + xr) * 4u;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            size_t o = c * plane + (size_t)yr * W + xr;
-            t[c] = tg[o];
-            w0[c] = s0[o];
-            w1[c] = s1[o];
+        for (int ch = 0; ch < 3; ++ch) {
+            t[ch] = bload(c.tg, o, ch * c.plane4);
+            w[ch] = mk2(bload(c.s0, o, ch * c.plane4), bload(c.s1, o, ch * c.plane4));
         }
-        HSum h0, h1;
-        hsum_row(h0, t, w0);
-        hsum_row(h1, t, w1);
+    };
+    auto body = [&](int i, HSum& h_old, HSum& h_new, const Center& c_prev, Center& c_cur) {
+        const int yy = y0 - 1 + i;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { c_cur.t[ch] = t[ch]; c_cur.w[ch] = w[ch]; }
+        load_row(yy + 1);   // next row flies during this row's math
+        HSum h;
+        hsum_row(h, c_cur.t, c_cur.w);
         const int py = yy - 1;
         if (i >= 2 && py < H && lane_ok) {
-            float r0 = reproj_value(a0, b0, h0, ct, c0, no_ssim);
-            float r1 = reproj_value(a1, b1, h1, ct, c1, no_ssim);
+            const f2 r = reproj_value(h_old, h_new, h, c_prev, no_ssim);
+            const unsigned o = (unsigned)(py * W + x) * 4u;
             if (avg) {
-                p.idl[((size_t)b * H + py) * W + x] = (r0 + r1) * 0.5f;
+                bstore(idl, o, 0, (r.x + r.y) * 0.5f);
             } else {
-                p.idl[((size_t)(b * 2 + 0) * H + py) * W + x] = r0;
-                p.idl[((size_t)(b * 2 + 1) * H + py) * W + x] = r1;
+                bstore(idl, o, 0, r.x);
+                bstore(idl, o, c.plane4, r.y);
             }
         }
-        a0 = b0; b0 = h0; a1 = b1; b1 = h1;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { ct[c] = t[c]; c0[c] = w0[c]; c1[c] = w1[c]; }
+        h_old = h;
+    };
+    load_row(y0 - 1);
+#pragma unroll 1
+    for (int i = 0; i < ID_ROWS + 2; i += 2) {
+        body(i, hA, hB, cB, cA);
+        body(i + 1, hB, hA, cA, cB);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward: wave (scale s, frame f).  grid (strips62, rowblocks, B), block 128*ns.
+// forward: wave = scale s, both source frames packed.  grid (strips62, rowblocks, B), block 64*ns.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void photo_fwd_kernel(PhotoArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2*ns waves][R_ROWS][64]
+template <bool LOGS>
+__global__ __launch_bounds__(256, 2) void photo_fwd_kernel(PhotoArgs p) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = wave >> 1, f = wave & 1;
+    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
     const int x = blockIdx.x * 62 - 1 + lane;
     const int y0 = blockIdx.y * R_ROWS;
     const int H = p.H, W = p.W;
     const int xr = reflect_clamp(x, W);
-    const size_t plane = (size_t)H * W;
-    const float* tg = p.target + (size_t)b * 3 * plane;
-    const float* sp = p.src[f] + (size_t)b * 3 * plane;
-    const int hs = p.hs[s], ws = p.ws[s];
-    const float* dp = p.disp[s] + (size_t)b * hs * ws;
-    const float ry = p.ry[s], rx = p.rx[s];
+    Ctx c;
+    make_ctx(c, p, b, s);
+    const unsigned plane = c.plane4 / 4;
     const bool no_ssim = p.flags & DC_OPT_NO_SSIM;
-    const bool ac = p.flags & DC_OPT_ALIGN_CORNERS;
-    const bool lane_ok = lane >= 1 && lane <= 62 && x < W;
-    Geo g;
-    load_geo(g, p.K, p.invK, p.T[f], b);
-    float* col = p.color[s][f];
-    float* smp = p.sample[s][f];
-    float* dep = (f == 0) ? p.depth[s] : nullptr;
-    float* my_lds = lds + (size_t)wave * R_ROWS * 64;
-
-    HSum ha, hb;
-    ha = hb = HSum{};
-    float ct[3] = {0.f, 0.f, 0.f}, cw[3] = {0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int i = 0; i < R_ROWS + 2; ++i) {
-        const int yy = y0 - 1 + i;
-        const int yr = reflect_clamp(yy, H);
-        float t[3], w[3];
-        float d = disp_at(dp, hs, ws, ry, rx, H, W, xr, yr);
-        Proj pr;
-        project_pixel(pr, g, d, p.min_disp, p.disp_range, xr, yr, H, W, p.inv_Wm1, p.inv_Hm1, ac);
-        Bilin bl = bilin_setup(pr.ix, pr.iy, H, W);
-        const float wx0 = 1.f - bl.wx1, wy0 = 1.f - bl.wy1;
-        const float wnw = wx0 * wy0, wne = bl.wx1 * wy0, wsw = wx0 * bl.wy1, wse = bl.wx1 * bl.wy1;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* pl = sp + c * plane;
-            t[c] = tg[c * plane + (size_t)yr * W + xr];
-            w[c] = pl[bl.o00] * wnw + pl[bl.o01] * wne + pl[bl.o10] * wsw + pl[bl.o11] * wse;
-        }
-        // optional log tensors (trainer.py:480-511), real rows / columns only
-        if ((col || smp || dep) && i >= 1 && i <= R_ROWS && yy < H && lane_ok) {
-            size_t o = (size_t)yy * W + x;
-            if (col) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) col[((size_t)b * 3 + c) * plane + o] = w[c];
-            }
-            if (smp) {
-                smp[((size_t)b * plane + o) * 2 + 0] = pr.gx;
-                smp[((size_t)b * plane + o) * 2 + 1] = pr.gy;
-            }
-            if (dep) dep[(size_t)b * plane + o] = pr.depth;
-        }
-        HSum h;
-        hsum_row(h, t, w);
-        if (i >= 2) my_lds[(i - 2) * 64 + lane] = reproj_value(ha, hb, h, ct, cw, no_ssim);
-        ha = hb; hb = h;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { ct[c] = t[c]; cw[c] = w[c]; }
-    }
-    __syncthreads();
-    // ---- min over [identity(-1), identity(+1), reproj(-1), reproj(+1)]  (trainer.py:592-610)
-    const float* r0p = lds + (size_t)(s * 2 + 0) * R_ROWS * 64;
-    const float* r1p = lds + (size_t)(s * 2 + 1) * R_ROWS * 64;
     const bool automask = !(p.flags & DC_OPT_NO_AUTOMASK);
     const bool avg = p.flags & DC_OPT_AVG_REPROJ;
-    const float* nz = p.noise[s];
-    uint8_t* am = p.argmin[s];
-    float* isel = p.idsel[s];
+    const bool lane_ok = lane >= 1 && lane <= 62 && x < W;
+    Geo g;
+    load_geo(g, p, b);
+    const unsigned nch4 = (avg ? 1u : 2u) * c.plane4;
+    const bool ext_noise = p.noise[s] != nullptr;
+    const rsrc_t nz = make_rsrc(ext_noise ? p.noise[s] + (size_t)b * (avg ? 1 : 2) * plane : p.idl, ext_noise ? nch4 : 0u);
+    const rsrc_t idl = make_rsrc(p.idl + (size_t)b * (avg ? 1 : 2) * plane, automask ? nch4 : 0u);
+    uint8_t* am = p.argmin[s] + (size_t)b * plane;
+    float* isel = p.idsel[s] ? p.idsel[s] + (size_t)b * plane : nullptr;
+
+    HSum hA = {}, hB = {};
+    Center cA = {}, cB = {};
+    float idnA[4] = {0.f, 0.f, 0.f, 0.f}, idnB[4] = {0.f, 0.f, 0.f, 0.f};
     float acc = 0.f;
-    for (int r = f; r < R_ROWS; r += 2) {
-        const int py = y0 + r;
-        if (py < H && lane_ok) {
-            float r0 = r0p[r * 64 + lane], r1 = r1p[r * 64 + lane];
+    Taps tp;
+    DispTaps dt;
+    RowLog lg_cur = {}, lg_nxt = {};
+
+    // One march step.  On entry `tp` holds the in-flight loads of row yy and `dt` those of the
+    // disparity of row yy+1.  All loads of the step are issued together right after the blend, so
+    // every later s_waitcnt of the step only waits for loads that are older than them.
+    auto body = [&](int i, HSum& h_old, HSum& h_new, const Center& c_prev, Center& c_cur, const float* idn_cur,
+                    float* idn_nxt) {
+        const int yy = y0 - 1 + i;
+        blend_row(tp, c_cur);
+        if (LOGS) lg_cur = lg_nxt;
+        issue_row<0, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), lg_nxt, nullptr);
+        {   // identity loss + tie-break noise of the row the NEXT step outputs (row yy)
+            const unsigned o = (unsigned)(min(max(yy, 0), H - 1) * W + xr) * 4u;
+            idn_nxt[0] = bload(idl, o, 0);
+            idn_nxt[1] = bload(idl, o, c.plane4);
+            idn_nxt[2] = bload(nz, o, 0);
+            idn_nxt[3] = bload(nz, o, c.plane4);
+        }
+        disp_issue(dt, c, xr, reflect_clamp(yy + 2, H));
+
+        // optional log tensors (trainer.py:480-511), real rows / columns only
+        if (LOGS && i >= 1 && i <= R_ROWS && yy < H && lane_ok) {
+            const unsigned o = (unsigned)(yy * W + x);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                if (float* col = p.color[s][f]) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) col[((size_t)b * 3 + ch) * plane + o] = f ? c_cur.w[ch].y : c_cur.w[ch].x;
+                }
+                if (float* smp = p.sample[s][f])
+                    reinterpret_cast<f2*>(smp)[(size_t)b * plane + o] = f ? lg_cur.g1 : lg_cur.g0;
+            }
+            if (float* dep = p.depth[s]) dep[(size_t)b * plane + o] = lg_cur.depth;
+        }
+        HSum h;
+        hsum_row(h, c_cur.t, c_cur.w);
+        const int py = yy - 1;
+        if (i >= 2 && py < H && lane_ok) {
+            // ---- min over [identity(-1), identity(+1), reproj(-1), reproj(+1)]  (trainer.py:592-610)
+            const f2 r = reproj_value(h_old, h_new, h, c_prev, no_ssim);
+            const unsigned o = (unsigned)(py * W + x);
             float best;
             int idx = 0;
-            const size_t o = (size_t)py * W + x;
             if (avg) {
-                float rr = (r0 + r1) * 0.5f;
+                const float rr = (r.x + r.y) * 0.5f;
                 best = rr;
                 if (automask) {
-                    float n0 = nz ? nz[(size_t)b * plane + o] : rng_normal(p.seed, (unsigned)(b * plane + o), s * 2);
-                    float id = __fadd_rn(p.idl[(size_t)b * plane + o], __fmul_rn(n0, 0.00001f));
+                    const float n0 = ext_noise ? idn_cur[2] : rng_normal(p.seed, b * plane + o, s * 2);
+                    const float id = __fadd_rn(idn_cur[0], __fmul_rn(n0, 0.00001f));
                     best = id;
                     if (rr < best) { best = rr; idx = 1; }
                 }
+            } else if (automask) {
+                const float n0 = ext_noise ? idn_cur[2] : rng_normal(p.seed, b * plane + o, s * 2);
+                const float n1 = ext_noise ? idn_cur[3] : rng_normal(p.seed, b * plane + o, s * 2 + 1);
+                const float i0 = __fadd_rn(idn_cur[0], __fmul_rn(n0, 0.00001f));
+                const float i1 = __fadd_rn(idn_cur[1], __fmul_rn(n1, 0.00001f));
+                best = i0;
+                if (i1 < best) { best = i1; idx = 1; }
+                if (r.x < best) { best = r.x; idx = 2; }
+                if (r.y < best) { best = r.y; idx = 3; }
             } else {
-                if (automask) {
-                    float n0 = nz ? nz[((size_t)b * 2 + 0) * plane + o]
-                                  : rng_normal(p.seed, (unsigned)(b * plane + o), s * 2);
-                    float n1 = nz ? nz[((size_t)b * 2 + 1) * plane + o]
-                                  : rng_normal(p.seed, (unsigned)(b * plane + o), s * 2 + 1);
-                    float i0 = __fadd_rn(p.idl[((size_t)b * 2 + 0) * plane + o], __fmul_rn(n0, 0.00001f));
-                    float i1 = __fadd_rn(p.idl[((size_t)b * 2 + 1) * plane + o], __fmul_rn(n1, 0.00001f));
-                    best = i0;
-                    if (i1 < best) { best = i1; idx = 1; }
-                    if (r0 < best) { best = r0; idx = 2; }
-                    if (r1 < best) { best = r1; idx = 3; }
-                } else {
-                    best = r0;
-                    if (r1 < best) { best = r1; idx = 1; }
-                }
+                best = r.x;
+                if (r.y < best) { best = r.y; idx = 1; }
             }
             acc += best;
-            am[(size_t)b * plane + o] = (uint8_t)idx;
-            if (isel && automask) isel[(size_t)b * plane + o] = (idx > (avg ? 0 : 1)) ? 1.f : 0.f;
+            am[o] = (uint8_t)idx;
+            if (isel && automask) isel[o] = (idx > (avg ? 0 : 1)) ? 1.f : 0.f;
         }
+        h_old = h;
+    };
+
+    disp_issue(dt, c, xr, reflect_clamp(y0 - 1, H));
+    issue_row<0, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(y0 - 1, H), lg_nxt, nullptr);
+    disp_issue(dt, c, xr, reflect_clamp(y0, H));
+#pragma unroll 1
+    for (int i = 0; i < R_ROWS + 2; i += 2) {
+        body(i, hA, hB, cB, cA, idnA, idnB);
+        body(i + 1, hB, hA, cA, cB, idnB, idnA);
     }
     acc = wave_sum(acc);
     if (lane == 0) {
-        int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        p.part_photo[((size_t)s * p.nblk_f + blk) * 2 + f] = acc;
+        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        p.part_photo[(size_t)s * p.nblk_f + blk] = acc;
     }
 }
 
@@ -381,274 +520,358 @@ __global__ __launch_bounds__(512) void photo_fwd_kernel(PhotoArgs p) {
 // ------------------------------------------------------------------------------------------------
 constexpr int SM_CHUNK = 2048;
 
-__device__ __forceinline__ float block_sum_256(float v, float* sm) {
-    v = wave_sum(v);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[w] = v;
-    __syncthreads();
-    return sm[0] + sm[1] + sm[2] + sm[3];
-}
-
 __global__ __launch_bounds__(256) void smooth_fwd_kernel(PhotoArgs p) {
-    __shared__ float sm[4];
+    __shared__ float sm[3][4];
     const int s = blockIdx.z, b = blockIdx.y;
     const int h = p.hs[s], w = p.ws[s];
     const int n = h * w;
     const int base = blockIdx.x * SM_CHUNK;
+    if (base >= n) return;
     float sd = 0.f, sx = 0.f, sy = 0.f;
-    if (base < n) {
-        const float* d = p.disp[s] + (size_t)b * n;
-        const float* im = p.color_s[s] + (size_t)b * 3 * n;
-        for (int i = base + threadIdx.x; i < min(base + SM_CHUNK, n); i += 256) {
-            const int y = i / w, x = i - y * w;
-            const float dv = d[i];
-            sd += dv;
-            if (x < w - 1) {
-                float gi = (fabsf(im[i] - im[i + 1]) + fabsf(im[n + i] - im[n + i + 1]) +
-                            fabsf(im[2 * n + i] - im[2 * n + i + 1])) * (1.f / 3.f);
-                sx += fabsf(dv - d[i + 1]) * __expf(-gi);
-            }
-            if (y < h - 1) {
-                float gi = (fabsf(im[i] - im[i + w]) + fabsf(im[n + i] - im[n + i + w]) +
-                            fabsf(im[2 * n + i] - im[2 * n + i + w])) * (1.f / 3.f);
-                sy += fabsf(dv - d[i + w]) * __expf(-gi);
-            }
+    const float* d = p.disp[s] + (size_t)b * n;
+    const float* im = p.color_s[s] + (size_t)b * 3 * n;
+    for (int i = base + threadIdx.x; i < min(base + SM_CHUNK, n); i += 256) {
+        const int y = i / w, x = i - y * w;
+        const float dv = d[i];
+        sd += dv;
+        if (x < w - 1) {
+            float gi = (fabsf(im[i] - im[i + 1]) + fabsf(im[n + i] - im[n + i + 1]) +
+                        fabsf(im[2 * n + i] - im[2 * n + i + 1])) * (1.f / 3.f);
+            sx += fabsf(dv - d[i + 1]) * __expf(-gi);
+        }
+        if (y < h - 1) {
+            float gi = (fabsf(im[i] - im[i + w]) + fabsf(im[n + i] - im[n + i + w]) +
+                        fabsf(im[2 * n + i] - im[2 * n + i + w])) * (1.f / 3.f);
+            sy += fabsf(dv - d[i + w]) * __expf(-gi);
         }
     }
-    sd = block_sum_256(sd, sm);
-    sx = block_sum_256(sx, sm);
-    sy = block_sum_256(sy, sm);
-    if (threadIdx.x == 0) {
+    sd = wave_sum(sd); sx = wave_sum(sx); sy = wave_sum(sy);
+    if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; sm[0][wv] = sd; sm[1][wv] = sx; sm[2][wv] = sy; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
         float* o = p.part_smooth + (((size_t)s * p.B + b) * p.nchunk + blockIdx.x) * 3;
-        o[0] = sd; o[1] = sx; o[2] = sy;
+        o[threadIdx.x] = sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3];
     }
 }
 
-// one block: fixed-order final sums -> losses[ns+1], stats[s][b] = (mean, Sx, Sy)
-__global__ __launch_bounds__(256) void finalize_kernel(PhotoArgs p) {
-    __shared__ float sm[4];
+// one 1024-thread block: fixed-order final sums -> losses[ns+1], stats[s][b] = (mean, Sx, Sy)
+__global__ __launch_bounds__(1024) void finalize_kernel(PhotoArgs p) {
+    __shared__ float sm[DC_MAX_SCALES][16];
     __shared__ float smooth_s[DC_MAX_SCALES];
     const int ns = p.ns, B = p.B;
-    // per (s,b) smoothness stats
-    for (int sb = threadIdx.x; sb < ns * B; sb += 256) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // photometric partial sums: all scales' loads in flight together
+    float ph[DC_MAX_SCALES] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = threadIdx.x; k < p.nblk_f; k += 1024)
+#pragma unroll
+        for (int s = 0; s < DC_MAX_SCALES; ++s)
+            if (s < ns) ph[s] += p.part_photo[(size_t)s * p.nblk_f + k];
+    // per (s,b) smoothness stats: one wave per pair, lanes over chunks
+    for (int sb = wv; sb < ns * B; sb += 16) {
         const int s = sb / B;
         const int n = p.hs[s] * p.ws[s];
         const int nch = (n + SM_CHUNK - 1) / SM_CHUNK;
         const float* q = p.part_smooth + (size_t)sb * p.nchunk * 3;
         float sd = 0.f, sx = 0.f, sy = 0.f;
-        for (int k = 0; k < nch; ++k) { sd += q[k * 3]; sx += q[k * 3 + 1]; sy += q[k * 3 + 2]; }
-        p.stats[sb * 3 + 0] = sd / (float)n;
-        p.stats[sb * 3 + 1] = sx;
-        p.stats[sb * 3 + 2] = sy;
+        for (int k = lane; k < nch; k += 64) { sd += q[k * 3]; sx += q[k * 3 + 1]; sy += q[k * 3 + 2]; }
+        sd = wave_sum(sd); sx = wave_sum(sx); sy = wave_sum(sy);
+        if (lane == 0) {
+            p.stats[sb * 3 + 0] = sd / (float)n;
+            p.stats[sb * 3 + 1] = sx;
+            p.stats[sb * 3 + 2] = sy;
+        }
     }
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < DC_MAX_SCALES; ++s) {
+        const float v = wave_sum(ph[s]);
+        if (lane == 0) sm[s][wv] = v;
+    }
+    __syncthreads();   // also orders the stats[] stores of this block before the reads below
     if (threadIdx.x < ns) {
         const int s = threadIdx.x;
         const int h = p.hs[s], w = p.ws[s];
         float tx = 0.f, ty = 0.f;
         for (int b = 0; b < B; ++b) {
-            float a = 1.f / (p.stats[(s * B + b) * 3] + 1e-7f);
+            const float a = 1.f / (p.stats[(s * B + b) * 3] + 1e-7f);
             tx += p.stats[(s * B + b) * 3 + 1] * a;
             ty += p.stats[(s * B + b) * 3 + 2] * a;
         }
         smooth_s[s] = tx / ((float)B * h * (w - 1)) + ty / ((float)B * (h - 1) * w);
     }
     __syncthreads();
-    float total = 0.f;
-    for (int s = 0; s < ns; ++s) {
-        float acc = 0.f;
-        const float* q = p.part_photo + (size_t)s * p.nblk_f * 2;
-        for (int k = threadIdx.x; k < p.nblk_f * 2; k += 256) acc += q[k];
-        acc = block_sum_256(acc, sm);
-        float loss = acc / ((float)B * p.H * p.W) + p.smoothness * smooth_s[s] / (float)(1 << s);
-        if (threadIdx.x == 0) p.losses[s] = loss;
-        total += loss;
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int s = 0; s < ns; ++s) {
+            float a = 0.f;
+            for (int k = 0; k < 16; ++k) a += sm[s][k];
+            const float loss = a / ((float)B * p.H * p.W) + p.smoothness * smooth_s[s] / (float)(1 << s);
+            p.losses[s] = loss;
+            total += loss;
+        }
+        p.losses[ns] = total / (float)ns;
     }
-    if (threadIdx.x == 0) p.losses[ns] = total / (float)ns;
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: wave (scale s, frame f), halo 2.  grid (strips60, rowblocks, B), block 128*ns.
+// backward: wave = scale s, both frames packed, halo 2.  grid (strips60, rowblocks, B), block 64*ns.
+//
+// Per march step (row yy):  A: blend the taps of row yy (value + coordinate derivatives);
+//   B: SSIM derivative coefficients of output pixel row p = yy-1, spread (transposed 3x3 with the
+//      ReflectionPad fold-back) onto the pending gradient accumulators of rows yy-2, yy-1, yy;
+//   C: row q = yy-2 is now complete: chain it through grid_sample / Project3D / BackprojectDepth /
+//      disp_to_depth, accumulate the pose gradient, store d(upsampled disp).
+// What C needs from A two rows earlier (dw/dcoords, projection) waits in a per-lane LDS ring; nothing
+// is recomputed and nothing but the final d(disp) is written to HBM.
 // ------------------------------------------------------------------------------------------------
-struct HAbc {
-    float a[3], b[3], c[3];
+constexpr int RING_VALS = 12;   // f2 Dx[3], Dy[3]              3 slots (written at A, read at C two rows later)
+constexpr int PARK_VALS = 7;    // u, v, zi (f2) + depth        4 slots (written one row ahead by issue_row)
+constexpr int BWD_LDS_PER_WAVE = (3 * RING_VALS + 4 * PARK_VALS) * 64;
+
+struct GAcc {
+    f2 g[3];
 };
 
-__global__ __launch_bounds__(512) void photo_bwd_kernel(PhotoArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2*ns][R_ROWS][64]
+__global__ __launch_bounds__(256, 1) void photo_bwd_kernel(PhotoArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [ns waves][BWD_LDS_PER_WAVE]
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = wave >> 1, f = wave & 1;
+    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
     const int x = blockIdx.x * 60 - 2 + lane;
     const int y0 = blockIdx.y * R_ROWS;
     const int H = p.H, W = p.W;
     const int xr = reflect_clamp(x, W);
-    const size_t plane = (size_t)H * W;
-    const float* tg = p.target + (size_t)b * 3 * plane;
-    const float* sp = p.src[f] + (size_t)b * 3 * plane;
-    const int hs = p.hs[s], ws = p.ws[s];
-    const float* dp = p.disp[s] + (size_t)b * hs * ws;
-    const float ry = p.ry[s], rx = p.rx[s];
+    Ctx c;
+    make_ctx(c, p, b, s);
+    const unsigned plane = c.plane4 / 4;
     const bool no_ssim = p.flags & DC_OPT_NO_SSIM;
-    const bool ac = p.flags & DC_OPT_ALIGN_CORNERS;
     const bool automask = !(p.flags & DC_OPT_NO_AUTOMASK);
     const bool avg = p.flags & DC_OPT_AVG_REPROJ;
     const bool col_ok = x >= 0 && x < W;
     const bool q_lane = lane >= 2 && lane <= 61 && col_ok;
     Geo g;
-    load_geo(g, p.K, p.invK, p.T[f], b);
-    const uint8_t* am = p.argmin[s] + (size_t)b * plane;
+    load_geo(g, p, b);
+    const rsrc_t am = make_rsrc(p.argmin[s] + (size_t)b * plane, plane);
     // d loss / d to_optimise(pixel) for this scale: mean over B*H*W, total = mean over scales
     const float wgt = uni((p.g_losses[s] + p.g_losses[p.ns] / (float)p.ns) / ((float)p.B * H * W));
     const float g_ssim = no_ssim ? 0.f : 0.85f / 3.f;
     const float g_l1 = no_ssim ? 1.f / 3.f : 0.15f / 3.f;
-    const int sel_idx = avg ? 1 : (automask ? 2 + f : f);
-    const float sel_val = avg ? 0.5f : 1.f;
+    // argmin value that routes the gradient to frame -1 / +1
+    const int sel0 = avg ? 1 : (automask ? 2 : 0), sel1 = avg ? 1 : (automask ? 3 : 1);
+    const float sel_val = (avg ? 0.5f : 1.f) * wgt;
     const bool sel_all = avg && !automask;   // single channel: to_optimise = combined
-    float* my_lds = lds + (size_t)wave * R_ROWS * 64;
+    float* ring = lds + (size_t)s * BWD_LDS_PER_WAVE + lane;
+    float* park = ring + 3 * RING_VALS * 64;
+    float* gout = p.gdup[s] + (size_t)b * plane;
+    const float fl = (x == 1) ? 2.f : 1.f, fr = (x == W - 2) ? 2.f : 1.f;   // ReflectionPad fold-back, x
 
-    HSum ha, hb;
-    HAbc ka, kb;
-    ha = hb = HSum{};
-    ka = kb = HAbc{};
-    float dP[12];
+    HSum hA = {}, hB = {};
+    Center cA = {}, cB = {};     // rows yy-2 / yy-1 (ping-pong)
+    GAcc gA = {}, gB = {};       // pending d/d(warped) of rows yy-2 / yy-1
+    int mA = 0, mB = 0, m_in = 0;
+    // pose-gradient accumulators; the lane's column x is constant along the march, so
+    //   sum dq_r*cam_j = (iK_j0*x + iK_j2) * sum(dq_r*depth) + iK_j1 * sum(dq_r*depth*y)
+    f2 accA[3], accB[3], accC[3];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) dP[k] = 0.f;
+    for (int k = 0; k < 3; ++k) accA[k] = accB[k] = accC[k] = splat(0.f);
+    Taps tp;
+    DispTaps dt;
+    RowLog nolog;
+    int slot3 = 0;   // i % 3
 
-#pragma unroll 1
-    for (int i = 0; i < R_ROWS + 4; ++i) {
+    auto body = [&](int i, HSum& h_old, HSum& h_new, Center& c_old, const Center& c_new, GAcc& g_old, GAcc& g_new,
+                    int& m_old, const int& m_new) {
         const int yy = y0 - 2 + i;
-        // ---------------- stage A: target + warped values on (reflected) row yy
-        HSum h;
+        // ---------------- stage A: warped values + their coordinate derivatives on (reflected) row yy
+        Center cur;
+        float* rs = ring + (size_t)slot3 * RING_VALS * 64;
         {
-            const int yr = reflect_clamp(yy, H);
-            float t[3], w[3];
-            float d = disp_at(dp, hs, ws, ry, rx, H, W, xr, yr);
-            Proj pr;
-            project_pixel(pr, g, d, p.min_disp, p.disp_range, xr, yr, H, W, p.inv_Wm1, p.inv_Hm1, ac);
-            Bilin bl = bilin_setup(pr.ix, pr.iy, H, W);
-            const float wx0 = 1.f - bl.wx1, wy0 = 1.f - bl.wy1;
-            const float wnw = wx0 * wy0, wne = bl.wx1 * wy0, wsw = wx0 * bl.wy1, wse = bl.wx1 * bl.wy1;
+            const f2 wx0 = 1.f - tp.wx1, wy0 = 1.f - tp.wy1;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float* pl = sp + c * plane;
-                t[c] = tg[c * plane + (size_t)yr * W + xr];
-                w[c] = pl[bl.o00] * wnw + pl[bl.o01] * wne + pl[bl.o10] * wsw + pl[bl.o11] * wse;
+            for (int ch = 0; ch < 3; ++ch) {
+                const f2 nw = tp.tap[ch][0], ne = tp.tap[ch][1], sw = tp.tap[ch][2], se = tp.tap[ch][3];
+                cur.w[ch] = (nw * wx0 + ne * tp.wx1) * wy0 + (sw * wx0 + se * tp.wx1) * tp.wy1;
+                cur.t[ch] = tp.t[ch];
+                const f2 Dx = ((ne - nw) * wy0 + (se - sw) * tp.wy1) * tp.sx;
+                const f2 Dy = ((sw - nw) * wx0 + (se - ne) * tp.wx1) * tp.sy;
+                rs[(ch * 4 + 0) * 64] = Dx.x; rs[(ch * 4 + 1) * 64] = Dx.y;
+                rs[(ch * 4 + 2) * 64] = Dy.x; rs[(ch * 4 + 3) * 64] = Dy.y;
             }
-            hsum_row(h, t, w);
         }
+        const int m_cur = m_in;
+        // ---------------- all loads of the step: row yy+1 (taps, target, argmin) and disparity of row yy+2
+        issue_row<1, false>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), nolog,
+                            park + (size_t)((i + 1) & 3) * PARK_VALS * 64);
+        m_in = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(am, (int)((unsigned)(min(max(yy + 1, 0), H - 1) * W + xr)), 0, 0);
+        disp_issue(dt, c, xr, reflect_clamp(yy + 2, H));
+
+        HSum h;
+        hsum_row(h, cur.t, cur.w);
         // ---------------- stage B: SSIM derivative coefficients at row p = yy-1
-        HAbc k;
         {
             const int py = yy - 1;
-            float gs = 0.f;
-            if (i >= 2 && py >= 0 && py < H && col_ok) {
-                bool sel = sel_all || (am[(size_t)py * W + x] == sel_idx);
-                gs = sel ? sel_val * wgt * g_ssim : 0.f;
-            }
-            float a[3], bb[3], cc[3];
+            f2 gs = splat(0.f);
+            if (i >= 2 && py >= 0 && py < H && col_ok)
+                gs = mk2((sel_all || m_new == sel0) ? sel_val * g_ssim : 0.f,
+                         (sel_all || m_new == sel1) ? sel_val * g_ssim : 0.f);
+            const float fu = (yy == 1) ? 2.f : 1.f;          // fold-back for q = yy   (p = q-1)
+            const float fd = (yy - 2 == H - 2) ? 2.f : 1.f;  // fold-back for q = yy-2 (p = q+1)
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                SsimTerms t = ssim_terms(ha, hb, h, ch);
-                float n = t.n1 * t.n2, dd = t.d1 * t.d2;
-                float id = 1.f / dd;
-                float v = (1.f - n * id) * 0.5f;
-                float G = (v >= 0.f && v <= 1.f) ? gs : 0.f;     // clamp(.,0,1) passes grad inclusively
-                float nid2 = n * id * id;
+                const SsimTerms t = ssim_terms(h_old, h_new, h, ch);
+                const f2 n = t.n1 * t.n2;
+                const f2 id = rcp2(t.d1 * t.d2);
+                const f2 v = (1.f - n * id) * 0.5f;
+                // clamp(.,0,1) passes the gradient inclusively
+                const f2 G = mk2((v.x >= 0.f && v.x <= 1.f) ? gs.x : 0.f, (v.y >= 0.f && v.y <= 1.f) ? gs.y : 0.f);
+                const f2 nid2 = n * id * id;
                 // d/d mu_x | d/d E[xx] | d/d E[xy]   (E[.] held fixed for mu_x)
-                a[ch] = G * (-t.mu_y * (t.n2 - t.n1) * id + nid2 * t.mu_x * (t.d2 - t.d1));
-                bb[ch] = G * 0.5f * nid2 * t.d1;
-                cc[ch] = -G * t.n1 * id;
-            }
-            // transposed 3x3 (with ReflectionPad fold-back) along x
-            const float fl = (x == 1) ? 2.f : 1.f, fr = (x == W - 2) ? 2.f : 1.f;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                k.a[ch] = fl * from_left(a[ch]) + a[ch] + fr * from_right(a[ch]);
-                k.b[ch] = fl * from_left(bb[ch]) + bb[ch] + fr * from_right(bb[ch]);
-                k.c[ch] = fl * from_left(cc[ch]) + cc[ch] + fr * from_right(cc[ch]);
+                const f2 a = G * (nid2 * t.mu_x * (t.d2 - t.d1) - t.mu_y * (t.n2 - t.n1) * id);
+                const f2 bb = G * 0.5f * nid2 * t.d1;
+                const f2 cc = -G * t.n1 * id;
+                // transposed 3x3 along x
+                const f2 ka = fl * left2(a) + a + fr * right2(a);
+                const f2 kb = fl * left2(bb) + bb + fr * right2(bb);
+                const f2 kc = fl * left2(cc) + cc + fr * right2(cc);
+                // ... and along y: row p feeds the pending rows q = p+1 (= yy), p (= yy-1), p-1 (= yy-2)
+                g_old.g[ch] += fd * (ka + 2.f * c_old.w[ch] * kb + c_old.t[ch] * kc);
+                g_new.g[ch] += ka + 2.f * c_new.w[ch] * kb + c_new.t[ch] * kc;
+                h_old.hx[ch] = fu * (ka + 2.f * cur.w[ch] * kb + cur.t[ch] * kc);   // parked in the dying ring slot
             }
         }
-        // ---------------- stage C: gradient at row q = yy-2
+        // ---------------- stage C: gradient at row q = yy-2 (its stage-A data comes back from the LDS ring)
         if (i >= 4) {
             const int qy = yy - 2;
-            float gd = 0.f;
             if (qy < H) {
-                const bool ok = q_lane;
-                const int xq = ok ? x : xr;
-                float d = disp_at(dp, hs, ws, ry, rx, H, W, xq, qy);
-                Proj pr;
-                project_pixel(pr, g, d, p.min_disp, p.disp_range, xq, qy, H, W, p.inv_Wm1, p.inv_Hm1, ac);
-                Bilin bl = bilin_setup(pr.ix, pr.iy, H, W);
-                const float wx0 = 1.f - bl.wx1, wy0 = 1.f - bl.wy1;
-                bool sel = sel_all || (am[(size_t)qy * W + xq] == sel_idx);
-                const float gl = (sel && ok) ? sel_val * wgt * g_l1 : 0.f;
-                const float fu = (qy == 1) ? 2.f : 1.f, fd = (qy == H - 2) ? 2.f : 1.f;
-                float gix = 0.f, giy = 0.f;
+                const int s2 = (slot3 == 0) ? 1 : ((slot3 == 1) ? 2 : 0);   // (i-2) % 3
+                const float* rq = ring + (size_t)s2 * RING_VALS * 64;
+                const float* pk = park + (size_t)((i - 2) & 3) * PARK_VALS * 64;
+                const f2 qu = mk2(pk[0 * 64], pk[1 * 64]), qv = mk2(pk[2 * 64], pk[3 * 64]);
+                const f2 qzi = mk2(pk[4 * 64], pk[5 * 64]);
+                const float qdepth = pk[6 * 64];
+                f2 gl = splat(0.f);
+                if (q_lane)
+                    gl = mk2((sel_all || m_old == sel0) ? sel_val * g_l1 : 0.f,
+                             (sel_all || m_old == sel1) ? sel_val * g_l1 : 0.f);
+                f2 du = splat(0.f), dv = splat(0.f);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    const float* pl = sp + ch * plane;
-                    float nw = pl[bl.o00], ne = pl[bl.o01], sw = pl[bl.o10], se = pl[bl.o11];
-                    float wv = (nw * wx0 + ne * bl.wx1) * wy0 + (sw * wx0 + se * bl.wx1) * bl.wy1;
-                    float tq = tg[ch * plane + (size_t)qy * W + xq];
-                    float SA = fu * ka.a[ch] + kb.a[ch] + fd * k.a[ch];
-                    float SB = fu * ka.b[ch] + kb.b[ch] + fd * k.b[ch];
-                    float SC = fu * ka.c[ch] + kb.c[ch] + fd * k.c[ch];
-                    float df = wv - tq;
-                    float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
-                    float gw = (SA + 2.f * wv * SB + tq * SC) * k9 + gl * sg;
-                    gix += gw * ((ne - nw) * wy0 + (se - sw) * bl.wy1);
-                    giy += gw * ((sw - nw) * wx0 + (se - ne) * bl.wx1);
+                    const f2 df = c_old.w[ch] - c_old.t[ch];
+                    const f2 sg = mk2((df.x > 0.f) ? 1.f : ((df.x < 0.f) ? -1.f : 0.f),
+                                      (df.y > 0.f) ? 1.f : ((df.y < 0.f) ? -1.f : 0.f));
+                    const f2 gw = g_old.g[ch] * k9 + gl * sg;
+                    du += gw * mk2(rq[(ch * 4 + 0) * 64], rq[(ch * 4 + 1) * 64]);
+                    dv += gw * mk2(rq[(ch * 4 + 2) * 64], rq[(ch * 4 + 3) * 64]);
                 }
-                if (!ok) { gix = 0.f; giy = 0.f; }
-                const float du = gix * pr.mx * 2.f * p.inv_Wm1;
-                const float dv = giy * pr.my * 2.f * p.inv_Hm1;
-                float dq[3];
-                dq[0] = du * pr.zi;
-                dq[1] = dv * pr.zi;
-                dq[2] = -(du * pr.u + dv * pr.v) * pr.zi;
-                float dcam[3] = {0.f, 0.f, 0.f};
+                if (!q_lane) { du = splat(0.f); dv = splat(0.f); }
+                f2 dq[3];
+                dq[0] = du * qzi;
+                dq[1] = dv * qzi;
+                dq[2] = -(du * qu + dv * qv) * qzi;
+                const float xf = (float)xr, yf = (float)qy;
+                float ray[3];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        dP[r * 4 + j] += dq[r] * pr.cam[j];
-                        dcam[j] += dq[r] * g.P[r * 4 + j];
-                    }
-                    dP[r * 4 + 3] += dq[r];
+                    float t = g.iK[r * 3 + 0] * xf;
+                    t = fmaf(g.iK[r * 3 + 1], yf, t);
+                    ray[r] = t + g.iK[r * 3 + 2];
                 }
-                float ddepth = dcam[0] * pr.ray[0] + dcam[1] * pr.ray[1] + dcam[2] * pr.ray[2];
-                gd = -ddepth * pr.depth * pr.depth * p.disp_range;
+                f2 dcam[3] = {splat(0.f), splat(0.f), splat(0.f)};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const f2 dqd = dq[r] * qdepth;
+                    accA[r] += dqd;
+                    accB[r] += dqd * yf;
+                    accC[r] += dq[r];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) dcam[j] += dq[r] * mk2(g.P[0][r * 4 + j], g.P[1][r * 4 + j]);
+                }
+                const f2 dd = dcam[0] * ray[0] + dcam[1] * ray[1] + dcam[2] * ray[2];
+                const float gd = -(dd.x + dd.y) * qdepth * qdepth * p.disp_range;
+                if (q_lane) gout[(unsigned)(qy * W + x)] = gd;
             }
-            my_lds[(i - 4) * 64 + lane] = gd;
         }
-        ha = hb; hb = h; ka = kb; kb = k;
+        // rotate: the slots of row yy-2 now take row yy
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            g_old.g[ch] = h_old.hx[ch];   // fresh accumulator of row yy (see stage B)
+            c_old.w[ch] = cur.w[ch];
+            c_old.t[ch] = cur.t[ch];
+        }
+        h_old = h;
+        m_old = m_cur;
+        slot3 = (slot3 == 2) ? 0 : slot3 + 1;
+    };
+
+    disp_issue(dt, c, xr, reflect_clamp(y0 - 2, H));
+    issue_row<1, false>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(y0 - 2, H), nolog, park + 0 * PARK_VALS * 64);
+    m_in = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(am, (int)((unsigned)(min(max(y0 - 2, 0), H - 1) * W + xr)), 0, 0);
+    disp_issue(dt, c, xr, reflect_clamp(y0 - 1, H));
+#pragma unroll 1
+    for (int i = 0; i < R_ROWS + 4; i += 2) {
+        body(i, hA, hB, cA, cB, gA, gB, mA, mB);
+        body(i + 1, hB, hA, cB, cA, gB, gA, mB, mA);
     }
     // pose-gradient partials: per wave, fixed shuffle tree
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    const float xf = (float)xr;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) dP[k] = wave_sum(dP[k]);
-    if (lane == 0) {
-        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    for (int f = 0; f < 2; ++f) {
         float* o = p.part_dP + ((((size_t)s * 2 + f) * p.B + b) * p.nblk_b_img + blk) * 12;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) o[k] = dP[k];
-    }
-    __syncthreads();
-    // d(upsampled disp) = frame(-1) + frame(+1) contributions
-    const float* g0 = lds + (size_t)(s * 2 + 0) * R_ROWS * 64;
-    const float* g1 = lds + (size_t)(s * 2 + 1) * R_ROWS * 64;
-    float* out = p.gdup[s] + (size_t)b * plane;
-    for (int r = f; r < R_ROWS; r += 2) {
-        const int qy = y0 + r;
-        if (qy < H && q_lane) out[(size_t)qy * W + x] = g0[r * 64 + lane] + g1[r * 64 + lane];
+        for (int r = 0; r < 3; ++r) {
+            const float A = f ? accA[r].y : accA[r].x, Bv = f ? accB[r].y : accB[r].x;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float v = wave_sum((g.iK[j * 3 + 0] * xf + g.iK[j * 3 + 2]) * A + g.iK[j * 3 + 1] * Bv);
+                if (lane == 0) o[r * 4 + j] = v;
+            }
+            const float v3 = wave_sum(f ? accC[r].y : accC[r].x);
+            if (lane == 0) o[r * 4 + 3] = v3;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// d_disp[s] = bilinear-upsample^T(gdup[s]) + smoothness gradient.   grid (chunks, B, ns), block 256
+// d_disp[s] = bilinear-upsample^T(gdup[s]) + smoothness gradient.   grid (chunks, B, ns), block 256.
+// The transposed upsample is a gather over the <= 2K+2 destination rows/cols that can reference a
+// low-res pixel; their 1-D weights are re-derived with the forward's own tap function.
 // ------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ float upsample_T(const float* gu, int y, int x, int h, int w, int H, int W, float ry,
+                                            float rx) {
+    constexpr int NT = 2 * K + 2;
+    const int ylo = K * (y - 1) + K / 2 - 1, xlo = K * (x - 1) + K / 2 - 1;
+    float wx[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int dx = xlo + j;
+        float v = 0.f;
+        if (dx >= 0 && dx < W) {
+            const LinTap t = lin_tap(dx, rx, w);
+            v = (t.i0 == x ? 1.f - t.w1 : 0.f) + (t.i1 == x ? t.w1 : 0.f);
+        }
+        wx[j] = v;
+    }
+    float acc = 0.f;
+#pragma unroll 2
+    for (int i = 0; i < NT; ++i) {
+        const int dy = ylo + i;
+        if (dy < 0 || dy >= H) continue;
+        const LinTap t = lin_tap(dy, ry, h);
+        const float wy = (t.i0 == y ? 1.f - t.w1 : 0.f) + (t.i1 == y ? t.w1 : 0.f);
+        if (wy == 0.f) continue;
+        const float* row = gu + (size_t)dy * W;
+        float r = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int dx = min(max(xlo + j, 0), W - 1);
+            r = fmaf(wx[j], row[dx], r);
+        }
+        acc = fmaf(wy, r, acc);
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void disp_grad_kernel(PhotoArgs p) {
     const int s = blockIdx.z, b = blockIdx.y;
     const int h = p.hs[s], w = p.ws[s];
@@ -658,29 +881,11 @@ __global__ __launch_bounds__(256) void disp_grad_kernel(PhotoArgs p) {
     const int H = p.H, W = p.W;
     const int y = i / w, x = i - y * w;
     const float* gu = p.gdup[s] + (size_t)b * H * W;
-    float acc = 0.f;
-    if (h == H && w == W) {
-        acc = gu[i];
-    } else {
-        const float ry = p.ry[s], rx = p.rx[s];
-        // destination rows/cols whose taps can touch (y,x): invert src = r*(dst+.5)-.5 with slack
-        int ylo = max((int)floorf(((float)y - 1.f + 0.5f) / ry - 0.5f) - 1, 0);
-        int yhi = min((int)ceilf(((float)y + 1.f + 0.5f) / ry - 0.5f) + 1, H - 1);
-        int xlo = max((int)floorf(((float)x - 1.f + 0.5f) / rx - 0.5f) - 1, 0);
-        int xhi = min((int)ceilf(((float)x + 1.f + 0.5f) / rx - 0.5f) + 1, W - 1);
-        for (int dy = ylo; dy <= yhi; ++dy) {
-            LinTap ty = lin_tap(dy, ry, h);
-            float wy = (ty.i0 == y ? 1.f - ty.w1 : 0.f) + (ty.i1 == y ? ty.w1 : 0.f);
-            if (wy == 0.f) continue;
-            float row = 0.f;
-            for (int dx = xlo; dx <= xhi; ++dx) {
-                LinTap tx = lin_tap(dx, rx, w);
-                float wx = (tx.i0 == x ? 1.f - tx.w1 : 0.f) + (tx.i1 == x ? tx.w1 : 0.f);
-                row += wx * gu[(size_t)dy * W + dx];
-            }
-            acc += wy * row;
-        }
-    }
+    float acc;
+    if (s == 0) acc = gu[i];
+    else if (s == 1) acc = upsample_T<2>(gu, y, x, h, w, H, W, p.ry[s], p.rx[s]);
+    else if (s == 2) acc = upsample_T<4>(gu, y, x, h, w, H, W, p.ry[s], p.rx[s]);
+    else acc = upsample_T<8>(gu, y, x, h, w, H, W, p.ry[s], p.rx[s]);
     // smoothness:  L = A*(cx*Sx + cy*Sy),  A = 1/(mean+eps)
     const float gsm = (p.g_losses[s] + p.g_losses[p.ns] / (float)p.ns) * p.smoothness / (float)(1 << s);
     const float* st = p.stats + ((size_t)s * p.B + b) * 3;
@@ -700,7 +905,7 @@ __global__ __launch_bounds__(256) void disp_grad_kernel(PhotoArgs p) {
     if (x > 0) gx -= sgn(d[i - 1] - dv) * ex(i - 1, i);
     if (y < h - 1) gy += sgn(dv - d[i + w]) * ex(i, i + w);
     if (y > 0) gy -= sgn(d[i - w] - dv) * ex(i - w, i);
-    float gs = A * (cx * gx + cy * gy) - A * A * (cx * st[1] + cy * st[2]) / (float)n;
+    const float gs = A * (cx * gx + cy * gy) - A * A * (cx * st[1] + cy * st[2]) / (float)n;
     p.d_disp[s][(size_t)b * n + i] = acc + gsm * gs;
 }
 
@@ -753,7 +958,7 @@ static Carve carve(const dc_photo_desc* d) {
     c.nchunk = ceil_div(d->H * d->W, SM_CHUNK);
     size_t off = 0;
     c.idl = off; off += align256(N * 2 * 4);
-    c.part_photo = off; off += align256((size_t)d->num_scales * c.nblk_f * 2 * 4);
+    c.part_photo = off; off += align256((size_t)d->num_scales * c.nblk_f * 4);
     c.part_smooth = off; off += align256((size_t)d->num_scales * d->B * c.nchunk * 3 * 4);
     c.stats = off; off += align256((size_t)d->num_scales * d->B * 3 * 4);
     for (int s = 0; s < DC_MAX_SCALES; ++s) {
@@ -790,6 +995,8 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
         a.disp[s] = d->disp[s]; a.color_s[s] = d->color_s[s];
         a.hs[s] = d->H >> s; a.ws[s] = d->W >> s;
         if (a.hs[s] < 2 || a.ws[s] < 2) return DC_EINVAL;
+        // exact 2^s pyramid (the reference asserts H, W multiples of 32, trainer.py:37-38)
+        if ((a.hs[s] << s) != d->H || (a.ws[s] << s) != d->W) return DC_EINVAL;
         a.ry[s] = (float)a.hs[s] / (float)d->H;
         a.rx[s] = (float)a.ws[s] / (float)d->W;
         a.noise[s] = d->noise[s]; a.argmin[s] = d->argmin[s];
@@ -832,16 +1039,20 @@ extern "C" int dc_photo_fwd(const dc_photo_desc* d, void* stream) {
     int rc = fill_args(d, a, c, false);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)2 * a.ns * R_ROWS * 64 * sizeof(float);
     if (!(a.flags & DC_OPT_NO_AUTOMASK)) {
-        hipLaunchKernelGGL(identity_kernel, dim3(c.strips_f, c.rowblocks, a.B), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(identity_kernel, dim3(c.strips_f, ceil_div(a.H, ID_ROWS), a.B), dim3(64), 0, st, a);
         DC_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3(c.nchunk, a.B, a.ns), dim3(256), 0, st, a);
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(photo_fwd_kernel, dim3(c.strips_f, c.rowblocks, a.B), dim3(128 * a.ns), lds, st, a);
+    bool logs = false;
+    for (int s = 0; s < a.ns; ++s) logs = logs || a.depth[s] || a.sample[s][0] || a.sample[s][1] || a.color[s][0] || a.color[s][1];
+    if (logs)
+        hipLaunchKernelGGL(photo_fwd_kernel<true>, dim3(c.strips_f, c.rowblocks, a.B), dim3(64 * a.ns), 0, st, a);
+    else
+        hipLaunchKernelGGL(photo_fwd_kernel<false>, dim3(c.strips_f, c.rowblocks, a.B), dim3(64 * a.ns), 0, st, a);
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, a);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -852,8 +1063,8 @@ extern "C" int dc_photo_bwd(const dc_photo_desc* d, void* stream) {
     int rc = fill_args(d, a, c, true);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)2 * a.ns * R_ROWS * 64 * sizeof(float);
-    hipLaunchKernelGGL(photo_bwd_kernel, dim3(c.strips_b, c.rowblocks, a.B), dim3(128 * a.ns), lds, st, a);
+    const size_t lds = (size_t)a.ns * BWD_LDS_PER_WAVE * sizeof(float);
+    hipLaunchKernelGGL(photo_bwd_kernel, dim3(c.strips_b, c.rowblocks, a.B), dim3(64 * a.ns), lds, st, a);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(disp_grad_kernel, dim3(ceil_div(a.H * a.W, 256), a.B, a.ns), dim3(256), 0, st, a);
     DC_CHECK_LAUNCH();
