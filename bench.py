@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/s of the self-supervised depth step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = reference trainer.py:233-237 on one synthetic KITTI-shaped batch: process_batch
+(resnet18 depth encoder + decoder on frame 0, pose encoder + decoder on the pairs (-1,0),(0,+1),
+4-scale fused warp + SSIM/L1 + automask + smoothness loss) -> backward -> (RCCL all-reduce) -> Adam.
+Workload = BASELINE.json configs[1]: resnet18, 192x640, per-GPU batch 12, fp32.  Weak scaling.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- the fused photometric backward kernel: SURVEY 8d algorithmic bytes per launch /
+                  its mean duration from hipEvents recorded on the launch stream inside the timed region;
+  cpu_baseline -- the CPU oracle's full training step timed on this host's cores (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "self-supervised-depth-estimation_amd"))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
+
+
+def host_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, os.cpu_count() or n, 64))
+
+
+def cpu_baseline(opt, trainer, seconds_budget=25.0):
+    """Time the CPU oracle (oracle/train_step.py, "port") on a BOUNDED sample of the same workload:
+    a B=1 paging step, a timed B=2 probe step, then one timed step at the largest batch <= opt.batch_size
+    that the probe predicts fits in ~seconds_budget.  images/s = sample batch / step time."""
+    from oracle import ref_cpu as R
+    from oracle.train_step import CpuTrainer
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    state = {k: {n: t.detach().cpu() for n, t in m.state_dict().items()} for k, m in trainer.models.items()}
+    ct = CpuTrainer(state, R.Opt(height=opt.height, width=opt.width), opt.num_layers, opt.learning_rate)
+    H, W = opt.height, opt.width
+
+    def step(b, seed):
+        inputs = R.synthetic_inputs(b, H, W, seed=seed)
+        noise = R.tiebreak_noise(b, H, W)
+        t0 = time.perf_counter()
+        ct.train_step(inputs, noise)
+        return time.perf_counter() - t0
+
+    step(1, 2)
+    t2 = step(2, 1)
+    print("cpu_baseline: %d threads, B=2 probe step %.2f s" % (cores, t2), file=sys.stderr, flush=True)
+    bs = int(max(1, min(opt.batch_size, seconds_budget / (t2 / 2.0))))
+    t = step(bs, 0) if bs != 2 else t2
+    print("cpu_baseline: B=%d step %.2f s" % (bs, t), file=sys.stderr, flush=True)
+    return {"value": round(bs / t, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "one full training step (fwd+bwd+Adam) of the CPU oracle at B=%d (of %d), %dx%d, resnet%d, "
+                      "fp32, torch %d threads, after a B=1 and a B=2 step" % (bs, opt.batch_size, H, W,
+                                                                             opt.num_layers, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--num-layers", type=int, default=18)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-noise", action="store_true", help="reference-style CPU randn tie-break noise + H2D copy")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+
+    from depthcore import ops
+    from depthcore.synthetic import synthetic_batch
+    import trainer as T
+
+    opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
+                            cpu_tiebreak_noise=args.cpu_noise)
+    tr = T.Trainer(opt, device=device, rank=rank, world_size=world)
+    tr.set_train()
+    inputs = synthetic_batch(args.batch, args.height, args.width, device, seed=100 + rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss0 = None
+    for _ in range(args.warmup):
+        _, losses = tr.train_step(inputs)
+        loss0 = losses["loss"] if loss0 is None else loss0
+    ops.profile_enable(args.steps + 8)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, losses = tr.train_step(inputs)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_collect()
+    ops.profile_enable(0)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_last = float(losses["loss"].detach())
+    if not (loss_last == loss_last):
+        raise SystemExit("loss is NaN")
+
+    if rank == 0:
+        N = args.batch * args.height * args.width
+        bytes_fwd = sum(36.0 * N + 16.0 * (N >> (2 * s)) for s in range(4))
+        bytes_bwd = sum(36.0 * N + 20.0 * (N >> (2 * s)) for s in range(4))
+        bwd_ms = prof["bwd_ms"] / max(prof["bwd_launches"], 1)
+        fwd_ms = prof["fwd_ms"] / max(prof["fwd_launches"], 1)
+        ach = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+        out = {
+            "metric": "training images/sec at 192x640 bs12 (resnet18 depth+pose, 4-scale photometric+smoothness)",
+            "value": round(world * args.batch * args.steps / dt, 3),
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: resnet18 depth+pose, %dx%d, per-GPU batch %d, 4 scales, "
+                                   "frames {0,-1,+1}, automasking, Adam lr 1e-4; random-init weights"
+                                   % (args.height, args.width, args.batch),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "tiebreak_noise": "cpu-randn+h2d" if args.cpu_noise else "on-device counter RNG"},
+            "roofline": {"kernel": "dc::photo_bwd_kernel (fused warp+SSIM+L1+automask backward, 4 scales x 2 frames)",
+                         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_bwd, "avg_kernel_ms": round(bwd_ms, 4),
+                         "launches": prof["bwd_launches"],
+                         "fwd_kernel": {"kernel": "dc::photo_fwd_kernel", "algorithmic_bytes_per_launch": bytes_fwd,
+                                        "avg_kernel_ms": round(fwd_ms, 4),
+                                        "achieved": round(bytes_fwd / (fwd_ms * 1e-3) / 1e9, 1) if fwd_ms > 0 else 0.0}},
+            "loss_first": round(float(loss0.detach()), 6), "loss_last": round(loss_last, 6),
+            "grad_bytes_allreduced_per_step": tr.buckets.nbytes if world > 1 else 0,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(opt, tr)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,23 +153,16 @@ typedef struct dc_photo_desc {
 size_t dc_photo_workspace(const dc_photo_desc* d);
 int dc_photo_fwd(const dc_photo_desc* d, void* stream);
 int dc_photo_bwd(const dc_photo_desc* d, void* stream);
-/* Names and per-launch algorithmic bytes of the two dominant kernels, for bench.py. */
+/* Per-launch algorithmic bytes of the fused forward / backward kernel, for bench.py. */
 double dc_photo_algorithmic_bytes(const dc_photo_desc* d, int backward);
 
-/* ------------------------------------------------------------------ a2/a3 decoder blocks */
-/* layers.py:106-136 + 196-199 and networks/depth_decoder.py:50-66:
- *   y = act( conv3x3( reflect_pad1( cat( up2?(x0), x1 ) ) ) + bias )
- * x0 (B,C0,h0,w0) optionally nearest-upsampled x2 on the fly (up0=1), x1 (B,C1,H,W) nullable skip;
- * weight (Co,C0+C1,3,3); act: 0 none, 1 ELU, 2 sigmoid.  Output (B,Co,H,W). */
-int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
-                   const float* bias, float* y, int B, int Co, int H, int W, int act, void* stream);
-/* Backward: gy (B,Co,H,W) is the gradient wrt the *activated* output y (the activation derivative is
- * applied from y, ELU/sigmoid being invertible from their outputs).  Produces dx0 (pre-upsample shape,
- * 2x2-summed when up0), dx1, dweight, dbias (each nullable).  ws: dc_conv3x3_bwd_workspace bytes. */
-size_t dc_conv3x3_bwd_workspace(int C0, int C1, int B, int Co, int H, int W);
-int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
-                   const float* y, const float* gy, float* dx0, float* dx1, float* dweight, float* dbias,
-                   void* ws, int B, int Co, int H, int W, int act, void* stream);
+/* Measurement hook (bench.py `roofline`): when enabled, dc_photo_fwd / dc_photo_bwd bracket their
+ * dominant kernel (photo_fwd_kernel / photo_bwd_kernel) with hipEvents on the launch stream.
+ * dc_profile_enable(n) allocates n event pairs per direction (0 disables and frees);
+ * dc_profile_collect synchronises on the recorded events and returns summed kernel milliseconds and
+ * launch counts since the last enable/collect. */
+int dc_profile_enable(int max_launches);
+int dc_profile_collect(double* fwd_ms, int* fwd_launches, double* bwd_ms, int* bwd_launches);
 
 #ifdef __cplusplus
 }

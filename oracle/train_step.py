@@ -1,0 +1,47 @@
+"""One full CPU training step of the oracle (TEST / BASELINE INFRASTRUCTURE, see oracle/__init__.py).
+
+process_batch (depth encoder on frame 0, depth decoder, pose encoder+decoder on the pairs (-1,0),(0,+1),
+8 warps, 16 reprojection terms, 4 smoothness terms) -> backward -> Adam, i.e. reference
+trainer.py:233-237 + 256-622 in the vanilla Monodepth2 wiring, on functional networks
+over plain state dicts.  Used as the checker of the full-step parity test and as bench.py's
+`cpu_baseline` ("port").
+"""
+import torch
+
+from . import ref_cpu as R
+from .resnet_ref import resnet_encoder_forward
+
+
+class CpuTrainer:
+    def __init__(self, state, opt=None, num_layers=18, lr=1e-4):
+        """state: {"encoder": sd, "depth": sd, "pose_encoder": sd, "pose": sd} of CPU fp32 tensors."""
+        self.opt = opt or R.Opt()
+        self.num_layers = num_layers
+        self.state = {k: {n: t.detach().clone() for n, t in sd.items()} for k, sd in state.items()}
+        self.params = []
+        for k, sd in self.state.items():
+            for n, t in sd.items():
+                if t.is_floating_point() and "running_" not in n:
+                    t.requires_grad_()
+                    self.params.append(t)
+        self.optim = torch.optim.Adam(self.params, lr)
+        self.num_ch_enc = [64, 64, 128, 256, 512] if num_layers <= 34 else [64, 256, 512, 1024, 2048]
+
+    def process_batch(self, inputs, noise):
+        o = self.opt
+        feats = resnet_encoder_forward(self.state["encoder"], inputs[("color_aug", 0, 0)], self.num_layers)
+        outputs = R.depth_decoder_forward(self.state["depth"], feats, self.num_ch_enc, tuple(o.scales))
+        outputs.update(R.predict_poses(
+            inputs,
+            lambda x: resnet_encoder_forward(self.state["pose_encoder"], x, self.num_layers),
+            lambda f: R.pose_decoder_forward(self.state["pose"], f, 2)))
+        R.generate_images_pred(inputs, outputs, o)
+        losses = R.compute_losses(inputs, outputs, o, noise)
+        return outputs, losses
+
+    def train_step(self, inputs, noise):
+        outputs, losses = self.process_batch(inputs, noise)
+        self.optim.zero_grad()
+        losses["loss"].backward()
+        self.optim.step()
+        return outputs, losses

@@ -12,6 +12,8 @@
 //   * backward recomputes the warp (halo 2) instead of saving it, routes the min() gradient by the
 //     1-byte argmin map the forward wrote, and reduces the pose gradient per wave -> per block ->
 //     fixed-order final sum (no float atomics, bitwise reproducible).
+#include <vector>
+
 #include "dc_common.h"
 
 namespace dc {
@@ -1028,6 +1030,66 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
 
 using namespace dc;
 
+// ---- measurement hook: hipEvent pairs around the dominant kernel of each direction -----------------
+namespace {
+struct ProfDir {
+    std::vector<hipEvent_t> e0, e1;
+    int used = 0;
+};
+ProfDir g_prof[2];
+int g_prof_cap = 0;
+
+void prof_free() {
+    for (auto& d : g_prof) {
+        for (auto e : d.e0) (void)hipEventDestroy(e);
+        for (auto e : d.e1) (void)hipEventDestroy(e);
+        d.e0.clear(); d.e1.clear(); d.used = 0;
+    }
+    g_prof_cap = 0;
+}
+inline hipEvent_t prof_begin(int dir, hipStream_t st) {
+    ProfDir& d = g_prof[dir];
+    if (d.used >= g_prof_cap) return nullptr;
+    (void)hipEventRecord(d.e0[d.used], st);
+    return d.e1[d.used++];
+}
+inline void prof_end(hipEvent_t e, hipStream_t st) {
+    if (e) (void)hipEventRecord(e, st);
+}
+}  // namespace
+
+extern "C" int dc_profile_enable(int max_launches) {
+    prof_free();
+    if (max_launches <= 0) return DC_OK;
+    for (auto& d : g_prof) {
+        d.e0.resize(max_launches); d.e1.resize(max_launches);
+        for (int i = 0; i < max_launches; ++i) {
+            if (hipEventCreate(&d.e0[i]) != hipSuccess || hipEventCreate(&d.e1[i]) != hipSuccess) return DC_ELAUNCH;
+        }
+    }
+    g_prof_cap = max_launches;
+    return DC_OK;
+}
+
+extern "C" int dc_profile_collect(double* fwd_ms, int* fwd_launches, double* bwd_ms, int* bwd_launches) {
+    double* ms[2] = {fwd_ms, bwd_ms};
+    int* cnt[2] = {fwd_launches, bwd_launches};
+    for (int dir = 0; dir < 2; ++dir) {
+        ProfDir& d = g_prof[dir];
+        double tot = 0.0;
+        for (int i = 0; i < d.used; ++i) {
+            float t = 0.f;
+            if (hipEventSynchronize(d.e1[i]) != hipSuccess || hipEventElapsedTime(&t, d.e0[i], d.e1[i]) != hipSuccess)
+                return DC_ELAUNCH;
+            tot += t;
+        }
+        if (ms[dir]) *ms[dir] = tot;
+        if (cnt[dir]) *cnt[dir] = d.used;
+        d.used = 0;
+    }
+    return DC_OK;
+}
+
 extern "C" size_t dc_photo_workspace(const dc_photo_desc* d) {
     if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->num_scales < 1 || d->num_scales > DC_MAX_SCALES) return 0;
     return carve(d).total;
@@ -1047,10 +1109,12 @@ extern "C" int dc_photo_fwd(const dc_photo_desc* d, void* stream) {
     DC_CHECK_LAUNCH();
     bool logs = false;
     for (int s = 0; s < a.ns; ++s) logs = logs || a.depth[s] || a.sample[s][0] || a.sample[s][1] || a.color[s][0] || a.color[s][1];
+    hipEvent_t pe = prof_begin(0, st);
     if (logs)
         hipLaunchKernelGGL(photo_fwd_kernel<true>, dim3(c.strips_f, c.rowblocks, a.B), dim3(64 * a.ns), 0, st, a);
     else
         hipLaunchKernelGGL(photo_fwd_kernel<false>, dim3(c.strips_f, c.rowblocks, a.B), dim3(64 * a.ns), 0, st, a);
+    prof_end(pe, st);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, a);
     DC_CHECK_LAUNCH();
@@ -1064,7 +1128,9 @@ extern "C" int dc_photo_bwd(const dc_photo_desc* d, void* stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)a.ns * BWD_LDS_PER_WAVE * sizeof(float);
+    hipEvent_t pe = prof_begin(1, st);
     hipLaunchKernelGGL(photo_bwd_kernel, dim3(c.strips_b, c.rowblocks, a.B), dim3(64 * a.ns), lds, st, a);
+    prof_end(pe, st);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(disp_grad_kernel, dim3(ceil_div(a.H * a.W, 256), a.B, a.ns), dim3(256), 0, st, a);
     DC_CHECK_LAUNCH();

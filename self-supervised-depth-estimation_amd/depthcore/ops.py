@@ -147,3 +147,268 @@ def photometric_loss(cfg, T_m1, T_p1, disps):
 def photo_algorithmic_bytes(cfg, T0, T1, disps, backward):
     d = _fill_desc(cfg, _c(T0.detach()), _c(T1.detach()), [_c(x.detach()) for x in disps])
     return _lib.lib().dc_photo_algorithmic_bytes(ctypes.byref(d), int(backward))
+
+
+# ----------------------------------------------------------------------------------------------
+# a5  transformation_from_parameters                                   (reference layers.py:28-103)
+# ----------------------------------------------------------------------------------------------
+class _PoseMatrix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert):
+        L = _lib.lib()
+        aa = _c(axisangle.detach().reshape(-1, 3))
+        tr = _c(translation.detach().reshape(-1, 3))
+        B = aa.shape[0]
+        M = torch.empty(B, 4, 4, dtype=torch.float32, device=aa.device)
+        check(L.dc_pose_matrix_fwd(ptr(aa), ptr(tr), int(bool(invert)), ptr(M), B, stream()), "dc_pose_matrix_fwd")
+        ctx.save_for_backward(aa, tr)
+        ctx.invert = int(bool(invert))
+        ctx.shapes = (axisangle.shape, translation.shape)
+        return M
+
+    @staticmethod
+    def backward(ctx, gM):
+        L = _lib.lib()
+        aa, tr = ctx.saved_tensors
+        B = aa.shape[0]
+        daa, dtr = torch.empty_like(aa), torch.empty_like(tr)
+        check(L.dc_pose_matrix_bwd(ptr(aa), ptr(tr), ctx.invert, ptr(_c(gM)), ptr(daa), ptr(dtr), B, stream()),
+              "dc_pose_matrix_bwd")
+        return daa.reshape(ctx.shapes[0]), dtr.reshape(ctx.shapes[1]), None
+
+
+def pose_matrix(axisangle, translation, invert=False):
+    return _PoseMatrix.apply(axisangle, translation, invert)
+
+
+# ----------------------------------------------------------------------------------------------
+# a6  disp_to_depth                                                      (reference layers.py:16-25)
+# ----------------------------------------------------------------------------------------------
+class _DispToDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, min_depth, max_depth):
+        L = _lib.lib()
+        d = _c(disp.detach())
+        scaled, depth = torch.empty_like(d), torch.empty_like(d)
+        check(L.dc_disp_to_depth_fwd(ptr(d), ptr(scaled), ptr(depth), d.numel(), float(min_depth), float(max_depth),
+                                     stream()), "dc_disp_to_depth_fwd")
+        ctx.save_for_backward(d)
+        ctx.lim = (float(min_depth), float(max_depth))
+        return scaled, depth
+
+    @staticmethod
+    def backward(ctx, gs, gd):
+        L = _lib.lib()
+        (d,) = ctx.saved_tensors
+        out = torch.empty_like(d)
+        check(L.dc_disp_to_depth_bwd(ptr(d), ptr(_c(gs)) if gs is not None else None,
+                                     ptr(_c(gd)) if gd is not None else None, ptr(out), d.numel(), ctx.lim[0],
+                                     ctx.lim[1], stream()), "dc_disp_to_depth_bwd")
+        return out, None, None
+
+
+def disp_to_depth(disp, min_depth, max_depth):
+    return _DispToDepth.apply(disp, min_depth, max_depth)
+
+
+# ----------------------------------------------------------------------------------------------
+# a7  BackprojectDepth                                                  (reference layers.py:139-168)
+# ----------------------------------------------------------------------------------------------
+def pix_coords(B, H, W, device):
+    L = _lib.lib()
+    pc = torch.empty(B, 3, H * W, dtype=torch.float32, device=device)
+    check(L.dc_pix_coords(ptr(pc), B, H, W, stream()), "dc_pix_coords")
+    return pc
+
+
+class _Backproject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, inv_K):
+        L = _lib.lib()
+        d, ik = _c(depth.detach()), _c(inv_K.detach())
+        B, _, H, W = d.shape
+        cam = torch.empty(B, 4, H * W, dtype=torch.float32, device=d.device)
+        check(L.dc_backproject_fwd(ptr(d), ptr(ik), ptr(cam), B, H, W, stream()), "dc_backproject_fwd")
+        ctx.save_for_backward(ik)
+        ctx.shape = d.shape
+        return cam
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        (ik,) = ctx.saved_tensors
+        B, _, H, W = ctx.shape
+        dd = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        check(L.dc_backproject_bwd(ptr(_c(g)), ptr(ik), ptr(dd), B, H, W, stream()), "dc_backproject_bwd")
+        return dd, None
+
+
+def backproject(depth, inv_K):
+    return _Backproject.apply(depth, inv_K)
+
+
+# ----------------------------------------------------------------------------------------------
+# a8  Project3D                                                         (reference layers.py:171-193)
+# ----------------------------------------------------------------------------------------------
+class _Project3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, K, T, H, W, eps):
+        L = _lib.lib()
+        p, k, t = _c(points.detach()), _c(K.detach()), _c(T.detach())
+        B = p.shape[0]
+        grid = torch.empty(B, H, W, 2, dtype=torch.float32, device=p.device)
+        check(L.dc_project3d_fwd(ptr(p), ptr(k), ptr(t), ptr(grid), B, H, W, float(eps), stream()), "dc_project3d_fwd")
+        ctx.save_for_backward(p, k, t)
+        ctx.dims = (B, H, W, float(eps))
+        return grid
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        p, k, t = ctx.saved_tensors
+        B, H, W, eps = ctx.dims
+        dp, dT = torch.empty_like(p), torch.empty_like(t)
+        ws = torch.empty(L.dc_project3d_bwd_workspace(B, H, W), dtype=torch.uint8, device=p.device)
+        check(L.dc_project3d_bwd(ptr(p), ptr(k), ptr(t), ptr(_c(g)), ptr(dp), ptr(dT), ws.data_ptr(), B, H, W, eps,
+                                 stream()), "dc_project3d_bwd")
+        return dp, None, dT, None, None, None
+
+
+def project3d(points, K, T, H, W, eps=1e-7):
+    return _Project3D.apply(points, K, T, H, W, eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# a9  F.grid_sample(bilinear, border)                                      (reference trainer.py:508)
+# ----------------------------------------------------------------------------------------------
+class _GridSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, grid, align_corners):
+        L = _lib.lib()
+        im, g = _c(img.detach()), _c(grid.detach())
+        B, C, H, W = im.shape
+        Ho, Wo = g.shape[1], g.shape[2]
+        out = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=im.device)
+        check(L.dc_grid_sample_fwd(ptr(im), ptr(g), ptr(out), B, C, H, W, Ho, Wo, int(bool(align_corners)), stream()),
+              "dc_grid_sample_fwd")
+        ctx.save_for_backward(im, g)
+        ctx.ac = int(bool(align_corners))
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        L = _lib.lib()
+        im, g = ctx.saved_tensors
+        B, C, H, W = im.shape
+        Ho, Wo = g.shape[1], g.shape[2]
+        dg = torch.empty_like(g)
+        check(L.dc_grid_sample_bwd(ptr(im), ptr(g), ptr(_c(go)), ptr(dg), B, C, H, W, Ho, Wo, ctx.ac, stream()),
+              "dc_grid_sample_bwd")
+        return None, dg, None       # images are leaves without grad on this path
+
+
+def grid_sample_border(img, grid, align_corners=False):
+    return _GridSample.apply(img, grid, align_corners)
+
+
+# ----------------------------------------------------------------------------------------------
+# a10 F.interpolate(bilinear, align_corners=False)                         (reference trainer.py:474)
+# ----------------------------------------------------------------------------------------------
+class _UpsampleBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        L = _lib.lib()
+        xx = _c(x.detach())
+        B, C, h, w = xx.shape
+        out = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=xx.device)
+        check(L.dc_upsample_bilinear_fwd(ptr(xx), ptr(out), B * C, h, w, Ho, Wo, stream()), "dc_upsample_bilinear_fwd")
+        ctx.dims = (B, C, h, w, Ho, Wo)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        L = _lib.lib()
+        B, C, h, w, Ho, Wo = ctx.dims
+        dx = torch.empty(B, C, h, w, dtype=torch.float32, device=go.device)
+        check(L.dc_upsample_bilinear_bwd(ptr(_c(go)), ptr(dx), B * C, h, w, Ho, Wo, stream()), "dc_upsample_bilinear_bwd")
+        return dx, None, None
+
+
+def upsample_bilinear(x, Ho, Wo):
+    return _UpsampleBilinear.apply(x, Ho, Wo)
+
+
+# ----------------------------------------------------------------------------------------------
+# a11 SSIM                                                              (reference layers.py:218-248)
+# ----------------------------------------------------------------------------------------------
+class _SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        L = _lib.lib()
+        xx, yy = _c(x.detach()), _c(y.detach())
+        B, C, H, W = xx.shape
+        out = torch.empty_like(xx)
+        check(L.dc_ssim_fwd(ptr(xx), ptr(yy), ptr(out), B * C, H, W, stream()), "dc_ssim_fwd")
+        ctx.save_for_backward(xx, yy)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        L = _lib.lib()
+        xx, yy = ctx.saved_tensors
+        B, C, H, W = xx.shape
+        dx = torch.empty_like(xx) if ctx.needs_input_grad[0] else None
+        dy = torch.empty_like(yy) if ctx.needs_input_grad[1] else None
+        check(L.dc_ssim_bwd(ptr(xx), ptr(yy), ptr(_c(go)), ptr(dx), ptr(dy), B * C, H, W, stream()), "dc_ssim_bwd")
+        return dx, dy
+
+
+def ssim(x, y):
+    return _SSIM.apply(x, y)
+
+
+# ----------------------------------------------------------------------------------------------
+# a13 get_smooth_loss                                                   (reference layers.py:202-215)
+# ----------------------------------------------------------------------------------------------
+class _Smooth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, img):
+        L = _lib.lib()
+        d, im = _c(disp.detach()), _c(img.detach())
+        B, _, h, w = d.shape
+        C = im.shape[1]
+        out = torch.empty(1, dtype=torch.float32, device=d.device)
+        ws = torch.empty(L.dc_smooth_workspace(B, h, w), dtype=torch.uint8, device=d.device)
+        check(L.dc_smooth_fwd(ptr(d), ptr(im), ptr(out), ws.data_ptr(), B, C, h, w, stream()), "dc_smooth_fwd")
+        ctx.save_for_backward(d, im)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        d, im = ctx.saved_tensors
+        B, _, h, w = d.shape
+        dd = torch.empty_like(d)
+        check(L.dc_smooth_bwd(ptr(d), ptr(im), ptr(_c(g.reshape(1))), ptr(dd), B, im.shape[1], h, w, stream()),
+              "dc_smooth_bwd")
+        return dd, None
+
+
+def smooth_loss(disp, img):
+    return _Smooth.apply(disp, img)
+
+
+# ----------------------------------------------------------------------------------------------
+# measurement hook (bench.py): hipEvent timing of the dominant photometric kernels
+# ----------------------------------------------------------------------------------------------
+def profile_enable(max_launches):
+    check(_lib.lib().dc_profile_enable(int(max_launches)), "dc_profile_enable")
+
+
+def profile_collect():
+    """-> dict(fwd_ms, fwd_launches, bwd_ms, bwd_launches); synchronises on the recorded events."""
+    fm, bm = ctypes.c_double(0), ctypes.c_double(0)
+    fn, bn = ctypes.c_int(0), ctypes.c_int(0)
+    check(_lib.lib().dc_profile_collect(ctypes.byref(fm), ctypes.byref(fn), ctypes.byref(bm), ctypes.byref(bn)),
+          "dc_profile_collect")
+    return {"fwd_ms": fm.value, "fwd_launches": fn.value, "bwd_ms": bm.value, "bwd_launches": bn.value}

@@ -1,0 +1,4 @@
+"""Drop-in for the reference's `networks` package on the hot path (networks/__init__.py:1-3)."""
+from .resnet_encoder import ResnetEncoder
+from .depth_decoder import DepthDecoder
+from .pose_decoder import PoseDecoder
