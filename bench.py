@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--num-layers", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-noise", action="store_true", help="reference-style CPU randn tie-break noise + H2D copy")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
+    ap.add_argument("--channels-last", action="store_true", help="run the ResNet trunks in NHWC")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,7 +103,11 @@ def main():
 
     opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
                             cpu_tiebreak_noise=args.cpu_noise)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     tr = T.Trainer(opt, device=device, rank=rank, world_size=world)
+    if args.channels_last:
+        for k in ("encoder", "pose_encoder"):
+            tr.models[k].to(memory_format=torch.channels_last)
     tr.set_train()
     inputs = synthetic_batch(args.batch, args.height, args.width, device, seed=100 + rank)
 

@@ -18,7 +18,13 @@
 
 namespace dc {
 
-constexpr int R_ROWS = 16;            // image rows produced per wave
+#ifndef DC_R_ROWS
+#define DC_R_ROWS 16
+#endif
+#ifndef FWD_WAVES
+#define FWD_WAVES 3
+#endif
+constexpr int R_ROWS = DC_R_ROWS;   // image rows produced per wave (even)
 constexpr float kC1 = 0.01f * 0.01f;  // layers.py:231-232
 constexpr float kC2 = 0.03f * 0.03f;
 constexpr float k9 = 1.f / 9.f;
@@ -168,23 +174,14 @@ __device__ __forceinline__ float disp_value(const DispTaps& t, const Ctx& c) {
 // ---- one pixel, both source frames: disp -> depth -> BackprojectDepth -> Project3D -> grid_sample
 // coordinates (layers.py:21-24,163-192; trainer.py:508-511), with the 3 + 12 + 12 loads left in flight.
 struct Taps {
-    float t[3];       // target
-    f2 tap[3][4];     // [channel][nw, ne, sw, se] x (frame -1, frame +1)
-    f2 wx1, wy1;      // bilinear weights
-    f2 sx, sy;        // backward only: d(ix)/du, d(iy)/dv incl. the border-clamp zero
+    float t[3];          // target
+    float tap[2][3][4];  // [frame][channel][nw, ne, sw, se]
+    float wx1[2], wy1[2];
+    float sx[2], sy[2];  // backward only: d(ix)/du, d(iy)/dv incl. the border-clamp zero
 };
-struct RowLog {       // forward, only when the log tensors are requested
-    f2 g0, g1;        // sampling grid (x,y) of frame -1 / +1
-    float depth;
+struct RowLog {          // forward, only when the log tensors are requested
+    float gx[2], gy[2], depth;
 };
-
-__device__ __forceinline__ void frame_coords(float u, float v, const Ctx& c, float& ix, float& iy, float& mx,
-                                             float& my, float& gx, float& gy) {
-    gx = (u * c.inv_Wm1 - 0.5f) * 2.f;      // layers.py:190-192
-    gy = (v * c.inv_Hm1 - 0.5f) * 2.f;
-    ix = unnormalize_clip(gx, c.W, c.ac, mx);
-    iy = unnormalize_clip(gy, c.H, c.ac, my);
-}
 
 struct TapOff {
     unsigned o00, o01, o10, o11;   // byte offsets inside one plane
@@ -224,104 +221,119 @@ __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, f
         ray = ray + g.iK[i * 3 + 2];
         cam[i] = depth * ray;
     }
-    f2 q[3];
+    if (MODE == 0 && LOGS) lg.depth = depth;
+    if (MODE == 1) park[6 * 64] = depth;
+    TapOff to[2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        f2 a = mk2(g.P[0][i * 4 + 0], g.P[1][i * 4 + 0]) * cam[0];
-        a = mk2(g.P[0][i * 4 + 1], g.P[1][i * 4 + 1]) * cam[1] + a;
-        a = mk2(g.P[0][i * 4 + 2], g.P[1][i * 4 + 2]) * cam[2] + a;
-        q[i] = a + mk2(g.P[0][i * 4 + 3], g.P[1][i * 4 + 3]);
+    for (int f = 0; f < 2; ++f) {
+        float q[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float a = g.P[f][i * 4 + 0] * cam[0];
+            a = fmaf(g.P[f][i * 4 + 1], cam[1], a);
+            a = fmaf(g.P[f][i * 4 + 2], cam[2], a);
+            q[i] = a + g.P[f][i * 4 + 3];
+        }
+        const float zi = frcp(q[2] + 1e-7f);
+        const float u = q[0] * zi, v = q[1] * zi;
+        const float gx = (u * c.inv_Wm1 - 0.5f) * 2.f;      // layers.py:190-192
+        const float gy = (v * c.inv_Hm1 - 0.5f) * 2.f;
+        float mx, my;
+        const float ix = unnormalize_clip(gx, c.W, c.ac, mx);
+        const float iy = unnormalize_clip(gy, c.H, c.ac, my);
+        if (MODE == 0 && LOGS) { lg.gx[f] = gx; lg.gy[f] = gy; }
+        if (MODE == 1) {
+            r.sx[f] = mx * (2.f * c.inv_Wm1);
+            r.sy[f] = my * (2.f * c.inv_Hm1);
+            park[(f * 3 + 0) * 64] = u; park[(f * 3 + 1) * 64] = v; park[(f * 3 + 2) * 64] = zi;
+        }
+        to[f] = tap_offsets(ix, iy, c.H, c.W);
+        r.wx1[f] = to[f].wx1;
+        r.wy1[f] = to[f].wy1;
     }
-    const f2 zi = rcp2(q[2] + 1e-7f);
-    const f2 u = q[0] * zi, v = q[1] * zi;
-    float ix0, iy0, ix1, iy1, gx0, gy0, gx1, gy1, mx0, my0, mx1, my1;
-    frame_coords(u.x, v.x, c, ix0, iy0, mx0, my0, gx0, gy0);
-    frame_coords(u.y, v.y, c, ix1, iy1, mx1, my1, gx1, gy1);
-    if (MODE == 0) {
-        if (LOGS) { lg.g0 = mk2(gx0, gy0); lg.g1 = mk2(gx1, gy1); lg.depth = depth; }
-    } else {
-        r.sx = mk2(mx0, mx1) * (2.f * c.inv_Wm1);
-        r.sy = mk2(my0, my1) * (2.f * c.inv_Hm1);
-        park[0 * 64] = u.x; park[1 * 64] = u.y; park[2 * 64] = v.x; park[3 * 64] = v.y;
-        park[4 * 64] = zi.x; park[5 * 64] = zi.y; park[6 * 64] = depth;
-    }
-    const TapOff b0 = tap_offsets(ix0, iy0, c.H, c.W), b1 = tap_offsets(ix1, iy1, c.H, c.W);
-    r.wx1 = mk2(b0.wx1, b1.wx1);
-    r.wy1 = mk2(b0.wy1, b1.wy1);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const unsigned so = ch * c.plane4;
-        r.tap[ch][0] = mk2(bload(c.s0, b0.o00, so), bload(c.s1, b1.o00, so));
-        r.tap[ch][1] = mk2(bload(c.s0, b0.o01, so), bload(c.s1, b1.o01, so));
-        r.tap[ch][2] = mk2(bload(c.s0, b0.o10, so), bload(c.s1, b1.o10, so));
-        r.tap[ch][3] = mk2(bload(c.s0, b0.o11, so), bload(c.s1, b1.o11, so));
+        r.tap[0][ch][0] = bload(c.s0, to[0].o00, so); r.tap[1][ch][0] = bload(c.s1, to[1].o00, so);
+        r.tap[0][ch][1] = bload(c.s0, to[0].o01, so); r.tap[1][ch][1] = bload(c.s1, to[1].o01, so);
+        r.tap[0][ch][2] = bload(c.s0, to[0].o10, so); r.tap[1][ch][2] = bload(c.s1, to[1].o10, so);
+        r.tap[0][ch][3] = bload(c.s0, to[0].o11, so); r.tap[1][ch][3] = bload(c.s1, to[1].o11, so);
     }
 }
 
-struct Center {   // values of one row at the lane's own pixel
+struct Row {   // raw values of one image row at the lane's own pixel: target + both warped frames
     float t[3];
-    f2 w[3];
+    float w[2][3];
 };
 
-__device__ __forceinline__ void blend_row(const Taps& r, Center& o) {
-    const f2 wx0 = 1.f - r.wx1, wy0 = 1.f - r.wy1;
-    const f2 wnw = wx0 * wy0, wne = r.wx1 * wy0, wsw = wx0 * r.wy1, wse = r.wx1 * r.wy1;
+__device__ __forceinline__ void blend_row(const Taps& r, Row& o) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        o.w[ch] = r.tap[ch][0] * wnw + r.tap[ch][1] * wne + r.tap[ch][2] * wsw + r.tap[ch][3] * wse;
-        o.t[ch] = r.t[ch];
+    for (int f = 0; f < 2; ++f) {
+        const float wx0 = 1.f - r.wx1[f], wy0 = 1.f - r.wy1[f];
+        const float wnw = wx0 * wy0, wne = r.wx1[f] * wy0, wsw = wx0 * r.wy1[f], wse = r.wx1[f] * r.wy1[f];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            o.w[f][ch] = r.tap[f][ch][0] * wnw + r.tap[f][ch][1] * wne + r.tap[f][ch][2] * wsw + r.tap[f][ch][3] * wse;
     }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) o.t[ch] = r.t[ch];
 }
 
-struct HSum {   // horizontal 3-sums of one row: target (scalar) and both warped frames (packed)
-    float hy[3], hyy[3];
-    f2 hx[3], hxx[3], hxy[3];
-};
+// 3-tap horizontal sum across lanes: two DPP-fused adds
+__device__ __forceinline__ float hsum3(float v) { return from_left(v) + v + from_right(v); }
 
-__device__ __forceinline__ void hsum_row(HSum& h, const float t[3], const f2 w[3]) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float tl = from_left(t[c]), tr = from_right(t[c]);
-        const f2 wl = left2(w[c]), wr = right2(w[c]);
-        h.hy[c] = tl + t[c] + tr;
-        h.hyy[c] = tl * tl + t[c] * t[c] + tr * tr;
-        h.hx[c] = wl + w[c] + wr;
-        h.hxx[c] = wl * wl + w[c] * w[c] + wr * wr;
-        h.hxy[c] = wl * tl + w[c] * t[c] + wr * tr;
-    }
+// Window statistics of one channel: vertical sums in-lane over the three rows held in registers, then
+// the horizontal 3-sum on the five column sums (instead of ringing five h-sums per channel and frame).
+struct TStat {
+    float mu_y, sig_y_c2, mu_yy_c1;   // mu_y, sig_y + C2, mu_y^2 + C1
+};
+__device__ __forceinline__ TStat target_stat(float a, float b, float c) {
+    const float sy = hsum3(a + b + c);
+    const float syy = hsum3(fmaf(a, a, fmaf(b, b, c * c)));
+    TStat s;
+    s.mu_y = sy * k9;
+    s.sig_y_c2 = fmaf(syy, k9, kC2) - s.mu_y * s.mu_y;
+    s.mu_yy_c1 = fmaf(s.mu_y, s.mu_y, kC1);
+    return s;
 }
-
-struct SsimTerms {
-    f2 mu_x, n1, n2, d1, d2;
-    float mu_y;
+struct WStat {
+    float mu_x, n1, n2, d1, d2;
 };
-__device__ __forceinline__ SsimTerms ssim_terms(const HSum& a, const HSum& b, const HSum& c, int ch) {
-    SsimTerms s;
-    s.mu_x = (a.hx[ch] + b.hx[ch] + c.hx[ch]) * k9;
-    s.mu_y = (a.hy[ch] + b.hy[ch] + c.hy[ch]) * k9;
-    const f2 sig_x = (a.hxx[ch] + b.hxx[ch] + c.hxx[ch]) * k9 - s.mu_x * s.mu_x;
-    const float sig_y = (a.hyy[ch] + b.hyy[ch] + c.hyy[ch]) * k9 - s.mu_y * s.mu_y;
-    const f2 sig_xy = (a.hxy[ch] + b.hxy[ch] + c.hxy[ch]) * k9 - s.mu_x * s.mu_y;
-    s.n1 = 2.f * s.mu_x * s.mu_y + kC1;
-    s.n2 = 2.f * sig_xy + kC2;
-    s.d1 = s.mu_x * s.mu_x + (s.mu_y * s.mu_y + kC1);
-    s.d2 = sig_x + (sig_y + kC2);
+__device__ __forceinline__ WStat warp_stat(const TStat& ts, float xa, float xb, float xc, float ya, float yb, float yc) {
+    const float sx = hsum3(xa + xb + xc);
+    const float sxx = hsum3(fmaf(xa, xa, fmaf(xb, xb, xc * xc)));
+    const float sxy = hsum3(fmaf(xa, ya, fmaf(xb, yb, xc * yc)));
+    WStat s;
+    s.mu_x = sx * k9;
+    const float sig_x = fmaf(sxx, k9, -s.mu_x * s.mu_x);
+    const float sig_xy = fmaf(sxy, k9, -s.mu_x * ts.mu_y);
+    s.n1 = fmaf(2.f * s.mu_x, ts.mu_y, kC1);
+    s.n2 = fmaf(2.f, sig_xy, kC2);
+    s.d1 = fmaf(s.mu_x, s.mu_x, ts.mu_yy_c1);
+    s.d2 = sig_x + ts.sig_y_c2;
     return s;
 }
 
-// 0.85 * mean_c SSIM + 0.15 * mean_c |t - w|      (trainer.py:517-529), both frames at once
-__device__ __forceinline__ f2 reproj_value(const HSum& a, const HSum& b, const HSum& c, const Center& ctr,
-                                           bool no_ssim) {
-    const f2 l1 = (abs2(ctr.t[0] - ctr.w[0]) + abs2(ctr.t[1] - ctr.w[1]) + abs2(ctr.t[2] - ctr.w[2])) * (1.f / 3.f);
-    if (no_ssim) return l1;
-    f2 ss = splat(0.f);
+// 0.85 * mean_c SSIM + 0.15 * mean_c |t - w|  (trainer.py:517-529) for both frames; rows a,b,c = p-1,p,p+1
+__device__ __forceinline__ void reproj_values(const Row& a, const Row& b, const Row& c, bool no_ssim, float out[2]) {
+    float ss[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const SsimTerms s = ssim_terms(a, b, c, ch);
-        const f2 v = (1.f - (s.n1 * s.n2) * rcp2(s.d1 * s.d2)) * 0.5f;
-        ss += clamp01(v);
+        TStat ts;
+        if (!no_ssim) ts = target_stat(a.t[ch], b.t[ch], c.t[ch]);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            l1[f] += fabsf(b.t[ch] - b.w[f][ch]);
+            if (!no_ssim) {
+                const WStat s = warp_stat(ts, a.w[f][ch], b.w[f][ch], c.w[f][ch], a.t[ch], b.t[ch], c.t[ch]);
+                const float v = fmaf(-(s.n1 * s.n2), 0.5f * frcp(s.d1 * s.d2), 0.5f);
+                ss[f] += fminf(fmaxf(v, 0.f), 1.f);
+            }
+        }
     }
-    return 0.85f * (ss * (1.f / 3.f)) + 0.15f * l1;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+        out[f] = no_ssim ? l1[f] * (1.f / 3.f) : fmaf(0.85f / 3.f, ss[f], (0.15f / 3.f) * l1[f]);
 }
 
 // counter-based N(0,1) for the on-device tie-break noise (used only when no noise tensor is given)
@@ -337,7 +349,7 @@ __device__ __forceinline__ float rng_normal(unsigned long long seed, unsigned id
 
 // ------------------------------------------------------------------------------------------------
 // identity reprojection losses: reprojection_loss(color(f,0), color(0,0)), f = -1,+1  (trainer.py:562-568)
-// one wave = one strip x ID_ROWS rows, both frames packed.   grid (strips62, rowblocks_id, B), block 64.
+// one wave = one strip x ID_ROWS rows, both frames.   grid (strips62, rowblocks_id, B), block 64.
 // ------------------------------------------------------------------------------------------------
 constexpr int ID_ROWS = 8;
 
@@ -355,51 +367,47 @@ __global__ __launch_bounds__(64) void identity_kernel(PhotoArgs p) {
     const bool lane_ok = lane >= 1 && lane <= 62 && x < W;
     const rsrc_t idl = make_rsrc(p.idl + (size_t)b * (avg ? 1 : 2) * (c.plane4 / 4), (avg ? 1u : 2u) * c.plane4);
 
-    HSum hA = {}, hB = {};
-    Center cA = {}, cB = {};
-    float t[3];
-    f2 w[3];
+    Row rA = {}, rB = {}, nxt;
     auto load_row = [&](int yy) {
         const unsigned o = (unsigned)(reflect_clamp(yy, H) * W + xr) * 4u;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            t[ch] = bload(c.tg, o, ch * c.plane4);
-            w[ch] = mk2(bload(c.s0, o, ch * c.plane4), bload(c.s1, o, ch * c.plane4));
+            nxt.t[ch] = bload(c.tg, o, ch * c.plane4);
+            nxt.w[0][ch] = bload(c.s0, o, ch * c.plane4);
+            nxt.w[1][ch] = bload(c.s1, o, ch * c.plane4);
         }
     };
-    auto body = [&](int i, HSum& h_old, HSum& h_new, const Center& c_prev, Center& c_cur) {
+    auto body = [&](int i, Row& r_old, const Row& r_new) {
         const int yy = y0 - 1 + i;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) { c_cur.t[ch] = t[ch]; c_cur.w[ch] = w[ch]; }
+        const Row cur = nxt;
         load_row(yy + 1);   // next row flies during this row's math
-        HSum h;
-        hsum_row(h, c_cur.t, c_cur.w);
+        float r[2];
+        reproj_values(r_old, r_new, cur, no_ssim, r);
         const int py = yy - 1;
         if (i >= 2 && py < H && lane_ok) {
-            const f2 r = reproj_value(h_old, h_new, h, c_prev, no_ssim);
             const unsigned o = (unsigned)(py * W + x) * 4u;
             if (avg) {
-                bstore(idl, o, 0, (r.x + r.y) * 0.5f);
+                bstore(idl, o, 0, (r[0] + r[1]) * 0.5f);
             } else {
-                bstore(idl, o, 0, r.x);
-                bstore(idl, o, c.plane4, r.y);
+                bstore(idl, o, 0, r[0]);
+                bstore(idl, o, c.plane4, r[1]);
             }
         }
-        h_old = h;
+        r_old = cur;
     };
     load_row(y0 - 1);
 #pragma unroll 1
     for (int i = 0; i < ID_ROWS + 2; i += 2) {
-        body(i, hA, hB, cB, cA);
-        body(i + 1, hB, hA, cA, cB);
+        body(i, rA, rB);
+        body(i + 1, rB, rA);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward: wave = scale s, both source frames packed.  grid (strips62, rowblocks, B), block 64*ns.
+// forward: wave = scale s, both source frames.  grid (strips62, rowblocks, B), block 64*ns.
 // ------------------------------------------------------------------------------------------------
 template <bool LOGS>
-__global__ __launch_bounds__(256, 2) void photo_fwd_kernel(PhotoArgs p) {
+__global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) {
     const int lane = threadIdx.x & 63;
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
@@ -423,8 +431,7 @@ __global__ __launch_bounds__(256, 2) void photo_fwd_kernel(PhotoArgs p) {
     uint8_t* am = p.argmin[s] + (size_t)b * plane;
     float* isel = p.idsel[s] ? p.idsel[s] + (size_t)b * plane : nullptr;
 
-    HSum hA = {}, hB = {};
-    Center cA = {}, cB = {};
+    Row rA = {}, rB = {};
     float idnA[4] = {0.f, 0.f, 0.f, 0.f}, idnB[4] = {0.f, 0.f, 0.f, 0.f};
     float acc = 0.f;
     Taps tp;
@@ -434,10 +441,10 @@ __global__ __launch_bounds__(256, 2) void photo_fwd_kernel(PhotoArgs p) {
     // One march step.  On entry `tp` holds the in-flight loads of row yy and `dt` those of the
     // disparity of row yy+1.  All loads of the step are issued together right after the blend, so
     // every later s_waitcnt of the step only waits for loads that are older than them.
-    auto body = [&](int i, HSum& h_old, HSum& h_new, const Center& c_prev, Center& c_cur, const float* idn_cur,
-                    float* idn_nxt) {
+    auto body = [&](int i, Row& r_old, const Row& r_new, const float* idn_cur, float* idn_nxt) {
         const int yy = y0 - 1 + i;
-        blend_row(tp, c_cur);
+        Row cur;
+        blend_row(tp, cur);
         if (LOGS) lg_cur = lg_nxt;
         issue_row<0, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), lg_nxt, nullptr);
         {   // identity loss + tie-break noise of the row the NEXT step outputs (row yy)
@@ -456,24 +463,23 @@ __global__ __launch_bounds__(256, 2) void photo_fwd_kernel(PhotoArgs p) {
             for (int f = 0; f < 2; ++f) {
                 if (float* col = p.color[s][f]) {
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) col[((size_t)b * 3 + ch) * plane + o] = f ? c_cur.w[ch].y : c_cur.w[ch].x;
+                    for (int ch = 0; ch < 3; ++ch) col[((size_t)b * 3 + ch) * plane + o] = cur.w[f][ch];
                 }
                 if (float* smp = p.sample[s][f])
-                    reinterpret_cast<f2*>(smp)[(size_t)b * plane + o] = f ? lg_cur.g1 : lg_cur.g0;
+                    reinterpret_cast<float2*>(smp)[(size_t)b * plane + o] = make_float2(lg_cur.gx[f], lg_cur.gy[f]);
             }
             if (float* dep = p.depth[s]) dep[(size_t)b * plane + o] = lg_cur.depth;
         }
-        HSum h;
-        hsum_row(h, c_cur.t, c_cur.w);
+        float r[2];
+        reproj_values(r_old, r_new, cur, no_ssim, r);
         const int py = yy - 1;
         if (i >= 2 && py < H && lane_ok) {
             // ---- min over [identity(-1), identity(+1), reproj(-1), reproj(+1)]  (trainer.py:592-610)
-            const f2 r = reproj_value(h_old, h_new, h, c_prev, no_ssim);
             const unsigned o = (unsigned)(py * W + x);
             float best;
             int idx = 0;
             if (avg) {
-                const float rr = (r.x + r.y) * 0.5f;
+                const float rr = (r[0] + r[1]) * 0.5f;
                 best = rr;
                 if (automask) {
                     const float n0 = ext_noise ? idn_cur[2] : rng_normal(p.seed, b * plane + o, s * 2);
@@ -488,17 +494,17 @@ __global__ __launch_bounds__(256, 2) void photo_fwd_kernel(PhotoArgs p) {
                 const float i1 = __fadd_rn(idn_cur[1], __fmul_rn(n1, 0.00001f));
                 best = i0;
                 if (i1 < best) { best = i1; idx = 1; }
-                if (r.x < best) { best = r.x; idx = 2; }
-                if (r.y < best) { best = r.y; idx = 3; }
+                if (r[0] < best) { best = r[0]; idx = 2; }
+                if (r[1] < best) { best = r[1]; idx = 3; }
             } else {
-                best = r.x;
-                if (r.y < best) { best = r.y; idx = 1; }
+                best = r[0];
+                if (r[1] < best) { best = r[1]; idx = 1; }
             }
             acc += best;
             am[o] = (uint8_t)idx;
             if (isel && automask) isel[o] = (idx > (avg ? 0 : 1)) ? 1.f : 0.f;
         }
-        h_old = h;
+        r_old = cur;
     };
 
     disp_issue(dt, c, xr, reflect_clamp(y0 - 1, H));
@@ -506,8 +512,8 @@ __global__ __launch_bounds__(256, 2) void photo_fwd_kernel(PhotoArgs p) {
     disp_issue(dt, c, xr, reflect_clamp(y0, H));
 #pragma unroll 1
     for (int i = 0; i < R_ROWS + 2; i += 2) {
-        body(i, hA, hB, cB, cA, idnA, idnB);
-        body(i + 1, hB, hA, cA, cB, idnB, idnA);
+        body(i, rA, rB, idnA, idnB);
+        body(i + 1, rB, rA, idnB, idnA);
     }
     acc = wave_sum(acc);
     if (lane == 0) {
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(PhotoArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: wave = scale s, both frames packed, halo 2.  grid (strips60, rowblocks, B), block 64*ns.
+// backward: wave = scale s, both frames, halo 2.  grid (strips60, rowblocks, B), block 64*ns.
 //
 // Per march step (row yy):  A: blend the taps of row yy (value + coordinate derivatives);
 //   B: SSIM derivative coefficients of output pixel row p = yy-1, spread (transposed 3x3 with the
@@ -625,15 +631,15 @@ __global__ __launch_bounds__(1024) void finalize_kernel(PhotoArgs p) {
 // What C needs from A two rows earlier (dw/dcoords, projection) waits in a per-lane LDS ring; nothing
 // is recomputed and nothing but the final d(disp) is written to HBM.
 // ------------------------------------------------------------------------------------------------
-constexpr int RING_VALS = 12;   // f2 Dx[3], Dy[3]              3 slots (written at A, read at C two rows later)
-constexpr int PARK_VALS = 7;    // u, v, zi (f2) + depth        4 slots (written one row ahead by issue_row)
+constexpr int RING_VALS = 12;   // Dx[2][3], Dy[2][3]          3 slots (written at A, read at C two rows later)
+constexpr int PARK_VALS = 7;    // (u, v, zi) x 2 + depth      4 slots (written one row ahead by issue_row)
 constexpr int BWD_LDS_PER_WAVE = (3 * RING_VALS + 4 * PARK_VALS) * 64;
 
 struct GAcc {
-    f2 g[3];
+    float g[2][3];
 };
 
-__global__ __launch_bounds__(256, 1) void photo_bwd_kernel(PhotoArgs p) {
+__global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [ns waves][BWD_LDS_PER_WAVE]
     const int lane = threadIdx.x & 63;
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(256, 1) void photo_bwd_kernel(PhotoArgs p) {
     const float g_ssim = no_ssim ? 0.f : 0.85f / 3.f;
     const float g_l1 = no_ssim ? 1.f / 3.f : 0.15f / 3.f;
     // argmin value that routes the gradient to frame -1 / +1
-    const int sel0 = avg ? 1 : (automask ? 2 : 0), sel1 = avg ? 1 : (automask ? 3 : 1);
+    const int selv[2] = {avg ? 1 : (automask ? 2 : 0), avg ? 1 : (automask ? 3 : 1)};
     const float sel_val = (avg ? 0.5f : 1.f) * wgt;
     const bool sel_all = avg && !automask;   // single channel: to_optimise = combined
     float* ring = lds + (size_t)s * BWD_LDS_PER_WAVE + lane;
@@ -666,78 +672,88 @@ __global__ __launch_bounds__(256, 1) void photo_bwd_kernel(PhotoArgs p) {
     float* gout = p.gdup[s] + (size_t)b * plane;
     const float fl = (x == 1) ? 2.f : 1.f, fr = (x == W - 2) ? 2.f : 1.f;   // ReflectionPad fold-back, x
 
-    HSum hA = {}, hB = {};
-    Center cA = {}, cB = {};     // rows yy-2 / yy-1 (ping-pong)
+    Row rA = {}, rB = {};        // rows yy-2 / yy-1 (ping-pong)
     GAcc gA = {}, gB = {};       // pending d/d(warped) of rows yy-2 / yy-1
     int mA = 0, mB = 0, m_in = 0;
     // pose-gradient accumulators; the lane's column x is constant along the march, so
     //   sum dq_r*cam_j = (iK_j0*x + iK_j2) * sum(dq_r*depth) + iK_j1 * sum(dq_r*depth*y)
-    f2 accA[3], accB[3], accC[3];
+    float accA[2][3], accB[2][3], accC[2][3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) accA[k] = accB[k] = accC[k] = splat(0.f);
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) accA[f][k] = accB[f][k] = accC[f][k] = 0.f;
     Taps tp;
     DispTaps dt;
     RowLog nolog;
     int slot3 = 0;   // i % 3
 
-    auto body = [&](int i, HSum& h_old, HSum& h_new, Center& c_old, const Center& c_new, GAcc& g_old, GAcc& g_new,
-                    int& m_old, const int& m_new) {
+    auto body = [&](int i, Row& r_old, const Row& r_new, GAcc& g_old, GAcc& g_new, int& m_old, const int& m_new) {
         const int yy = y0 - 2 + i;
         // ---------------- stage A: warped values + their coordinate derivatives on (reflected) row yy
-        Center cur;
+        Row cur;
         float* rs = ring + (size_t)slot3 * RING_VALS * 64;
-        {
-            const f2 wx0 = 1.f - tp.wx1, wy0 = 1.f - tp.wy1;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const float wx1 = tp.wx1[f], wy1 = tp.wy1[f], wx0 = 1.f - wx1, wy0 = 1.f - wy1;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const f2 nw = tp.tap[ch][0], ne = tp.tap[ch][1], sw = tp.tap[ch][2], se = tp.tap[ch][3];
-                cur.w[ch] = (nw * wx0 + ne * tp.wx1) * wy0 + (sw * wx0 + se * tp.wx1) * tp.wy1;
-                cur.t[ch] = tp.t[ch];
-                const f2 Dx = ((ne - nw) * wy0 + (se - sw) * tp.wy1) * tp.sx;
-                const f2 Dy = ((sw - nw) * wx0 + (se - ne) * tp.wx1) * tp.sy;
-                rs[(ch * 4 + 0) * 64] = Dx.x; rs[(ch * 4 + 1) * 64] = Dx.y;
-                rs[(ch * 4 + 2) * 64] = Dy.x; rs[(ch * 4 + 3) * 64] = Dy.y;
+                const float nw = tp.tap[f][ch][0], ne = tp.tap[f][ch][1], sw = tp.tap[f][ch][2], se = tp.tap[f][ch][3];
+                const float top = fmaf(ne - nw, wx1, nw), bot = fmaf(se - sw, wx1, sw);
+                cur.w[f][ch] = fmaf(bot - top, wy1, top);
+                const float Dx = fmaf((se - sw) - (ne - nw), wy1, ne - nw) * tp.sx[f];
+                const float Dy = (bot - top) * tp.sy[f];
+                rs[((f * 3 + ch) * 2 + 0) * 64] = Dx;
+                rs[((f * 3 + ch) * 2 + 1) * 64] = Dy;
             }
         }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) cur.t[ch] = tp.t[ch];
         const int m_cur = m_in;
         // ---------------- all loads of the step: row yy+1 (taps, target, argmin) and disparity of row yy+2
         issue_row<1, false>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), nolog,
                             park + (size_t)((i + 1) & 3) * PARK_VALS * 64);
-        m_in = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(am, (int)((unsigned)(min(max(yy + 1, 0), H - 1) * W + xr)), 0, 0);
+        m_in = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(am, min(max(yy + 1, 0), H - 1) * W + xr, 0, 0);
         disp_issue(dt, c, xr, reflect_clamp(yy + 2, H));
 
-        HSum h;
-        hsum_row(h, cur.t, cur.w);
-        // ---------------- stage B: SSIM derivative coefficients at row p = yy-1
+        // ---------------- stage B: SSIM derivative coefficients at row p = yy-1 (window rows yy-2, yy-1, yy)
+        float g_tmp[2][3];
         {
             const int py = yy - 1;
-            f2 gs = splat(0.f);
-            if (i >= 2 && py >= 0 && py < H && col_ok)
-                gs = mk2((sel_all || m_new == sel0) ? sel_val * g_ssim : 0.f,
-                         (sel_all || m_new == sel1) ? sel_val * g_ssim : 0.f);
+            float gs[2] = {0.f, 0.f};
+            if (i >= 2 && py >= 0 && py < H && col_ok) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f) gs[f] = (sel_all || m_new == selv[f]) ? sel_val * g_ssim : 0.f;
+            }
             const float fu = (yy == 1) ? 2.f : 1.f;          // fold-back for q = yy   (p = q-1)
             const float fd = (yy - 2 == H - 2) ? 2.f : 1.f;  // fold-back for q = yy-2 (p = q+1)
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const SsimTerms t = ssim_terms(h_old, h_new, h, ch);
-                const f2 n = t.n1 * t.n2;
-                const f2 id = rcp2(t.d1 * t.d2);
-                const f2 v = (1.f - n * id) * 0.5f;
-                // clamp(.,0,1) passes the gradient inclusively
-                const f2 G = mk2((v.x >= 0.f && v.x <= 1.f) ? gs.x : 0.f, (v.y >= 0.f && v.y <= 1.f) ? gs.y : 0.f);
-                const f2 nid2 = n * id * id;
-                // d/d mu_x | d/d E[xx] | d/d E[xy]   (E[.] held fixed for mu_x)
-                const f2 a = G * (nid2 * t.mu_x * (t.d2 - t.d1) - t.mu_y * (t.n2 - t.n1) * id);
-                const f2 bb = G * 0.5f * nid2 * t.d1;
-                const f2 cc = -G * t.n1 * id;
-                // transposed 3x3 along x
-                const f2 ka = fl * left2(a) + a + fr * right2(a);
-                const f2 kb = fl * left2(bb) + bb + fr * right2(bb);
-                const f2 kc = fl * left2(cc) + cc + fr * right2(cc);
-                // ... and along y: row p feeds the pending rows q = p+1 (= yy), p (= yy-1), p-1 (= yy-2)
-                g_old.g[ch] += fd * (ka + 2.f * c_old.w[ch] * kb + c_old.t[ch] * kc);
-                g_new.g[ch] += ka + 2.f * c_new.w[ch] * kb + c_new.t[ch] * kc;
-                h_old.hx[ch] = fu * (ka + 2.f * cur.w[ch] * kb + cur.t[ch] * kc);   // parked in the dying ring slot
+                const TStat ts = target_stat(r_old.t[ch], r_new.t[ch], cur.t[ch]);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const WStat t = warp_stat(ts, r_old.w[f][ch], r_new.w[f][ch], cur.w[f][ch], r_old.t[ch],
+                                              r_new.t[ch], cur.t[ch]);
+                    const float n = t.n1 * t.n2;
+                    const float id = frcp(t.d1 * t.d2);
+                    const float nid = n * id;
+                    const float v = fmaf(-0.5f, nid, 0.5f);
+                    // clamp(.,0,1) passes the gradient inclusively
+                    const float G = (v >= 0.f && v <= 1.f) ? gs[f] : 0.f;
+                    const float Gid = G * id;
+                    // d/d mu_x | d/d E[xx] | d/d E[xy]   (E[.] held fixed for mu_x)
+                    const float a = Gid * fmaf(nid * t.mu_x, t.d2 - t.d1, -ts.mu_y * (t.n2 - t.n1));
+                    const float bb = 0.5f * Gid * nid * t.d1;
+                    const float cc = -Gid * t.n1;
+                    // transposed 3x3 along x ...
+                    const float ka = fmaf(fr, from_right(a), fmaf(fl, from_left(a), a));
+                    const float kb = fmaf(fr, from_right(bb), fmaf(fl, from_left(bb), bb));
+                    const float kc = fmaf(fr, from_right(cc), fmaf(fl, from_left(cc), cc));
+                    const float kb2 = kb + kb;
+                    // ... and along y: row p feeds the pending rows q = p-1 (= yy-2), p (= yy-1), p+1 (= yy)
+                    g_old.g[f][ch] = fmaf(fd, fmaf(r_old.t[ch], kc, fmaf(r_old.w[f][ch], kb2, ka)), g_old.g[f][ch]);
+                    g_new.g[f][ch] += fmaf(r_new.t[ch], kc, fmaf(r_new.w[f][ch], kb2, ka));
+                    g_tmp[f][ch] = fu * fmaf(cur.t[ch], kc, fmaf(cur.w[f][ch], kb2, ka));   // fresh accumulator of row yy
+                }
             }
         }
         // ---------------- stage C: gradient at row q = yy-2 (its stage-A data comes back from the LDS ring)
@@ -747,28 +763,7 @@ __global__ __launch_bounds__(256, 1) void photo_bwd_kernel(PhotoArgs p) {
                 const int s2 = (slot3 == 0) ? 1 : ((slot3 == 1) ? 2 : 0);   // (i-2) % 3
                 const float* rq = ring + (size_t)s2 * RING_VALS * 64;
                 const float* pk = park + (size_t)((i - 2) & 3) * PARK_VALS * 64;
-                const f2 qu = mk2(pk[0 * 64], pk[1 * 64]), qv = mk2(pk[2 * 64], pk[3 * 64]);
-                const f2 qzi = mk2(pk[4 * 64], pk[5 * 64]);
                 const float qdepth = pk[6 * 64];
-                f2 gl = splat(0.f);
-                if (q_lane)
-                    gl = mk2((sel_all || m_old == sel0) ? sel_val * g_l1 : 0.f,
-                             (sel_all || m_old == sel1) ? sel_val * g_l1 : 0.f);
-                f2 du = splat(0.f), dv = splat(0.f);
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const f2 df = c_old.w[ch] - c_old.t[ch];
-                    const f2 sg = mk2((df.x > 0.f) ? 1.f : ((df.x < 0.f) ? -1.f : 0.f),
-                                      (df.y > 0.f) ? 1.f : ((df.y < 0.f) ? -1.f : 0.f));
-                    const f2 gw = g_old.g[ch] * k9 + gl * sg;
-                    du += gw * mk2(rq[(ch * 4 + 0) * 64], rq[(ch * 4 + 1) * 64]);
-                    dv += gw * mk2(rq[(ch * 4 + 2) * 64], rq[(ch * 4 + 3) * 64]);
-                }
-                if (!q_lane) { du = splat(0.f); dv = splat(0.f); }
-                f2 dq[3];
-                dq[0] = du * qzi;
-                dq[1] = dv * qzi;
-                dq[2] = -(du * qu + dv * qv) * qzi;
                 const float xf = (float)xr, yf = (float)qy;
                 float ray[3];
 #pragma unroll
@@ -777,41 +772,58 @@ __global__ __launch_bounds__(256, 1) void photo_bwd_kernel(PhotoArgs p) {
                     t = fmaf(g.iK[r * 3 + 1], yf, t);
                     ray[r] = t + g.iK[r * 3 + 2];
                 }
-                f2 dcam[3] = {splat(0.f), splat(0.f), splat(0.f)};
+                float dcam[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const f2 dqd = dq[r] * qdepth;
-                    accA[r] += dqd;
-                    accB[r] += dqd * yf;
-                    accC[r] += dq[r];
+                for (int f = 0; f < 2; ++f) {
+                    const float gl = (q_lane && (sel_all || m_old == selv[f])) ? sel_val * g_l1 : 0.f;
+                    float du = 0.f, dv = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) dcam[j] += dq[r] * mk2(g.P[0][r * 4 + j], g.P[1][r * 4 + j]);
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float df = r_old.w[f][ch] - r_old.t[ch];
+                        const float sg = (df > 0.f) ? gl : ((df < 0.f) ? -gl : 0.f);
+                        const float gw = fmaf(g_old.g[f][ch], k9, sg);
+                        du = fmaf(gw, rq[((f * 3 + ch) * 2 + 0) * 64], du);
+                        dv = fmaf(gw, rq[((f * 3 + ch) * 2 + 1) * 64], dv);
+                    }
+                    if (!q_lane) { du = 0.f; dv = 0.f; }
+                    const float qu = pk[(f * 3 + 0) * 64], qv = pk[(f * 3 + 1) * 64], qzi = pk[(f * 3 + 2) * 64];
+                    float dq[3];
+                    dq[0] = du * qzi;
+                    dq[1] = dv * qzi;
+                    dq[2] = -fmaf(du, qu, dv * qv) * qzi;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float dqd = dq[r] * qdepth;
+                        accA[f][r] += dqd;
+                        accB[f][r] = fmaf(dqd, yf, accB[f][r]);
+                        accC[f][r] += dq[r];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) dcam[j] = fmaf(dq[r], g.P[f][r * 4 + j], dcam[j]);
+                    }
                 }
-                const f2 dd = dcam[0] * ray[0] + dcam[1] * ray[1] + dcam[2] * ray[2];
-                const float gd = -(dd.x + dd.y) * qdepth * qdepth * p.disp_range;
+                const float dd = fmaf(dcam[0], ray[0], fmaf(dcam[1], ray[1], dcam[2] * ray[2]));
+                const float gd = -dd * qdepth * qdepth * p.disp_range;
                 if (q_lane) gout[(unsigned)(qy * W + x)] = gd;
             }
         }
         // rotate: the slots of row yy-2 now take row yy
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            g_old.g[ch] = h_old.hx[ch];   // fresh accumulator of row yy (see stage B)
-            c_old.w[ch] = cur.w[ch];
-            c_old.t[ch] = cur.t[ch];
-        }
-        h_old = h;
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) g_old.g[f][ch] = g_tmp[f][ch];
+        r_old = cur;
         m_old = m_cur;
         slot3 = (slot3 == 2) ? 0 : slot3 + 1;
     };
 
     disp_issue(dt, c, xr, reflect_clamp(y0 - 2, H));
     issue_row<1, false>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(y0 - 2, H), nolog, park + 0 * PARK_VALS * 64);
-    m_in = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(am, (int)((unsigned)(min(max(y0 - 2, 0), H - 1) * W + xr)), 0, 0);
+    m_in = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(am, min(max(y0 - 2, 0), H - 1) * W + xr, 0, 0);
     disp_issue(dt, c, xr, reflect_clamp(y0 - 1, H));
 #pragma unroll 1
     for (int i = 0; i < R_ROWS + 4; i += 2) {
-        body(i, hA, hB, cA, cB, gA, gB, mA, mB);
-        body(i + 1, hB, hA, cB, cA, gB, gA, mB, mA);
+        body(i, rA, rB, gA, gB, mA, mB);
+        body(i + 1, rB, rA, gB, gA, mB, mA);
     }
     // pose-gradient partials: per wave, fixed shuffle tree
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
@@ -821,94 +833,110 @@ __global__ __launch_bounds__(256, 1) void photo_bwd_kernel(PhotoArgs p) {
         float* o = p.part_dP + ((((size_t)s * 2 + f) * p.B + b) * p.nblk_b_img + blk) * 12;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float A = f ? accA[r].y : accA[r].x, Bv = f ? accB[r].y : accB[r].x;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float v = wave_sum((g.iK[j * 3 + 0] * xf + g.iK[j * 3 + 2]) * A + g.iK[j * 3 + 1] * Bv);
+                const float v = wave_sum((g.iK[j * 3 + 0] * xf + g.iK[j * 3 + 2]) * accA[f][r] + g.iK[j * 3 + 1] * accB[f][r]);
                 if (lane == 0) o[r * 4 + j] = v;
             }
-            const float v3 = wave_sum(f ? accC[r].y : accC[r].x);
+            const float v3 = wave_sum(accC[f][r]);
             if (lane == 0) o[r * 4 + 3] = v3;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// d_disp[s] = bilinear-upsample^T(gdup[s]) + smoothness gradient.   grid (chunks, B, ns), block 256.
-// The transposed upsample is a gather over the <= 2K+2 destination rows/cols that can reference a
-// low-res pixel; their 1-D weights are re-derived with the forward's own tap function.
+// d_disp[s] = bilinear-upsample^T(gdup[s]) + smoothness gradient.
+// grid (tiles_x, tiles_y, ns*B), block 256.  A block owns a (128/K) x (32/K) tile of scale-s pixels: it
+// stages the (128+K) x (32+K) full-resolution footprint in LDS with coalesced row reads, then applies
+// the transposed interpolation separably (x, then y).  The 1-D tap weights are re-derived with the
+// forward's own `lin_tap`, so forward and backward cannot disagree about a tap.
 // ------------------------------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ float upsample_T(const float* gu, int y, int x, int h, int w, int H, int W, float ry,
-                                            float rx) {
-    constexpr int NT = 2 * K + 2;
-    const int ylo = K * (y - 1) + K / 2 - 1, xlo = K * (x - 1) + K / 2 - 1;
-    float wx[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int dx = xlo + j;
-        float v = 0.f;
-        if (dx >= 0 && dx < W) {
-            const LinTap t = lin_tap(dx, rx, w);
-            v = (t.i0 == x ? 1.f - t.w1 : 0.f) + (t.i1 == x ? t.w1 : 0.f);
-        }
-        wx[j] = v;
-    }
-    float acc = 0.f;
-#pragma unroll 2
-    for (int i = 0; i < NT; ++i) {
-        const int dy = ylo + i;
-        if (dy < 0 || dy >= H) continue;
-        const LinTap t = lin_tap(dy, ry, h);
-        const float wy = (t.i0 == y ? 1.f - t.w1 : 0.f) + (t.i1 == y ? t.w1 : 0.f);
-        if (wy == 0.f) continue;
-        const float* row = gu + (size_t)dy * W;
-        float r = 0.f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int dx = min(max(xlo + j, 0), W - 1);
-            r = fmaf(wx[j], row[dx], r);
-        }
-        acc = fmaf(wy, r, acc);
-    }
-    return acc;
+constexpr int DG_W = 128, DG_H = 32;          // full-resolution core footprint of one block
+constexpr int DG_MAXK = 8;
+constexpr int DG_RW = DG_W + DG_MAXK, DG_RH = DG_H + DG_MAXK;
+
+__device__ __forceinline__ float tapw(int dst, float ratio, int n_in, int j) {
+    const LinTap t = lin_tap(dst, ratio, n_in);
+    return (t.i0 == j ? 1.f - t.w1 : 0.f) + (t.i1 == j ? t.w1 : 0.f);
 }
 
 __global__ __launch_bounds__(256) void disp_grad_kernel(PhotoArgs p) {
-    const int s = blockIdx.z, b = blockIdx.y;
-    const int h = p.hs[s], w = p.ws[s];
-    const int n = h * w;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float reg[DG_RH * DG_RW];                 // full-res footprint
+    __shared__ float hs[DG_RH * (DG_W / 2)];             // after the x pass: [footprint row][tile column]
+    const int s = blockIdx.z / p.B, b = blockIdx.z - s * p.B;
+    const int K = 1 << s;
+    const int h = p.hs[s], w = p.ws[s], n = h * w;
     const int H = p.H, W = p.W;
-    const int y = i / w, x = i - y * w;
+    const int tw = DG_W / K, th = DG_H / K;              // tile size in scale-s pixels
+    const int tx0 = blockIdx.x * tw, ty0 = blockIdx.y * th;
+    if (tx0 >= w || ty0 >= h) return;
     const float* gu = p.gdup[s] + (size_t)b * H * W;
-    float acc;
-    if (s == 0) acc = gu[i];
-    else if (s == 1) acc = upsample_T<2>(gu, y, x, h, w, H, W, p.ry[s], p.rx[s]);
-    else if (s == 2) acc = upsample_T<4>(gu, y, x, h, w, H, W, p.ry[s], p.rx[s]);
-    else acc = upsample_T<8>(gu, y, x, h, w, H, W, p.ry[s], p.rx[s]);
-    // smoothness:  L = A*(cx*Sx + cy*Sy),  A = 1/(mean+eps)
+    float up = 0.f;
+    const int lx = threadIdx.x % tw, ly0 = threadIdx.x / tw;   // this thread's tile cells: (lx, ly0 + k*rows)
+    const int rows_per_pass = 256 / tw;
+    if (K == 1) {
+        // scale 0: the upsample is the identity
+    } else {
+        const int fx0 = tx0 * K - K / 2, fy0 = ty0 * K - K / 2;   // footprint origin (may be negative)
+        const int rw = DG_W + K, rh = DG_H + K;
+        for (int k = threadIdx.x; k < rw * rh; k += 256) {
+            const int ry = k / rw, rx = k - ry * rw;
+            const int gy = fy0 + ry, gx = fx0 + rx;
+            reg[ry * DG_RW + rx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gu[(size_t)gy * W + gx] : 0.f;
+        }
+        __syncthreads();
+        // x pass: cell column cx gathers the 2K footprint columns [cx*K, cx*K + 2K)
+        for (int k = threadIdx.x; k < rh * tw; k += 256) {
+            const int ry = k / tw, cx = k - ry * tw;
+            const int jx = tx0 + cx;
+            float acc = 0.f;
+            if (jx < w) {
+                for (int t = 0; t < 2 * K; ++t) {
+                    const int rx = cx * K + t, gx = fx0 + rx;
+                    if (gx >= 0 && gx < W) acc = fmaf(tapw(gx, p.rx[s], w, jx), reg[ry * DG_RW + rx], acc);
+                }
+            }
+            hs[ry * (DG_W / 2) + cx] = acc;
+        }
+        __syncthreads();
+    }
+    // y pass + smoothness gradient, one scale-s pixel per iteration
     const float gsm = (p.g_losses[s] + p.g_losses[p.ns] / (float)p.ns) * p.smoothness / (float)(1 << s);
     const float* st = p.stats + ((size_t)s * p.B + b) * 3;
     const float A = 1.f / (st[0] + 1e-7f);
-    const float cx = 1.f / ((float)p.B * h * (w - 1)), cy = 1.f / ((float)p.B * (h - 1) * w);
+    const float cx_ = 1.f / ((float)p.B * h * (w - 1)), cy_ = 1.f / ((float)p.B * (h - 1) * w);
     const float* d = p.disp[s] + (size_t)b * n;
     const float* im = p.color_s[s] + (size_t)b * 3 * n;
     auto sgn = [](float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); };
     auto ex = [&](int i0, int i1) {
-        float gi = (fabsf(im[i0] - im[i1]) + fabsf(im[n + i0] - im[n + i1]) +
-                    fabsf(im[2 * n + i0] - im[2 * n + i1])) * (1.f / 3.f);
+        const float gi = (fabsf(im[i0] - im[i1]) + fabsf(im[n + i0] - im[n + i1]) +
+                          fabsf(im[2 * n + i0] - im[2 * n + i1])) * (1.f / 3.f);
         return __expf(-gi);
     };
-    const float dv = d[i];
-    float gx = 0.f, gy = 0.f;
-    if (x < w - 1) gx += sgn(dv - d[i + 1]) * ex(i, i + 1);
-    if (x > 0) gx -= sgn(d[i - 1] - dv) * ex(i - 1, i);
-    if (y < h - 1) gy += sgn(dv - d[i + w]) * ex(i, i + w);
-    if (y > 0) gy -= sgn(d[i - w] - dv) * ex(i - w, i);
-    const float gs = A * (cx * gx + cy * gy) - A * A * (cx * st[1] + cy * st[2]) / (float)n;
-    p.d_disp[s][(size_t)b * n + i] = acc + gsm * gs;
+    for (int cy = ly0; cy < th; cy += rows_per_pass) {
+        const int x = tx0 + lx, y = ty0 + cy;
+        if (x >= w || y >= h) continue;
+        const int i = y * w + x;
+        if (K == 1) {
+            up = gu[i];
+        } else {
+            const int fy0 = ty0 * K - K / 2;
+            up = 0.f;
+            for (int t = 0; t < 2 * K; ++t) {
+                const int ry = cy * K + t, gy = fy0 + ry;
+                if (gy >= 0 && gy < H) up = fmaf(tapw(gy, p.ry[s], h, y), hs[ry * (DG_W / 2) + lx], up);
+            }
+        }
+        // smoothness:  L = A*(cx*Sx + cy*Sy),  A = 1/(mean+eps)
+        const float dv = d[i];
+        float gx = 0.f, gy = 0.f;
+        if (x < w - 1) gx += sgn(dv - d[i + 1]) * ex(i, i + 1);
+        if (x > 0) gx -= sgn(d[i - 1] - dv) * ex(i - 1, i);
+        if (y < h - 1) gy += sgn(dv - d[i + w]) * ex(i, i + w);
+        if (y > 0) gy -= sgn(d[i - w] - dv) * ex(i - w, i);
+        const float gs = A * (cx_ * gx + cy_ * gy) - A * A * (cx_ * st[1] + cy_ * st[2]) / (float)n;
+        p.d_disp[s][(size_t)b * n + i] = up + gsm * gs;
+    }
 }
 
 // d_T[f][b] = K[b][:3,:]^T @ sum_{s,blk} dP      grid (B, 2), block 64
@@ -1132,7 +1160,14 @@ extern "C" int dc_photo_bwd(const dc_photo_desc* d, void* stream) {
     hipLaunchKernelGGL(photo_bwd_kernel, dim3(c.strips_b, c.rowblocks, a.B), dim3(64 * a.ns), lds, st, a);
     prof_end(pe, st);
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(disp_grad_kernel, dim3(ceil_div(a.H * a.W, 256), a.B, a.ns), dim3(256), 0, st, a);
+    {
+        int gx = 0, gy = 0;   // widest tile grid over the scales (smaller scales exit early)
+        for (int sc = 0; sc < a.ns; ++sc) {
+            gx = std::max(gx, ceil_div(a.ws[sc], DG_W >> sc));
+            gy = std::max(gy, ceil_div(a.hs[sc], DG_H >> sc));
+        }
+        hipLaunchKernelGGL(disp_grad_kernel, dim3(gx, gy, a.ns * a.B), dim3(256), 0, st, a);
+    }
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(pose_grad_kernel, dim3(a.B, 2), dim3(64), 0, st, a);
     DC_CHECK_LAUNCH();
@@ -1150,3 +1185,4 @@ extern "C" double dc_photo_algorithmic_bytes(const dc_photo_desc* d, int backwar
     }
     return tot;
 }
+

@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdepthcore.so")
+LIB_PATH = os.environ.get("DEPTHCORE_LIB", os.path.join(_HERE, "libdepthcore.so"))   # env: tuning sweeps only
 MAX_SCALES = 4
 
 OPT_NO_AUTOMASK = 1

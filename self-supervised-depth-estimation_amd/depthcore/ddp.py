@@ -11,11 +11,17 @@ import torch.distributed as dist
 
 
 class GradBuckets:
+    """Single GPU: gradients stay where autograd puts them (no copies at all).
+    Multi GPU: when the last gradient of a bucket has been produced, the bucket is packed with ONE
+    multi-tensor copy, all-reduced asynchronously (overlapping the rest of backward), and unpacked
+    (one multi-tensor copy) in finish()."""
+
     def __init__(self, named_params, bucket_mb=32, world_size=1, process_group=None):
         self.world = world_size
         self.pg = process_group
         # reverse registration order ~ order in which backward produces gradients
         params = [(n, p) for n, p in named_params if p.requires_grad and ".fc." not in n]  # fc never gets a grad
+        self.all_params = [p for _, p in named_params]
         params = params[::-1]
         self.buckets = []
         cur, cur_n = [], 0
@@ -28,45 +34,63 @@ class GradBuckets:
             cur_n += p.numel()
         if cur:
             self.buckets.append(cur)
-        self.flat, self.pending, self.handles = [], [], []
+        self.flat, self.views, self.pending, self.handles, self.launched = [], [], [], [], []
+        self.nbytes = sum(p.numel() * 4 for plist in self.buckets for p in plist)
+        if self.world == 1:
+            return
         for bi, plist in enumerate(self.buckets):
             n = sum(p.numel() for p in plist)
             flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
-            off = 0
+            off, views = 0, []
             for p in plist:
-                p.grad = flat[off:off + p.numel()].view_as(p)
+                views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-                if self.world > 1:
-                    p.register_post_accumulate_grad_hook(self._make_hook(bi))
+                p.register_post_accumulate_grad_hook(self._make_hook(bi))
             self.flat.append(flat)
+            self.views.append(views)
             self.pending.append(len(plist))
-        self.nbytes = sum(f.numel() * 4 for f in self.flat)
+            self.launched.append(False)
+
+    def _launch(self, bi):
+        plist = self.buckets[bi]
+        have = [i for i, p in enumerate(plist) if p.grad is not None]
+        if len(have) != len(plist):
+            self.flat[bi].zero_()
+        if have:
+            torch._foreach_copy_([self.views[bi][i] for i in have], [plist[i].grad for i in have])
+        self.handles.append(dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self.launched[bi] = True
 
     def _make_hook(self, bi):
         def hook(param):
             self.pending[bi] -= 1
             if self.pending[bi] == 0:
-                self.handles.append(dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._launch(bi)
         return hook
 
     def zero(self):
-        for bi, f in enumerate(self.flat):
-            f.zero_()
+        """model_optimizer.zero_grad(set_to_none=True) + reset of the bucket state."""
+        for p in self.all_params:
+            p.grad = None
+        for bi in range(len(self.flat)):
             self.pending[bi] = len(self.buckets[bi])
+            self.launched[bi] = False
         self.handles = []
 
     def finish(self):
         """Wait for the exchanges and turn sums into means (call before optimizer.step)."""
         if self.world == 1:
             return
-        for bi, n in enumerate(self.pending):   # buckets with a parameter that got no gradient this step
-            if n != 0:
-                self.handles.append(dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        for bi in range(len(self.flat)):      # buckets with a parameter that got no gradient this step
+            if not self.launched[bi]:
+                self._launch(bi)
         for h in self.handles:
             h.wait()
         inv = 1.0 / self.world
-        for f in self.flat:
-            f.mul_(inv)
+        for bi, plist in enumerate(self.buckets):
+            self.flat[bi].mul_(inv)
+            for p, v in zip(plist, self.views[bi]):
+                p.grad = v
 
 
 def broadcast_parameters(modules, src=0, process_group=None):

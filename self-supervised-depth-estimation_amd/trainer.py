@@ -66,7 +66,8 @@ class Trainer:
             broadcast_parameters(self.models.values(), 0, process_group)
         named = [(k + "." + n, p) for k, m in self.models.items() for n, p in m.named_parameters()]
         self.buckets = GradBuckets(named, self.opt.bucket_mb, world_size, process_group)
-        self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate)
+        self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate,
+                                          fused=self.device.type == "cuda")
         self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
 
         self.ssim = SSIM()
@@ -213,7 +214,7 @@ class Trainer:
     # ------------------------------------------------------------------ trainer.py:233-237
     def train_step(self, inputs):
         outputs, losses = self.process_batch(inputs)
-        self.buckets.zero()                     # model_optimizer.zero_grad(): grads are views of the buckets
+        self.buckets.zero()                     # model_optimizer.zero_grad(set_to_none=True)
         losses["loss"].backward()
         self.buckets.finish()                   # RCCL all-reduce (mean) launched from the backward hooks
         self.model_optimizer.step()

@@ -27,7 +27,15 @@ def main():
         t = torch.eye(4, device=dev).repeat(B, 1, 1)
         t[:, :3, 3] = 0.01 * torch.randn(B, 3, device=dev, generator=g)
         T.append(t.requires_grad_())
-    disps = [torch.rand(B, 1, H >> s, W >> s, device=dev, generator=g).requires_grad_() for s in range(4)]
+    # smooth disparity fields (a network's output is smooth; per-pixel white noise would scatter every
+    # bilinear gather over 64 cache lines and benchmark the texture path instead of the kernel)
+    def smooth_disp(h, w):
+        lo = torch.rand(B, 1, 6, 20, device=dev, generator=g)
+        return torch.nn.functional.interpolate(lo, size=(h, w), mode="bicubic", align_corners=False).clamp(0.01, 0.99)
+    if os.environ.get("DC_WHITE_NOISE_DISP"):
+        disps = [torch.rand(B, 1, H >> s, W >> s, device=dev, generator=g).requires_grad_() for s in range(4)]
+    else:
+        disps = [smooth_disp(H >> s, W >> s).contiguous().requires_grad_() for s in range(4)]
     noise = [torch.randn(B, 2, H, W, device=dev, generator=g) for _ in range(4)]
     for mode, nz in (("external-noise", noise), ("device-rng", None)):
         cfg = ops.PhotoConfig(imgs[0], imgs[1], imgs[2], color_s, K, invK, noise=nz)
