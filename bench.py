@@ -88,12 +88,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    local = local % torch.cuda.device_count()          # (rehearsals with several ranks on one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("DC_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
 
@@ -130,8 +135,16 @@ def main():
     prof = ops.profile_collect()
     ops.profile_enable(0)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    lossv = losses["loss"].detach().clone().reshape(1)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # replicas must stay in lock-step: after K identical Adam steps on averaged gradients the weights agree
+        wsum = torch.stack([p.detach().double().sum() for p in tr.parameters_to_train[:8]])
+        wmax, wmin = wsum.clone(), wsum.clone()
+        dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(wmin, op=dist.ReduceOp.MIN)
+        if float((wmax - wmin).abs().max()) > 1e-6 * float(wmax.abs().max() + 1):
+            raise SystemExit("replicas diverged: %r vs %r" % (wmax.tolist(), wmin.tolist()))
     dt = float(tmax.item())
     loss_last = float(losses["loss"].detach())
     if not (loss_last == loss_last):

@@ -164,6 +164,24 @@ double dc_photo_algorithmic_bytes(const dc_photo_desc* d, int backward);
 int dc_profile_enable(int max_launches);
 int dc_profile_collect(double* fwd_ms, int* fwd_launches, double* bwd_ms, int* bwd_launches);
 
+/* ------------------------------------------------------------------ a2/a3 decoder blocks */
+/* layers.py:106-136 + 196-199 and networks/depth_decoder.py:50-66 as ONE fp32-MFMA implicit GEMM:
+ *   y = act( conv3x3( pad1( cat( up2?(x0), x1 ) ) ) + bias )
+ * x0 (B,C0,H>>up0,W>>up0) nearest-upsampled x2 on the fly when up0=1, x1 (B,C1,H,W) nullable skip,
+ * weight (Co,C0+C1,3,3), bias nullable; act: 0 none, 1 ELU, 2 sigmoid; pad_mode: 0 ReflectionPad2d(1),
+ * 1 ZeroPad2d(1).  Output (B,Co,H,W).  ws: dc_conv3x3_fwd_workspace bytes. */
+size_t dc_conv3x3_fwd_workspace(int C0, int C1, int Co);
+int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
+                   const float* bias, float* y, void* ws, int B, int Co, int H, int W, int act, int pad_mode,
+                   void* stream);
+/* Backward: gy (B,Co,H,W) is the gradient wrt the *activated* output y (ELU / sigmoid derivatives are
+ * taken from y).  Produces dx0 (pre-upsample shape, 2x2-summed when up0), dx1, dweight, dbias (each
+ * nullable).  ws: dc_conv3x3_bwd_workspace bytes.  Deterministic (no atomics). */
+size_t dc_conv3x3_bwd_workspace(int C0, int C1, int B, int Co, int H, int W);
+int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
+                   const float* y, const float* gy, float* dx0, float* dx1, float* dweight, float* dbias,
+                   void* ws, int B, int Co, int H, int W, int act, int pad_mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

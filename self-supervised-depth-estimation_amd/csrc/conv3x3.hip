@@ -1,0 +1,489 @@
+// Fused 3x3 convolution blocks of the depth decoder (reference layers.py:106-136,196-199 and
+// networks/depth_decoder.py:50-66) as fp32 MFMA implicit GEMMs for gfx950:
+//
+//     y = act( conv3x3( pad1( cat( nearest_x2?(x0), x1 ) ) ) + bias )
+//
+// forward : M = Co, N = pixels, K = Cin*9.  The nearest x2 upsample, the channel concat and the
+//           ReflectionPad (or ZeroPad) are index arithmetic in the global->LDS staging of the input patch;
+//           bias + ELU / sigmoid are the epilogue.  None of those tensors ever exists in HBM.
+// dgrad   : the same GEMM on g' = gy * act'(y) with flipped / transposed weights over the PADDED output
+//           domain (H+2 x W+2); `conv_fold_kernel` then folds the reflected border back, sums the 2x2
+//           blocks of the upsampled half and splits the concat -- deterministic, no atomics.
+// wgrad   : M = Co, N = Cin*9, K = pixels, split-K over pixel tiles into fp32 partial slabs + fixed-order
+//           reduce (also produces dbias).
+// Exact fp32: v_mfma_f32_16x16x4_f32 (k-ordered fmaf chain), so parity with the fp32 reference holds to
+// summation order.
+#include "dc_common.h"
+
+namespace dc {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int CT = 16;                 // pixel tile: CT x CT outputs per block
+constexpr int CK = 8;                  // input channels per K chunk
+constexpr int PW_ = CT + 2;            // patch width / height
+constexpr int PS_ = 336;               // patch plane stride in floats (>= 18*18, == 16 mod 32)
+
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2 };
+enum { PAD_REFLECT = 0, PAD_ZERO = 1 };
+
+struct ConvArgs {
+    const float* x0; int C0; int up0;
+    const float* x1; int C1;
+    const float* wt;       // prepared weights: fwd [9][Cin][Co]; dgrad [9][Co][Cin] (flipped taps)
+    const float* bias;
+    const float* y;        // dgrad / wgrad: activated output (for act')
+    const float* gy;
+    float* out;            // fwd: y (B,Co,H,W); dgrad: dxpad (B,Cin,H+2,W+2)
+    int B, Co, H, W, act, pad;
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
+    if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+// derivative expressed through the activated output y
+__device__ __forceinline__ float act_bwd(float y, int act) {
+    if (act == ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    if (act == ACT_SIGMOID) return y * (1.f - y);
+    return 1.f;
+}
+
+__device__ __forceinline__ int pad_index(int i, int n, int pad, bool& ok) {
+    ok = true;
+    if (i >= 0 && i < n) return i;
+    if (pad == PAD_REFLECT) {
+        i = i < 0 ? -i : 2 * n - 2 - i;
+        return min(max(i, 0), n - 1);
+    }
+    ok = false;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight preparation: W (Co,Cin,3,3) -> wf [9][Cin][Co] and wd [9][Co][Cin] with flipped taps
+// ------------------------------------------------------------------------------------------------
+__global__ void conv_wprep_kernel(const float* w, float* wf, float* wd, int Co, int Cin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = Co * Cin * 9;
+    if (i >= n) return;
+    const int t = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
+    const float v = w[i];
+    if (wf) wf[((size_t)t * Cin + ci) * Co + co] = v;
+    if (wd) wd[((size_t)(8 - t) * Co + co) * Cin + ci] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad GEMM.  grid (tiles_x*tiles_y, ceil(M/(16*MR)), B), block 256 (4 waves, wave w = rows 4w..4w+3)
+// ------------------------------------------------------------------------------------------------
+template <int MR, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+    constexpr int MT = 16 * MR;
+    constexpr int WS = MT + 16 + (MR == 1 ? 16 : 0);      // weight row stride, == 16 mod 32
+    __shared__ float patch[CK * PS_];
+    __shared__ float wl[9 * CK * WS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, b = blockIdx.z;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * CT, ox0 = tx * CT;               // tile origin in the OUTPUT domain
+    const int m0 = blockIdx.y * MT;
+    const int H = a.H, W = a.W;
+    const int Cin = a.C0 + a.C1;
+    // GEMM dims of this mode
+    const int Mtot = DGRAD ? Cin : a.Co;
+    const int Ktot = DGRAD ? a.Co : Cin;
+    const int OH = DGRAD ? H + 2 : H, OW = DGRAD ? W + 2 : W;
+    const int h0 = H >> a.up0, w0 = W >> a.up0;
+
+    f4 acc[MR][4];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < Ktot; k0 += CK) {
+        // ---- stage the input patch of CK channels (fused upsample / concat / padding, or g' for dgrad)
+        for (int e = tid; e < CK * PW_ * PW_; e += 256) {
+            const int kc = e / (PW_ * PW_), rem = e - kc * (PW_ * PW_);
+            const int r = rem / PW_, c = rem - r * PW_;
+            const int ch = k0 + kc;
+            float v = 0.f;
+            if (ch < Ktot) {
+                if (!DGRAD) {
+                    bool oky, okx;
+                    const int yy = pad_index(oy0 + r - 1, H, a.pad, oky), xx = pad_index(ox0 + c - 1, W, a.pad, okx);
+                    if (oky && okx) {
+                        v = (ch < a.C0) ? a.x0[(((size_t)b * a.C0 + ch) * h0 + (yy >> a.up0)) * w0 + (xx >> a.up0)]
+                                        : a.x1[(((size_t)b * a.C1 + (ch - a.C0)) * H + yy) * W + xx];
+                    }
+                } else {
+                    const int yy = oy0 + r - 2, xx = ox0 + c - 2;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        const size_t o = (((size_t)b * a.Co + ch) * H + yy) * W + xx;
+                        v = a.gy[o] * act_bwd(a.y[o], a.act);
+                    }
+                }
+            }
+            patch[kc * PS_ + r * PW_ + c] = v;
+        }
+        // ---- stage the weights of the chunk: wl[t][kc][m] = wt[t][k0+kc][m0+m]
+        for (int e = tid; e < 9 * CK * MT; e += 256) {
+            const int m = e % MT, kc = (e / MT) % CK, t = e / (MT * CK);
+            float v = 0.f;
+            if (k0 + kc < Ktot && m0 + m < Mtot) v = a.wt[((size_t)t * Ktot + k0 + kc) * Mtot + m0 + m];
+            wl[(t * CK + kc) * WS + m] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+            for (int kk = 0; kk < CK / 4; ++kk) {
+                const int kc = kk * 4 + (lane >> 4);
+                float af[MR], bf[4];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) af[i] = wl[(t * CK + kc) * WS + i * 16 + (lane & 15)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = patch[kc * PS_ + (wave * 4 + j + ky) * PW_ + (lane & 15) + kx];
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C/D layout col (pixel x) = lane&15, row (m) = (lane>>4)*4 + reg
+    const int px = ox0 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int py = oy0 + wave * 4 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + (lane >> 4) * 4 + r;
+                if (m < Mtot && py < OH && px < OW) {
+                    float v = acc[i][j][r];
+                    if (!DGRAD) v = act_fwd(v + (a.bias ? a.bias[m] : 0.f), a.act);
+                    a.out[(((size_t)b * Mtot + m) * OH + py) * OW + px] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fold: dxpad (B,Cin,H+2,W+2) -> dx0 (B,C0,H>>up,W>>up) [2x2 sum when up], dx1 (B,C1,H,W)
+// reflect:  d x[r] = dxpad[r] + (r==1 ? dxpad[-1] : 0) + (r==H-2 ? dxpad[H] : 0), same along x.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fold_at(const float* p, int r, int c, int H, int W, int pad) {
+    const int PWd = W + 2;
+    // padded coordinates that map onto (r,c)
+    int rs[3], cs[3], nr = 1, nc = 1;
+    rs[0] = r; cs[0] = c; rs[1] = r; cs[1] = c;
+    if (pad == PAD_REFLECT) {
+        if (r == 1) rs[nr++] = -1;
+        if (r == H - 2) rs[nr++] = H;
+        if (c == 1) cs[nc++] = -1;
+        if (c == W - 2) cs[nc++] = W;
+    }
+    // (H == 3 would need three sources per axis; H, W >= 4 is enforced by the entry point)
+    float v = 0.f;
+    for (int i = 0; i < nr; ++i)
+        for (int j = 0; j < nc; ++j) v += p[(size_t)(rs[i] + 1) * PWd + cs[j] + 1];
+    return v;
+}
+
+__global__ void conv_fold_kernel(const float* dxpad, float* dx0, float* dx1, int B, int C0, int C1, int up0, int H,
+                                 int W, int pad) {
+    const int Cin = C0 + C1;
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const float* p = dxpad + ((size_t)b * Cin + ch) * (H + 2) * (W + 2);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < C0) {
+        if (!dx0) return;
+        const int h0 = H >> up0, w0 = W >> up0;
+        if (i >= h0 * w0) return;
+        const int y = i / w0, x = i - y * w0;
+        float v;
+        if (up0) {
+            v = (fold_at(p, 2 * y, 2 * x, H, W, pad) + fold_at(p, 2 * y, 2 * x + 1, H, W, pad)) +
+                (fold_at(p, 2 * y + 1, 2 * x, H, W, pad) + fold_at(p, 2 * y + 1, 2 * x + 1, H, W, pad));
+        } else {
+            v = fold_at(p, y, x, H, W, pad);
+        }
+        dx0[((size_t)b * C0 + ch) * h0 * w0 + i] = v;
+    } else {
+        if (!dx1) return;
+        if (i >= H * W) return;
+        const int y = i / W, x = i - y * W;
+        dx1[((size_t)b * C1 + (ch - C0)) * H * W + i] = fold_at(p, y, x, H, W, pad);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dW[co][ci][t] = sum_{b,y,x} g'[b,co,y,x] * xpad[b,ci,y+ky-1,x+kx-1]
+// GEMM M = Co (16*MR per block), N = 16 (ci) per n-subtile x 9 taps, K = pixels (4 per MFMA).
+// grid (split, ceil(Co/(16*MR)), ceil(Cin/CW)), block 256; block loops over its share of the pixel tiles.
+// Each wave takes a quarter of the tile's pixel rows and all (ci, tap) columns of the chunk; the four
+// waves' accumulators are summed through LDS in fixed order, then written as one partial slab.
+// ------------------------------------------------------------------------------------------------
+constexpr int CW = 16;                 // input channels per wgrad block
+constexpr int GS_ = 273;               // g' plane stride (16*16 + 17), odd
+constexpr int XS_ = 325;               // x patch plane stride (18*18 + 1), odd
+
+struct WgradArgs {
+    const float* x0; int C0; int up0;
+    const float* x1; int C1;
+    const float* y; const float* gy;
+    float* part;           // [split][Co][Cin*9]
+    float* pbias;          // [split][Co]  (written by the blocks with blockIdx.z == 0)
+    int B, Co, H, W, act, pad;
+    int tiles_x, tiles_y, split;
+};
+
+template <int MR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int MT = 16 * MR;
+    __shared__ float gl[MT * GS_];
+    __shared__ float xl[CW * XS_];
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * MT, c0 = blockIdx.z * CW;
+    const int H = a.H, W = a.W, Cin = a.C0 + a.C1;
+    const int h0 = H >> a.up0, w0 = W >> a.up0;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+
+    f4 acc[MR][9];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = f4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;    // dbias partial of channel m0 + (tid % MT) over a slice of pixels (tid / MT)
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += a.split) {
+        const int b = tile / (a.tiles_x * a.tiles_y), tt = tile - b * (a.tiles_x * a.tiles_y);
+        const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+        const int oy0 = ty * CT, ox0 = tx * CT;
+        // g' tile [MT][16x16]
+        for (int e = tid; e < MT * CT * CT; e += 256) {
+            const int m = e / (CT * CT), rem = e - m * (CT * CT);
+            const int r = rem / CT, c = rem - r * CT;
+            const int yy = oy0 + r, xx = ox0 + c, co = m0 + m;
+            float v = 0.f;
+            if (co < a.Co && yy < H && xx < W) {
+                const size_t o = (((size_t)b * a.Co + co) * H + yy) * W + xx;
+                v = a.gy[o] * act_bwd(a.y[o], a.act);
+            }
+            gl[m * GS_ + r * CT + c] = v;
+        }
+        // x patch [CW][18x18] (fused upsample / concat / padding)
+        for (int e = tid; e < CW * PW_ * PW_; e += 256) {
+            const int kc = e / (PW_ * PW_), rem = e - kc * (PW_ * PW_);
+            const int r = rem / PW_, c = rem - r * PW_;
+            const int ch = c0 + kc;
+            float v = 0.f;
+            if (ch < Cin) {
+                bool oky, okx;
+                const int yy = pad_index(oy0 + r - 1, H, a.pad, oky), xx = pad_index(ox0 + c - 1, W, a.pad, okx);
+                if (oky && okx && (oy0 + r - 1) <= H && (ox0 + c - 1) <= W) {
+                    v = (ch < a.C0) ? a.x0[(((size_t)b * a.C0 + ch) * h0 + (yy >> a.up0)) * w0 + (xx >> a.up0)]
+                                    : a.x1[(((size_t)b * a.C1 + (ch - a.C0)) * H + yy) * W + xx];
+                }
+            }
+            xl[kc * XS_ + r * PW_ + c] = v;
+        }
+        __syncthreads();
+        if (blockIdx.z == 0 && tid < MT * (256 / MT)) {
+            const int m = tid % MT, sl = tid / MT, nsl = 256 / MT;
+            for (int q = sl; q < CT * CT; q += nsl) bsum += gl[m * GS_ + q];
+        }
+        // K loop: the wave's 4 rows x 16 columns = 64 pixels, 4 pixels (along x) per MFMA
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 4 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = q * 4 + (lane >> 4);       // pixel of this lane's k index
+                float af[MR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) af[i] = gl[(i * 16 + (lane & 15)) * GS_ + row * CT + col];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t - ky * 3;
+                    const float bf = xl[(lane & 15) * XS_ + (row + ky) * PW_ + col + kx];
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- sum the four waves (fixed order) and write the slab: part[split][co][ci*9 + t]
+    float* slab = a.part + (size_t)blockIdx.x * a.Co * Cin * 9;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[wave][lane] = acc[i][t][r];
+                __syncthreads();
+                if (wave == 0) {
+                    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+                    const int co = m0 + i * 16 + (lane >> 4) * 4 + r, ci = c0 + (lane & 15);
+                    if (co < a.Co && ci < Cin) slab[((size_t)co * Cin + ci) * 9 + t] = v;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (blockIdx.z == 0) {
+        // dbias partial: reduce the 256/MT slices per channel through LDS (gl is free now)
+        __syncthreads();
+        gl[tid] = bsum;
+        __syncthreads();
+        if (tid < MT && m0 + tid < a.Co) {
+            float v = 0.f;
+            for (int sl = 0; sl < 256 / MT; ++sl) v += gl[sl * MT + tid];
+            a.pbias[(size_t)blockIdx.x * a.Co + m0 + tid] = v;
+        }
+    }
+}
+
+// fixed-order reduction of the split-K slabs: block = 16 outputs x 16 slab groups; each thread sums its
+// group's slabs in order, the 16 group sums are then added in order through LDS.
+__global__ __launch_bounds__(256) void conv_wreduce_kernel(const float* part, const float* pbias, float* dw, float* db,
+                                                           int split, int nW, int Co) {
+    __shared__ float sm[16][17];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
+    const int per = (split + 15) / 16;
+    float v = 0.f;
+    if (i < nW + Co) {
+        const float* src = (i < nW) ? part + i : pbias + (i - nW);
+        const size_t stride = (i < nW) ? (size_t)nW : (size_t)Co;
+        const int s1 = min(split, (grp + 1) * per);
+        for (int s = grp * per; s < s1; ++s) v += src[(size_t)s * stride];
+    }
+    sm[grp][o] = v;
+    __syncthreads();
+    if (grp == 0 && i < nW + Co) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][o];
+        if (i < nW) { if (dw) dw[i] = t; }
+        else if (db) db[i - nW] = t;
+    }
+}
+
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline int pick_mr(int M) { return M > 32 ? 4 : (M > 16 ? 2 : 1); }
+static inline int pick_mr_w(int M) { return M > 16 ? 2 : 1; }   // wgrad: LDS holds the g' tile of 16*MR channels
+static inline int pick_split(int B, int H, int W, int Co, int Cin) {
+    const int ntiles = ceil_div(W, CT) * ceil_div(H, CT) * B;
+    const int outer = ceil_div(Co, 16 * pick_mr_w(Co)) * ceil_div(Cin, CW);
+    int split = std::max(1, std::min(ntiles, 2048 / std::max(outer, 1)));
+    return std::min(split, 512);
+}
+
+}  // namespace dc
+
+using namespace dc;
+#define ST ((hipStream_t)stream)
+
+extern "C" size_t dc_conv3x3_fwd_workspace(int C0, int C1, int Co) {
+    if (C0 < 0 || C1 < 0 || C0 + C1 <= 0 || Co <= 0) return 0;
+    return al256((size_t)9 * (C0 + C1) * Co * sizeof(float));
+}
+
+extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
+                              const float* bias, float* y, void* ws, int B, int Co, int H, int W, int act,
+                              int pad_mode, void* stream) {
+    if (!x0 || C0 <= 0 || (C1 > 0 && !x1) || C1 < 0 || !weight || !y || !ws || B <= 0 || Co <= 0 || H < 2 || W < 2)
+        return DC_EINVAL;
+    if (up0 && ((H | W) & 1)) return DC_EINVAL;
+    if (act < 0 || act > 2 || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
+    const int Cin = C0 + C1;
+    float* wf = (float*)ws;
+    hipLaunchKernelGGL(conv_wprep_kernel, dim3(ceil_div(Co * Cin * 9, 256)), dim3(256), 0, ST, weight, wf,
+                       (float*)nullptr, Co, Cin);
+    DC_CHECK_LAUNCH();
+    ConvArgs a{};
+    a.x0 = x0; a.C0 = C0; a.up0 = up0 ? 1 : 0; a.x1 = x1; a.C1 = C1; a.wt = wf; a.bias = bias; a.out = y;
+    a.B = B; a.Co = Co; a.H = H; a.W = W; a.act = act; a.pad = pad_mode;
+    a.tiles_x = ceil_div(W, CT); a.tiles_y = ceil_div(H, CT);
+    const int mr = pick_mr(Co);
+    const dim3 grid(a.tiles_x * a.tiles_y, ceil_div(Co, 16 * mr), B);
+    if (mr == 4) hipLaunchKernelGGL((conv_gemm_kernel<4, false>), grid, dim3(256), 0, ST, a);
+    else if (mr == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, false>), grid, dim3(256), 0, ST, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<1, false>), grid, dim3(256), 0, ST, a);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" size_t dc_conv3x3_bwd_workspace(int C0, int C1, int B, int Co, int H, int W) {
+    if (C0 <= 0 || C1 < 0 || B <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;
+    const int Cin = C0 + C1;
+    const size_t nW = (size_t)Co * Cin * 9;
+    const int split = pick_split(B, H, W, Co, Cin);
+    return al256(nW * 4) + al256((size_t)B * Cin * (H + 2) * (W + 2) * 4) + al256((size_t)split * nW * 4) +
+           al256((size_t)split * Co * 4);
+}
+
+extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
+                              const float* y, const float* gy, float* dx0, float* dx1, float* dweight, float* dbias,
+                              void* ws, int B, int Co, int H, int W, int act, int pad_mode, void* stream) {
+    if (!x0 || C0 <= 0 || (C1 > 0 && !x1) || C1 < 0 || !weight || !y || !gy || !ws || B <= 0 || Co <= 0 || H < 2 || W < 2)
+        return DC_EINVAL;
+    if (up0 && ((H | W) & 1)) return DC_EINVAL;
+    if (act < 0 || act > 2 || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
+    const int Cin = C0 + C1;
+    const size_t nW = (size_t)Co * Cin * 9;
+    const int split = pick_split(B, H, W, Co, Cin);
+    char* p = (char*)ws;
+    float* wd = (float*)p; p += al256(nW * 4);
+    float* dxpad = (float*)p; p += al256((size_t)B * Cin * (H + 2) * (W + 2) * 4);
+    float* part = (float*)p; p += al256((size_t)split * nW * 4);
+    float* pbias = (float*)p;
+    const int tiles_x = ceil_div(W, CT), tiles_y = ceil_div(H, CT);
+    if (dx0 || dx1) {
+        hipLaunchKernelGGL(conv_wprep_kernel, dim3(ceil_div((int)nW, 256)), dim3(256), 0, ST, weight, (float*)nullptr, wd,
+                           Co, Cin);
+        DC_CHECK_LAUNCH();
+        ConvArgs a{};
+        a.C0 = C0; a.C1 = C1; a.up0 = up0 ? 1 : 0; a.wt = wd; a.y = y; a.gy = gy; a.out = dxpad;
+        a.B = B; a.Co = Co; a.H = H; a.W = W; a.act = act; a.pad = pad_mode;
+        a.tiles_x = ceil_div(W + 2, CT); a.tiles_y = ceil_div(H + 2, CT);
+        const int mr = pick_mr(Cin);
+        const dim3 grid(a.tiles_x * a.tiles_y, ceil_div(Cin, 16 * mr), B);
+        if (mr == 4) hipLaunchKernelGGL((conv_gemm_kernel<4, true>), grid, dim3(256), 0, ST, a);
+        else if (mr == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, true>), grid, dim3(256), 0, ST, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<1, true>), grid, dim3(256), 0, ST, a);
+        DC_CHECK_LAUNCH();
+        const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
+        hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0,
+                           C1, up0 ? 1 : 0, H, W, pad_mode);
+        DC_CHECK_LAUNCH();
+    }
+    if (dweight || dbias) {
+        WgradArgs g{};
+        g.x0 = x0; g.C0 = C0; g.up0 = up0 ? 1 : 0; g.x1 = x1; g.C1 = C1; g.y = y; g.gy = gy; g.part = part; g.pbias = pbias;
+        g.B = B; g.Co = Co; g.H = H; g.W = W; g.act = act; g.pad = pad_mode;
+        g.tiles_x = tiles_x; g.tiles_y = tiles_y; g.split = split;
+        const int mr = pick_mr_w(Co);
+        const dim3 grid(split, ceil_div(Co, 16 * mr), ceil_div(Cin, CW));
+        if (mr == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, ST, g);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), 0, ST, g);
+        DC_CHECK_LAUNCH();
+        hipLaunchKernelGGL(conv_wreduce_kernel, dim3(ceil_div((int)nW + Co, 16)), dim3(256), 0, ST, part, pbias, dweight,
+                           dbias, split, (int)nW, Co);
+        DC_CHECK_LAUNCH();
+    }
+    return DC_OK;
+}

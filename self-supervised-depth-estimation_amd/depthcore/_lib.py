@@ -78,6 +78,10 @@ def _sig(lib):
         "dc_photo_fwd": (i, [POINTER(PhotoDesc), p]),
         "dc_photo_bwd": (i, [POINTER(PhotoDesc), p]),
         "dc_photo_algorithmic_bytes": (c_double, [POINTER(PhotoDesc), i]),
+        "dc_conv3x3_fwd_workspace": (z, [i, i, i]),
+        "dc_conv3x3_fwd": (i, [p, i, i, p, i, p, p, p, p, i, i, i, i, i, i, p]),
+        "dc_conv3x3_bwd_workspace": (z, [i, i, i, i, i, i]),
+        "dc_conv3x3_bwd": (i, [p, i, i, p, i, p, p, p, p, p, p, p, p, i, i, i, i, i, i, p]),
         "dc_profile_enable": (i, [i]),
         "dc_profile_collect": (i, [POINTER(c_double), POINTER(c_int), POINTER(c_double), POINTER(c_int)]),
     }

@@ -412,3 +412,58 @@ def profile_collect():
     check(_lib.lib().dc_profile_collect(ctypes.byref(fm), ctypes.byref(fn), ctypes.byref(bm), ctypes.byref(bn)),
           "dc_profile_collect")
     return {"fwd_ms": fm.value, "fwd_launches": fn.value, "bwd_ms": bm.value, "bwd_launches": bn.value}
+
+
+# ----------------------------------------------------------------------------------------------
+# a2/a3 fused decoder block: act(conv3x3(pad1(cat(up2?(x0), x1))) + bias)
+#                                   (reference layers.py:106-136,196-199; networks/depth_decoder.py:50-66)
+# ----------------------------------------------------------------------------------------------
+ACT_NONE, ACT_ELU, ACT_SIGMOID = 0, 1, 2
+PAD_REFLECT, PAD_ZERO = 0, 1
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, up0, act, pad):
+        L = _lib.lib()
+        a0 = _c(x0.detach())
+        a1 = _c(x1.detach()) if x1 is not None else None
+        w = _c(weight.detach())
+        bs = _c(bias.detach()) if bias is not None else None
+        B, C0, h0, w0 = a0.shape
+        H, W = (h0 * 2, w0 * 2) if up0 else (h0, w0)
+        C1 = 0 if a1 is None else a1.shape[1]
+        Co = w.shape[0]
+        if tuple(w.shape) != (Co, C0 + C1, 3, 3):
+            raise _lib.DepthcoreError("weight %s does not match inputs (%d+%d channels)" % (tuple(w.shape), C0, C1))
+        if a1 is not None and tuple(a1.shape) != (B, C1, H, W):
+            raise _lib.DepthcoreError("skip tensor %s must be %s" % (tuple(a1.shape), (B, C1, H, W)))
+        y = torch.empty(B, Co, H, W, dtype=torch.float32, device=a0.device)
+        ws = torch.empty(L.dc_conv3x3_fwd_workspace(C0, C1, Co), dtype=torch.uint8, device=a0.device)
+        check(L.dc_conv3x3_fwd(ptr(a0), C0, int(up0), ptr(a1), C1, ptr(w), ptr(bs), ptr(y), ws.data_ptr(), B, Co, H, W,
+                               int(act), int(pad), stream()), "dc_conv3x3_fwd")
+        ctx.save_for_backward(a0, a1, w, y)
+        ctx.cfg = (int(up0), int(act), int(pad), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        a0, a1, w, y = ctx.saved_tensors
+        up0, act, pad, has_bias = ctx.cfg
+        B, C0 = a0.shape[0], a0.shape[1]
+        C1 = 0 if a1 is None else a1.shape[1]
+        Co, H, W = y.shape[1], y.shape[2], y.shape[3]
+        need = ctx.needs_input_grad
+        dx0 = torch.empty_like(a0) if need[0] else None
+        dx1 = torch.empty_like(a1) if (a1 is not None and need[1]) else None
+        dw = torch.empty_like(w) if need[2] else None
+        db = torch.empty(Co, dtype=torch.float32, device=y.device) if (has_bias and need[3]) else None
+        ws = torch.empty(L.dc_conv3x3_bwd_workspace(C0, C1, B, Co, H, W), dtype=torch.uint8, device=y.device)
+        check(L.dc_conv3x3_bwd(ptr(a0), C0, up0, ptr(a1), C1, ptr(w), ptr(y), ptr(_c(gy)), ptr(dx0), ptr(dx1), ptr(dw),
+                               ptr(db), ws.data_ptr(), B, Co, H, W, act, pad, stream()), "dc_conv3x3_bwd")
+        return dx0, dx1, dw, db, None, None, None
+
+
+def conv3x3_block(x0, x1, weight, bias, up0=False, act=ACT_NONE, pad=PAD_REFLECT):
+    return _Conv3x3.apply(x0, x1, weight, bias, up0, act, pad)

@@ -34,29 +34,46 @@ def rot_from_axisangle(vec):
     return _ops.pose_matrix(vec, torch.zeros_like(vec), False)
 
 
+FUSED_CONV_MIN_PIXELS = 48 * 160     # output pixels per image from which the fused MFMA block is used
+
+
 class Conv3x3(nn.Module):
-    """layers.py:119-136: pad (reflection or zero) + 3x3 conv.  Sub-modules `.pad`, `.conv` as in the
-    reference so state_dict keys match (`conv.weight`, `conv.bias`)."""
+    """layers.py:119-136: pad (reflection or zero) + 3x3 conv, as one dc_conv3x3 launch.  Sub-modules `.pad`,
+    `.conv` are kept as in the reference so state_dict keys match (`conv.weight`, `conv.bias`); `.conv` only
+    holds the parameters."""
 
     def __init__(self, in_channels, out_channels, use_refl=True):
         super().__init__()
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
+        self._pad_mode = _ops.PAD_REFLECT if use_refl else _ops.PAD_ZERO
 
-    def forward(self, x):
-        return self.conv(self.pad(x))
+    def forward(self, x, skip=None, up=False, act=_ops.ACT_NONE):
+        H, W = (x.shape[2] * 2, x.shape[3] * 2) if up else (x.shape[2], x.shape[3])
+        if H * W >= FUSED_CONV_MIN_PIXELS:
+            return _ops.conv3x3_block(x, skip, self.conv.weight, self.conv.bias, up, act, self._pad_mode)
+        # Small maps with wide channels (decoder levels 4-3: 6x20 .. 24x80) are dense contractions whose 16x16
+        # pixel tiles would be mostly padding; they take the library GEMM path until the batched-N variant of
+        # the MFMA kernel lands (DESIGN.md section 7).  Same arithmetic, separate launches.
+        if up:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+        if skip is not None:
+            x = torch.cat([x, skip], 1)
+        y = self.conv(self.pad(x))
+        return F.elu(y) if act == _ops.ACT_ELU else (torch.sigmoid(y) if act == _ops.ACT_SIGMOID else y)
 
 
 class ConvBlock(nn.Module):
-    """layers.py:106-116: Conv3x3 + ELU."""
+    """layers.py:106-116: Conv3x3 + ELU (fused).  `forward(x, skip, up=True)` additionally fuses the decoder's
+    `upsample(x)` + `torch.cat([.., skip], 1)` (networks/depth_decoder.py:56-60) into the same launch."""
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.conv = Conv3x3(in_channels, out_channels)
         self.nonlin = nn.ELU(inplace=True)
 
-    def forward(self, x):
-        return self.nonlin(self.conv(x))
+    def forward(self, x, skip=None, up=False):
+        return self.conv(x, skip, up, _ops.ACT_ELU)
 
 
 class BackprojectDepth(nn.Module):

@@ -7,7 +7,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from layers import ConvBlock, Conv3x3, upsample
+from layers import ConvBlock, Conv3x3
+from depthcore.ops import ACT_SIGMOID as _ACT_SIGMOID
 
 
 class DepthDecoder(nn.Module):
@@ -32,14 +33,14 @@ class DepthDecoder(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, input_features, pre_disp=False):
+        """depth_decoder.py:50-67.  Each level is two launches: upconv(i,0), then nearest-x2 + skip concat +
+        upconv(i,1) fused; the dispconv + sigmoid is a third."""
         self.outputs = {}
         x = input_features[-1]
         for i in range(4, -1, -1):
             x = self.convs[("upconv", i, 0)](x)
-            x = [upsample(x)]
-            if self.use_skips and i > 0:
-                x += [input_features[i - 1]]
-            x = self.convs[("upconv", i, 1)](torch.cat(x, 1))
+            skip = input_features[i - 1] if (self.use_skips and i > 0) else None
+            x = self.convs[("upconv", i, 1)](x, skip, up=True)
             if i in self.scales:
-                self.outputs[("disp", i)] = x if pre_disp else self.sigmoid(self.convs[("dispconv", i)](x))
+                self.outputs[("disp", i)] = x if pre_disp else self.convs[("dispconv", i)](x, act=_ACT_SIGMOID)
         return self.outputs

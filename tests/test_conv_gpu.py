@@ -1,0 +1,127 @@
+"""The fused decoder conv blocks (dc_conv3x3_fwd/bwd: fp32 MFMA implicit GEMM with fused nearest-x2,
+concat, reflection pad, bias, ELU/sigmoid) vs the CPU oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu as R
+import make_golden as MG
+from helpers import T, close, close_frac, rel_l2
+from self_check_shapes import dec_state, pose_state
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def oracle_block(x0, x1, w, b, up, act, pad):
+    x = R.upsample_nearest2(x0) if up else x0
+    if x1 is not None:
+        x = torch.cat([x, x1], 1)
+    xp = R._reflect_pad1(x) if pad == 0 else F.pad(x, (1, 1, 1, 1))
+    y = F.conv2d(xp, w, b)
+    return F.elu(y) if act == 1 else (torch.sigmoid(y) if act == 2 else y)
+
+
+CASES = [
+    # B, C0, C1, Co, H, W, up, act, pad
+    (2, 5, 0, 7, 10, 12, False, 1, 0),
+    (1, 16, 0, 16, 32, 48, True, 1, 0),
+    (2, 32, 64, 32, 24, 40, True, 1, 0),
+    (2, 24, 0, 1, 20, 36, False, 2, 0),
+    (1, 40, 24, 72, 18, 22, True, 1, 0),
+    (2, 12, 0, 20, 17, 19, False, 0, 1),
+    (1, 64, 0, 64, 6, 20, False, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_block_vs_oracle(case):
+    from depthcore import ops
+    B, C0, C1, Co, H, W, up, act, pad = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case))
+    h0, w0 = (H // 2, W // 2) if up else (H, W)
+    x0 = torch.randn(B, C0, h0, w0, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    w = torch.randn(Co, C0 + C1, 3, 3, generator=g) * (1.0 / np.sqrt(9 * (C0 + C1)))
+    b = torch.randn(Co, generator=g) * 0.1
+    cot = torch.randn(B, Co, H, W, generator=g)
+    leaves = [t.clone().requires_grad_() for t in (x0, w, b)] + ([x1.clone().requires_grad_()] if C1 else [])
+    yo = oracle_block(leaves[0], leaves[3] if C1 else None, leaves[1], leaves[2], up, act, pad)
+    go = torch.autograd.grad((yo * cot).sum(), leaves)
+    dl = [t.to(DEV).requires_grad_() for t in (x0, w, b)] + ([x1.to(DEV).requires_grad_()] if C1 else [])
+    yh = ops.conv3x3_block(dl[0], dl[3] if C1 else None, dl[1], dl[2], up, act, pad)
+    gh = torch.autograd.grad((yh * cot.to(DEV)).sum(), dl)
+    close(yh, yo, rtol=1e-4, atol=1e-5)
+    for a, c, name in zip(gh, go, ["dx0", "dw", "db", "dx1"]):
+        assert rel_l2(a, c) < 1e-4, (name, rel_l2(a, c))
+        close(a, c, rtol=1e-3, atol=1e-3 * float(c.abs().max()), msg=name)
+
+
+def test_convblock_golden(golden):
+    import layers
+    g = golden["layers_ops"]
+    cb = layers.ConvBlock(5, 7).to(DEV)
+    with torch.no_grad():
+        cb.conv.conv.weight.copy_(T(g["cb_w"]))
+        cb.conv.conv.bias.copy_(T(g["cb_b"]))
+    x = T(g["cb_x"]).to(DEV).requires_grad_()
+    y = layers.upsample(cb(x))
+    close(y, g["cb_out"], rtol=1e-4, atol=1e-5)
+    gx, gw, gb = torch.autograd.grad((y * T(g["cb_cot"]).to(DEV)).sum(), [x, cb.conv.conv.weight, cb.conv.conv.bias])
+    close(gx, g["cb_gx"], rtol=1e-3, atol=1e-4)
+    close(gw, g["cb_gw"], rtol=1e-3, atol=1e-3)
+    close(gb, g["cb_gb"], rtol=1e-3, atol=1e-3)
+
+
+def test_depth_decoder_golden(golden, monkeypatch):
+    """networks.DepthDecoder (all levels through dc_conv3x3) vs the reference decoder's golden outputs/grads."""
+    import networks
+    import layers
+    monkeypatch.setattr(layers, "FUSED_CONV_MIN_PIXELS", 0)
+    g = golden["decoders"]
+    nce = np.array([64, 64, 128, 256, 512])
+    dec = networks.DepthDecoder(nce).to(DEV)
+    sd = dec_state(nce, 3)
+    assert list(dec.state_dict().keys()) == list(g["dec_keys"])
+    dec.load_state_dict(sd)
+    feats, gen = MG.decoder_features(nce)
+    feats = [f.to(DEV).requires_grad_() for f in feats]
+    o = dec(feats)
+    tot = 0
+    for s in range(4):
+        close(o[("disp", s)], g["dec_disp%d" % s], rtol=1e-3, atol=1e-5)
+        tot = tot + (o[("disp", s)] * T(g["dec_cot%d" % s]).to(DEV)).sum()
+    names = [n for n, _ in dec.named_parameters()]
+    grads = torch.autograd.grad(tot, feats + [p for _, p in dec.named_parameters()])
+    for i in range(5):
+        got = grads[i].cpu() if i >= 3 else torch.from_numpy(MG.summ(grads[i]))
+        close(got, g["dec_gfeat%d" % i], rtol=2e-3, atol=2e-4)
+    for j, k in enumerate(names):
+        gk = grads[5 + j].cpu()
+        got = gk if gk.numel() <= 4096 else torch.from_numpy(MG.summ(gk))
+        close(got, g["dec_g_" + k], rtol=3e-3, atol=3e-3)
+    o2 = dec([f.detach() for f in feats], pre_disp=True)
+    close(MG.summ(o2[("disp", 0)]), g["dec_predisp0"], rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("min_pixels", [0, 48 * 160])
+def test_decoder_full_size_determinism(min_pixels, monkeypatch):
+    import networks
+    import layers
+    monkeypatch.setattr(layers, "FUSED_CONV_MIN_PIXELS", min_pixels)
+    nce = np.array([64, 64, 128, 256, 512])
+    torch.manual_seed(0)
+    dec = networks.DepthDecoder(nce).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    feats = [torch.randn(4, int(c), 96 >> i, 320 >> i, device=DEV, generator=g, requires_grad=True) for i, c in enumerate(nce)]
+    res = []
+    for _ in range(2):
+        o = dec(feats)
+        tot = sum(o[("disp", s)].square().sum() for s in range(4))
+        gr = torch.autograd.grad(tot, feats + list(dec.parameters()))
+        res.append([o[("disp", s)].clone() for s in range(4)] + [x.clone() for x in gr])
+    if min_pixels == 0:
+        for a, b in zip(*res):
+            assert torch.equal(a, b)          # split-K slabs reduced in fixed order: bitwise reproducible
+    assert o[("disp", 0)].shape == (4, 1, 192, 640)

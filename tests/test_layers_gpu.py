@@ -44,7 +44,7 @@ def test_disp_to_depth(golden):
     (gd,) = torch.autograd.grad(dep.sum() + 2 * sd.sum(), [d])
     rng = 1 / 0.1 - 1 / 100.0
     want = (-(dep.detach().double() ** 2) * rng + 2 * rng).float()
-    close(gd, want, rtol=1e-4, atol=1e-2)          # |d depth/d disp| reaches 1e5 at disp -> 0
+    assert float(((gd - want).abs() / (want.abs() + 1.0)).max()) < 1e-4     # |d depth/d disp| reaches 1e5
     e = layers.disp_to_depth(torch.tensor([0.0, 1.0], device=DEV), 0.1, 100.0)
     close(e[0], [0.01, 10.0]); close(e[1], [100.0, 0.1], rtol=1e-6)
 
