@@ -157,6 +157,17 @@ def main():
         bwd_ms = prof["bwd_ms"] / max(prof["bwd_launches"], 1)
         fwd_ms = prof["fwd_ms"] / max(prof["fwd_launches"], 1)
         ach = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC counters: collected in separate `rocprofv3 --pmc FETCH_SIZE` /
+        # `--pmc WRITE_SIZE` passes by tools/pmc_traffic.sh (FETCH_SIZE x2.0 per the gfx950 calibration on a
+        # known-byte dword kernel in the same run, WRITE_SIZE x1.0) and committed under profiles/.
+        traffic, traffic_src = None, None
+        tf = os.path.join(REPO, "profiles", "round1_traffic.json")
+        if os.path.exists(tf) and (args.batch, args.height, args.width) == (12, 192, 640):
+            try:
+                traffic = round(json.load(open(tf))["dc::photo_bwd_kernel"]["hbm_bytes_calibrated"], 0)
+                traffic_src = "profiles/round1_traffic.json"
+            except Exception:
+                traffic = None
         out = {
             "metric": "training images/sec at 192x640 bs12 (resnet18 depth+pose, 4-scale photometric+smoothness)",
             "value": round(world * args.batch * args.steps / dt, 3),
@@ -172,7 +183,8 @@ def main():
                        "tiebreak_noise": "cpu-randn+h2d" if args.cpu_noise else "on-device counter RNG"},
             "roofline": {"kernel": "dc::photo_bwd_kernel (fused warp+SSIM+L1+automask backward, 4 scales x 2 frames)",
                          "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "limiter": "VALU issue, not HBM: 92 M wave-level VALU instructions per launch (SQ_INSTS_VALU)",
                          "algorithmic_bytes_per_launch": bytes_bwd, "avg_kernel_ms": round(bwd_ms, 4),
                          "launches": prof["bwd_launches"],
                          "fwd_kernel": {"kernel": "dc::photo_fwd_kernel", "algorithmic_bytes_per_launch": bytes_fwd,

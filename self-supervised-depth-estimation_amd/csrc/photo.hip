@@ -46,7 +46,8 @@ struct PhotoArgs {
     float ry[DC_MAX_SCALES], rx[DC_MAX_SCALES];
     const float* noise[DC_MAX_SCALES];
     unsigned long long seed;
-    float* idl;                        // identity losses (B, 2|1, H, W)
+    float* idl;                        // identity losses, pixel-interleaved (B, H, W, 2|1)
+    float* pk[3];                      // pixel-interleaved RGBx copies (B,H,W,4) of target / source -1 / source +1
     uint8_t* argmin[DC_MAX_SCALES];
     float* depth[DC_MAX_SCALES];
     float* sample[DC_MAX_SCALES][2];
@@ -86,6 +87,25 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 __device__ __forceinline__ float bload(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
+typedef float f3 __attribute__((ext_vector_type(3)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef int i3 __attribute__((ext_vector_type(3)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f3 bload3(rsrc_t r, unsigned voff) {      // one RGB pixel of a packed image
+    return __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, 0, 0));
+}
+__device__ __forceinline__ f2 bload2(rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0));
+}
+__device__ __forceinline__ void bstore4(rsrc_t r, unsigned voff, float a, float b, float c, float d) {
+    f4v v = {a, b, c, d};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void bstore2(rsrc_t r, unsigned voff, float a, float b) {
+    f2 v = {a, b};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i2, v), r, (int)voff, 0, 0);
+}
 __device__ __forceinline__ void bstore(rsrc_t r, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 0);
 }
@@ -124,6 +144,7 @@ struct Ctx {   // per-wave constants (scalar registers)
     int H, W;
     unsigned plane4;        // bytes of one channel plane
     rsrc_t tg, s0, s1;      // target / source -1 / source +1 of this batch element (3 planes each)
+    rsrc_t ptg, ps0, ps1;   // their pixel-interleaved RGBx copies (16 B per pixel)
     rsrc_t dp;              // disparity of this (scale, batch element)
     int hs, ws;
     float ry, rx;
@@ -140,6 +161,9 @@ __device__ __forceinline__ void make_ctx(Ctx& c, const PhotoArgs& p, int b, int 
     c.tg = make_rsrc(p.target + img, 3u * c.plane4);
     c.s0 = make_rsrc(p.src[0] + img, 3u * c.plane4);
     c.s1 = make_rsrc(p.src[1] + img, 3u * c.plane4);
+    c.ptg = make_rsrc(p.pk[0] + (size_t)b * plane * 4, 4u * c.plane4);
+    c.ps0 = make_rsrc(p.pk[1] + (size_t)b * plane * 4, 4u * c.plane4);
+    c.ps1 = make_rsrc(p.pk[2] + (size_t)b * plane * 4, 4u * c.plane4);
     c.hs = p.hs[s]; c.ws = p.ws[s];
     c.ry = p.ry[s]; c.rx = p.rx[s];
     c.full = (c.hs == p.H && c.ws == p.W);
@@ -174,8 +198,8 @@ __device__ __forceinline__ float disp_value(const DispTaps& t, const Ctx& c) {
 // ---- one pixel, both source frames: disp -> depth -> BackprojectDepth -> Project3D -> grid_sample
 // coordinates (layers.py:21-24,163-192; trainer.py:508-511), with the 3 + 12 + 12 loads left in flight.
 struct Taps {
-    float t[3];          // target
-    float tap[2][3][4];  // [frame][channel][nw, ne, sw, se]
+    f3 t;                // target pixel (RGB)
+    f3 tap[2][4];        // [frame][nw, ne, sw, se] RGB pixels
     float wx1[2], wy1[2];
     float sx[2], sy[2];  // backward only: d(ix)/du, d(iy)/dv incl. the border-clamp zero
 };
@@ -184,7 +208,7 @@ struct RowLog {          // forward, only when the log tensors are requested
 };
 
 struct TapOff {
-    unsigned o00, o01, o10, o11;   // byte offsets inside one plane
+    unsigned o00, o01, o10, o11;   // byte offsets inside a packed (16 B / pixel) image
     float wx1, wy1;
 };
 __device__ __forceinline__ TapOff tap_offsets(float x, float y, int H, int W) {
@@ -195,10 +219,10 @@ __device__ __forceinline__ TapOff tap_offsets(float x, float y, int H, int W) {
     t.wx1 = x - xf;
     t.wy1 = y - yf;
     const int r0 = y0 * W, r1 = y1 * W;
-    t.o00 = (unsigned)(r0 + x0) * 4u;
-    t.o01 = (unsigned)(r0 + x1) * 4u;
-    t.o10 = (unsigned)(r1 + x0) * 4u;
-    t.o11 = (unsigned)(r1 + x1) * 4u;
+    t.o00 = (unsigned)(r0 + x0) * 16u;
+    t.o01 = (unsigned)(r0 + x1) * 16u;
+    t.o10 = (unsigned)(r1 + x0) * 16u;
+    t.o11 = (unsigned)(r1 + x1) * 16u;
     return t;
 }
 
@@ -207,9 +231,7 @@ __device__ __forceinline__ TapOff tap_offsets(float x, float y, int H, int W) {
 template <int MODE, bool LOGS>
 __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, float disp, int x, int y, RowLog& lg,
                                           float* park) {
-    const unsigned o = (unsigned)(y * c.W + x) * 4u;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) r.t[ch] = bload(c.tg, o, ch * c.plane4);
+    r.t = bload3(c.ptg, (unsigned)(y * c.W + x) * 16u);
     const float scaled = c.min_disp + c.disp_range * disp;
     const float depth = frcp(scaled);
     const float xf = (float)x, yf = (float)y;
@@ -251,14 +273,10 @@ __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, f
         r.wx1[f] = to[f].wx1;
         r.wy1[f] = to[f].wy1;
     }
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const unsigned so = ch * c.plane4;
-        r.tap[0][ch][0] = bload(c.s0, to[0].o00, so); r.tap[1][ch][0] = bload(c.s1, to[1].o00, so);
-        r.tap[0][ch][1] = bload(c.s0, to[0].o01, so); r.tap[1][ch][1] = bload(c.s1, to[1].o01, so);
-        r.tap[0][ch][2] = bload(c.s0, to[0].o10, so); r.tap[1][ch][2] = bload(c.s1, to[1].o10, so);
-        r.tap[0][ch][3] = bload(c.s0, to[0].o11, so); r.tap[1][ch][3] = bload(c.s1, to[1].o11, so);
-    }
+    r.tap[0][0] = bload3(c.ps0, to[0].o00); r.tap[1][0] = bload3(c.ps1, to[1].o00);
+    r.tap[0][1] = bload3(c.ps0, to[0].o01); r.tap[1][1] = bload3(c.ps1, to[1].o01);
+    r.tap[0][2] = bload3(c.ps0, to[0].o10); r.tap[1][2] = bload3(c.ps1, to[1].o10);
+    r.tap[0][3] = bload3(c.ps0, to[0].o11); r.tap[1][3] = bload3(c.ps1, to[1].o11);
 }
 
 struct Row {   // raw values of one image row at the lane's own pixel: target + both warped frames
@@ -273,7 +291,7 @@ __device__ __forceinline__ void blend_row(const Taps& r, Row& o) {
         const float wnw = wx0 * wy0, wne = r.wx1[f] * wy0, wsw = wx0 * r.wy1[f], wse = r.wx1[f] * r.wy1[f];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
-            o.w[f][ch] = r.tap[f][ch][0] * wnw + r.tap[f][ch][1] * wne + r.tap[f][ch][2] * wsw + r.tap[f][ch][3] * wse;
+            o.w[f][ch] = r.tap[f][0][ch] * wnw + r.tap[f][1][ch] * wne + r.tap[f][2][ch] * wsw + r.tap[f][3][ch] * wse;
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) o.t[ch] = r.t[ch];
@@ -353,6 +371,8 @@ __device__ __forceinline__ float rng_normal(unsigned long long seed, unsigned id
 // ------------------------------------------------------------------------------------------------
 constexpr int ID_ROWS = 8;
 
+// IDENT = false: only the repack (opt.disable_automasking)
+template <bool IDENT>
 __global__ __launch_bounds__(64) void identity_kernel(PhotoArgs p) {
     const int lane = threadIdx.x;
     const int b = blockIdx.z;
@@ -365,7 +385,8 @@ __global__ __launch_bounds__(64) void identity_kernel(PhotoArgs p) {
     const bool no_ssim = p.flags & DC_OPT_NO_SSIM;
     const bool avg = p.flags & DC_OPT_AVG_REPROJ;
     const bool lane_ok = lane >= 1 && lane <= 62 && x < W;
-    const rsrc_t idl = make_rsrc(p.idl + (size_t)b * (avg ? 1 : 2) * (c.plane4 / 4), (avg ? 1u : 2u) * c.plane4);
+    const unsigned nidl = avg ? 1u : 2u;
+    const rsrc_t idl = make_rsrc(p.idl + (size_t)b * nidl * (c.plane4 / 4), nidl * c.plane4);
 
     Row rA = {}, rB = {}, nxt;
     auto load_row = [&](int yy) {
@@ -381,16 +402,21 @@ __global__ __launch_bounds__(64) void identity_kernel(PhotoArgs p) {
         const int yy = y0 - 1 + i;
         const Row cur = nxt;
         load_row(yy + 1);   // next row flies during this row's math
-        float r[2];
-        reproj_values(r_old, r_new, cur, no_ssim, r);
-        const int py = yy - 1;
-        if (i >= 2 && py < H && lane_ok) {
-            const unsigned o = (unsigned)(py * W + x) * 4u;
-            if (avg) {
-                bstore(idl, o, 0, (r[0] + r[1]) * 0.5f);
-            } else {
-                bstore(idl, o, 0, r[0]);
-                bstore(idl, o, c.plane4, r[1]);
+        // pixel-interleaved copies of the three images for the gather kernels (rows this wave owns)
+        if (i >= 1 && i <= ID_ROWS && yy < H && lane_ok) {
+            const unsigned o = (unsigned)(yy * W + x) * 16u;
+            bstore4(c.ptg, o, cur.t[0], cur.t[1], cur.t[2], 0.f);
+            bstore4(c.ps0, o, cur.w[0][0], cur.w[0][1], cur.w[0][2], 0.f);
+            bstore4(c.ps1, o, cur.w[1][0], cur.w[1][1], cur.w[1][2], 0.f);
+        }
+        if (IDENT) {
+            float r[2];
+            reproj_values(r_old, r_new, cur, no_ssim, r);
+            const int py = yy - 1;
+            if (i >= 2 && py < H && lane_ok) {
+                const unsigned o = (unsigned)(py * W + x);
+                if (avg) bstore(idl, o * 4u, 0, (r[0] + r[1]) * 0.5f);
+                else bstore2(idl, o * 8u, r[0], r[1]);
             }
         }
         r_old = cur;
@@ -427,7 +453,8 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
     const unsigned nch4 = (avg ? 1u : 2u) * c.plane4;
     const bool ext_noise = p.noise[s] != nullptr;
     const rsrc_t nz = make_rsrc(ext_noise ? p.noise[s] + (size_t)b * (avg ? 1 : 2) * plane : p.idl, ext_noise ? nch4 : 0u);
-    const rsrc_t idl = make_rsrc(p.idl + (size_t)b * (avg ? 1 : 2) * plane, automask ? nch4 : 0u);
+    const rsrc_t idl = make_rsrc(p.idl + (size_t)b * (avg ? 1 : 2) * plane, automask ? nch4 : 0u);   // (B,H,W,2|1)
+    const unsigned idl_px = avg ? 4u : 8u;
     uint8_t* am = p.argmin[s] + (size_t)b * plane;
     float* isel = p.idsel[s] ? p.idsel[s] + (size_t)b * plane : nullptr;
 
@@ -448,11 +475,12 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
         if (LOGS) lg_cur = lg_nxt;
         issue_row<0, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), lg_nxt, nullptr);
         {   // identity loss + tie-break noise of the row the NEXT step outputs (row yy)
-            const unsigned o = (unsigned)(min(max(yy, 0), H - 1) * W + xr) * 4u;
-            idn_nxt[0] = bload(idl, o, 0);
-            idn_nxt[1] = bload(idl, o, c.plane4);
-            idn_nxt[2] = bload(nz, o, 0);
-            idn_nxt[3] = bload(nz, o, c.plane4);
+            const unsigned px = (unsigned)(min(max(yy, 0), H - 1) * W + xr);
+            const f2 id2 = bload2(idl, px * idl_px);       // avg: .x is the value (the .y read is discarded)
+            idn_nxt[0] = id2.x;
+            idn_nxt[1] = id2.y;
+            idn_nxt[2] = bload(nz, px * 4u, 0);
+            idn_nxt[3] = bload(nz, px * 4u, c.plane4);
         }
         disp_issue(dt, c, xr, reflect_clamp(yy + 2, H));
 
@@ -697,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
             const float wx1 = tp.wx1[f], wy1 = tp.wy1[f], wx0 = 1.f - wx1, wy0 = 1.f - wy1;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const float nw = tp.tap[f][ch][0], ne = tp.tap[f][ch][1], sw = tp.tap[f][ch][2], se = tp.tap[f][ch][3];
+                const float nw = tp.tap[f][0][ch], ne = tp.tap[f][1][ch], sw = tp.tap[f][2][ch], se = tp.tap[f][3][ch];
                 const float top = fmaf(ne - nw, wx1, nw), bot = fmaf(se - sw, wx1, sw);
                 cur.w[f][ch] = fmaf(bot - top, wy1, top);
                 const float Dx = fmaf((se - sw) - (ne - nw), wy1, ne - nw) * tp.sx[f];
@@ -973,7 +1001,7 @@ __global__ __launch_bounds__(64) void pose_grad_kernel(PhotoArgs p) {
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Carve {
-    size_t idl, part_photo, part_smooth, stats, gdup[DC_MAX_SCALES], part_dP, total;
+    size_t idl, pk[3], part_photo, part_smooth, stats, gdup[DC_MAX_SCALES], part_dP, total;
     int nblk_f, nchunk, nblk_b_img, strips_f, strips_b, rowblocks;
 };
 
@@ -988,6 +1016,7 @@ static Carve carve(const dc_photo_desc* d) {
     c.nchunk = ceil_div(d->H * d->W, SM_CHUNK);
     size_t off = 0;
     c.idl = off; off += align256(N * 2 * 4);
+    for (int k = 0; k < 3; ++k) { c.pk[k] = off; off += align256(N * 16); }
     c.part_photo = off; off += align256((size_t)d->num_scales * c.nblk_f * 4);
     c.part_smooth = off; off += align256((size_t)d->num_scales * d->B * c.nchunk * 3 * 4);
     c.stats = off; off += align256((size_t)d->num_scales * d->B * 3 * 4);
@@ -1046,6 +1075,7 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
     }
     a.losses = d->losses;
     a.idl = (float*)(ws + c.idl);
+    for (int k = 0; k < 3; ++k) a.pk[k] = (float*)(ws + c.pk[k]);
     a.part_photo = (float*)(ws + c.part_photo);
     a.part_smooth = (float*)(ws + c.part_smooth);
     a.stats = (float*)(ws + c.stats);
@@ -1129,10 +1159,12 @@ extern "C" int dc_photo_fwd(const dc_photo_desc* d, void* stream) {
     int rc = fill_args(d, a, c, false);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (!(a.flags & DC_OPT_NO_AUTOMASK)) {
-        hipLaunchKernelGGL(identity_kernel, dim3(c.strips_f, ceil_div(a.H, ID_ROWS), a.B), dim3(64), 0, st, a);
-        DC_CHECK_LAUNCH();
-    }
+    // identity losses + the pixel-interleaved image copies the gather kernels read (forward AND backward)
+    if (!(a.flags & DC_OPT_NO_AUTOMASK))
+        hipLaunchKernelGGL(identity_kernel<true>, dim3(c.strips_f, ceil_div(a.H, ID_ROWS), a.B), dim3(64), 0, st, a);
+    else
+        hipLaunchKernelGGL(identity_kernel<false>, dim3(c.strips_f, ceil_div(a.H, ID_ROWS), a.B), dim3(64), 0, st, a);
+    DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3(c.nchunk, a.B, a.ns), dim3(256), 0, st, a);
     DC_CHECK_LAUNCH();
     bool logs = false;

@@ -172,7 +172,8 @@ class _PoseMatrix(torch.autograd.Function):
         aa, tr = ctx.saved_tensors
         B = aa.shape[0]
         daa, dtr = torch.empty_like(aa), torch.empty_like(tr)
-        check(L.dc_pose_matrix_bwd(ptr(aa), ptr(tr), ctx.invert, ptr(_c(gM)), ptr(daa), ptr(dtr), B, stream()),
+        g_c = _c(gM)      # named: stays alive until the launch is enqueued
+        check(L.dc_pose_matrix_bwd(ptr(aa), ptr(tr), ctx.invert, ptr(g_c), ptr(daa), ptr(dtr), B, stream()),
               "dc_pose_matrix_bwd")
         return daa.reshape(ctx.shapes[0]), dtr.reshape(ctx.shapes[1]), None
 
@@ -201,9 +202,12 @@ class _DispToDepth(torch.autograd.Function):
         L = _lib.lib()
         (d,) = ctx.saved_tensors
         out = torch.empty_like(d)
-        check(L.dc_disp_to_depth_bwd(ptr(d), ptr(_c(gs)) if gs is not None else None,
-                                     ptr(_c(gd)) if gd is not None else None, ptr(out), d.numel(), ctx.lim[0],
-                                     ctx.lim[1], stream()), "dc_disp_to_depth_bwd")
+        # keep both contiguous temporaries alive across the call: two unnamed temporaries would be freed and
+        # could be handed the SAME block by the caching allocator before the launch
+        gs_c = _c(gs) if gs is not None else None
+        gd_c = _c(gd) if gd is not None else None
+        check(L.dc_disp_to_depth_bwd(ptr(d), ptr(gs_c), ptr(gd_c), ptr(out), d.numel(), ctx.lim[0], ctx.lim[1],
+                                     stream()), "dc_disp_to_depth_bwd")
         return out, None, None
 
 
@@ -239,7 +243,8 @@ class _Backproject(torch.autograd.Function):
         (ik,) = ctx.saved_tensors
         B, _, H, W = ctx.shape
         dd = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
-        check(L.dc_backproject_bwd(ptr(_c(g)), ptr(ik), ptr(dd), B, H, W, stream()), "dc_backproject_bwd")
+        g_c = _c(g)      # named: stays alive until the launch is enqueued
+        check(L.dc_backproject_bwd(ptr(g_c), ptr(ik), ptr(dd), B, H, W, stream()), "dc_backproject_bwd")
         return dd, None
 
 
@@ -269,7 +274,8 @@ class _Project3D(torch.autograd.Function):
         B, H, W, eps = ctx.dims
         dp, dT = torch.empty_like(p), torch.empty_like(t)
         ws = torch.empty(L.dc_project3d_bwd_workspace(B, H, W), dtype=torch.uint8, device=p.device)
-        check(L.dc_project3d_bwd(ptr(p), ptr(k), ptr(t), ptr(_c(g)), ptr(dp), ptr(dT), ws.data_ptr(), B, H, W, eps,
+        g_c = _c(g)      # named: stays alive until the launch is enqueued
+        check(L.dc_project3d_bwd(ptr(p), ptr(k), ptr(t), ptr(g_c), ptr(dp), ptr(dT), ws.data_ptr(), B, H, W, eps,
                                  stream()), "dc_project3d_bwd")
         return dp, None, dT, None, None, None
 
@@ -302,7 +308,8 @@ class _GridSample(torch.autograd.Function):
         B, C, H, W = im.shape
         Ho, Wo = g.shape[1], g.shape[2]
         dg = torch.empty_like(g)
-        check(L.dc_grid_sample_bwd(ptr(im), ptr(g), ptr(_c(go)), ptr(dg), B, C, H, W, Ho, Wo, ctx.ac, stream()),
+        g_c = _c(go)      # named: stays alive until the launch is enqueued
+        check(L.dc_grid_sample_bwd(ptr(im), ptr(g), ptr(g_c), ptr(dg), B, C, H, W, Ho, Wo, ctx.ac, stream()),
               "dc_grid_sample_bwd")
         return None, dg, None       # images are leaves without grad on this path
 
@@ -330,7 +337,8 @@ class _UpsampleBilinear(torch.autograd.Function):
         L = _lib.lib()
         B, C, h, w, Ho, Wo = ctx.dims
         dx = torch.empty(B, C, h, w, dtype=torch.float32, device=go.device)
-        check(L.dc_upsample_bilinear_bwd(ptr(_c(go)), ptr(dx), B * C, h, w, Ho, Wo, stream()), "dc_upsample_bilinear_bwd")
+        g_c = _c(go)      # named: stays alive until the launch is enqueued
+        check(L.dc_upsample_bilinear_bwd(ptr(g_c), ptr(dx), B * C, h, w, Ho, Wo, stream()), "dc_upsample_bilinear_bwd")
         return dx, None, None
 
 
@@ -359,7 +367,8 @@ class _SSIM(torch.autograd.Function):
         B, C, H, W = xx.shape
         dx = torch.empty_like(xx) if ctx.needs_input_grad[0] else None
         dy = torch.empty_like(yy) if ctx.needs_input_grad[1] else None
-        check(L.dc_ssim_bwd(ptr(xx), ptr(yy), ptr(_c(go)), ptr(dx), ptr(dy), B * C, H, W, stream()), "dc_ssim_bwd")
+        g_c = _c(go)      # named: stays alive until the launch is enqueued
+        check(L.dc_ssim_bwd(ptr(xx), ptr(yy), ptr(g_c), ptr(dx), ptr(dy), B * C, H, W, stream()), "dc_ssim_bwd")
         return dx, dy
 
 
@@ -389,7 +398,8 @@ class _Smooth(torch.autograd.Function):
         d, im = ctx.saved_tensors
         B, _, h, w = d.shape
         dd = torch.empty_like(d)
-        check(L.dc_smooth_bwd(ptr(d), ptr(im), ptr(_c(g.reshape(1))), ptr(dd), B, im.shape[1], h, w, stream()),
+        g_c = _c(g.reshape(1))      # named: stays alive until the launch is enqueued
+        check(L.dc_smooth_bwd(ptr(d), ptr(im), ptr(g_c), ptr(dd), B, im.shape[1], h, w, stream()),
               "dc_smooth_bwd")
         return dd, None
 
@@ -460,7 +470,8 @@ class _Conv3x3(torch.autograd.Function):
         dw = torch.empty_like(w) if need[2] else None
         db = torch.empty(Co, dtype=torch.float32, device=y.device) if (has_bias and need[3]) else None
         ws = torch.empty(L.dc_conv3x3_bwd_workspace(C0, C1, B, Co, H, W), dtype=torch.uint8, device=y.device)
-        check(L.dc_conv3x3_bwd(ptr(a0), C0, up0, ptr(a1), C1, ptr(w), ptr(y), ptr(_c(gy)), ptr(dx0), ptr(dx1), ptr(dw),
+        g_c = _c(gy)      # named: stays alive until the launch is enqueued
+        check(L.dc_conv3x3_bwd(ptr(a0), C0, up0, ptr(a1), C1, ptr(w), ptr(y), ptr(g_c), ptr(dx0), ptr(dx1), ptr(dw),
                                ptr(db), ws.data_ptr(), B, Co, H, W, act, pad, stream()), "dc_conv3x3_bwd")
         return dx0, dx1, dw, db, None, None, None
 

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Workload for the HBM-traffic PMC passes: a calibration kernel with a KNOWN dword-access byte count
+(dc_disp_to_depth_fwd on 64 Mi floats: reads 256 MiB, writes 512 MiB) followed by the fused photometric
+forward + backward at BASELINE config 2.  Run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+(separate passes); tools/pmc_traffic.sh prints calibrated bytes per launch."""
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "self-supervised-depth-estimation_amd"))
+from depthcore import ops  # noqa: E402
+from depthcore.synthetic import synthetic_batch  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    big = torch.rand(64 << 20, device=dev)
+    for _ in range(3):
+        ops.disp_to_depth(big, 0.1, 100.0)
+    torch.cuda.synchronize()
+    B, H, W = 12, 192, 640
+    inp = synthetic_batch(B, H, W, dev, seed=0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    disps = []
+    for s in range(4):
+        lo = torch.rand(B, 1, 6, 20, device=dev, generator=g)
+        disps.append(torch.nn.functional.interpolate(lo, size=(H >> s, W >> s), mode="bicubic").clamp(0.01, 0.99)
+                     .contiguous().requires_grad_())
+    T = []
+    for f in range(2):
+        t = torch.eye(4, device=dev).repeat(B, 1, 1)
+        t[:, :3, 3] = 0.01 * torch.randn(B, 3, device=dev, generator=g)
+        T.append(t.requires_grad_())
+    cfg = ops.PhotoConfig(inp[("color", 0, 0)], inp[("color", -1, 0)], inp[("color", 1, 0)],
+                          [inp[("color", 0, s)] for s in range(4)], inp[("K", 0)], inp[("inv_K", 0)])
+    for _ in range(5):
+        # flush the 256 MiB Infinity Cache between steps so that reads come from HBM, as in a training step
+        big.mul_(1.0)
+        l = ops.photometric_loss(cfg, T[0], T[1], disps)
+        l[4].backward()
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()

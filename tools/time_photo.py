@@ -37,8 +37,12 @@ def main():
     else:
         disps = [smooth_disp(H >> s, W >> s).contiguous().requires_grad_() for s in range(4)]
     noise = [torch.randn(B, 2, H, W, device=dev, generator=g) for _ in range(4)]
+    kw = {}
+    for k in os.environ.get("DC_PHOTO_FLAGS", "").split(","):
+        if k:
+            kw[k] = True
     for mode, nz in (("external-noise", noise), ("device-rng", None)):
-        cfg = ops.PhotoConfig(imgs[0], imgs[1], imgs[2], color_s, K, invK, noise=nz)
+        cfg = ops.PhotoConfig(imgs[0], imgs[1], imgs[2], color_s, K, invK, noise=nz, **kw)
         for _ in range(3):
             l = ops.photometric_loss(cfg, T[0], T[1], disps)
             l[4].backward()
