@@ -150,7 +150,10 @@ struct Ctx {   // per-wave constants (scalar registers)
     float ry, rx;
     bool full;              // scale 0: the upsample is the identity
     float min_disp, disp_range, inv_Wm1, inv_Hm1;
-    bool ac;
+    // source pixel coordinate of a projected point: ix = u*ax + bx, iy = v*ay + by.  This is Project3D's
+    // (u/(W-1) - 0.5)*2 (layers.py:190-192) composed with grid_sample's un-normalisation: for
+    // align_corners=False ix = ((g+1)*W - 1)/2 = u*W/(W-1) - 0.5, for True ix = u.
+    float ax, bx, ay, by;
 };
 
 __device__ __forceinline__ void make_ctx(Ctx& c, const PhotoArgs& p, int b, int s) {
@@ -170,7 +173,9 @@ __device__ __forceinline__ void make_ctx(Ctx& c, const PhotoArgs& p, int b, int 
     c.dp = make_rsrc(p.disp[s] + (size_t)b * c.hs * c.ws, (unsigned)(c.hs * c.ws) * 4u);
     c.min_disp = p.min_disp; c.disp_range = p.disp_range;
     c.inv_Wm1 = p.inv_Wm1; c.inv_Hm1 = p.inv_Hm1;
-    c.ac = p.flags & DC_OPT_ALIGN_CORNERS;
+    const bool ac = p.flags & DC_OPT_ALIGN_CORNERS;
+    c.ax = ac ? 1.f : (float)p.W * p.inv_Wm1; c.bx = ac ? 0.f : -0.5f;
+    c.ay = ac ? 1.f : (float)p.H * p.inv_Hm1; c.by = ac ? 0.f : -0.5f;
 }
 
 // ---- F.interpolate(disp_s, [H,W], bilinear, align_corners=False) at one pixel (trainer.py:474-475),
@@ -258,15 +263,14 @@ __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, f
         }
         const float zi = frcp(q[2] + 1e-7f);
         const float u = q[0] * zi, v = q[1] * zi;
-        const float gx = (u * c.inv_Wm1 - 0.5f) * 2.f;      // layers.py:190-192
-        const float gy = (v * c.inv_Hm1 - 0.5f) * 2.f;
-        float mx, my;
-        const float ix = unnormalize_clip(gx, c.W, c.ac, mx);
-        const float iy = unnormalize_clip(gy, c.H, c.ac, my);
-        if (MODE == 0 && LOGS) { lg.gx[f] = gx; lg.gy[f] = gy; }
+        // border padding: clamp, and no gradient where the unclamped coordinate is <= 0 or >= size-1 (ATen)
+        const float ixu = fmaf(u, c.ax, c.bx), iyu = fmaf(v, c.ay, c.by);
+        const float hx = (float)(c.W - 1), hy = (float)(c.H - 1);
+        const float ix = fminf(fmaxf(ixu, 0.f), hx), iy = fminf(fmaxf(iyu, 0.f), hy);
+        if (MODE == 0 && LOGS) { lg.gx[f] = (u * c.inv_Wm1 - 0.5f) * 2.f; lg.gy[f] = (v * c.inv_Hm1 - 0.5f) * 2.f; }
         if (MODE == 1) {
-            r.sx[f] = mx * (2.f * c.inv_Wm1);
-            r.sy[f] = my * (2.f * c.inv_Hm1);
+            r.sx[f] = (ixu > 0.f && ixu < hx) ? c.ax : 0.f;      // d(ix)/du
+            r.sy[f] = (iyu > 0.f && iyu < hy) ? c.ay : 0.f;
             park[(f * 3 + 0) * 64] = u; park[(f * 3 + 1) * 64] = v; park[(f * 3 + 2) * 64] = zi;
         }
         to[f] = tap_offsets(ix, iy, c.H, c.W);
@@ -354,15 +358,16 @@ __device__ __forceinline__ void reproj_values(const Row& a, const Row& b, const 
         out[f] = no_ssim ? l1[f] * (1.f / 3.f) : fmaf(0.85f / 3.f, ss[f], (0.15f / 3.f) * l1[f]);
 }
 
-// counter-based N(0,1) for the on-device tie-break noise (used only when no noise tensor is given)
+// On-device tie-break noise (used only when no noise tensor is given; trainer.py:594-595 adds randn*1e-5 to the
+// identity losses purely to break ties).  Counter-based: a 32-bit integer hash of (seed, pixel, stream); the
+// four bytes of the hash are summed (v_sad_u8) into an Irwin-Hall(4) variate, scaled to zero mean / unit variance.
 __device__ __forceinline__ float rng_normal(unsigned long long seed, unsigned idx, unsigned stream) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)idx * 8ull + stream + 1ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    float u1 = ((unsigned)(z >> 40) + 1u) * (1.f / 16777217.f);
-    float u2 = (unsigned)(z & 0xFFFFFFu) * (1.f / 16777216.f);
-    return sqrtf(-2.f * __logf(u1)) * __cosf(6.2831853f * u2);
+    unsigned h = idx * 0x9E3779B1u + (unsigned)seed + stream * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    h ^= h >> 12; h *= 0x297A2D39u;
+    h ^= h >> 15;
+    const unsigned sum4 = __builtin_amdgcn_sad_u8(h, 0u, 0u);       // sum of the four bytes, mean 510, sigma 147.8
+    return fmaf((float)sum4, 1.f / 147.8f, -510.f / 147.8f);
 }
 
 // ------------------------------------------------------------------------------------------------
