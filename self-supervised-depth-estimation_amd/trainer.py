@@ -10,6 +10,8 @@ Two equivalent loss paths, both on hand-written gfx950 kernels:
     (`depthcore.ops.photometric_loss`); log tensors are produced only when asked for;
   * layer-by-layer (`opt.fused_loss = False`): the reference's own sequence of `layers.*` calls.
 """
+import json
+import os
 import types
 
 import torch
@@ -210,6 +212,32 @@ class Trainer:
             losses["loss/{}".format(scale)] = loss
         losses["loss"] = total_loss / self.num_scales
         return losses
+
+    # ------------------------------------------------------------------ trainer.py:700-763
+    def save_model(self, folder):
+        """Reference checkpoint layout (trainer.py:711-729): `{name}.pth` = state_dict per model (the encoder's
+        additionally carries height / width / use_stereo) + `adam.pth`; options next to them as opt.json."""
+        os.makedirs(folder, exist_ok=True)
+        for name, model in self.models.items():
+            to_save = model.state_dict()
+            if name == "encoder":
+                to_save["height"], to_save["width"], to_save["use_stereo"] = self.opt.height, self.opt.width, False
+            torch.save(to_save, os.path.join(folder, "{}.pth".format(name)))
+        torch.save(self.model_optimizer.state_dict(), os.path.join(folder, "adam.pth"))
+        with open(os.path.join(folder, "opt.json"), "w") as f:
+            json.dump({k: v for k, v in vars(self.opt).items() if isinstance(v, (int, float, str, bool, list))}, f, indent=2)
+
+    def load_model(self, folder, models_to_load=("encoder", "depth", "pose_encoder", "pose")):
+        """trainer.py:731-763: keep only the keys the current model has (drops height/width/use_stereo)."""
+        for name in models_to_load:
+            path = os.path.join(folder, "{}.pth".format(name))
+            model_dict = self.models[name].state_dict()
+            pretrained = torch.load(path, map_location=self.device)
+            model_dict.update({k: v for k, v in pretrained.items() if k in model_dict})
+            self.models[name].load_state_dict(model_dict)
+        adam = os.path.join(folder, "adam.pth")
+        if os.path.isfile(adam):
+            self.model_optimizer.load_state_dict(torch.load(adam, map_location=self.device))
 
     # ------------------------------------------------------------------ trainer.py:233-237
     def train_step(self, inputs):
