@@ -182,6 +182,21 @@ int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, co
                    const float* y, const float* gy, float* dx0, float* dx1, float* dweight, float* dbias,
                    void* ws, int B, int Co, int H, int W, int act, int pad_mode, void* stream);
 
+/* ------------------------------------------------------------------ a1 BatchNorm + residual + ReLU */
+/* Training-mode nn.BatchNorm2d fused with the residual add and ReLU of torchvision's BasicBlock / Bottleneck
+ * (reached from networks/resnet_encoder.py:87-98): y = relu?( bn(x) [+ res] ).  x, res, y: (N,C,H,W) with
+ * HW = H*W; gamma, beta, save_mean, save_invstd, running_*: (C).  running_* nullable (then not updated);
+ * they are updated like torch (momentum, unbiased variance).  ws: dc_bn_workspace(N,C,HW) bytes. */
+size_t dc_bn_workspace(int N, int C, int HW);
+int dc_bn_relu_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                   float* save_mean, float* save_invstd, float* running_mean, float* running_var, void* ws,
+                   int N, int C, int HW, float eps, float momentum, int relu, void* stream);
+/* gy is the gradient wrt y; the ReLU mask is taken from y (required when relu=1).  dres (nullable) receives
+ * the gradient of the residual input; dgamma, dbeta nullable. */
+int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
+                   const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, void* ws,
+                   int N, int C, int HW, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

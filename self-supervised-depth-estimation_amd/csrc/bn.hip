@@ -1,0 +1,226 @@
+// Training-mode BatchNorm2d fused with the residual add and the ReLU of the ResNet trunks
+// (reference networks/resnet_encoder.py:87-98 via torchvision BasicBlock / Bottleneck:
+//   out = relu(bn(x));   out = relu(bn(x) + identity)).
+// All passes are HBM-bound streaming passes over NCHW fp32 tensors with float4 accesses:
+//   forward  : (1) per-channel sum / sum-of-squares partials, (2) finalize mean / invstd (+ running
+//              stats, momentum 0.1, unbiased variance like torch), (3) y = relu?(x_hat*gamma + beta [+ res]);
+//   backward : (1) per-channel partials of sum(g), sum(g*x_hat) with g = gy * [y > 0] (ReLU mask taken from
+//              the saved output), (2) dx = gamma*invstd*(g - mean(g) - x_hat*mean(g*x_hat)), dres = g.
+// Deterministic: fixed-order partial reductions, no atomics.
+#include "dc_common.h"
+
+namespace dc {
+
+constexpr int BN_CHUNK = 4096;     // elements of one (n, c) plane slice handled by one block in the stats passes
+
+__device__ __forceinline__ float block_sum256(float v, float* sm) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// grid (chunks_per_plane, C, N), block 256: partial[(c*N + n)*chunks + chunk] = {sum, sumsq}
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, float* part, int C, int HW) {
+    __shared__ float sm[4];
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float* p = x + ((size_t)n * C + c) * HW;
+    const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
+    float s = 0.f, q = 0.f;
+    if ((HW & 3) == 0) {
+        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            s += (v.x + v.y) + (v.z + v.w);
+            q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) { const float v = p[i]; s += v; q += v * v; }
+    }
+    s = block_sum256(s, sm);
+    q = block_sum256(q, sm);
+    if (threadIdx.x == 0) {
+        float* o = part + (((size_t)c * gridDim.z + n) * gridDim.x + blockIdx.x) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+
+// grid (C), block 64: mean / invstd (saved for backward) + running statistics
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* part, float* mean, float* invstd, float* run_mean,
+                                                         float* run_var, int nparts, float count, float eps,
+                                                         float momentum) {
+    const int c = blockIdx.x;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 64) { s += part[((size_t)c * nparts + i) * 2]; q += part[((size_t)c * nparts + i) * 2 + 1]; }
+    s = wave_sum(s); q = wave_sum(q);
+    if (threadIdx.x == 0) {
+        const float m = s / count;
+        const float var = fmaxf(q / count - m * m, 0.f);          // biased (used to normalise)
+        mean[c] = m;
+        invstd[c] = rsqrtf(var + eps);
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+        }
+    }
+}
+
+// grid (chunks, C, N), block 256: y = relu?((x - mean)*invstd*gamma + beta [+ res])
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* res, const float* mean,
+                                                       const float* invstd, const float* gamma, const float* beta,
+                                                       float* y, int C, int HW, int relu) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const size_t base = ((size_t)n * C + c) * HW;
+    const float a = invstd[c] * gamma[c], b = beta[c] - mean[c] * a;
+    const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
+    if ((HW & 3) == 0) {
+        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            float4 v = *reinterpret_cast<const float4*>(x + base + i);
+            v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
+            if (res) {
+                const float4 r = *reinterpret_cast<const float4*>(res + base + i);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(y + base + i) = v;
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            float v = fmaf(x[base + i], a, b);
+            if (res) v += res[base + i];
+            y[base + i] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+// backward stats: partial {sum g, sum g*x_hat}, g = gy*[y>0] when relu
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const float* y, const float* gy,
+                                                           const float* mean, const float* invstd, float* part, int C,
+                                                           int HW, int relu) {
+    __shared__ float sm[4];
+    const int c = blockIdx.y, n = blockIdx.z;
+    const size_t base = ((size_t)n * C + c) * HW;
+    const float m = mean[c], is = invstd[c];
+    const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
+    float s = 0.f, q = 0.f;
+    if ((HW & 3) == 0) {
+        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+            float4 g = *reinterpret_cast<const float4*>(gy + base + i);
+            if (relu) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            }
+            s += (g.x + g.y) + (g.z + g.w);
+            q += (g.x * (xv.x - m) + g.y * (xv.y - m)) + (g.z * (xv.z - m) + g.w * (xv.w - m));
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            float g = gy[base + i];
+            if (relu && !(y[base + i] > 0.f)) g = 0.f;
+            s += g; q += g * (x[base + i] - m);
+        }
+    }
+    s = block_sum256(s, sm);
+    q = block_sum256(q, sm) * is;
+    if (threadIdx.x == 0) {
+        float* o = part + (((size_t)c * gridDim.z + n) * gridDim.x + blockIdx.x) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+
+// grid (C), block 64: dgamma, dbeta + the two means the dx pass needs
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* part, float* dgamma, float* dbeta, float* mg,
+                                                             float* mgx, int nparts, float count) {
+    const int c = blockIdx.x;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 64) { s += part[((size_t)c * nparts + i) * 2]; q += part[((size_t)c * nparts + i) * 2 + 1]; }
+    s = wave_sum(s); q = wave_sum(q);
+    if (threadIdx.x == 0) {
+        if (dbeta) dbeta[c] = s;
+        if (dgamma) dgamma[c] = q;
+        mg[c] = s / count;
+        mgx[c] = q / count;
+    }
+}
+
+// dx = gamma*invstd*(g - mean(g) - x_hat*mean(g*x_hat)); dres = g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const float* y, const float* gy,
+                                                           const float* mean, const float* invstd, const float* gamma,
+                                                           const float* mg, const float* mgx, float* dx, float* dres,
+                                                           int C, int HW, int relu) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const size_t base = ((size_t)n * C + c) * HW;
+    const float m = mean[c], is = invstd[c], k = gamma[c] * is, a = mg[c], bq = mgx[c] * is;
+    const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
+    if ((HW & 3) == 0) {
+        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+            float4 g = *reinterpret_cast<const float4*>(gy + base + i);
+            if (relu) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            }
+            if (dres) *reinterpret_cast<float4*>(dres + base + i) = g;
+            float4 d;
+            d.x = k * (g.x - a - (xv.x - m) * bq); d.y = k * (g.y - a - (xv.y - m) * bq);
+            d.z = k * (g.z - a - (xv.z - m) * bq); d.w = k * (g.w - a - (xv.w - m) * bq);
+            *reinterpret_cast<float4*>(dx + base + i) = d;
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            float g = gy[base + i];
+            if (relu && !(y[base + i] > 0.f)) g = 0.f;
+            if (dres) dres[base + i] = g;
+            dx[base + i] = k * (g - a - (x[base + i] - m) * bq);
+        }
+    }
+}
+
+}  // namespace dc
+
+using namespace dc;
+#define ST ((hipStream_t)stream)
+
+extern "C" size_t dc_bn_workspace(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    return ((size_t)C * N * ceil_div(HW, BN_CHUNK) * 2 + 2 * (size_t)C) * sizeof(float);
+}
+
+extern "C" int dc_bn_relu_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                              float* save_mean, float* save_invstd, float* running_mean, float* running_var, void* ws,
+                              int N, int C, int HW, float eps, float momentum, int relu, void* stream) {
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || N <= 0 || C <= 0 || HW <= 0) return DC_EINVAL;
+    const int chunks = ceil_div(HW, BN_CHUNK);
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, part, C, HW);
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, ST, part, save_mean, save_invstd, running_mean,
+                       running_var, N * chunks, (float)N * (float)HW, eps, momentum);
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, res, save_mean, save_invstd, gamma, beta,
+                       y, C, HW, relu);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, const float* gamma,
+                              const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dgamma,
+                              float* dbeta, void* ws, int N, int C, int HW, int relu, void* stream) {
+    if (!x || !gy || !gamma || !save_mean || !save_invstd || !dx || !ws || N <= 0 || C <= 0 || HW <= 0) return DC_EINVAL;
+    if (relu && !y) return DC_EINVAL;
+    const int chunks = ceil_div(HW, BN_CHUNK);
+    float* part = (float*)ws;
+    float* mg = part + (size_t)C * N * chunks * 2;
+    float* mgx = mg + C;
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, part, C,
+                       HW, relu);
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST, part, dgamma, dbeta, mg, mgx, N * chunks,
+                       (float)N * (float)HW);
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, gamma,
+                       mg, mgx, dx, dres, C, HW, relu);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}

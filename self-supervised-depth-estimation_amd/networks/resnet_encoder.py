@@ -10,6 +10,20 @@ without touching the module tree.
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+from depthcore import ops as _ops
+
+
+def _bn_act(x, bn, res=None, relu=True):
+    """BatchNorm2d (+ residual) (+ ReLU): one fused depthcore launch chain in training mode on the GPU;
+    eval mode (running statistics, not on the training hot path) uses the stock functional ops."""
+    if bn.training and x.is_cuda:
+        return _ops.bn_relu(x, bn, res, relu)
+    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum or 0.1, bn.eps)
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu else y
 
 
 class BasicBlock(nn.Module):
@@ -25,10 +39,9 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + idt)
+        idt = x if self.downsample is None else _bn_act(self.downsample[0](x), self.downsample[1], relu=False)
+        out = _bn_act(self.conv1(x), self.bn1)
+        return _bn_act(self.conv2(out), self.bn2, res=idt)          # relu(bn2(conv2) + identity), one pass
 
 
 class Bottleneck(nn.Module):
@@ -46,11 +59,10 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + idt)
+        idt = x if self.downsample is None else _bn_act(self.downsample[0](x), self.downsample[1], relu=False)
+        out = _bn_act(self.conv1(x), self.bn1)
+        out = _bn_act(self.conv2(out), self.bn2)
+        return _bn_act(self.conv3(out), self.bn3, res=idt)
 
 
 _CFG = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3)),
@@ -106,15 +118,24 @@ class ResnetEncoder(nn.Module):
         self.encoder = ResNetTrunk(num_layers, num_input_images)
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
+        self._nbt = None
+
+    def _apply(self, fn, *a, **k):
+        self._nbt = None            # tensors may be re-created by .to() / .cuda()
+        return super()._apply(fn, *a, **k)
 
     def forward(self, input_image):
         e = self.encoder
         self.features = []
         x = (input_image - 0.45) / 0.225
-        x = e.relu(e.bn1(e.conv1(x)))
+        x = _bn_act(e.conv1(x), e.bn1)
         self.features.append(x)
         self.features.append(e.layer1(e.maxpool(x)))
         self.features.append(e.layer2(self.features[-1]))
         self.features.append(e.layer3(self.features[-1]))
         self.features.append(e.layer4(self.features[-1]))
+        if self.training:   # nn.BatchNorm2d bookkeeping, one multi-tensor launch instead of one per layer
+            if self._nbt is None:
+                self._nbt = [m.num_batches_tracked for m in e.modules() if isinstance(m, nn.BatchNorm2d)]
+            torch._foreach_add_(self._nbt, 1)
         return self.features

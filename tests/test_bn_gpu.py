@@ -1,0 +1,61 @@
+"""Fused training-mode BatchNorm (+ residual) (+ ReLU) kernels (dc_bn_relu_fwd/bwd) vs plain torch on the CPU."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from helpers import close, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("shape,with_res,relu", [((3, 8, 10, 12), False, True), ((2, 64, 24, 40), True, True),
+                                                 ((4, 16, 7, 9), True, False), ((12, 64, 96, 320), False, True),
+                                                 ((2, 5, 3, 5), False, False)])
+def test_bn_relu_vs_torch(shape, with_res, relu):
+    from depthcore import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g) * 1.7 + 0.3
+    res = torch.randn(shape, generator=g) if with_res else None
+    cot = torch.randn(shape, generator=g)
+    C = shape[1]
+    bn_ref, bn_hip = nn.BatchNorm2d(C), nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.rand(C, generator=g) + 0.5); bn_ref.bias.copy_(torch.randn(C, generator=g))
+        bn_hip.weight.copy_(bn_ref.weight); bn_hip.bias.copy_(bn_ref.bias)
+    xr = x.clone().requires_grad_()
+    rr = res.clone().requires_grad_() if with_res else None
+    y = bn_ref(xr)
+    if with_res:
+        y = y + rr
+    if relu:
+        y = F.relu(y)
+    leaves = [xr, bn_ref.weight, bn_ref.bias] + ([rr] if with_res else [])
+    gr = torch.autograd.grad((y * cot).sum(), leaves)
+    xh = x.to(DEV).requires_grad_()
+    rh = res.to(DEV).requires_grad_() if with_res else None
+    yh = ops.bn_relu(xh, bn_hip, rh, relu)
+    lh = [xh, bn_hip.weight, bn_hip.bias] + ([rh] if with_res else [])
+    gh = torch.autograd.grad((yh * cot.to(DEV)).sum(), lh)
+    close(yh, y, rtol=1e-4, atol=1e-5)
+    close(bn_hip.running_mean, bn_ref.running_mean, rtol=1e-5, atol=1e-6)
+    close(bn_hip.running_var, bn_ref.running_var, rtol=1e-4, atol=1e-6)
+    for a, b, name in zip(gh, gr, ["dx", "dgamma", "dbeta", "dres"]):
+        assert rel_l2(a, b) < 2e-4, (name, rel_l2(a, b))
+
+
+def test_encoder_matches_oracle_resnet():
+    """networks.ResnetEncoder (fused BN/ReLU kernels + MIOpen convs) vs the functional CPU ResNet of the oracle."""
+    import networks
+    from oracle.resnet_ref import resnet_encoder_forward
+    torch.manual_seed(0)
+    enc = networks.ResnetEncoder(18, False).to(DEV)
+    enc.train()
+    state = {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(1))
+    want = resnet_encoder_forward(state, x, 18, training=True)
+    got = enc(x.to(DEV))
+    for a, b in zip(got, want):
+        close(a, b, rtol=2e-3, atol=2e-4)
+    assert int(enc.encoder.bn1.num_batches_tracked) == 1 and int(enc.encoder.layer4[1].bn2.num_batches_tracked) == 1
