@@ -197,6 +197,12 @@ int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, const float*
                    const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, void* ws,
                    int N, int C, int HW, int relu, void* stream);
 
+/* nn.MaxPool2d(3, 2, 1) of the ResNet stem (networks/resnet_encoder.py:93).  x (NC planes of HxW) ->
+ * y (NC planes of Ho x Wo, Ho = (H-1)/2+1) and `code` (one byte per output: window position of the first
+ * maximum, ATen's tie-break).  NC <= 65535.  Backward: gather, no atomics. */
+int dc_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* code, int NC, int H, int W, void* stream);
+int dc_maxpool3x3s2_bwd(const float* gy, const uint8_t* code, float* dx, int NC, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,3 +224,76 @@ extern "C" int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, c
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, padding 1) of the ResNet stem (torchvision ResNet.maxpool, reached from
+// networks/resnet_encoder.py:93).  Forward stores the window position of the maximum (first maximum in
+// row-major scan order, like ATen) as one byte per output; backward is a gather over the <= 4 windows that
+// cover an input pixel -- no atomics.
+// ------------------------------------------------------------------------------------------------
+namespace dc {
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, float* y, uint8_t* code, int H, int W, int Ho,
+                                                          int Wo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t plane = blockIdx.y;
+    if (i >= Ho * Wo) return;
+    const int oy = i / Wo, ox = i - oy * Wo;
+    const float* p = x + plane * H * W;
+    float best = -INFINITY;
+    int bc = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = oy * 2 - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = ox * 2 - 1 + kx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const float v = p[(size_t)yy * W + xx];
+                if (v > best || v != v) { best = v; bc = ky * 3 + kx; }
+            }
+        }
+    }
+    y[plane * Ho * Wo + i] = best;
+    code[plane * Ho * Wo + i] = (uint8_t)bc;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* gy, const uint8_t* code, float* dx, int H, int W,
+                                                          int Ho, int Wo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t plane = blockIdx.y;
+    if (i >= H * W) return;
+    const int yy = i / W, xx = i - yy * W;
+    const float* g = gy + plane * Ho * Wo;
+    const uint8_t* cd = code + plane * Ho * Wo;
+    float acc = 0.f;
+    // windows oy with oy*2-1 <= yy <= oy*2+1
+    const int oy0 = max((yy - 1 + 1) >> 1, 0), oy1 = min((yy + 1) >> 1, Ho - 1);
+    const int ox0 = max((xx - 1 + 1) >> 1, 0), ox1 = min((xx + 1) >> 1, Wo - 1);
+    for (int oy = oy0; oy <= oy1; ++oy)
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const int want = (yy - (oy * 2 - 1)) * 3 + (xx - (ox * 2 - 1));
+            if (cd[oy * Wo + ox] == want) acc += g[oy * Wo + ox];
+        }
+    dx[plane * H * W + i] = acc;
+}
+
+}  // namespace dc
+
+extern "C" int dc_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* code, int NC, int H, int W, void* stream) {
+    if (!x || !y || !code || NC <= 0 || H < 2 || W < 2 || NC > 65535) return DC_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(dc::maxpool_fwd_kernel, dim3(dc::ceil_div(Ho * Wo, 256), NC), dim3(256), 0, (hipStream_t)stream, x, y,
+                       code, H, W, Ho, Wo);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_maxpool3x3s2_bwd(const float* gy, const uint8_t* code, float* dx, int NC, int H, int W, void* stream) {
+    if (!gy || !code || !dx || NC <= 0 || H < 2 || W < 2 || NC > 65535) return DC_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(dc::maxpool_bwd_kernel, dim3(dc::ceil_div(H * W, 256), NC), dim3(256), 0, (hipStream_t)stream, gy, code,
+                       dx, H, W, Ho, Wo);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}

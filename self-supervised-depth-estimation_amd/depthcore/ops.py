@@ -524,3 +524,35 @@ def bn_relu(x, bn, res=None, relu=True):
     running_mean / running_var in place; `num_batches_tracked` is advanced by the caller)."""
     mom = 0.1 if bn.momentum is None else bn.momentum
     return _BNReLU.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1 nn.MaxPool2d(3, 2, 1) of the ResNet stem
+# ----------------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.lib()
+        xx = _c(x.detach())
+        N, C, H, W = xx.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(N, C, Ho, Wo, dtype=torch.float32, device=xx.device)
+        code = torch.empty(N, C, Ho, Wo, dtype=torch.uint8, device=xx.device)
+        check(L.dc_maxpool3x3s2_fwd(ptr(xx), ptr(y), code.data_ptr(), N * C, H, W, stream()), "dc_maxpool3x3s2_fwd")
+        ctx.save_for_backward(code)
+        ctx.dims = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        (code,) = ctx.saved_tensors
+        N, C, H, W = ctx.dims
+        g_c = _c(gy)
+        dx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
+        check(L.dc_maxpool3x3s2_bwd(ptr(g_c), code.data_ptr(), ptr(dx), N * C, H, W, stream()), "dc_maxpool3x3s2_bwd")
+        return dx
+
+
+def maxpool3x3s2(x):
+    return _MaxPool.apply(x)

@@ -130,7 +130,7 @@ class ResnetEncoder(nn.Module):
         x = (input_image - 0.45) / 0.225
         x = _bn_act(e.conv1(x), e.bn1)
         self.features.append(x)
-        self.features.append(e.layer1(e.maxpool(x)))
+        self.features.append(e.layer1(_ops.maxpool3x3s2(x) if x.is_cuda else e.maxpool(x)))
         self.features.append(e.layer2(self.features[-1]))
         self.features.append(e.layer3(self.features[-1]))
         self.features.append(e.layer4(self.features[-1]))

@@ -59,3 +59,19 @@ def test_encoder_matches_oracle_resnet():
     for a, b in zip(got, want):
         close(a, b, rtol=2e-3, atol=2e-4)
     assert int(enc.encoder.bn1.num_batches_tracked) == 1 and int(enc.encoder.layer4[1].bn2.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 12, 16), (1, 3, 9, 11), (12, 64, 96, 320)])
+def test_maxpool_vs_torch(shape):
+    from depthcore import ops
+    g = torch.Generator().manual_seed(7)
+    x = F.relu(torch.randn(shape, generator=g))          # post-ReLU input: many exact ties at 0
+    xr = x.clone().requires_grad_()
+    y = F.max_pool2d(xr, 3, 2, 1)
+    cot = torch.randn(y.shape, generator=g)
+    (gr,) = torch.autograd.grad((y * cot).sum(), [xr])
+    xh = x.to(DEV).requires_grad_()
+    yh = ops.maxpool3x3s2(xh)
+    (gh,) = torch.autograd.grad((yh * cot.to(DEV)).sum(), [xh])
+    assert torch.equal(yh.cpu(), y.detach())
+    assert torch.equal(gh.cpu(), gr)                       # same tie-break as ATen -> identical routing
