@@ -186,16 +186,19 @@ int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, co
 /* Training-mode nn.BatchNorm2d fused with the residual add and ReLU of torchvision's BasicBlock / Bottleneck
  * (reached from networks/resnet_encoder.py:87-98): y = relu?( bn(x) [+ res] ).  x, res, y: (N,C,H,W) with
  * HW = H*W; gamma, beta, save_mean, save_invstd, running_*: (C).  running_* nullable (then not updated);
- * they are updated like torch (momentum, unbiased variance).  ws: dc_bn_workspace(N,C,HW) bytes. */
+ * they are updated like torch (momentum, unbiased variance).  `groups` > 1 normalises `groups` equal
+ * sub-batches independently (save_mean / save_invstd then hold groups*C values) -- bit-for-bit the statistics
+ * and running-stat updates of calling the module once per sub-batch in order; it lets the two pose pairs of
+ * trainer.py:404-405 share one encoder pass.  ws: dc_bn_workspace(N,C,HW) bytes. */
 size_t dc_bn_workspace(int N, int C, int HW);
 int dc_bn_relu_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                    float* save_mean, float* save_invstd, float* running_mean, float* running_var, void* ws,
-                   int N, int C, int HW, float eps, float momentum, int relu, void* stream);
+                   int N, int C, int HW, float eps, float momentum, int relu, int groups, void* stream);
 /* gy is the gradient wrt y; the ReLU mask is taken from y (required when relu=1).  dres (nullable) receives
  * the gradient of the residual input; dgamma, dbeta nullable. */
 int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
                    const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, void* ws,
-                   int N, int C, int HW, int relu, void* stream);
+                   int N, int C, int HW, int relu, int groups, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) of the ResNet stem (networks/resnet_encoder.py:93).  x (NC planes of HxW) ->
  * y (NC planes of Ho x Wo, Ho = (H-1)/2+1) and `code` (one byte per output: window position of the first

@@ -45,33 +45,44 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, float* pa
     }
 }
 
-// grid (C), block 64: mean / invstd (saved for backward) + running statistics
+// grid (C), block 64: mean / invstd per (group, channel) (saved for backward) + running statistics.
+// `groups` > 1: the batch is `groups` independent sub-batches normalised separately (statistics per group),
+// exactly as if the module had been called once per sub-batch in order -- including the sequence of
+// running-statistics updates.
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* part, float* mean, float* invstd, float* run_mean,
                                                          float* run_var, int nparts, float count, float eps,
-                                                         float momentum) {
-    const int c = blockIdx.x;
-    float s = 0.f, q = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 64) { s += part[((size_t)c * nparts + i) * 2]; q += part[((size_t)c * nparts + i) * 2 + 1]; }
-    s = wave_sum(s); q = wave_sum(q);
-    if (threadIdx.x == 0) {
+                                                         float momentum, int groups) {
+    const int c = blockIdx.x, C = gridDim.x;
+    const int per = nparts / groups;
+    float rm = 0.f, rv = 0.f;
+    if (run_mean) { rm = run_mean[c]; rv = run_var[c]; }
+    for (int gidx = 0; gidx < groups; ++gidx) {
+        float s = 0.f, q = 0.f;
+        for (int i = threadIdx.x; i < per; i += 64) {
+            s += part[((size_t)c * nparts + gidx * per + i) * 2];
+            q += part[((size_t)c * nparts + gidx * per + i) * 2 + 1];
+        }
+        s = wave_sum(s); q = wave_sum(q);
         const float m = s / count;
         const float var = fmaxf(q / count - m * m, 0.f);          // biased (used to normalise)
-        mean[c] = m;
-        invstd[c] = rsqrtf(var + eps);
-        if (run_mean) {
-            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
-            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+        if (threadIdx.x == 0) {
+            mean[gidx * C + c] = m;
+            invstd[gidx * C + c] = rsqrtf(var + eps);
         }
+        rm = (1.f - momentum) * rm + momentum * m;
+        rv = (1.f - momentum) * rv + momentum * var * (count / fmaxf(count - 1.f, 1.f));
     }
+    if (run_mean && threadIdx.x == 0) { run_mean[c] = rm; run_var[c] = rv; }
 }
 
 // grid (chunks, C, N), block 256: y = relu?((x - mean)*invstd*gamma + beta [+ res])
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* res, const float* mean,
                                                        const float* invstd, const float* gamma, const float* beta,
-                                                       float* y, int C, int HW, int relu) {
+                                                       float* y, int C, int HW, int relu, int n_per_group) {
     const int c = blockIdx.y, n = blockIdx.z;
     const size_t base = ((size_t)n * C + c) * HW;
-    const float a = invstd[c] * gamma[c], b = beta[c] - mean[c] * a;
+    const int gc = (n / n_per_group) * C + c;
+    const float a = invstd[gc] * gamma[c], b = beta[c] - mean[gc] * a;
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     if ((HW & 3) == 0) {
         for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
@@ -96,11 +107,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
 // backward stats: partial {sum g, sum g*x_hat}, g = gy*[y>0] when relu
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const float* y, const float* gy,
                                                            const float* mean, const float* invstd, float* part, int C,
-                                                           int HW, int relu) {
+                                                           int HW, int relu, int n_per_group) {
     __shared__ float sm[4];
     const int c = blockIdx.y, n = blockIdx.z;
     const size_t base = ((size_t)n * C + c) * HW;
-    const float m = mean[c], is = invstd[c];
+    const int gc = (n / n_per_group) * C + c;
+    const float m = mean[gc], is = invstd[gc];
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     float s = 0.f, q = 0.f;
     if ((HW & 3) == 0) {
@@ -131,16 +143,23 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const
 
 // grid (C), block 64: dgamma, dbeta + the two means the dx pass needs
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* part, float* dgamma, float* dbeta, float* mg,
-                                                             float* mgx, int nparts, float count) {
-    const int c = blockIdx.x;
-    float s = 0.f, q = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 64) { s += part[((size_t)c * nparts + i) * 2]; q += part[((size_t)c * nparts + i) * 2 + 1]; }
-    s = wave_sum(s); q = wave_sum(q);
+                                                             float* mgx, int nparts, float count, int groups) {
+    const int c = blockIdx.x, C = gridDim.x;
+    const int per = nparts / groups;
+    float ts = 0.f, tq = 0.f;
+    for (int gidx = 0; gidx < groups; ++gidx) {
+        float s = 0.f, q = 0.f;
+        for (int i = threadIdx.x; i < per; i += 64) {
+            s += part[((size_t)c * nparts + gidx * per + i) * 2];
+            q += part[((size_t)c * nparts + gidx * per + i) * 2 + 1];
+        }
+        s = wave_sum(s); q = wave_sum(q);
+        if (threadIdx.x == 0) { mg[gidx * C + c] = s / count; mgx[gidx * C + c] = q / count; }
+        ts += s; tq += q;
+    }
     if (threadIdx.x == 0) {
-        if (dbeta) dbeta[c] = s;
-        if (dgamma) dgamma[c] = q;
-        mg[c] = s / count;
-        mgx[c] = q / count;
+        if (dbeta) dbeta[c] = ts;
+        if (dgamma) dgamma[c] = tq;
     }
 }
 
@@ -148,10 +167,11 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* part, 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const float* y, const float* gy,
                                                            const float* mean, const float* invstd, const float* gamma,
                                                            const float* mg, const float* mgx, float* dx, float* dres,
-                                                           int C, int HW, int relu) {
+                                                           int C, int HW, int relu, int n_per_group) {
     const int c = blockIdx.y, n = blockIdx.z;
     const size_t base = ((size_t)n * C + c) * HW;
-    const float m = mean[c], is = invstd[c], k = gamma[c] * is, a = mg[c], bq = mgx[c] * is;
+    const int gc = (n / n_per_group) * C + c;
+    const float m = mean[gc], is = invstd[gc], k = gamma[c] * is, a = mg[gc], bq = mgx[gc] * is;
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     if ((HW & 3) == 0) {
         for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
@@ -184,43 +204,45 @@ using namespace dc;
 
 extern "C" size_t dc_bn_workspace(int N, int C, int HW) {
     if (N <= 0 || C <= 0 || HW <= 0) return 0;
-    return ((size_t)C * N * ceil_div(HW, BN_CHUNK) * 2 + 2 * (size_t)C) * sizeof(float);
+    return ((size_t)C * N * ceil_div(HW, BN_CHUNK) * 2 + 2 * (size_t)C * N) * sizeof(float);   // partials + per-group means
 }
 
 extern "C" int dc_bn_relu_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                               float* save_mean, float* save_invstd, float* running_mean, float* running_var, void* ws,
-                              int N, int C, int HW, float eps, float momentum, int relu, void* stream) {
+                              int N, int C, int HW, float eps, float momentum, int relu, int groups, void* stream) {
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || N <= 0 || C <= 0 || HW <= 0) return DC_EINVAL;
+    if (groups < 1 || N % groups) return DC_EINVAL;
     const int chunks = ceil_div(HW, BN_CHUNK);
     float* part = (float*)ws;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, part, C, HW);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, ST, part, save_mean, save_invstd, running_mean,
-                       running_var, N * chunks, (float)N * (float)HW, eps, momentum);
+                       running_var, N * chunks, (float)(N / groups) * (float)HW, eps, momentum, groups);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, res, save_mean, save_invstd, gamma, beta,
-                       y, C, HW, relu);
+                       y, C, HW, relu, N / groups);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
 
 extern "C" int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, const float* gamma,
                               const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dgamma,
-                              float* dbeta, void* ws, int N, int C, int HW, int relu, void* stream) {
+                              float* dbeta, void* ws, int N, int C, int HW, int relu, int groups, void* stream) {
     if (!x || !gy || !gamma || !save_mean || !save_invstd || !dx || !ws || N <= 0 || C <= 0 || HW <= 0) return DC_EINVAL;
     if (relu && !y) return DC_EINVAL;
+    if (groups < 1 || N % groups) return DC_EINVAL;
     const int chunks = ceil_div(HW, BN_CHUNK);
     float* part = (float*)ws;
     float* mg = part + (size_t)C * N * chunks * 2;
-    float* mgx = mg + C;
+    float* mgx = mg + (size_t)C * groups;
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, part, C,
-                       HW, relu);
+                       HW, relu, N / groups);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST, part, dgamma, dbeta, mg, mgx, N * chunks,
-                       (float)N * (float)HW);
+                       (float)(N / groups) * (float)HW, groups);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, gamma,
-                       mg, mgx, dx, dres, C, HW, relu);
+                       mg, mgx, dx, dres, C, HW, relu, N / groups);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }

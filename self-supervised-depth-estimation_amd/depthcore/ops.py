@@ -485,28 +485,28 @@ def conv3x3_block(x0, x1, weight, bias, up0=False, act=ACT_NONE, pad=PAD_REFLECT
 # ----------------------------------------------------------------------------------------------
 class _BNReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum, relu, groups):
         L = _lib.lib()
         xx = _c(x.detach())
         rr = _c(res.detach()) if res is not None else None
         g, b = _c(gamma.detach()), _c(beta.detach())
         N, C, H, W = xx.shape
         y = torch.empty_like(xx)
-        mean = torch.empty(C, dtype=torch.float32, device=xx.device)
-        invstd = torch.empty(C, dtype=torch.float32, device=xx.device)
+        mean = torch.empty(groups * C, dtype=torch.float32, device=xx.device)
+        invstd = torch.empty(groups * C, dtype=torch.float32, device=xx.device)
         ws = torch.empty(L.dc_bn_workspace(N, C, H * W), dtype=torch.uint8, device=xx.device)
         check(L.dc_bn_relu_fwd(ptr(xx), ptr(rr), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(invstd),
                                ptr(running_mean), ptr(running_var), ws.data_ptr(), N, C, H * W, float(eps),
-                               float(momentum), int(relu), stream()), "dc_bn_relu_fwd")
+                               float(momentum), int(relu), int(groups), stream()), "dc_bn_relu_fwd")
         ctx.save_for_backward(xx, y, g, mean, invstd)
-        ctx.cfg = (int(relu), res is not None)
+        ctx.cfg = (int(relu), res is not None, int(groups))
         return y
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.lib()
         xx, y, g, mean, invstd = ctx.saved_tensors
-        relu, has_res = ctx.cfg
+        relu, has_res, groups = ctx.cfg
         N, C, H, W = xx.shape
         g_c = _c(gy)
         dx = torch.empty_like(xx)
@@ -515,15 +515,16 @@ class _BNReLU(torch.autograd.Function):
         dbeta = torch.empty_like(g)
         ws = torch.empty(L.dc_bn_workspace(N, C, H * W), dtype=torch.uint8, device=xx.device)
         check(L.dc_bn_relu_bwd(ptr(xx), ptr(y), ptr(g_c), ptr(g), ptr(mean), ptr(invstd), ptr(dx), ptr(dres), ptr(dgamma),
-                               ptr(dbeta), ws.data_ptr(), N, C, H * W, relu, stream()), "dc_bn_relu_bwd")
-        return dx, dres, dgamma, dbeta, None, None, None, None, None
+                               ptr(dbeta), ws.data_ptr(), N, C, H * W, relu, groups, stream()), "dc_bn_relu_bwd")
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 
-def bn_relu(x, bn, res=None, relu=True):
+def bn_relu(x, bn, res=None, relu=True, groups=1):
     """y = relu?(bn(x) [+ res]) with `bn` an nn.BatchNorm2d in training mode (batch statistics; updates its
-    running_mean / running_var in place; `num_batches_tracked` is advanced by the caller)."""
+    running_mean / running_var in place; `num_batches_tracked` is advanced by the caller).  `groups` > 1:
+    the batch is that many independent sub-batches (statistics and running-stat updates per sub-batch)."""
     mom = 0.1 if bn.momentum is None else bn.momentum
-    return _BNReLU.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
+    return _BNReLU.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu, groups)
 
 
 # ----------------------------------------------------------------------------------------------

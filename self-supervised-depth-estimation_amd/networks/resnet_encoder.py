@@ -15,12 +15,17 @@ import torch.nn.functional as F
 from depthcore import ops as _ops
 
 
-def _bn_act(x, bn, res=None, relu=True):
+def _bn_act(x, bn, res=None, relu=True, groups=1):
     """BatchNorm2d (+ residual) (+ ReLU): one fused depthcore launch chain in training mode on the GPU;
-    eval mode (running statistics, not on the training hot path) uses the stock functional ops."""
+    eval mode (running statistics, not on the training hot path) uses the stock functional ops.
+    `groups`: number of independent sub-batches stacked along dim 0 (statistics per sub-batch)."""
     if bn.training and x.is_cuda:
-        return _ops.bn_relu(x, bn, res, relu)
-    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum or 0.1, bn.eps)
+        return _ops.bn_relu(x, bn, res, relu, groups)
+    if bn.training and groups > 1:
+        y = torch.cat([F.batch_norm(c, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum or 0.1,
+                                    bn.eps) for c in x.chunk(groups)])
+    else:
+        y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum or 0.1, bn.eps)
     if res is not None:
         y = y + res
     return F.relu(y) if relu else y
@@ -29,8 +34,9 @@ def _bn_act(x, bn, res=None, relu=True):
 class BasicBlock(nn.Module):
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups_ref=None):
         super().__init__()
+        self._g = groups_ref if groups_ref is not None else [1]
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
@@ -39,16 +45,18 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else _bn_act(self.downsample[0](x), self.downsample[1], relu=False)
-        out = _bn_act(self.conv1(x), self.bn1)
-        return _bn_act(self.conv2(out), self.bn2, res=idt)          # relu(bn2(conv2) + identity), one pass
+        g = self._g[0]
+        idt = x if self.downsample is None else _bn_act(self.downsample[0](x), self.downsample[1], relu=False, groups=g)
+        out = _bn_act(self.conv1(x), self.bn1, groups=g)
+        return _bn_act(self.conv2(out), self.bn2, res=idt, groups=g)   # relu(bn2(conv2) + identity), one pass
 
 
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups_ref=None):
         super().__init__()
+        self._g = groups_ref if groups_ref is not None else [1]
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)   # v1.5: stride on the 3x3
@@ -59,10 +67,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else _bn_act(self.downsample[0](x), self.downsample[1], relu=False)
-        out = _bn_act(self.conv1(x), self.bn1)
-        out = _bn_act(self.conv2(out), self.bn2)
-        return _bn_act(self.conv3(out), self.bn3, res=idt)
+        g = self._g[0]
+        idt = x if self.downsample is None else _bn_act(self.downsample[0](x), self.downsample[1], relu=False, groups=g)
+        out = _bn_act(self.conv1(x), self.bn1, groups=g)
+        out = _bn_act(self.conv2(out), self.bn2, groups=g)
+        return _bn_act(self.conv3(out), self.bn3, res=idt, groups=g)
 
 
 _CFG = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3)),
@@ -76,6 +85,7 @@ class ResNetTrunk(nn.Module):
         super().__init__()
         block, layers = _CFG[num_layers]
         self.inplanes = 64
+        self._g = [1]       # number of independent sub-batches in the current forward (shared with the blocks)
         self.conv1 = nn.Conv2d(num_input_images * 3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
@@ -98,10 +108,10 @@ class ResNetTrunk(nn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
                                  nn.BatchNorm2d(planes * block.expansion))
-        layers = [block(self.inplanes, planes, stride, down)]
+        layers = [block(self.inplanes, planes, stride, down, groups_ref=self._g)]
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes))
+            layers.append(block(self.inplanes, planes, groups_ref=self._g))
         return nn.Sequential(*layers)
 
 
@@ -124,11 +134,15 @@ class ResnetEncoder(nn.Module):
         self._nbt = None            # tensors may be re-created by .to() / .cuda()
         return super()._apply(fn, *a, **k)
 
-    def forward(self, input_image):
+    def forward(self, input_image, bn_groups=1):
+        """networks/resnet_encoder.py:87-98.  `bn_groups` > 1: `input_image` stacks that many independent
+        sub-batches along dim 0; BatchNorm statistics (and running-stat updates) are kept per sub-batch, so the
+        result equals `bn_groups` separate calls -- used to push both pose pairs through the trunk at once."""
         e = self.encoder
+        e._g[0] = int(bn_groups)
         self.features = []
         x = (input_image - 0.45) / 0.225
-        x = _bn_act(e.conv1(x), e.bn1)
+        x = _bn_act(e.conv1(x), e.bn1, groups=e._g[0])
         self.features.append(x)
         self.features.append(e.layer1(_ops.maxpool3x3s2(x) if x.is_cuda else e.maxpool(x)))
         self.features.append(e.layer2(self.features[-1]))
@@ -137,5 +151,6 @@ class ResnetEncoder(nn.Module):
         if self.training:   # nn.BatchNorm2d bookkeeping, one multi-tensor launch instead of one per layer
             if self._nbt is None:
                 self._nbt = [m.num_batches_tracked for m in e.modules() if isinstance(m, nn.BatchNorm2d)]
-            torch._foreach_add_(self._nbt, 1)
+            torch._foreach_add_(self._nbt, int(bn_groups))
+        e._g[0] = 1
         return self.features

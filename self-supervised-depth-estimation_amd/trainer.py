@@ -105,16 +105,20 @@ class Trainer:
 
     # ------------------------------------------------------------------ trainer.py:378-442 (pairs mode)
     def predict_poses(self, inputs, features):
+        """Both temporally ordered pairs (-1,0), (0,+1) go through the pose encoder in ONE pass: they are stacked
+        along the batch and BatchNorm keeps separate statistics per pair (`bn_groups=2`), which is exactly the
+        arithmetic of the reference's two sequential passes (trainer.py:398-419) at twice the GEMM N."""
         outputs = {}
         pose_feats = {f: inputs[("color_aug", f, 0)] for f in (-1, 0, 1)}
-        for f in (-1, 1):
-            pair = [pose_feats[f], pose_feats[0]] if f < 0 else [pose_feats[0], pose_feats[f]]   # temporal order
-            pose_inputs = [self.models["pose_encoder"](torch.cat(pair, 1))]
-            axisangle, translation = self.models["pose"](pose_inputs)
-            outputs[("axisangle", 0, f)] = axisangle
-            outputs[("translation", 0, f)] = translation
-            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(
-                axisangle[:, 0], translation[:, 0], invert=(f < 0))
+        pairs = [torch.cat([pose_feats[-1], pose_feats[0]], 1), torch.cat([pose_feats[0], pose_feats[1]], 1)]
+        B = pairs[0].shape[0]
+        feats = self.models["pose_encoder"](torch.cat(pairs, 0), bn_groups=2)
+        axisangle, translation = self.models["pose"]([feats])
+        for i, f in enumerate((-1, 1)):
+            aa, tr = axisangle[i * B:(i + 1) * B], translation[i * B:(i + 1) * B]
+            outputs[("axisangle", 0, f)] = aa
+            outputs[("translation", 0, f)] = tr
+            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(aa[:, 0], tr[:, 0], invert=(f < 0))
         return outputs
 
     # ------------------------------------------------------------------ fused a14 + a15

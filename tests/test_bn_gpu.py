@@ -75,3 +75,33 @@ def test_maxpool_vs_torch(shape):
     (gh,) = torch.autograd.grad((yh * cot.to(DEV)).sum(), [xh])
     assert torch.equal(yh.cpu(), y.detach())
     assert torch.equal(gh.cpu(), gr)                       # same tie-break as ATen -> identical routing
+
+
+def test_grouped_bn_equals_separate_calls():
+    """bn_groups=2 on a stacked batch == two sequential calls (outputs, grads, running statistics)."""
+    import networks
+    torch.manual_seed(0)
+    a = networks.ResnetEncoder(18, False, num_input_images=2).to(DEV)
+    b = networks.ResnetEncoder(18, False, num_input_images=2).to(DEV)
+    b.load_state_dict(a.state_dict())
+    a.train(); b.train()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x1 = torch.rand(2, 6, 64, 96, device=DEV, generator=g)
+    x2 = torch.rand(2, 6, 64, 96, device=DEV, generator=g)
+    fa = a(torch.cat([x1, x2], 0), bn_groups=2)
+    f1 = [t.clone() for t in b(x1)]
+    f2 = b(x2)
+    for s, u, v in zip(fa, f1, f2):
+        close(s[:2], u, rtol=1e-5, atol=1e-6)
+        close(s[2:], v, rtol=1e-5, atol=1e-6)
+    (fa[-1].square().sum()).backward()
+    (f1[-1].square().sum() + f2[-1].square().sum()).backward()
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if p.grad is not None:
+            assert rel_l2(p.grad, q.grad) < 1e-4, n
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if "running" in k:
+            close(sa[k], sb[k], rtol=1e-5, atol=1e-7)
+        if "num_batches_tracked" in k:
+            assert int(sa[k]) == int(sb[k]) == 2
