@@ -45,44 +45,51 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, float* pa
     }
 }
 
-// grid (C), block 64: mean / invstd per (group, channel) (saved for backward) + running statistics.
-// `groups` > 1: the batch is `groups` independent sub-batches normalised separately (statistics per group),
-// exactly as if the module had been called once per sub-batch in order -- including the sequence of
-// running-statistics updates.
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* part, float* mean, float* invstd, float* run_mean,
-                                                         float* run_var, int nparts, float count, float eps,
-                                                         float momentum, int groups) {
-    const int c = blockIdx.x, C = gridDim.x;
-    const int per = nparts / groups;
-    float rm = 0.f, rv = 0.f;
-    if (run_mean) { rm = run_mean[c]; rv = run_var[c]; }
-    for (int gidx = 0; gidx < groups; ++gidx) {
-        float s = 0.f, q = 0.f;
-        for (int i = threadIdx.x; i < per; i += 64) {
-            s += part[((size_t)c * nparts + gidx * per + i) * 2];
-            q += part[((size_t)c * nparts + gidx * per + i) * 2 + 1];
-        }
-        s = wave_sum(s); q = wave_sum(q);
-        const float m = s / count;
-        const float var = fmaxf(q / count - m * m, 0.f);          // biased (used to normalise)
-        if (threadIdx.x == 0) {
-            mean[gidx * C + c] = m;
-            invstd[gidx * C + c] = rsqrtf(var + eps);
-        }
-        rm = (1.f - momentum) * rm + momentum * m;
-        rv = (1.f - momentum) * rv + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+// Per-(group, channel) statistics from the partial sums, recomputed by every block that needs them (a few dozen
+// L2-resident floats; cheaper than a separate finalize launch per layer).  Fixed summation order -> every block
+// gets bit-identical values.
+__device__ __forceinline__ void bn_reduce_partials(const float* part, int c, int nparts, int per, int gidx, float* sm,
+                                                   float& s, float& q) {
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        a += part[((size_t)c * nparts + gidx * per + i) * 2];
+        b += part[((size_t)c * nparts + gidx * per + i) * 2 + 1];
     }
-    if (run_mean && threadIdx.x == 0) { run_mean[c] = rm; run_var[c] = rv; }
+    s = block_sum256(a, sm);
+    q = block_sum256(b, sm);
 }
 
-// grid (chunks, C, N), block 256: y = relu?((x - mean)*invstd*gamma + beta [+ res])
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* res, const float* mean,
-                                                       const float* invstd, const float* gamma, const float* beta,
-                                                       float* y, int C, int HW, int relu, int n_per_group) {
-    const int c = blockIdx.y, n = blockIdx.z;
+// grid (chunks, C, N), block 256: y = relu?((x - mean)*invstd*gamma + beta [+ res]); block (0, c, first sample of
+// a group) also publishes mean / invstd for the backward, block (0, c, 0) the running statistics.
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* res, const float* part,
+                                                       float* mean, float* invstd, float* run_mean, float* run_var,
+                                                       const float* gamma, const float* beta, float* y, int C, int HW,
+                                                       int relu, int n_per_group, int groups, float eps, float momentum) {
+    __shared__ float sm[4];
+    const int c = blockIdx.y, n = blockIdx.z, N = gridDim.z;
+    const int nparts = N * gridDim.x, per = nparts / groups;
+    const int gidx = n / n_per_group;
+    const float count = (float)n_per_group * (float)HW;
+    float s, q;
+    bn_reduce_partials(part, c, nparts, per, gidx, sm, s, q);
+    const float m = s / count;
+    const float var = fmaxf(q / count - m * m, 0.f);          // biased (used to normalise)
+    const float is = rsqrtf(var + eps);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n == gidx * n_per_group) { mean[gidx * C + c] = m; invstd[gidx * C + c] = is; }
+    if (blockIdx.x == 0 && n == 0 && run_mean) {
+        // sequential running-stat updates, one per group, as separate module calls would do
+        float rm = run_mean[c], rv = run_var[c];
+        for (int g2 = 0; g2 < groups; ++g2) {
+            float s2, q2;
+            bn_reduce_partials(part, c, nparts, per, g2, sm, s2, q2);
+            const float m2 = s2 / count, v2 = fmaxf(q2 / count - m2 * m2, 0.f);
+            rm = (1.f - momentum) * rm + momentum * m2;
+            rv = (1.f - momentum) * rv + momentum * v2 * (count / fmaxf(count - 1.f, 1.f));
+        }
+        if (threadIdx.x == 0) { run_mean[c] = rm; run_var[c] = rv; }
+    }
     const size_t base = ((size_t)n * C + c) * HW;
-    const int gc = (n / n_per_group) * C + c;
-    const float a = invstd[gc] * gamma[c], b = beta[c] - mean[gc] * a;
+    const float a = is * gamma[c], b = beta[c] - m * a;
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     if ((HW & 3) == 0) {
         for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
@@ -141,37 +148,35 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const
     }
 }
 
-// grid (C), block 64: dgamma, dbeta + the two means the dx pass needs
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* part, float* dgamma, float* dbeta, float* mg,
-                                                             float* mgx, int nparts, float count, int groups) {
-    const int c = blockIdx.x, C = gridDim.x;
-    const int per = nparts / groups;
-    float ts = 0.f, tq = 0.f;
-    for (int gidx = 0; gidx < groups; ++gidx) {
-        float s = 0.f, q = 0.f;
-        for (int i = threadIdx.x; i < per; i += 64) {
-            s += part[((size_t)c * nparts + gidx * per + i) * 2];
-            q += part[((size_t)c * nparts + gidx * per + i) * 2 + 1];
-        }
-        s = wave_sum(s); q = wave_sum(q);
-        if (threadIdx.x == 0) { mg[gidx * C + c] = s / count; mgx[gidx * C + c] = q / count; }
-        ts += s; tq += q;
-    }
-    if (threadIdx.x == 0) {
-        if (dbeta) dbeta[c] = ts;
-        if (dgamma) dgamma[c] = tq;
-    }
-}
-
-// dx = gamma*invstd*(g - mean(g) - x_hat*mean(g*x_hat)); dres = g
+// dx = gamma*invstd*(g - mean(g) - x_hat*mean(g*x_hat)); dres = g.  The two means come from the partials (reduced
+// by every block, see bn_reduce_partials); block (0, c, 0) also writes dgamma / dbeta (sums over all groups).
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const float* y, const float* gy,
                                                            const float* mean, const float* invstd, const float* gamma,
-                                                           const float* mg, const float* mgx, float* dx, float* dres,
-                                                           int C, int HW, int relu, int n_per_group) {
-    const int c = blockIdx.y, n = blockIdx.z;
+                                                           const float* part, float* dgamma, float* dbeta, float* dx,
+                                                           float* dres, int C, int HW, int relu, int n_per_group,
+                                                           int groups) {
+    __shared__ float sm[4];
+    const int c = blockIdx.y, n = blockIdx.z, N = gridDim.z;
+    const int nparts = N * gridDim.x, per = nparts / groups;
+    const int gidx = n / n_per_group;
+    const float count = (float)n_per_group * (float)HW;
+    float s, q;
+    bn_reduce_partials(part, c, nparts, per, gidx, sm, s, q);
+    if (blockIdx.x == 0 && n == 0) {
+        float ts = 0.f, tq = 0.f;
+        for (int g2 = 0; g2 < groups; ++g2) {
+            float s2, q2;
+            bn_reduce_partials(part, c, nparts, per, g2, sm, s2, q2);
+            ts += s2; tq += q2;
+        }
+        if (threadIdx.x == 0) {
+            if (dbeta) dbeta[c] = ts;
+            if (dgamma) dgamma[c] = tq;
+        }
+    }
     const size_t base = ((size_t)n * C + c) * HW;
-    const int gc = (n / n_per_group) * C + c;
-    const float m = mean[gc], is = invstd[gc], k = gamma[c] * is, a = mg[gc], bq = mgx[gc] * is;
+    const int gc = gidx * C + c;
+    const float m = mean[gc], is = invstd[gc], k = gamma[c] * is, a = s / count, bq = (q / count) * is;
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     if ((HW & 3) == 0) {
         for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
@@ -216,11 +221,8 @@ extern "C" int dc_bn_relu_fwd(const float* x, const float* res, const float* gam
     float* part = (float*)ws;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, part, C, HW);
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, ST, part, save_mean, save_invstd, running_mean,
-                       running_var, N * chunks, (float)(N / groups) * (float)HW, eps, momentum, groups);
-    DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, res, save_mean, save_invstd, gamma, beta,
-                       y, C, HW, relu, N / groups);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, res, (const float*)part, save_mean,
+                       save_invstd, running_mean, running_var, gamma, beta, y, C, HW, relu, N / groups, groups, eps, momentum);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -233,16 +235,11 @@ extern "C" int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, c
     if (groups < 1 || N % groups) return DC_EINVAL;
     const int chunks = ceil_div(HW, BN_CHUNK);
     float* part = (float*)ws;
-    float* mg = part + (size_t)C * N * chunks * 2;
-    float* mgx = mg + (size_t)C * groups;
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, part, C,
                        HW, relu, N / groups);
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST, part, dgamma, dbeta, mg, mgx, N * chunks,
-                       (float)(N / groups) * (float)HW, groups);
-    DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, gamma,
-                       mg, mgx, dx, dres, C, HW, relu, N / groups);
+                       (const float*)part, dgamma, dbeta, dx, dres, C, HW, relu, N / groups, groups);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -280,24 +277,61 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, float*
     code[plane * Ho * Wo + i] = (uint8_t)bc;
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* gy, const uint8_t* code, float* dx, int H, int W,
-                                                          int Ho, int Wo) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const size_t plane = blockIdx.y;
-    if (i >= H * W) return;
-    const int yy = i / W, xx = i - yy * W;
-    const float* g = gy + plane * Ho * Wo;
-    const uint8_t* cd = code + plane * Ho * Wo;
+__device__ __forceinline__ float maxpool_gather(const float* g, const uint8_t* cd, int yy, int xx, int Ho, int Wo) {
     float acc = 0.f;
     // windows oy with oy*2-1 <= yy <= oy*2+1
-    const int oy0 = max((yy - 1 + 1) >> 1, 0), oy1 = min((yy + 1) >> 1, Ho - 1);
-    const int ox0 = max((xx - 1 + 1) >> 1, 0), ox1 = min((xx + 1) >> 1, Wo - 1);
+    const int oy0 = max(yy >> 1, 0), oy1 = min((yy + 1) >> 1, Ho - 1);
+    const int ox0 = max(xx >> 1, 0), ox1 = min((xx + 1) >> 1, Wo - 1);
     for (int oy = oy0; oy <= oy1; ++oy)
         for (int ox = ox0; ox <= ox1; ++ox) {
             const int want = (yy - (oy * 2 - 1)) * 3 + (xx - (ox * 2 - 1));
             if (cd[oy * Wo + ox] == want) acc += g[oy * Wo + ox];
         }
-    dx[plane * H * W + i] = acc;
+    return acc;
+}
+
+// VEC4: one thread = 4 consecutive input pixels (x0 % 4 == 0) of one row.  They are covered by the three
+// windows ox = x0/2 .. x0/2+2 of one or two window rows: 3-6 (code, gy) pairs are fetched once and routed to
+// the four pixels, instead of 16 byte loads + 16 float loads.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* gy, const uint8_t* code, float* dx, int H, int W,
+                                                          int Ho, int Wo) {
+    const size_t plane = blockIdx.y;
+    const float* g = gy + plane * Ho * Wo;
+    const uint8_t* cd = code + plane * Ho * Wo;
+    if (!VEC4) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= H * W) return;
+        const int yy = i / W, xx = i - yy * W;
+        dx[plane * H * W + i] = maxpool_gather(g, cd, yy, xx, Ho, Wo);
+        return;
+    }
+    const int W4 = W >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W4) return;
+    const int yy = i / W4, x0 = (i - yy * W4) * 4;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int oy0 = yy >> 1, oy1 = min((yy + 1) >> 1, Ho - 1);
+    const int oxb = x0 >> 1;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        const int ky = yy - (oy * 2 - 1);             // row of the pixel inside that window
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ox = oxb + j;
+            if (ox < Wo) {
+                const int cdv = cd[oy * Wo + ox];
+                if (cdv / 3 == ky) {
+                    const float gv = g[oy * Wo + ox];
+                    const int px = ox * 2 - 1 + (cdv - ky * 3) - x0;    // pixel inside the group hit by this window
+                    if (px == 0) out.x += gv;
+                    else if (px == 1) out.y += gv;
+                    else if (px == 2) out.z += gv;
+                    else if (px == 3) out.w += gv;
+                }
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(dx + plane * H * W + (size_t)yy * W + x0) = out;
 }
 
 }  // namespace dc
@@ -314,8 +348,12 @@ extern "C" int dc_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* code, int 
 extern "C" int dc_maxpool3x3s2_bwd(const float* gy, const uint8_t* code, float* dx, int NC, int H, int W, void* stream) {
     if (!gy || !code || !dx || NC <= 0 || H < 2 || W < 2 || NC > 65535) return DC_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(dc::maxpool_bwd_kernel, dim3(dc::ceil_div(H * W, 256), NC), dim3(256), 0, (hipStream_t)stream, gy, code,
-                       dx, H, W, Ho, Wo);
+    if ((W & 3) == 0)
+        hipLaunchKernelGGL(dc::maxpool_bwd_kernel<true>, dim3(dc::ceil_div(H * (W >> 2), 256), NC), dim3(256), 0,
+                           (hipStream_t)stream, gy, code, dx, H, W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(dc::maxpool_bwd_kernel<false>, dim3(dc::ceil_div(H * W, 256), NC), dim3(256), 0,
+                           (hipStream_t)stream, gy, code, dx, H, W, Ho, Wo);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
