@@ -34,6 +34,7 @@ struct ConvArgs {
     const float* bias;
     const float* y;        // dgrad / wgrad: activated output (for act')
     const float* gy;
+    const float* gp;       // dgrad v2: precomputed g' = gy * act'(y), dense (B,Co,H,W)
     float* out;            // fwd: y (B,Co,H,W); dgrad: dxpad (B,Cin,H+2,W+2)
     int B, Co, H, W, act, pad;
     int tiles_x, tiles_y;
@@ -177,6 +178,212 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// v2 of the forward / dgrad GEMM for W % 16 == 0 (every decoder level >= 48x160): the same MFMA core, but
+//   * staging moves 16-byte vectors: the 16 interior columns of a patch row are 64-byte aligned in NCHW, so a
+//     row is 4 float4 (2 for the nearest-upsampled half, each value written twice) + 2 edge dwords instead of
+//     18 dword gathers, and weight rows ([tap][k][m], m contiguous) are float4 as well;
+//   * the next chunk's global loads are issued before the MFMA phase of the current one and land in registers
+//     (software double buffering), so HBM/L2 latency overlaps the matrix work inside a block;
+//   * dgrad reads the precomputed g' = gy*act'(y) (one elementwise pass shared with wgrad) instead of gy and y.
+// ------------------------------------------------------------------------------------------------
+__global__ void conv_gprime_kernel(const float* gy, const float* y, float* gp, size_t n4, int act) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 g = reinterpret_cast<const float4*>(gy)[i];
+        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        g.x *= act_bwd(v.x, act); g.y *= act_bwd(v.y, act); g.z *= act_bwd(v.z, act); g.w *= act_bwd(v.w, act);
+        reinterpret_cast<float4*>(gp)[i] = g;
+    }
+}
+
+template <int MR, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_gemm_v2_kernel(ConvArgs a) {
+    constexpr int MT = 16 * MR;
+    constexpr int WS = MT + 16 + (MR == 1 ? 16 : 0);      // weight row stride, == 16 mod 32
+    constexpr int NVEC = 3, NEDGE = 2, NWV = (9 * CK * (MT / 4) + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float patch[CK * PS_];
+    __shared__ __attribute__((aligned(16))) float wl[9 * CK * WS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, b = blockIdx.z;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * CT, ox0 = tx * CT;
+    const int m0 = blockIdx.y * MT;
+    const int H = a.H, W = a.W;
+    const int Cin = a.C0 + a.C1;
+    const int Mtot = DGRAD ? Cin : a.Co;
+    const int Ktot = DGRAD ? a.Co : Cin;
+    const int OH = DGRAD ? H + 2 : H, OW = DGRAD ? W + 2 : W;
+    const int h0 = H >> a.up0, w0 = W >> a.up0;
+
+    f4 acc[MR][4];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    float4 rv[NVEC];      // vector items of the patch
+    float re[NEDGE];      // edge items
+    float4 rw[NWV];       // weight items
+
+    // ---- issue the global loads of the chunk starting at channel k0 (values land in rv / re / rw)
+    auto prefetch = [&](int k0) {
+        const bool upmode = !DGRAD && a.up0 && k0 < a.C0;          // chunk comes from the half-resolution x0
+        const int quads = upmode ? 2 : 4;
+#pragma unroll
+        for (int j = 0; j < NVEC; ++j) {
+            const int it = tid + j * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < CK * PW_ * quads) {
+                const int kc = it / (PW_ * quads), rem = it - kc * (PW_ * quads);
+                const int r = rem / quads, q = rem - r * quads;
+                const int ch = k0 + kc;
+                if (ch < Ktot) {
+                    if (DGRAD) {
+                        const int yy = oy0 + r - 2, xx = ox0 + 4 * q;
+                        if (yy >= 0 && yy < H && xx < W)
+                            v = *reinterpret_cast<const float4*>(a.gp + (((size_t)b * a.Co + ch) * H + yy) * W + xx);
+                    } else {
+                        bool oky;
+                        const int yy = pad_index(oy0 + r - 1, H, a.pad, oky);
+                        if (oky) {
+                            if (upmode)
+                                v = *reinterpret_cast<const float4*>(a.x0 + (((size_t)b * a.C0 + ch) * h0 + (yy >> 1)) * w0 + (ox0 >> 1) + 4 * q);
+                            else if (ch < a.C0)
+                                v = *reinterpret_cast<const float4*>(a.x0 + (((size_t)b * a.C0 + ch) * H + yy) * W + ox0 + 4 * q);
+                            else
+                                v = *reinterpret_cast<const float4*>(a.x1 + (((size_t)b * a.C1 + (ch - a.C0)) * H + yy) * W + ox0 + 4 * q);
+                        }
+                    }
+                }
+            }
+            rv[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NEDGE; ++j) {
+            const int it = tid + j * 256;
+            float v = 0.f;
+            if (it < CK * PW_ * 2) {
+                const int kc = it / (PW_ * 2), rem = it - kc * (PW_ * 2);
+                const int r = rem >> 1, side = rem & 1;
+                const int ch = k0 + kc;
+                if (ch < Ktot) {
+                    if (DGRAD) {
+                        const int yy = oy0 + r - 2, xx = ox0 - 2 + side;       // patch columns 0, 1
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = a.gp[(((size_t)b * a.Co + ch) * H + yy) * W + xx];
+                    } else {
+                        bool oky, okx;
+                        const int yy = pad_index(oy0 + r - 1, H, a.pad, oky);
+                        const int xx = pad_index(side ? ox0 + CT : ox0 - 1, W, a.pad, okx);   // patch columns 0, 17
+                        if (oky && okx) {
+                            v = (ch < a.C0) ? a.x0[(((size_t)b * a.C0 + ch) * h0 + (yy >> a.up0)) * w0 + (xx >> a.up0)]
+                                            : a.x1[(((size_t)b * a.C1 + (ch - a.C0)) * H + yy) * W + xx];
+                        }
+                    }
+                }
+            }
+            re[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const int it = tid + j * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < 9 * CK * (MT / 4)) {
+                const int m4 = it % (MT / 4), kc = (it / (MT / 4)) % CK, t = it / ((MT / 4) * CK);
+                if (k0 + kc < Ktot && m0 + 4 * m4 < Mtot)
+                    v = *reinterpret_cast<const float4*>(a.wt + ((size_t)t * Ktot + k0 + kc) * Mtot + m0 + 4 * m4);
+            }
+            rw[j] = v;
+        }
+    };
+    // ---- registers -> LDS
+    auto commit = [&](int k0) {
+        const bool upmode = !DGRAD && a.up0 && k0 < a.C0;
+        const int quads = upmode ? 2 : 4;
+#pragma unroll
+        for (int j = 0; j < NVEC; ++j) {
+            const int it = tid + j * 256;
+            if (it < CK * PW_ * quads) {
+                const int kc = it / (PW_ * quads), rem = it - kc * (PW_ * quads);
+                const int r = rem / quads, q = rem - r * quads;
+                float* dst = patch + kc * PS_ + r * PW_;
+                const float4 v = rv[j];
+                if (DGRAD) {
+                    dst += 2 + 4 * q;
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                } else if (upmode) {
+                    dst += 1 + 8 * q;
+                    dst[0] = v.x; dst[1] = v.x; dst[2] = v.y; dst[3] = v.y; dst[4] = v.z; dst[5] = v.z; dst[6] = v.w; dst[7] = v.w;
+                } else {
+                    dst += 1 + 4 * q;
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NEDGE; ++j) {
+            const int it = tid + j * 256;
+            if (it < CK * PW_ * 2) {
+                const int kc = it / (PW_ * 2), rem = it - kc * (PW_ * 2);
+                const int r = rem >> 1, side = rem & 1;
+                patch[kc * PS_ + r * PW_ + (DGRAD ? side : side * (PW_ - 1))] = re[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const int it = tid + j * 256;
+            if (it < 9 * CK * (MT / 4)) {
+                const int m4 = it % (MT / 4), kc = (it / (MT / 4)) % CK, t = it / ((MT / 4) * CK);
+                *reinterpret_cast<float4*>(wl + (t * CK + kc) * WS + 4 * m4) = rw[j];
+            }
+        }
+    };
+
+    prefetch(0);
+    for (int k0 = 0; k0 < Ktot; k0 += CK) {
+        __syncthreads();              // the previous chunk's MFMAs are done with the LDS tiles
+        commit(k0);
+        __syncthreads();
+        if (k0 + CK < Ktot) prefetch(k0 + CK);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+            for (int kk = 0; kk < CK / 4; ++kk) {
+                const int kc = kk * 4 + (lane >> 4);
+                float af[MR], bf[4];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) af[i] = wl[(t * CK + kc) * WS + i * 16 + (lane & 15)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = patch[kc * PS_ + (wave * 4 + j + ky) * PW_ + (lane & 15) + kx];
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    const int px = ox0 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int py = oy0 + wave * 4 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + (lane >> 4) * 4 + r;
+                if (m < Mtot && py < OH && px < OW) {
+                    float v = acc[i][j][r];
+                    if (!DGRAD) v = act_fwd(v + (a.bias ? a.bias[m] : 0.f), a.act);
+                    a.out[(((size_t)b * Mtot + m) * OH + py) * OW + px] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fold: dxpad (B,Cin,H+2,W+2) -> dx0 (B,C0,H>>up,W>>up) [2x2 sum when up], dx1 (B,C1,H,W)
 // reflect:  d x[r] = dxpad[r] + (r==1 ? dxpad[-1] : 0) + (r==H-2 ? dxpad[H] : 0), same along x.
 // ------------------------------------------------------------------------------------------------
@@ -240,6 +447,7 @@ struct WgradArgs {
     const float* x0; int C0; int up0;
     const float* x1; int C1;
     const float* y; const float* gy;
+    const float* gp;       // v2: precomputed g' = gy * act'(y)
     float* part;           // [split][Co][Cin*9]
     float* pbias;          // [split][Co]  (written by the blocks with blockIdx.z == 0)
     int B, Co, H, W, act, pad;
@@ -356,6 +564,191 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad v2 for W % 16 == 0: same MFMA core and slab protocol as conv_wgrad_kernel, but the g' tile and the x
+// patch are staged with float4 loads (15 loads per thread and tile instead of 84) from the precomputed g', and
+// the next tile's loads are issued before the current tile's MFMA phase.
+// ------------------------------------------------------------------------------------------------
+template <int MR>
+__global__ __launch_bounds__(256) void conv_wgrad_v2_kernel(WgradArgs a) {
+    constexpr int MT = 16 * MR;
+    constexpr int NG = (MT * CT * 4 + 255) / 256;           // float4 items of the g' tile per thread
+    constexpr int NXV = (CW * PW_ * 4 + 255) / 256, NXE = (CW * PW_ * 2 + 255) / 256;
+    __shared__ float gl[MT * GS_];
+    __shared__ float xl[CW * XS_];
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * MT, c0 = blockIdx.z * CW;
+    const int H = a.H, W = a.W, Cin = a.C0 + a.C1;
+    const int h0 = H >> a.up0, w0 = W >> a.up0;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const bool upmode = a.up0 && c0 < a.C0;                  // this block's channels live in the half-res x0
+    const int quads = upmode ? 2 : 4;
+
+    f4 acc[MR][9];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = f4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    float4 rg[NG], rxv[NXV];
+    float rxe[NXE];
+    auto prefetch = [&](int tile) {
+        const int b = tile / (a.tiles_x * a.tiles_y), tt = tile - b * (a.tiles_x * a.tiles_y);
+        const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+        const int oy0 = ty * CT, ox0 = tx * CT;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int it = tid + j * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < MT * CT * 4) {
+                const int m = it / (CT * 4), rem = it - m * (CT * 4);
+                const int r = rem >> 2, q = rem & 3;
+                const int yy = oy0 + r, co = m0 + m;
+                if (co < a.Co && yy < H) v = *reinterpret_cast<const float4*>(a.gp + (((size_t)b * a.Co + co) * H + yy) * W + ox0 + 4 * q);
+            }
+            rg[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NXV; ++j) {
+            const int it = tid + j * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < CW * PW_ * quads) {
+                const int kc = it / (PW_ * quads), rem = it - kc * (PW_ * quads);
+                const int r = rem / quads, q = rem - r * quads;
+                const int ch = c0 + kc;
+                bool oky;
+                const int yy = pad_index(oy0 + r - 1, H, a.pad, oky);
+                if (ch < Cin && oky) {
+                    if (upmode)
+                        v = *reinterpret_cast<const float4*>(a.x0 + (((size_t)b * a.C0 + ch) * h0 + (yy >> 1)) * w0 + (ox0 >> 1) + 4 * q);
+                    else if (ch < a.C0)
+                        v = *reinterpret_cast<const float4*>(a.x0 + (((size_t)b * a.C0 + ch) * H + yy) * W + ox0 + 4 * q);
+                    else
+                        v = *reinterpret_cast<const float4*>(a.x1 + (((size_t)b * a.C1 + (ch - a.C0)) * H + yy) * W + ox0 + 4 * q);
+                }
+            }
+            rxv[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NXE; ++j) {
+            const int it = tid + j * 256;
+            float v = 0.f;
+            if (it < CW * PW_ * 2) {
+                const int kc = it / (PW_ * 2), rem = it - kc * (PW_ * 2);
+                const int r = rem >> 1, side = rem & 1;
+                const int ch = c0 + kc;
+                bool oky, okx;
+                const int yy = pad_index(oy0 + r - 1, H, a.pad, oky);
+                const int xx = pad_index(side ? ox0 + CT : ox0 - 1, W, a.pad, okx);
+                if (ch < Cin && oky && okx)
+                    v = (ch < a.C0) ? a.x0[(((size_t)b * a.C0 + ch) * h0 + (yy >> a.up0)) * w0 + (xx >> a.up0)]
+                                    : a.x1[(((size_t)b * a.C1 + (ch - a.C0)) * H + yy) * W + xx];
+            }
+            rxe[j] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int it = tid + j * 256;
+            if (it < MT * CT * 4) {
+                const int m = it / (CT * 4), rem = it - m * (CT * 4);
+                float* dst = gl + m * GS_ + (rem >> 2) * CT + (rem & 3) * 4;
+                const float4 v = rg[j];
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NXV; ++j) {
+            const int it = tid + j * 256;
+            if (it < CW * PW_ * quads) {
+                const int kc = it / (PW_ * quads), rem = it - kc * (PW_ * quads);
+                const int r = rem / quads, q = rem - r * quads;
+                float* dst = xl + kc * XS_ + r * PW_;
+                const float4 v = rxv[j];
+                if (upmode) {
+                    dst += 1 + 8 * q;
+                    dst[0] = v.x; dst[1] = v.x; dst[2] = v.y; dst[3] = v.y; dst[4] = v.z; dst[5] = v.z; dst[6] = v.w; dst[7] = v.w;
+                } else {
+                    dst += 1 + 4 * q;
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NXE; ++j) {
+            const int it = tid + j * 256;
+            if (it < CW * PW_ * 2) {
+                const int kc = it / (PW_ * 2), rem = it - kc * (PW_ * 2);
+                xl[kc * XS_ + (rem >> 1) * PW_ + (rem & 1) * (PW_ - 1)] = rxe[j];
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += a.split) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (tile + a.split < ntiles) prefetch(tile + a.split);
+        if (blockIdx.z == 0 && tid < MT * (256 / MT)) {
+            const int m = tid % MT, sl = tid / MT, nsl = 256 / MT;
+            for (int q = sl; q < CT * CT; q += nsl) bsum += gl[m * GS_ + q];
+        }
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 4 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = q * 4 + (lane >> 4);
+                float af[MR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) af[i] = gl[(i * 16 + (lane & 15)) * GS_ + row * CT + col];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t - ky * 3;
+                    const float bf = xl[(lane & 15) * XS_ + (row + ky) * PW_ + col + kx];
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* slab = a.part + (size_t)blockIdx.x * a.Co * Cin * 9;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[wave][lane] = acc[i][t][r];
+                __syncthreads();
+                if (wave == 0) {
+                    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+                    const int co = m0 + i * 16 + (lane >> 4) * 4 + r, ci = c0 + (lane & 15);
+                    if (co < a.Co && ci < Cin) slab[((size_t)co * Cin + ci) * 9 + t] = v;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (blockIdx.z == 0) {
+        __syncthreads();
+        gl[tid] = bsum;
+        __syncthreads();
+        if (tid < MT && m0 + tid < a.Co) {
+            float v = 0.f;
+            for (int sl = 0; sl < 256 / MT; ++sl) v += gl[sl * MT + tid];
+            a.pbias[(size_t)blockIdx.x * a.Co + m0 + tid] = v;
+        }
+    }
+}
+
 // fixed-order reduction of the split-K slabs: block = 16 outputs x 16 slab groups; each thread sums its
 // group's slabs in order, the 16 group sums are then added in order through LDS.
 __global__ __launch_bounds__(256) void conv_wreduce_kernel(const float* part, const float* pbias, float* dw, float* db,
@@ -420,9 +813,16 @@ extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1,
     a.tiles_x = ceil_div(W, CT); a.tiles_y = ceil_div(H, CT);
     const int mr = pick_mr(Co);
     const dim3 grid(a.tiles_x * a.tiles_y, ceil_div(Co, 16 * mr), B);
-    if (mr == 4) hipLaunchKernelGGL((conv_gemm_kernel<4, false>), grid, dim3(256), 0, ST, a);
-    else if (mr == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, false>), grid, dim3(256), 0, ST, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<1, false>), grid, dim3(256), 0, ST, a);
+    const bool fast = (W % 16 == 0) && (C1 == 0 || C0 % CK == 0) && (Co % 4 == 0);
+    if (fast) {
+        if (mr == 4) hipLaunchKernelGGL((conv_gemm_v2_kernel<4, false>), grid, dim3(256), 0, ST, a);
+        else if (mr == 2) hipLaunchKernelGGL((conv_gemm_v2_kernel<2, false>), grid, dim3(256), 0, ST, a);
+        else hipLaunchKernelGGL((conv_gemm_v2_kernel<1, false>), grid, dim3(256), 0, ST, a);
+    } else {
+        if (mr == 4) hipLaunchKernelGGL((conv_gemm_kernel<4, false>), grid, dim3(256), 0, ST, a);
+        else if (mr == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, false>), grid, dim3(256), 0, ST, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<1, false>), grid, dim3(256), 0, ST, a);
+    }
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -433,7 +833,7 @@ extern "C" size_t dc_conv3x3_bwd_workspace(int C0, int C1, int B, int Co, int H,
     const size_t nW = (size_t)Co * Cin * 9;
     const int split = pick_split(B, H, W, Co, Cin);
     return al256(nW * 4) + al256((size_t)B * Cin * (H + 2) * (W + 2) * 4) + al256((size_t)split * nW * 4) +
-           al256((size_t)split * Co * 4);
+           al256((size_t)split * Co * 4) + al256((size_t)B * Co * H * W * 4);
 }
 
 extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
@@ -450,21 +850,38 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     float* wd = (float*)p; p += al256(nW * 4);
     float* dxpad = (float*)p; p += al256((size_t)B * Cin * (H + 2) * (W + 2) * 4);
     float* part = (float*)p; p += al256((size_t)split * nW * 4);
-    float* pbias = (float*)p;
+    float* pbias = (float*)p; p += al256((size_t)split * Co * 4);
+    float* gpbuf = (float*)p;
     const int tiles_x = ceil_div(W, CT), tiles_y = ceil_div(H, CT);
+    // fast path (v2 kernels): full 16-wide tiles, 16-byte aligned rows, chunks that do not straddle the concat
+    const bool fast = (W % 16 == 0) && (C1 == 0 || C0 % CK == 0) && (C1 == 0 || C0 % CW == 0) && (Cin % 4 == 0);
+    const float* gp = gy;
+    if (fast && act != ACT_NONE) {
+        const size_t n4 = (size_t)B * Co * H * W / 4;
+        hipLaunchKernelGGL(conv_gprime_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, ST, gy, y,
+                           gpbuf, n4, act);
+        DC_CHECK_LAUNCH();
+        gp = gpbuf;
+    }
     if (dx0 || dx1) {
         hipLaunchKernelGGL(conv_wprep_kernel, dim3(ceil_div((int)nW, 256)), dim3(256), 0, ST, weight, (float*)nullptr, wd,
                            Co, Cin);
         DC_CHECK_LAUNCH();
         ConvArgs a{};
-        a.C0 = C0; a.C1 = C1; a.up0 = up0 ? 1 : 0; a.wt = wd; a.y = y; a.gy = gy; a.out = dxpad;
+        a.C0 = C0; a.C1 = C1; a.up0 = up0 ? 1 : 0; a.wt = wd; a.y = y; a.gy = gy; a.gp = gp; a.out = dxpad;
         a.B = B; a.Co = Co; a.H = H; a.W = W; a.act = act; a.pad = pad_mode;
         a.tiles_x = ceil_div(W + 2, CT); a.tiles_y = ceil_div(H + 2, CT);
         const int mr = pick_mr(Cin);
         const dim3 grid(a.tiles_x * a.tiles_y, ceil_div(Cin, 16 * mr), B);
-        if (mr == 4) hipLaunchKernelGGL((conv_gemm_kernel<4, true>), grid, dim3(256), 0, ST, a);
-        else if (mr == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, true>), grid, dim3(256), 0, ST, a);
-        else hipLaunchKernelGGL((conv_gemm_kernel<1, true>), grid, dim3(256), 0, ST, a);
+        if (fast) {
+            if (mr == 4) hipLaunchKernelGGL((conv_gemm_v2_kernel<4, true>), grid, dim3(256), 0, ST, a);
+            else if (mr == 2) hipLaunchKernelGGL((conv_gemm_v2_kernel<2, true>), grid, dim3(256), 0, ST, a);
+            else hipLaunchKernelGGL((conv_gemm_v2_kernel<1, true>), grid, dim3(256), 0, ST, a);
+        } else {
+            if (mr == 4) hipLaunchKernelGGL((conv_gemm_kernel<4, true>), grid, dim3(256), 0, ST, a);
+            else if (mr == 2) hipLaunchKernelGGL((conv_gemm_kernel<2, true>), grid, dim3(256), 0, ST, a);
+            else hipLaunchKernelGGL((conv_gemm_kernel<1, true>), grid, dim3(256), 0, ST, a);
+        }
         DC_CHECK_LAUNCH();
         const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
         hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0,
@@ -473,13 +890,18 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     }
     if (dweight || dbias) {
         WgradArgs g{};
-        g.x0 = x0; g.C0 = C0; g.up0 = up0 ? 1 : 0; g.x1 = x1; g.C1 = C1; g.y = y; g.gy = gy; g.part = part; g.pbias = pbias;
+        g.x0 = x0; g.C0 = C0; g.up0 = up0 ? 1 : 0; g.x1 = x1; g.C1 = C1; g.y = y; g.gy = gy; g.gp = gp; g.part = part; g.pbias = pbias;
         g.B = B; g.Co = Co; g.H = H; g.W = W; g.act = act; g.pad = pad_mode;
         g.tiles_x = tiles_x; g.tiles_y = tiles_y; g.split = split;
         const int mr = pick_mr_w(Co);
         const dim3 grid(split, ceil_div(Co, 16 * mr), ceil_div(Cin, CW));
-        if (mr == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, ST, g);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), 0, ST, g);
+        if (fast) {
+            if (mr == 2) hipLaunchKernelGGL((conv_wgrad_v2_kernel<2>), grid, dim3(256), 0, ST, g);
+            else hipLaunchKernelGGL((conv_wgrad_v2_kernel<1>), grid, dim3(256), 0, ST, g);
+        } else {
+            if (mr == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, ST, g);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(256), 0, ST, g);
+        }
         DC_CHECK_LAUNCH();
         hipLaunchKernelGGL(conv_wreduce_kernel, dim3(ceil_div((int)nW + Co, 16)), dim3(256), 0, ST, part, pbias, dweight,
                            dbias, split, (int)nW, Co);

@@ -32,6 +32,13 @@ CASES = [
     (1, 40, 24, 72, 18, 22, True, 1, 0),
     (2, 12, 0, 20, 17, 19, False, 0, 1),
     (1, 64, 0, 64, 6, 20, False, 1, 0),
+    # W % 16 == 0: the vectorised / double-buffered v2 kernels
+    (2, 32, 64, 32, 32, 48, True, 1, 0),
+    (1, 24, 0, 8, 16, 32, False, 1, 0),
+    (2, 16, 16, 20, 32, 64, True, 1, 0),
+    (1, 40, 0, 36, 48, 80, False, 0, 1),
+    (2, 8, 0, 1, 32, 32, False, 2, 0),
+    (1, 16, 32, 16, 20, 16, False, 1, 0),
 ]
 
 
