@@ -290,8 +290,18 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(ConvArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (it < 9 * CK * (MT / 4)) {
                 const int m4 = it % (MT / 4), kc = (it / (MT / 4)) % CK, t = it / ((MT / 4) * CK);
-                if (k0 + kc < Ktot && m0 + 4 * m4 < Mtot)
-                    v = *reinterpret_cast<const float4*>(a.wt + ((size_t)t * Ktot + k0 + kc) * Mtot + m0 + 4 * m4);
+                if (k0 + kc < Ktot && m0 + 4 * m4 < Mtot) {
+                    const float* wp = a.wt + ((size_t)t * Ktot + k0 + kc) * Mtot + m0 + 4 * m4;
+                    if ((Mtot & 3) == 0) {
+                        v = *reinterpret_cast<const float4*>(wp);
+                    } else {                      // e.g. the Co = 1 dispconv: rows are not 16-byte aligned
+                        const int left = Mtot - (m0 + 4 * m4);
+                        v.x = wp[0];
+                        if (left > 1) v.y = wp[1];
+                        if (left > 2) v.z = wp[2];
+                        if (left > 3) v.w = wp[3];
+                    }
+                }
             }
             rw[j] = v;
         }
@@ -813,7 +823,7 @@ extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1,
     a.tiles_x = ceil_div(W, CT); a.tiles_y = ceil_div(H, CT);
     const int mr = pick_mr(Co);
     const dim3 grid(a.tiles_x * a.tiles_y, ceil_div(Co, 16 * mr), B);
-    const bool fast = (W % 16 == 0) && (C1 == 0 || C0 % CK == 0) && (Co % 4 == 0);
+    const bool fast = (W % 16 == 0) && (C1 == 0 || C0 % CK == 0);
     if (fast) {
         if (mr == 4) hipLaunchKernelGGL((conv_gemm_v2_kernel<4, false>), grid, dim3(256), 0, ST, a);
         else if (mr == 2) hipLaunchKernelGGL((conv_gemm_v2_kernel<2, false>), grid, dim3(256), 0, ST, a);
@@ -854,7 +864,7 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     float* gpbuf = (float*)p;
     const int tiles_x = ceil_div(W, CT), tiles_y = ceil_div(H, CT);
     // fast path (v2 kernels): full 16-wide tiles, 16-byte aligned rows, chunks that do not straddle the concat
-    const bool fast = (W % 16 == 0) && (C1 == 0 || C0 % CK == 0) && (C1 == 0 || C0 % CW == 0) && (Cin % 4 == 0);
+    const bool fast = (W % 16 == 0) && (C1 == 0 || C0 % CK == 0) && (C1 == 0 || C0 % CW == 0);
     const float* gp = gy;
     if (fast && act != ACT_NONE) {
         const size_t n4 = (size_t)B * Co * H * W / 4;
