@@ -169,16 +169,21 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "training images/sec at 192x640 bs12 (resnet18 depth+pose, 4-scale photometric+smoothness)",
+            "metric": "training images/sec at %dx%d bs%d (resnet%d depth+pose, 4-scale photometric+smoothness)"
+                      % (args.height, args.width, args.batch, args.num_layers),
             "value": round(world * args.batch * args.steps / dt, 3),
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: resnet18 depth+pose, %dx%d, per-GPU batch %d, 4 scales, "
+            "config": {"workload": "%sresnet%d depth+pose, %dx%d, per-GPU batch %d, 4 scales, "
                                    "frames {0,-1,+1}, automasking, Adam lr 1e-4; random-init weights"
-                                   % (args.height, args.width, args.batch),
+                                   % ("BASELINE configs[1]: " if (args.num_layers, args.height, args.width, args.batch)
+                                      == (18, 192, 640, 12) else
+                                      "BASELINE configs[2] (per-rank): " if (args.num_layers, args.height, args.width,
+                                                                             args.batch) == (50, 320, 1024, 8) else "",
+                                      args.num_layers, args.height, args.width, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "tiebreak_noise": "cpu-randn+h2d" if args.cpu_noise else "on-device counter RNG"},
             "roofline": {"kernel": "dc::photo_bwd_kernel (fused warp+SSIM+L1+automask backward, 4 scales x 2 frames)",
