@@ -584,9 +584,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_v2_kernel(WgradArgs a) {
     constexpr int MT = 16 * MR;
     constexpr int NG = (MT * CT * 4 + 255) / 256;           // float4 items of the g' tile per thread
     constexpr int NXV = (CW * PW_ * 4 + 255) / 256, NXE = (CW * PW_ * 2 + 255) / 256;
-    __shared__ float gl[MT * GS_];
-    __shared__ float xl[CW * XS_];
-    __shared__ float red[4][64];
+    constexpr int ACC_PER_WAVE = MR * 9 * 4 * 64;                      // accumulator floats of one wave
+    constexpr int SMEM = (MT * GS_ + CW * XS_) > 3 * ACC_PER_WAVE ? (MT * GS_ + CW * XS_) : 3 * ACC_PER_WAVE;
+    __shared__ float smem[SMEM];
+    float* gl = smem;
+    float* xl = smem + MT * GS_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * MT, c0 = blockIdx.z * CW;
     const int H = a.H, W = a.W, Cin = a.C0 + a.C1;
@@ -728,27 +730,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_v2_kernel(WgradArgs a) {
             }
         }
     }
+    // ---- dbias partials first (they live in the g' tile area), then the four waves' accumulators are summed in
+    // fixed order through LDS in one shot: waves 1-3 park theirs, wave 0 adds them to its own and writes the slab.
     __syncthreads();
-    float* slab = a.part + (size_t)blockIdx.x * a.Co * Cin * 9;
-#pragma unroll
-    for (int i = 0; i < MR; ++i) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                red[wave][lane] = acc[i][t][r];
-                __syncthreads();
-                if (wave == 0) {
-                    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-                    const int co = m0 + i * 16 + (lane >> 4) * 4 + r, ci = c0 + (lane & 15);
-                    if (co < a.Co && ci < Cin) slab[((size_t)co * Cin + ci) * 9 + t] = v;
-                }
-                __syncthreads();
-            }
-        }
-    }
     if (blockIdx.z == 0) {
-        __syncthreads();
         gl[tid] = bsum;
         __syncthreads();
         if (tid < MT && m0 + tid < a.Co) {
@@ -756,6 +741,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_v2_kernel(WgradArgs a) {
             for (int sl = 0; sl < 256 / MT; ++sl) v += gl[sl * MT + tid];
             a.pbias[(size_t)blockIdx.x * a.Co + m0 + tid] = v;
         }
+        __syncthreads();
+    }
+    if (wave > 0) {
+        float* dst = smem + (size_t)(wave - 1) * ACC_PER_WAVE + lane;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[((i * 9 + t) * 4 + r) * 64] = acc[i][t][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* slab = a.part + (size_t)blockIdx.x * a.Co * Cin * 9;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = ((i * 9 + t) * 4 + r) * 64 + lane;
+                    const float v = (acc[i][t][r] + smem[o]) + (smem[ACC_PER_WAVE + o] + smem[2 * ACC_PER_WAVE + o]);
+                    const int co = m0 + i * 16 + (lane >> 4) * 4 + r, ci = c0 + (lane & 15);
+                    if (co < a.Co && ci < Cin) slab[((size_t)co * Cin + ci) * 9 + t] = v;
+                }
     }
 }
 
@@ -791,7 +801,10 @@ static inline int pick_mr_w(int M) { return M > 16 ? 2 : 1; }   // wgrad: LDS ho
 static inline int pick_split(int B, int H, int W, int Co, int Cin) {
     const int ntiles = ceil_div(W, CT) * ceil_div(H, CT) * B;
     const int outer = ceil_div(Co, 16 * pick_mr_w(Co)) * ceil_div(Cin, CW);
+    // enough blocks to fill 256 CUs a few times over, but at least ~4 pixel tiles per block so that the
+    // pipeline prologue and the slab epilogue are amortised
     int split = std::max(1, std::min(ntiles, 2048 / std::max(outer, 1)));
+    split = std::min(split, std::max(1, ntiles / 4));
     return std::min(split, 512);
 }
 
