@@ -87,6 +87,9 @@ def _sig(lib):
         "dc_bn_relu_bwd": (i, [p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, i, p]),
         "dc_maxpool3x3s2_fwd": (i, [p, p, p, i, i, i, p]),
         "dc_maxpool3x3s2_bwd": (i, [p, p, p, i, i, i, p]),
+        "dc_wino3x3_workspace": (z, [i, i]),
+        "dc_wino3x3_fwd": (i, [p, p, p, p, i, i, i, i, i, p]),
+        "dc_wino3x3_dgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_profile_enable": (i, [i]),
         "dc_profile_collect": (i, [POINTER(c_double), POINTER(c_int), POINTER(c_double), POINTER(c_int)]),
     }

@@ -557,3 +557,45 @@ class _MaxPool(torch.autograd.Function):
 
 def maxpool3x3s2(x):
     return _MaxPool.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1 trunk conv3x3 (stride 1, zero pad 1, no bias): fused Winograd F(2x2,3x3) forward and data gradient
+# ----------------------------------------------------------------------------------------------
+class _WinoConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        L = _lib.lib()
+        xx, ww = _c(x.detach()), _c(weight.detach())
+        B, Ci, H, W = xx.shape
+        Co = ww.shape[0]
+        y = torch.empty(B, Co, H, W, dtype=torch.float32, device=xx.device)
+        ws = torch.empty(L.dc_wino3x3_workspace(Ci, Co), dtype=torch.uint8, device=xx.device)
+        check(L.dc_wino3x3_fwd(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, stream()), "dc_wino3x3_fwd")
+        ctx.save_for_backward(xx, ww)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        xx, ww = ctx.saved_tensors
+        B, Ci, H, W = xx.shape
+        Co = ww.shape[0]
+        g_c = _c(gy)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(xx)
+            ws = torch.empty(L.dc_wino3x3_workspace(Ci, Co), dtype=torch.uint8, device=xx.device)
+            check(L.dc_wino3x3_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), B, Ci, Co, H, W, stream()),
+                  "dc_wino3x3_dgrad")
+        if ctx.needs_input_grad[1]:
+            # the weight gradient stays on the library's implicit-GEMM wrw (measured faster than dc_conv3x3_bwd's
+            # split-K wgrad at the trunk shapes, tools/bench_wgrad.py)
+            gw = torch.ops.aten.convolution_backward(g_c, xx, ww, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return gx, gw
+
+
+def wino_conv3x3(x, weight):
+    """F.conv2d(x, weight, None, 1, 1) for 3x3 kernels on even-width maps (fused Winograd on the matrix cores)."""
+    return _WinoConv.apply(x, weight)

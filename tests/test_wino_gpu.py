@@ -1,0 +1,56 @@
+"""Winograd F(2x2,3x3) trunk convolution (dc_wino3x3_*) against the plain fp32 torch convolution.
+
+Floating-point kernel -> the checker is torch's direct conv2d in fp64 on the same inputs; tolerance 2e-5 of the
+output scale (Winograd rounding; the north-star tolerance for the path is 1e-3)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, Ci, Co, H, W
+    (2, 64, 64, 48, 160),      # layer1 (2x8 regions, MR 2 or 1)
+    (12, 64, 64, 48, 160),     # layer1 at the bench batch (MR 2)
+    (3, 128, 128, 24, 80),     # layer2
+    (2, 256, 256, 12, 40),     # layer3 (3x5 regions)
+    (2, 512, 512, 6, 20),      # layer4 (3x5 regions)
+    (1, 3, 5, 7, 10),          # ragged: odd H, channel counts below one block
+    (2, 20, 40, 9, 34),        # K not a multiple of the chunk, M straddles blocks
+    (1, 8, 16, 2, 2),          # single tile
+    (2, 64, 256, 80, 256),     # bottleneck-style, C3 geometry
+]
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", CASES)
+def test_wino_forward_and_grads(B, Ci, Co, H, W):
+    from depthcore import ops
+    g = torch.Generator().manual_seed(B * 1000 + Ci + H)
+    x = torch.randn(B, Ci, H, W, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5).cuda().requires_grad_(True)
+    gy = torch.randn(B, Co, H, W, generator=g).cuda()
+    y = ops.wino_conv3x3(x, w)
+    y.backward(gy)
+    xr = x.detach().double().requires_grad_(True)
+    wr = w.detach().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    yr.backward(gy.double())
+    for name, got, ref in (("y", y, yr), ("dx", x.grad, xr.grad), ("dw", w.grad, wr.grad)):
+        err = (got.double() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert err <= 2e-5 * scale, "%s: max err %.3e vs scale %.3e" % (name, err, scale)
+
+
+def test_wino_rejects_odd_width():
+    from depthcore import ops
+    x = torch.randn(1, 4, 6, 7).cuda()
+    w = torch.randn(4, 4, 3, 3).cuda()
+    with pytest.raises(RuntimeError):
+        ops.wino_conv3x3(x, w)
+
+
+def test_wino_deterministic():
+    from depthcore import ops
+    x = torch.randn(2, 64, 24, 80).cuda()
+    w = torch.randn(64, 64, 3, 3).cuda()
+    assert torch.equal(ops.wino_conv3x3(x, w), ops.wino_conv3x3(x, w))
