@@ -27,6 +27,7 @@
 #include "dc_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace dc {
 
@@ -44,6 +45,7 @@ struct WinoArgs {
     int regs_x, regs_y, nreg;         // regions per image / total
     int nchunks;
     unsigned xbytes;
+    int dbg;                          // timing experiments only (DC_WINO_DBG): 1 no loads, 2 no commit/barriers, 4 no MFMA phase
 };
 
 // U = G g G^T for every (m, k), written in staging order.  grid over padded (Mp x Kp); one thread per (m, k).
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs a) {
     constexpr int MT = 16 * MR;
     constexpr int UF4 = WK * 4 * MT;                  // float4 items of one U chunk
     constexpr int NU = UF4 / 256;                     // per thread (MR)
-    __shared__ f4 ul[UF4];
+    __shared__ f4 ul[2][UF4];
     __shared__ float xl[4][WK * WSLAB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kk = lane >> 4;
@@ -148,9 +150,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs a) {
             px[k] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)vo, (int)(img0 + (unsigned)ch * plane), 0));
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](f4* udst) {
 #pragma unroll
-        for (int j = 0; j < NU; ++j) ul[tid + j * 256] = pu[j];
+        for (int j = 0; j < NU; ++j) udst[tid + j * 256] = pu[j];
         if (swr) {
 #pragma unroll
             for (int k = 0; k < WK; ++k) {
@@ -160,23 +162,22 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs a) {
         }
     };
 
-    prefetch(0);
-    for (int c = 0; c < a.nchunks; ++c) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        if (c + 1 < a.nchunks) prefetch(c + 1);
-#pragma unroll
-        for (int ks = 0; ks < WK / 4; ++ks) {
-            // raw 4x4 patch of (channel ks*4+kk, tile n), then V = B^T d B
+    // One chunk's MFMA phase, software-pipelined by hand: group g = (k-step g>>2, positions 4*(g&3)..+3); the A
+    // operands of group g+1 and the raw patch of the next k-step are requested before group g's MFMAs issue.
+    auto compute = [&](const f4* ucur) {
+        const f4* up = ucur + (kk * 4) * MT + n;
+        float d[4][4], v[16];
+        f4 ua[2][MR];
+        auto read_patch = [&](int ks) {
             const float* src = xw + ks * 4 * PS + rd0;
-            float d[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f2w lo = *reinterpret_cast<const f2w*>(src + i * RS);
                 const f2w hi = *reinterpret_cast<const f2w*>(src + i * RS + 2);
                 d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
             }
+        };
+        auto transform = [&]() {
             float t[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -185,7 +186,6 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs a) {
                 t[2][j] = d[2][j] - d[1][j];
                 t[3][j] = d[1][j] - d[3][j];
             }
-            float v[16];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v[i * 4 + 0] = t[i][0] - t[i][2];
@@ -193,19 +193,46 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs a) {
                 v[i * 4 + 2] = t[i][2] - t[i][1];
                 v[i * 4 + 3] = t[i][1] - t[i][3];
             }
-            const f4* up = ul + ((ks * 4 + kk) * 4) * MT + n;
+        };
+        read_patch(0);
 #pragma unroll
-            for (int pq = 0; pq < 4; ++pq) {
+        for (int i = 0; i < MR; ++i) ua[0][i] = up[i * 16];
+        transform();
 #pragma unroll
-                for (int i = 0; i < MR; ++i) {
-                    const f4 u = up[pq * MT + i * 16];
-                    acc[i][pq * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, v[pq * 4 + 0], acc[i][pq * 4 + 0], 0, 0, 0);
-                    acc[i][pq * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, v[pq * 4 + 1], acc[i][pq * 4 + 1], 0, 0, 0);
-                    acc[i][pq * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v[pq * 4 + 2], acc[i][pq * 4 + 2], 0, 0, 0);
-                    acc[i][pq * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, v[pq * 4 + 3], acc[i][pq * 4 + 3], 0, 0, 0);
-                }
+        for (int g = 0; g < WK; ++g) {                // WK/4 k-steps x 4 position groups
+            const int ks = g >> 2, pq = g & 3;
+            if (g + 1 < WK) {
+                const int ks1 = (g + 1) >> 2, pq1 = (g + 1) & 3;
+#pragma unroll
+                for (int i = 0; i < MR; ++i) ua[(g + 1) & 1][i] = up[((ks1 * 16 + pq1) * MT) + i * 16];
             }
+            if (pq == 0 && ks + 1 < WK / 4) read_patch(ks + 1);        // d is dead once v exists
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const f4 u = ua[g & 1][i];
+                acc[i][pq * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, v[pq * 4 + 0], acc[i][pq * 4 + 0], 0, 0, 0);
+                acc[i][pq * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, v[pq * 4 + 1], acc[i][pq * 4 + 1], 0, 0, 0);
+                acc[i][pq * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v[pq * 4 + 2], acc[i][pq * 4 + 2], 0, 0, 0);
+                acc[i][pq * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, v[pq * 4 + 3], acc[i][pq * 4 + 3], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (pq == 3 && ks + 1 < WK / 4) transform();
         }
+    };
+
+    // U is double-buffered in LDS, the x slab is wave-private: one barrier per chunk.
+    prefetch(0);
+    commit(ul[0]);
+    if (a.nchunks > 1) prefetch(1);
+    __syncthreads();
+    for (int c = 0; c < a.nchunks; ++c) {
+        if (!(a.dbg & 4)) compute(ul[c & 1]);
+        if (c + 1 < a.nchunks) {
+            if (!(a.dbg & 2)) commit(ul[(c + 1) & 1]);
+            if (c + 2 < a.nchunks && !(a.dbg & 1)) prefetch(c + 2);
+        }
+        __syncthreads();
     }
 
     // ---- output transform Y = A^T M A in registers; D layout: row m = kk*4 + r, column = tile n
@@ -262,6 +289,7 @@ static int wino_run(const float* x, const float* w, float* y, void* ws, int B, i
     a.regs_x = ceil_div(TW, a.RW); a.regs_y = ceil_div(TH, a.RH); a.nreg = a.regs_x * a.regs_y * B;
     a.nchunks = ceil_div(K, WK);
     a.xbytes = (unsigned)xb;
+    { const char* e = getenv("DC_WINO_DBG"); a.dbg = e ? atoi(e) : 0; }
     const int mr = wino_pick_mr(M, a.nreg), MT = 16 * mr;
     const int Mp = ceil_div(M, MT) * MT, Kp = a.nchunks * WK;
     if (dgrad)

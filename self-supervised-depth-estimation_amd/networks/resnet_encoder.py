@@ -31,6 +31,19 @@ def _bn_act(x, bn, res=None, relu=True, groups=1):
     return F.relu(y) if relu else y
 
 
+WINO_TRUNK = True     # stride-1 3x3 trunk convolutions on depthcore's fused Winograd kernel (GPU, even widths)
+
+
+def _conv(conv, x):
+    """nn.Conv2d call of the trunk; the stride-1 3x3 ones (84 % of the trunk's multiplies) run on
+    dc_wino3x3_fwd / dc_wino3x3_dgrad, the rest (7x7 stem, stride-2 3x3, 1x1) on the library convolution."""
+    if (WINO_TRUNK and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and x.shape[-1] % 2 == 0
+            and x.dtype == torch.float32):
+        return _ops.wino_conv3x3(x, conv.weight)
+    return conv(x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -47,8 +60,8 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         g = self._g[0]
         idt = x if self.downsample is None else _bn_act(self.downsample[0](x), self.downsample[1], relu=False, groups=g)
-        out = _bn_act(self.conv1(x), self.bn1, groups=g)
-        return _bn_act(self.conv2(out), self.bn2, res=idt, groups=g)   # relu(bn2(conv2) + identity), one pass
+        out = _bn_act(_conv(self.conv1, x), self.bn1, groups=g)
+        return _bn_act(_conv(self.conv2, out), self.bn2, res=idt, groups=g)   # relu(bn2(conv2) + identity), one pass
 
 
 class Bottleneck(nn.Module):
@@ -70,7 +83,7 @@ class Bottleneck(nn.Module):
         g = self._g[0]
         idt = x if self.downsample is None else _bn_act(self.downsample[0](x), self.downsample[1], relu=False, groups=g)
         out = _bn_act(self.conv1(x), self.bn1, groups=g)
-        out = _bn_act(self.conv2(out), self.bn2, groups=g)
+        out = _bn_act(_conv(self.conv2, out), self.bn2, groups=g)
         return _bn_act(self.conv3(out), self.bn3, res=idt, groups=g)
 
 

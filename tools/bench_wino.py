@@ -12,8 +12,8 @@ from depthcore import _lib  # noqa: E402
 from depthcore.ops import ptr  # noqa: E402
 
 
-def timed(fn, iters=30):
-    for _ in range(5):
+def timed(fn, iters=100):
+    for _ in range(20):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
