@@ -35,7 +35,6 @@ using f4 = __attribute__((ext_vector_type(4))) float;
 using f2w = __attribute__((ext_vector_type(2))) float;
 using wrsrc_t = __amdgpu_buffer_rsrc_t;
 
-constexpr int WK = 8;                 // reduction channels per staged chunk (2 MFMA k-steps)
 constexpr int WSLAB = 176;            // floats per channel of a wave's input slab (max over the region shapes)
 
 struct WinoArgs {
@@ -51,7 +50,7 @@ struct WinoArgs {
 // U = G g G^T for every (m, k), written in staging order.  grid over padded (Mp x Kp); one thread per (m, k).
 template <bool DGRAD>
 __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ uhat,
-                                                           int Co, int Ci, int MT, int Mp, int Kp) {
+                                                           int Co, int Ci, int MT, int Mp, int Kp, int WK) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Mp * Kp) return;
     const int m = idx / Kp, k = idx - m * Kp;
@@ -90,11 +89,12 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
         *reinterpret_cast<float4*>(dst + (size_t)pq * MT * 4) = make_float4(u[pq][0], u[pq][1], u[pq][2], u[pq][3]);
 }
 
-template <int MR>
+// MR = 16-channel output blocks per wave, WK = reduction channels per staged chunk (WK/4 MFMA k-steps)
+template <int MR, int WK>
 __global__ __launch_bounds__(256, 2) void wino_conv_kernel(WinoArgs a) {
     constexpr int MT = 16 * MR;
     constexpr int UF4 = WK * 4 * MT;                  // float4 items of one U chunk
-    constexpr int NU = UF4 / 256;                     // per thread (MR)
+    constexpr int NU = UF4 / 256;                     // per thread
     __shared__ f4 ul[2][UF4];
     __shared__ float xl[4][WK * WSLAB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -287,19 +287,22 @@ static int wino_run(const float* x, const float* w, float* y, void* ws, int B, i
     const int TH = ceil_div(H, 2), TW = W / 2;
     wino_pick_region(TH, TW, a.RH, a.RW, a.RS);
     a.regs_x = ceil_div(TW, a.RW); a.regs_y = ceil_div(TH, a.RH); a.nreg = a.regs_x * a.regs_y * B;
-    a.nchunks = ceil_div(K, WK);
     a.xbytes = (unsigned)xb;
     { const char* e = getenv("DC_WINO_DBG"); a.dbg = e ? atoi(e) : 0; }
-    const int mr = wino_pick_mr(M, a.nreg), MT = 16 * mr;
+    int mr = wino_pick_mr(M, a.nreg);
+    { const char* e = getenv("DC_WINO_MR"); if (e && M > 16) mr = atoi(e) == 2 ? 2 : 1; }
+    const int MT = 16 * mr;
+    const int WK = 8;
+    a.nchunks = ceil_div(K, WK);
     const int Mp = ceil_div(M, MT) * MT, Kp = a.nchunks * WK;
     if (dgrad)
-        hipLaunchKernelGGL((wino_weights_kernel<true>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, w, (float*)ws, Co, Ci, MT, Mp, Kp);
+        hipLaunchKernelGGL((wino_weights_kernel<true>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, w, (float*)ws, Co, Ci, MT, Mp, Kp, WK);
     else
-        hipLaunchKernelGGL((wino_weights_kernel<false>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, w, (float*)ws, Co, Ci, MT, Mp, Kp);
+        hipLaunchKernelGGL((wino_weights_kernel<false>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, w, (float*)ws, Co, Ci, MT, Mp, Kp, WK);
     DC_CHECK_LAUNCH();
     const dim3 grid(ceil_div(a.nreg, 4), Mp / MT);
-    if (mr == 2) hipLaunchKernelGGL((wino_conv_kernel<2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wino_conv_kernel<1>), grid, dim3(256), 0, st, a);
+    if (mr == 2) hipLaunchKernelGGL((wino_conv_kernel<2, 8>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wino_conv_kernel<1, 8>), grid, dim3(256), 0, st, a);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
