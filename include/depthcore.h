@@ -209,9 +209,10 @@ int dc_maxpool3x3s2_bwd(const float* gy, const uint8_t* code, float* dx, int NC,
 /* Stride-1 3x3 convolution with zero padding 1 and no bias -- the conv3x3 of the ResNet trunks (reference
  * networks/resnet_encoder.py:74-98 -> torchvision BasicBlock/Bottleneck) -- as a fused Winograd F(2x2,3x3) on the
  * fp32 matrix cores.  x (B,Ci,H,W), weight (Co,Ci,3,3), y (B,Co,H,W); dgrad: gy (B,Co,H,W) -> gx (B,Ci,H,W).
- * W must be even.  ws: dc_wino3x3_workspace(Ci, Co) bytes (transformed weights, rebuilt on every call).
+ * W must be even.  ws: dc_wino3x3_workspace bytes (transformed weights, rebuilt on every call, and the partial
+ * outputs of the channel-split used on small maps, summed in fixed order).
  * Result differs from a direct fp32 convolution by the usual Winograd rounding (~1e-6 relative). */
-size_t dc_wino3x3_workspace(int Ci, int Co);
+size_t dc_wino3x3_workspace(int B, int Ci, int Co, int H, int W);
 int dc_wino3x3_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int H, int W,
                    void* stream);
 int dc_wino3x3_dgrad(const float* gy, const float* weight, float* gx, void* ws, int B, int Ci, int Co, int H, int W,

@@ -87,7 +87,7 @@ def _sig(lib):
         "dc_bn_relu_bwd": (i, [p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, i, p]),
         "dc_maxpool3x3s2_fwd": (i, [p, p, p, i, i, i, p]),
         "dc_maxpool3x3s2_bwd": (i, [p, p, p, i, i, i, p]),
-        "dc_wino3x3_workspace": (z, [i, i]),
+        "dc_wino3x3_workspace": (z, [i, i, i, i, i]),
         "dc_wino3x3_fwd": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_wino3x3_dgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_profile_enable": (i, [i]),

@@ -570,7 +570,7 @@ class _WinoConv(torch.autograd.Function):
         B, Ci, H, W = xx.shape
         Co = ww.shape[0]
         y = torch.empty(B, Co, H, W, dtype=torch.float32, device=xx.device)
-        ws = torch.empty(L.dc_wino3x3_workspace(Ci, Co), dtype=torch.uint8, device=xx.device)
+        ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
         check(L.dc_wino3x3_fwd(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, stream()), "dc_wino3x3_fwd")
         ctx.save_for_backward(xx, ww)
         return y
@@ -585,7 +585,7 @@ class _WinoConv(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xx)
-            ws = torch.empty(L.dc_wino3x3_workspace(Ci, Co), dtype=torch.uint8, device=xx.device)
+            ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
             check(L.dc_wino3x3_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), B, Ci, Co, H, W, stream()),
                   "dc_wino3x3_dgrad")
         if ctx.needs_input_grad[1]:

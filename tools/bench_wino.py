@@ -37,7 +37,7 @@ def main():
             x = torch.randn(B, Ci, H, W, device="cuda")
             w = torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05
             y = torch.empty(B, Co, H, W, device="cuda")
-            ws = torch.empty(L.dc_wino3x3_workspace(Ci, Co), dtype=torch.uint8, device="cuda")
+            ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device="cuda")
             st = torch.cuda.current_stream().cuda_stream
             t_f = timed(lambda: L.dc_wino3x3_fwd(ptr(x), ptr(w), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, st))
             t_fl = timed(lambda: F.conv2d(x, w, None, 1, 1))
@@ -48,7 +48,7 @@ def main():
         w = torch.randn(C, C, 3, 3, device="cuda") * 0.05
         gy = torch.randn(B, C, H, W, device="cuda")
         y = torch.empty_like(x)
-        ws = torch.empty(L.dc_wino3x3_workspace(C, C), dtype=torch.uint8, device="cuda")
+        ws = torch.empty(L.dc_wino3x3_workspace(B, C, C, H, W), dtype=torch.uint8, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
         t_f = timed(lambda: L.dc_wino3x3_fwd(ptr(x), ptr(w), ptr(y), ws.data_ptr(), B, C, C, H, W, st))
         ref = F.conv2d(x, w, None, 1, 1)
@@ -62,7 +62,7 @@ def main():
                                                                  1, [True, False, False]))
         gflop = 2.0 * B * C * C * 9 * H * W / 1e9
         print("B=%d C=%d %dx%d: fwd %.1f us (lib %.1f) err %.1e | dgrad %.1f us (lib %.1f) err %.1e | %.0f TF direct-equiv"
-              % (B, C, H, W, t_f, t_fl, err_f, t_d, t_dl, err_d, gflop / t_f * 1e3 / 1e3), flush=True)
+              % (B, C, H, W, t_f, t_fl, err_f, t_d, t_dl, err_d, gflop / t_f * 1e3), flush=True)
 
 
 if __name__ == "__main__":

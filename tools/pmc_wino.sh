@@ -12,7 +12,7 @@ f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"][:40] + " grid " + r.get("Grid_Size", "?")
-    if "wino_conv" in k:
+    if "wino_" in k and "weights" not in k:
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
     print(k, {c: round(sum(x) / len(x) / 1e6, 3) for c, x in v.items()}, "(millions)")
