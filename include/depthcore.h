@@ -218,6 +218,13 @@ int dc_wino3x3_fwd(const float* x, const float* weight, float* y, void* ws, int 
 int dc_wino3x3_dgrad(const float* gy, const float* weight, float* gx, void* ws, int B, int Ci, int Co, int H, int W,
                      void* stream);
 
+/* Weight gradient of the same convolution, also in the Winograd domain (16 GEMMs reduced over all 2x2 tiles of the
+ * batch, split over blocks and summed in fixed order -- deterministic, no atomics).  x (B,Ci,H,W), gy (B,Co,H,W)
+ * -> dweight (Co,Ci,3,3), overwritten.  W even.  ws: dc_wino3x3_wgrad_workspace bytes. */
+size_t dc_wino3x3_wgrad_workspace(int B, int Ci, int Co, int H, int W);
+int dc_wino3x3_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int H, int W,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

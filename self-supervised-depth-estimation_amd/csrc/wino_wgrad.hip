@@ -1,0 +1,329 @@
+// Weight gradient of the stride-1 3x3 convolution in the Winograd F(2x2,3x3) domain, fp32 matrix cores (gfx950).
+//
+// Forward (wino.hip): Y_tile = A^T [ sum_k U .* V ] A with U = G g G^T, V = B^T d B.  Hence
+//     dU_p[m][k] = sum_tiles dM_p[m][tile] * V_p[k][tile],   dM = A dY A^T (4x4 from the 2x2 tile of gy),
+//     dg[m][k]   = G^T dU G                                   (4x4 -> 3x3),
+// i.e. 16 GEMMs with the reduction over ALL 2x2 tiles of the batch -- 2.25x fewer multiplies than the direct
+// correlation of x with gy.  Replaces the library weight-gradient call behind the trunk's nn.Conv2d
+// (reference networks/resnet_encoder.py:74-98; loss.backward() at trainer.py:236).
+//
+// Mapping to CDNA4 (wino_wgrad_kernel)
+//   * v_mfma_f32_16x16x4_f32: rows = 16 output channels m, cols = 16 input channels k, K = 4 tiles.
+//     A operand lane (m = lane&15, tile = lane>>4) holds dM_p[m][tile], B operand lane (tile, k) holds V_p[k][tile].
+//   * a block = 4 waves = the 4 ROWS of the Winograd domain (as in wino_ps_kernel): row a of dM needs the tile's
+//     two gy rows (2 fma + 2 add), row a of V two raw patch rows (4 fma + 4 add).  The signs of row/column 3 of
+//     dM are applied once to the accumulators at the end.
+//   * a wave keeps 4 x MR x KR accumulator tiles (MR,KR = 4,2: 64 m x 32 k per block, 128 VGPRs).
+//   * the reduction runs over sub-regions of <= 16 tiles (2x8, 4x4 or 3x5, whichever divides the map); per chunk
+//     the block stages 64 channels of gy and 32 channels of x (with halo) into double-buffered LDS slabs; the next
+//     chunk's 16 buffer_load_b64 per thread are in flight during the 128 MFMAs per wave of the current chunk.
+//     Channel strides are = 2 (mod 32) floats so that the 16 channels of a 16-lane group hit distinct banks.
+//   * split reduction without atomics: block (split, m-block, k-block) writes q[a][.] = (dU G)[a][.] (3 values per
+//     row a) to its slab with lane-contiguous stores; wino_wreduce_kernel sums the slabs in fixed order and applies
+//     G^T.  Deterministic.
+// Requires even W; H arbitrary.
+#include "dc_common.h"
+
+#include <algorithm>
+
+namespace dc {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+using f2w = __attribute__((ext_vector_type(2))) float;
+using wrsrc_t = __amdgpu_buffer_rsrc_t;
+
+constexpr int WG_MR = 4, WG_KR = 2;                    // 16-channel tiles per wave: gy side, x side
+constexpr int WG_MT = 16 * WG_MR, WG_KT = 16 * WG_KR;  // channels per block
+constexpr int WG_GPS = 66;                             // gy slab channel stride (floats), = 2 mod 32, >= 64
+constexpr int WG_XPS = 130;                            // x slab channel stride, = 2 mod 32, >= 120
+constexpr int WG_SLAB = 4 * WG_MR * WG_KR * 4 * 3 * 64;   // floats one block writes
+
+struct WinoWgArgs {
+    const float* x; const float* gy; float* slab;
+    int B, K, M, H, W;
+    int RH, RW, GRS, XRS;             // sub-region shape in tiles; LDS row strides of the gy and x slabs
+    int regs_x, regs_y, nsub;
+    int splits, kblocks;
+    unsigned xbytes, gbytes;
+};
+
+__global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
+    constexpr int MR = WG_MR, KR = WG_KR;
+    __shared__ float gl[2][WG_MT * WG_GPS];
+    __shared__ float xl[2][WG_KT * WG_XPS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, tq = lane >> 4;          // channel within a 16-block, tile within a k-step
+    const int H = a.H, W = a.W, RH = a.RH, RW = a.RW, GRS = a.GRS, XRS = a.XRS;
+    const int mb = blockIdx.y / a.kblocks, kb = blockIdx.y - mb * a.kblocks;
+    const int per_img = a.regs_x * a.regs_y;
+    const unsigned plane = (unsigned)(H * W) * 4u;
+    const wrsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), (short)0, (int)a.gbytes, 0x00020000);
+    const wrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
+
+    // ---- staging roles
+    // gy: 32 pair slots per channel (rows 2RH x column pairs RW), thread -> (slot, channels cg + 8q)
+    const int gslot = tid & 31, gcg = tid >> 5;
+    const int grow = gslot / RW, gcp = gslot - grow * RW;
+    const bool g_in = gslot < 2 * RH * RW;
+    const int glds = gcg * WG_GPS + grow * GRS + 2 * gcp;
+    // x: 64 pair slots per channel (rows 2RH+2 x column pairs RW+2), thread -> (slot, channels cg + 4q)
+    const int xslot = tid & 63, xcg = tid >> 6;
+    const int XPR = RW + 2;
+    const int xrow = xslot / XPR, xcp = xslot - xrow * XPR;
+    const bool x_in = xslot < (2 * RH + 2) * XPR;
+    const int xlds0 = xcg * WG_XPS + xrow * XRS + max(2 * xcp - 1, 0), xlds1 = xcg * WG_XPS + xrow * XRS + 2 * xcp;
+
+    f2w pg[8], px[8];
+    auto prefetch = [&](int sub) {
+        const int b = sub / per_img, rq = sub - b * per_img;
+        const int ry = rq / a.regs_x, rx = rq - ry * a.regs_x;
+        const int Y0 = ry * RH * 2, X0 = rx * RW * 2;
+        {
+            const int y = Y0 + grow, xx = X0 + 2 * gcp;
+            const bool ok = g_in && y < H && xx < W;
+            const unsigned vo = ok ? ((unsigned)(b * a.M + mb * WG_MT + gcg) * plane + (unsigned)(y * W + xx) * 4u) : 0x80000000u;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                pg[q] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(gr, (int)vo, (int)((unsigned)(8 * q) * plane), 0));
+        }
+        {
+            const int y = Y0 - 1 + xrow, xx = X0 - 2 + 2 * xcp;
+            const bool ok = x_in && y >= 0 && y < H && xx >= 0 && xx < W;
+            const unsigned vo = ok ? ((unsigned)(b * a.K + kb * WG_KT + xcg) * plane + (unsigned)(y * W + xx) * 4u) : 0x80000000u;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                px[q] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)vo, (int)((unsigned)(4 * q) * plane), 0));
+        }
+    };
+    auto commit = [&](int buf) {
+        if (g_in) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<f2w*>(&gl[buf][glds + 8 * q * WG_GPS]) = pg[q];
+        }
+        if (x_in) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                xl[buf][xlds0 + 4 * q * WG_XPS] = px[q].x;      // (pair 0: the discarded column lands on, and is overwritten by, .y)
+                xl[buf][xlds1 + 4 * q * WG_XPS] = px[q].y;
+            }
+        }
+    };
+
+    // ---- compute role: wave = Winograd row a
+    // dM row a = (gy[ga] + gs * gy[gb]) expanded to [r0, r0 + r1, r0 - r1, r1]; V row a from patch rows ra, rb
+    const int ga = wave == 3 ? 1 : 0, gb = 1 - ga;
+    const float gs = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+    const float sgn = wave == 1 ? 1.f : -1.f;
+    int goffA[4], goffB[4], xoffA[4], xoffB[4];
+    unsigned tvalid = 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int t = ks * 4 + tq;
+        const bool v = t < RH * RW;
+        const int tl = v ? t : 0;
+        const int ty = tl / RW, tx = tl - ty * RW;
+        tvalid |= v ? (1u << ks) : 0u;
+        goffA[ks] = cl * WG_GPS + (2 * ty + ga) * GRS + 2 * tx;
+        goffB[ks] = cl * WG_GPS + (2 * ty + gb) * GRS + 2 * tx;
+        xoffA[ks] = cl * WG_XPS + (2 * ty + ra) * XRS + 2 * tx;
+        xoffB[ks] = cl * WG_XPS + (2 * ty + rb) * XRS + 2 * tx;
+    }
+
+    f4 acc[MR][KR][4];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < KR; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][j][q] = f4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const float* gs_ = gl[buf];
+        const float* xs_ = xl[buf];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            // the two B sets (x side) of this k-step
+            float v[KR][4];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const float* pa = xs_ + j * 16 * WG_XPS + xoffA[ks];
+                const float* pb = xs_ + j * 16 * WG_XPS + xoffB[ks];
+                const f2w a0 = *reinterpret_cast<const f2w*>(pa), a1 = *reinterpret_cast<const f2w*>(pa + 2);
+                const f2w b0 = *reinterpret_cast<const f2w*>(pb), b1 = *reinterpret_cast<const f2w*>(pb + 2);
+                const float t0 = fmaf(b0.x, sgn, a0.x), t1 = fmaf(b0.y, sgn, a0.y);
+                const float t2 = fmaf(b1.x, sgn, a1.x), t3 = fmaf(b1.y, sgn, a1.y);
+                v[j][0] = t0 - t2; v[j][1] = t1 + t2; v[j][2] = t2 - t1; v[j][3] = t1 - t3;
+            }
+            const bool tv = (tvalid >> ks) & 1u;
+            f2w graw[2][2];
+            graw[0][0] = *reinterpret_cast<const f2w*>(gs_ + goffA[ks]);
+            graw[0][1] = *reinterpret_cast<const f2w*>(gs_ + goffB[ks]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                if (i + 1 < MR) {
+                    graw[(i + 1) & 1][0] = *reinterpret_cast<const f2w*>(gs_ + (i + 1) * 16 * WG_GPS + goffA[ks]);
+                    graw[(i + 1) & 1][1] = *reinterpret_cast<const f2w*>(gs_ + (i + 1) * 16 * WG_GPS + goffB[ks]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float r0 = fmaf(graw[i & 1][1].x, gs, graw[i & 1][0].x);
+                float r1 = fmaf(graw[i & 1][1].y, gs, graw[i & 1][0].y);
+                r0 = tv ? r0 : 0.f;
+                r1 = tv ? r1 : 0.f;
+                const float d1 = r0 + r1, d2 = r0 - r1;
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(r0, v[j][0], acc[i][j][0], 0, 0, 0);
+                    acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1, v[j][1], acc[i][j][1], 0, 0, 0);
+                    acc[i][j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(d2, v[j][2], acc[i][j][2], 0, 0, 0);
+                    acc[i][j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(r1, v[j][3], acc[i][j][3], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // ---- reduction over this block's sub-regions: split, split + splits, ...
+    int sub = blockIdx.x;
+    if (sub < a.nsub) {
+        prefetch(sub);
+        commit(0);
+        if (sub + a.splits < a.nsub) prefetch(sub + a.splits);
+    }
+    __syncthreads();
+    for (int it = 0; sub < a.nsub; sub += a.splits, ++it) {
+        compute(it & 1);
+        if (sub + a.splits < a.nsub) {
+            commit((it + 1) & 1);
+            if (sub + 2 * a.splits < a.nsub) prefetch(sub + 2 * a.splits);
+        }
+        __syncthreads();
+    }
+
+    // ---- q[a][.] = (sigma dU)[a][.] G and the slab write (lane-contiguous):
+    // slab[((((blk*4 + a)*MR + i)*KR + j)*4 + r)*3 + qq][lane],  blk = blockIdx.x * gridDim.y + blockIdx.y
+    const float sa = wave == 3 ? -1.f : 1.f;
+    float* dst = a.slab + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (MR * KR * 4 * 3 * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < KR; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u0 = sa * acc[i][j][0][r], u1 = sa * acc[i][j][1][r], u2 = sa * acc[i][j][2][r];
+                const float u3 = -sa * acc[i][j][3][r];
+                const float h = 0.5f * (u1 + u2);
+                float* d = dst + (size_t)(((i * KR + j) * 4 + r) * 3) * 64;
+                d[0] = u0 + h;
+                d[64] = 0.5f * (u1 - u2);
+                d[128] = h + u3;
+            }
+}
+
+// dw[m][k][3x3] = G^T (sum over splits of q), fixed order.  One block per (m-block, k-block, i, j, r): 64 lanes x 16
+// split groups; a group sums its contiguous range of splits, the 16 partial sums are then added in order through LDS.
+constexpr int WR_GROUPS = 16;
+__global__ __launch_bounds__(64 * WR_GROUPS) void wino_wreduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                      int splits, int nmk, int kblocks, int M, int K) {
+    constexpr int MR = WG_MR, KR = WG_KR;
+    constexpr size_t WAVE_SLAB = (size_t)MR * KR * 4 * 3 * 64;       // floats one wave (row a) of one block wrote
+    __shared__ float part[WR_GROUPS][12][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    int e = blockIdx.x;                                 // ((mk*MR + i)*KR + j)*4 + r
+    const int r = e & 3; e >>= 2;
+    const int j = e % KR; e /= KR;
+    const int i = e % MR; e /= MR;
+    const int mk = e;
+    float q[4][3];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[w][c] = 0.f;
+    const int groups = blockDim.x >> 6;                 // <= WR_GROUPS, chosen by the host from the split count
+    const int per = (splits + groups - 1) / groups;
+    const int s1 = min(splits, (grp + 1) * per);
+    for (int s = grp * per; s < s1; ++s) {
+        const float* src = slab + ((size_t)(s * nmk + mk) * 4) * WAVE_SLAB + (size_t)(((i * KR + j) * 4 + r) * 3) * 64 + lane;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[w][c] += src[(size_t)w * WAVE_SLAB + c * 64];
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[grp][w * 3 + c][lane] = q[w][c];
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t = part[0][w * 3 + c][lane];
+            for (int g = 1; g < groups; ++g) t += part[g][w * 3 + c][lane];
+            q[w][c] = t;
+        }
+    const int mbk = mk / kblocks, kbk = mk - mbk * kblocks;
+    const int m = mbk * WG_MT + i * 16 + (lane >> 4) * 4 + r, k = kbk * WG_KT + j * 16 + (lane & 15);
+    if (m >= M || k >= K) return;
+    float* out = dw + ((size_t)m * K + k) * 9;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float h = 0.5f * (q[1][c] + q[2][c]);
+        out[0 + c] = q[0][c] + h;
+        out[3 + c] = 0.5f * (q[1][c] - q[2][c]);
+        out[6 + c] = h + q[3][c];
+    }
+}
+
+struct WgPlan { int RH, RW, GRS, XRS, regs_x, regs_y, nsub, mblocks, kblocks, splits; };
+
+static WgPlan wg_plan(int B, int Ci, int Co, int H, int W) {
+    WgPlan p{};
+    const int TH = ceil_div(H, 2), TW = W / 2;
+    // RH, RW, GRS = 2 RW, XRS = 2 RW + 4 (the last column pair spills one column past the 2 RW + 2 that are read)
+    const int cand[3][4] = {{2, 8, 16, 20}, {4, 4, 8, 12}, {3, 5, 10, 14}};
+    double best = -1.0;
+    for (auto& c : cand) {
+        const double util = (double)TH * TW / ((double)ceil_div(TH, c[0]) * ceil_div(TW, c[1]) * 16.0);
+        if (util > best + 1e-9) { best = util; p.RH = c[0]; p.RW = c[1]; p.GRS = c[2]; p.XRS = c[3]; }
+    }
+    p.regs_x = ceil_div(TW, p.RW); p.regs_y = ceil_div(TH, p.RH); p.nsub = p.regs_x * p.regs_y * B;
+    p.mblocks = ceil_div(Co, WG_MT); p.kblocks = ceil_div(Ci, WG_KT);
+    const int nmk = p.mblocks * p.kblocks;
+    // 256 CUs x 2 blocks; at least two chunks per block so that the pipeline has something to overlap
+    p.splits = std::max(1, std::min(std::max(1, p.nsub / 2), ceil_div(512, nmk)));
+    return p;
+}
+
+}  // namespace dc
+
+using namespace dc;
+
+extern "C" size_t dc_wino3x3_wgrad_workspace(int B, int Ci, int Co, int H, int W) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W < 2 || (W & 1)) return 0;
+    const WgPlan p = wg_plan(B, Ci, Co, H, W);
+    return (size_t)p.splits * p.mblocks * p.kblocks * WG_SLAB * sizeof(float);
+}
+
+extern "C" int dc_wino3x3_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int H, int W,
+                                void* stream) {
+    if (!x || !gy || !dweight || !ws || B <= 0 || Ci <= 0 || Co <= 0 || H < 1 || W < 2 || (W & 1)) return DC_EINVAL;
+    const size_t xb = (size_t)B * Ci * H * W * 4, gb = (size_t)B * Co * H * W * 4;
+    if (xb >= 0x7fffffffull || gb >= 0x7fffffffull) return DC_EINVAL;      // 32-bit buffer offsets
+    hipStream_t st = (hipStream_t)stream;
+    const WgPlan p = wg_plan(B, Ci, Co, H, W);
+    WinoWgArgs a{};
+    a.x = x; a.gy = gy; a.slab = (float*)ws; a.B = B; a.K = Ci; a.M = Co; a.H = H; a.W = W;
+    a.RH = p.RH; a.RW = p.RW; a.GRS = p.GRS; a.XRS = p.XRS;
+    a.regs_x = p.regs_x; a.regs_y = p.regs_y; a.nsub = p.nsub; a.splits = p.splits; a.kblocks = p.kblocks;
+    a.xbytes = (unsigned)xb; a.gbytes = (unsigned)gb;
+    const int nmk = p.mblocks * p.kblocks;
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(p.splits, nmk), dim3(256), 0, st, a);
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wino_wreduce_kernel, dim3(nmk * WG_MR * WG_KR * 4), dim3(64 * std::min(WR_GROUPS, std::max(1, p.splits / 2))), 0, st, (const float*)ws, dweight,
+                       p.splits, nmk, p.kblocks, Co, Ci);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}

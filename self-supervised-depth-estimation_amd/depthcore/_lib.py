@@ -90,6 +90,8 @@ def _sig(lib):
         "dc_wino3x3_workspace": (z, [i, i, i, i, i]),
         "dc_wino3x3_fwd": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_wino3x3_dgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
+        "dc_wino3x3_wgrad_workspace": (z, [i, i, i, i, i]),
+        "dc_wino3x3_wgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_profile_enable": (i, [i]),
         "dc_profile_collect": (i, [POINTER(c_double), POINTER(c_int), POINTER(c_double), POINTER(c_int)]),
     }

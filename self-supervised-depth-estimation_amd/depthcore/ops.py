@@ -589,10 +589,10 @@ class _WinoConv(torch.autograd.Function):
             check(L.dc_wino3x3_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), B, Ci, Co, H, W, stream()),
                   "dc_wino3x3_dgrad")
         if ctx.needs_input_grad[1]:
-            # the weight gradient stays on the library's implicit-GEMM wrw (measured faster than dc_conv3x3_bwd's
-            # split-K wgrad at the trunk shapes, tools/bench_wgrad.py)
-            gw = torch.ops.aten.convolution_backward(g_c, xx, ww, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            gw = torch.empty_like(ww)
+            ws = torch.empty(L.dc_wino3x3_wgrad_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
+            check(L.dc_wino3x3_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, H, W, stream()),
+                  "dc_wino3x3_wgrad")
         return gx, gw
 
 

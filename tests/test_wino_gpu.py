@@ -50,7 +50,16 @@ def test_wino_rejects_odd_width():
 
 
 def test_wino_deterministic():
+    """forward, data gradient and the split-reduced weight gradient are bit-reproducible (no atomics)"""
     from depthcore import ops
-    x = torch.randn(2, 64, 24, 80).cuda()
-    w = torch.randn(64, 64, 3, 3).cuda()
-    assert torch.equal(ops.wino_conv3x3(x, w), ops.wino_conv3x3(x, w))
+    x = torch.randn(2, 64, 24, 80).cuda().requires_grad_(True)
+    w = torch.randn(64, 64, 3, 3).cuda().requires_grad_(True)
+    gy = torch.randn(2, 64, 24, 80).cuda()
+    outs = []
+    for _ in range(2):
+        x.grad = w.grad = None
+        y = ops.wino_conv3x3(x, w)
+        y.backward(gy)
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
