@@ -170,7 +170,7 @@ int dc_profile_collect(double* fwd_ms, int* fwd_launches, double* bwd_ms, int* b
  * x0 (B,C0,H>>up0,W>>up0) nearest-upsampled x2 on the fly when up0=1, x1 (B,C1,H,W) nullable skip,
  * weight (Co,C0+C1,3,3), bias nullable; act: 0 none, 1 ELU, 2 sigmoid; pad_mode: 0 ReflectionPad2d(1),
  * 1 ZeroPad2d(1).  Output (B,Co,H,W).  ws: dc_conv3x3_fwd_workspace bytes. */
-size_t dc_conv3x3_fwd_workspace(int C0, int C1, int Co);
+size_t dc_conv3x3_fwd_workspace(int C0, int C1, int B, int Co, int H, int W);
 int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
                    const float* bias, float* y, void* ws, int B, int Co, int H, int W, int act, int pad_mode,
                    void* stream);

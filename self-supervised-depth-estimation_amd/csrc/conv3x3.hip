@@ -14,6 +14,9 @@
 // Exact fp32: v_mfma_f32_16x16x4_f32 (k-ordered fmaf chain), so parity with the fp32 reference holds to
 // summation order.
 #include "dc_common.h"
+#include "wino.h"
+
+#include <cstdlib>
 
 namespace dc {
 
@@ -23,9 +26,6 @@ constexpr int CT = 16;                 // pixel tile: CT x CT outputs per block
 constexpr int CK = 8;                  // input channels per K chunk
 constexpr int PW_ = CT + 2;            // patch width / height
 constexpr int PS_ = 336;               // patch plane stride in floats (>= 18*18, == 16 mod 32)
-
-enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2 };
-enum { PAD_REFLECT = 0, PAD_ZERO = 1 };
 
 struct ConvArgs {
     const float* x0; int C0; int up0;
@@ -39,18 +39,6 @@ struct ConvArgs {
     int B, Co, H, W, act, pad;
     int tiles_x, tiles_y;
 };
-
-__device__ __forceinline__ float act_fwd(float v, int act) {
-    if (act == ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
-    if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-    return v;
-}
-// derivative expressed through the activated output y
-__device__ __forceinline__ float act_bwd(float y, int act) {
-    if (act == ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
-    if (act == ACT_SIGMOID) return y * (1.f - y);
-    return 1.f;
-}
 
 __device__ __forceinline__ int pad_index(int i, int n, int pad, bool& ok) {
     ok = true;
@@ -795,7 +783,33 @@ __global__ __launch_bounds__(256) void conv_wreduce_kernel(const float* part, co
     }
 }
 
+// dbias partials for the Winograd backward path: block (co, s) sums slice s of {b, pixel} of gp[:, co]; tree in LDS
+// (fixed order), the DB_SPLIT partials per channel are then added in order by conv_wreduce_kernel.
+constexpr int DB_SPLIT = 8;
+__global__ __launch_bounds__(256) void conv_dbias_kernel(const float* __restrict__ gp, float* __restrict__ pbias, int B, int Co, int HW) {
+    __shared__ float sm[256];
+    const int co = blockIdx.x, sp = blockIdx.y;
+    const int total = B * HW, per = (total + DB_SPLIT - 1) / DB_SPLIT;
+    const int i1 = min(total, (sp + 1) * per);
+    float v = 0.f;
+    for (int i = sp * per + threadIdx.x; i < i1; i += 256) {
+        const int b = i / HW, q = i - b * HW;
+        v += gp[((size_t)b * Co + co) * HW + q];
+    }
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pbias[(size_t)sp * Co + co] = sm[0];
+}
+
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+// Winograd (wino.hip, wino_wgrad.hip) or direct implicit GEMM (this file), decided per pass from measurements on the
+// decoder pyramid (tools/bench_convblock.py, B=12): the forward wins at every width; the data gradient from 32 input
+// channels; the weight gradient, whose blocks tile 64 x 32 channels and pay for split slabs, from 64 output channels.
+// DC_CONV_WINO=0 forces the direct kernels (benchmarks only); read once.
 static inline int pick_mr(int M) { return M > 32 ? 4 : (M > 16 ? 2 : 1); }
 static inline int pick_mr_w(int M) { return M > 16 ? 2 : 1; }   // wgrad: LDS holds the g' tile of 16*MR channels
 static inline int pick_split(int B, int H, int W, int Co, int Cin) {
@@ -808,14 +822,28 @@ static inline int pick_split(int B, int H, int W, int Co, int Cin) {
     return std::min(split, 512);
 }
 
+static bool wino_enabled() {
+    static const bool v = [] { const char* e = getenv("DC_CONV_WINO"); return !e || atoi(e) != 0; }();
+    return v;
+}
+static inline bool wino_fwd(int C0, int C1, int Co, int H, int W) { return wino_enabled() && wino_conv_eligible(C0, C1, H, W); }
+static inline bool wino_gp_ok(int B, int Co, int H, int W, int act) { return act == ACT_NONE || ((size_t)B * Co * H * W) % 4 == 0; }
+static inline bool wino_dx(int C0, int C1, int B, int Co, int H, int W, int act) {
+    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && wino_gp_ok(B, Co, H, W, act);
+}
+static inline bool wino_dw(int C0, int C1, int B, int Co, int H, int W, int act) {
+    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && Co >= 64 && wino_gp_ok(B, Co, H, W, act);
+}
+
 }  // namespace dc
 
 using namespace dc;
 #define ST ((hipStream_t)stream)
 
-extern "C" size_t dc_conv3x3_fwd_workspace(int C0, int C1, int Co) {
-    if (C0 < 0 || C1 < 0 || C0 + C1 <= 0 || Co <= 0) return 0;
-    return al256((size_t)9 * (C0 + C1) * Co * sizeof(float));
+extern "C" size_t dc_conv3x3_fwd_workspace(int C0, int C1, int B, int Co, int H, int W) {
+    if (C0 < 0 || C1 < 0 || C0 + C1 <= 0 || Co <= 0 || B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t direct = al256((size_t)9 * (C0 + C1) * Co * sizeof(float));
+    return wino_fwd(C0, C1, Co, H, W) ? std::max(direct, wino_conv_ws_bytes(B, C0 + C1, Co, H, W)) : direct;
 }
 
 extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
@@ -826,6 +854,9 @@ extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1,
     if (up0 && ((H | W) & 1)) return DC_EINVAL;
     if (act < 0 || act > 2 || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
     const int Cin = C0 + C1;
+    // even widths: fused Winograd F(2x2,3x3) (wino.hip); otherwise the direct implicit GEMM below
+    if (wino_fwd(C0, C1, Co, H, W))
+        return wino_conv_fused_fwd(x0, C0, up0 ? 1 : 0, x1, C1, weight, bias, y, ws, B, Co, H, W, act, pad_mode, ST);
     float* wf = (float*)ws;
     hipLaunchKernelGGL(conv_wprep_kernel, dim3(ceil_div(Co * Cin * 9, 256)), dim3(256), 0, ST, weight, wf,
                        (float*)nullptr, Co, Cin);
@@ -855,8 +886,13 @@ extern "C" size_t dc_conv3x3_bwd_workspace(int C0, int C1, int B, int Co, int H,
     const int Cin = C0 + C1;
     const size_t nW = (size_t)Co * Cin * 9;
     const int split = pick_split(B, H, W, Co, Cin);
-    return al256(nW * 4) + al256((size_t)B * Cin * (H + 2) * (W + 2) * 4) + al256((size_t)split * nW * 4) +
-           al256((size_t)split * Co * 4) + al256((size_t)B * Co * H * W * 4);
+    const size_t direct = al256(nW * 4) + al256((size_t)B * Cin * (H + 2) * (W + 2) * 4) + al256((size_t)split * nW * 4) +
+                          al256((size_t)split * Co * 4) + al256((size_t)B * Co * H * W * 4);
+    // the Winograd passes keep their scratch behind the direct layout (dxpad and g' are shared)
+    size_t extra = 0;
+    if (wino_dx(C0, C1, B, Co, H, W, ACT_NONE)) extra += al256(wino_conv_ws_bytes(B, Cin, Co, H, W));
+    if (wino_dw(C0, C1, B, Co, H, W, ACT_NONE)) extra += al256(wino_wgrad_ws_bytes(B, Cin, Co, H, W)) + al256((size_t)DB_SPLIT * Co * 4);
+    return direct + extra;
 }
 
 extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
@@ -874,19 +910,32 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     float* dxpad = (float*)p; p += al256((size_t)B * Cin * (H + 2) * (W + 2) * 4);
     float* part = (float*)p; p += al256((size_t)split * nW * 4);
     float* pbias = (float*)p; p += al256((size_t)split * Co * 4);
-    float* gpbuf = (float*)p;
+    float* gpbuf = (float*)p; p += al256((size_t)B * Co * H * W * 4);
+    const bool w_dx = (dx0 || dx1) && wino_dx(C0, C1, B, Co, H, W, act);
+    const bool w_dw = dweight && wino_dw(C0, C1, B, Co, H, W, act);
+    void* wws = p; if (wino_dx(C0, C1, B, Co, H, W, ACT_NONE)) p += al256(wino_conv_ws_bytes(B, Cin, Co, H, W));
+    void* gws = p; if (wino_dw(C0, C1, B, Co, H, W, ACT_NONE)) p += al256(wino_wgrad_ws_bytes(B, Cin, Co, H, W));
+    float* pb2 = (float*)p;
     const int tiles_x = ceil_div(W, CT), tiles_y = ceil_div(H, CT);
     // fast path (v2 kernels): full 16-wide tiles, 16-byte aligned rows, chunks that do not straddle the concat
     const bool fast = (W % 16 == 0) && (C1 == 0 || C0 % CK == 0) && (C1 == 0 || C0 % CW == 0);
     const float* gp = gy;
-    if (fast && act != ACT_NONE) {
+    if ((fast || w_dx || w_dw) && act != ACT_NONE && ((size_t)B * Co * H * W) % 4 == 0) {
         const size_t n4 = (size_t)B * Co * H * W / 4;
         hipLaunchKernelGGL(conv_gprime_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, ST, gy, y,
                            gpbuf, n4, act);
         DC_CHECK_LAUNCH();
         gp = gpbuf;
     }
-    if (dx0 || dx1) {
+    if (w_dx) {
+        // full correlation of g' with the rotated weights in the Winograd domain, then the same fold as below
+        const int rc = wino_conv_full_dgrad(gp, weight, dxpad, wws, B, Cin, Co, H, W, ST);
+        if (rc != DC_OK) return rc;
+        const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
+        hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0, C1,
+                           up0 ? 1 : 0, H, W, pad_mode);
+        DC_CHECK_LAUNCH();
+    } else if (dx0 || dx1) {
         hipLaunchKernelGGL(conv_wprep_kernel, dim3(ceil_div((int)nW, 256)), dim3(256), 0, ST, weight, (float*)nullptr, wd,
                            Co, Cin);
         DC_CHECK_LAUNCH();
@@ -911,7 +960,17 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
                            C1, up0 ? 1 : 0, H, W, pad_mode);
         DC_CHECK_LAUNCH();
     }
-    if (dweight || dbias) {
+    if (w_dw) {
+        const int rc = wino_wgrad_fused(x0, C0, up0 ? 1 : 0, x1, C1, pad_mode, gp, dweight, gws, B, Co, H, W, ST);
+        if (rc != DC_OK) return rc;
+        if (dbias) {
+            hipLaunchKernelGGL(conv_dbias_kernel, dim3(Co, DB_SPLIT), dim3(256), 0, ST, gp, pb2, B, Co, H * W);
+            DC_CHECK_LAUNCH();
+            hipLaunchKernelGGL(conv_wreduce_kernel, dim3(ceil_div(Co, 16)), dim3(256), 0, ST, (const float*)nullptr, pb2,
+                               (float*)nullptr, dbias, DB_SPLIT, 0, Co);
+            DC_CHECK_LAUNCH();
+        }
+    } else if (dweight || dbias) {
         WgradArgs g{};
         g.x0 = x0; g.C0 = C0; g.up0 = up0 ? 1 : 0; g.x1 = x1; g.C1 = C1; g.y = y; g.gy = gy; g.gp = gp; g.part = part; g.pbias = pbias;
         g.B = B; g.Co = Co; g.H = H; g.W = W; g.act = act; g.pad = pad_mode;

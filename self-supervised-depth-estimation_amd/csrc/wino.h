@@ -1,0 +1,21 @@
+// Internal interface of the Winograd kernels (wino.hip, wino_wgrad.hip) used by the fused conv block (conv3x3.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace dc {
+
+// forward / full-correlation data gradient of the fused block  y = act(conv3x3(pad1(cat(up2?(x0), x1))) + bias)
+bool wino_conv_eligible(int C0, int C1, int H, int W);
+size_t wino_conv_ws_bytes(int B, int Ci, int Co, int H, int W);
+int wino_conv_fused_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight, const float* bias, float* y,
+                        void* ws, int B, int Co, int H, int W, int act, int pad, hipStream_t st);
+int wino_conv_full_dgrad(const float* gp, const float* weight, float* dxpad, void* ws, int B, int Ci, int Co, int H, int W,
+                         hipStream_t st);
+
+// weight gradient of the fused block from gp = gy * act'(y): dweight (Co, C0+C1, 3, 3)
+size_t wino_wgrad_ws_bytes(int B, int Ci, int Co, int H, int W);
+int wino_wgrad_fused(const float* x0, int C0, int up0, const float* x1, int C1, int pad, const float* gp, float* dweight, void* ws,
+                     int B, int Co, int H, int W, hipStream_t st);
+
+}  // namespace dc

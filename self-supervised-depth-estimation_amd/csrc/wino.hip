@@ -30,6 +30,7 @@
 // dgrad is the same kernel on the 180-degree-rotated, transposed weights (wino_weights_kernel<DGRAD>).
 // Requires even W (8-byte row alignment); H arbitrary.
 #include "dc_common.h"
+#include "wino.h"
 
 #include <algorithm>
 
@@ -90,7 +91,12 @@ constexpr int PSUB = 240;             // floats per (channel, sub-region) plane,
 
 struct WinoPsArgs {
     const float* x; const float* uhat; float* y;
-    int B, K, M, H, W;
+    int B, K, M, H, W;                // input maps are H x W; K = reduction channels, M = output channels
+    int Ho, Wo;                       // output map (H x W, or (H+2) x (W+2) for the full correlation P = 2)
+    // FUSED only: x = cat(up2?(x0), x1) along channels, padding mode, patch origin = output - P, bias + activation
+    const float* x1; const float* bias;
+    int C0, up0, pad, P, act;
+    unsigned x1bytes;
     int RH, RW, RS, SUBS;             // sub-region shape in tiles, LDS row stride, plane floats (rows * RS)
     int regs_x, regs_y, nsub;         // sub-regions per image / total
     int nchunks, chunks_per_split;
@@ -100,7 +106,7 @@ struct WinoPsArgs {
     unsigned long long* diag;         // WINO_DIAG builds only: per block {compute, commit(+load wait), issue, barrier, total} cycles
 };
 
-template <int MR, int NR>
+template <int MR, int NR, bool FUSED>
 __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
     constexpr int MT = 16 * MR, G = NR / 2;
     constexpr int UF4 = PSK * 4 * MT, NU = UF4 / 256;
@@ -128,13 +134,34 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
     const int sb = sq / per_img, srq = sq - sb * per_img;
     const int sry = srq / a.regs_x, srx = srq - sry * a.regs_x;
     const int sr = sp / PR, scp = sp - sr * PR;
-    const int iy = sry * RH * 2 - 1 + sr, ix = srx * RW * 2 - 2 + 2 * scp;
-    const bool sok = s_act && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    // image position of this thread's column pair (ix even) and the source it is read from:
+    //   plain: zero padding, P = 1.  FUSED: ReflectionPad2d(1) folds row -1 -> 1, H -> H-2 and redirects the two border
+    //   pairs to the aligned pair that holds the mirrored column (pair (-2,-1) -> (0,1): .y lands on slab column 0;
+    //   pair (W,W+1) -> (W-2,W-1): .x lands on the column of W); nearest-2x upsampling reads x0[iy>>1][ix>>1] once and
+    //   duplicates it; P = 2 shifts the patch origin for the full correlation (slab column 0 = image column X0-2).
+    const int P = FUSED ? a.P : 1;
+    const int iy = sry * RH * 2 - P + sr, ix = srx * RW * 2 - 2 + 2 * scp;
+    int sy = iy, sx = ix;
+    if (FUSED && a.pad == PAD_REFLECT) {
+        sy = iy == -1 ? 1 : (iy == H ? H - 2 : iy);
+        sx = ix == -2 ? 0 : (ix == W ? W - 2 : ix);
+    }
+    const bool sok = s_act && sy >= 0 && sy < H && sx >= 0 && sx < W;
     const bool swr = sg_ < G && sp < SR * PR;
-    const unsigned plane = (unsigned)(H * W) * 4u;
-    const unsigned svoff = sok ? (unsigned)sb * (unsigned)a.K * plane + (unsigned)(iy * W + ix) * 4u : 0x80000000u;
-    const int slds0 = sg_ * SUBS + sr * RS + max(2 * scp - 1, 0), slds1 = sg_ * SUBS + sr * RS + 2 * scp;
+    const unsigned plane = (unsigned)(H * W) * 4u;                       // full-resolution plane bytes
+    const int up0 = FUSED ? a.up0 : 0;
+    const int C0 = FUSED ? a.C0 : a.K;
+    const unsigned plane0 = up0 ? (unsigned)((H >> 1) * (W >> 1)) * 4u : plane;
+    // byte offsets inside source 0 (x / x0) and source 1 (x1)
+    const unsigned svoff = sok ? (unsigned)sb * (unsigned)C0 * plane0 +
+                                     (up0 ? (unsigned)((sy >> 1) * (W >> 1) + (sx >> 1)) : (unsigned)(sy * W + sx)) * 4u
+                               : 0x80000000u;
+    const unsigned svoff1 = (FUSED && sok) ? (unsigned)sb * (unsigned)(a.K - C0) * plane + (unsigned)(sy * W + sx) * 4u : 0x80000000u;
+    const int shift = 2 - P;                          // slab column of the pair's first element = 2 scp - shift
+    const int slds0 = sg_ * SUBS + sr * RS + max(2 * scp - shift, 0), slds1 = sg_ * SUBS + sr * RS + 2 * scp + 1 - shift;
     const wrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
+    const wrsrc_t x1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FUSED ? a.x1 : a.x), (short)0,
+                                                          (int)(FUSED ? a.x1bytes : a.xbytes), 0x00020000);
 
     // ---- compute role: wave = Winograd row; lane = (tile slot n + 16 j, reduction channel kk)
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
@@ -169,11 +196,31 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
     };
     auto load_x = [&](int c, f2w* dst) {
         if (G == 2 || wave < 2) {
+            const int ch0 = c * PSK;
+            if (!FUSED || ch0 < C0) {                 // chunks never straddle the concat (C0 % PSK == 0, host-checked)
+                if (FUSED && up0) {
 #pragma unroll
-            for (int k = 0; k < PSK; ++k) {
-                const int ch = c * PSK + k;
-                const unsigned vo = ch < a.K ? svoff : 0x80000000u;
-                dst[k] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)vo, (int)((unsigned)ch * plane), 0));
+                    for (int k = 0; k < PSK; ++k) {
+                        const int ch = ch0 + k;
+                        const unsigned vo = ch < C0 ? svoff : 0x80000000u;
+                        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)vo, (int)((unsigned)ch * plane0), 0));
+                        dst[k] = f2w{v, v};
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PSK; ++k) {
+                        const int ch = ch0 + k;
+                        const unsigned vo = ch < C0 ? svoff : 0x80000000u;
+                        dst[k] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)vo, (int)((unsigned)ch * plane0), 0));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PSK; ++k) {
+                    const int ch = ch0 + k;
+                    const unsigned vo = ch < a.K ? svoff1 : 0x80000000u;
+                    dst[k] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(x1r, (int)vo, (int)((unsigned)(ch - C0) * plane), 0));
+                }
             }
         }
     };
@@ -290,7 +337,9 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
     const int otl = o_act ? olocal : 0;
     const int oty = otl / RW, otx = otl - oty * RW;
     const int oy = ory * RH * 2 + 2 * oty, ox = orx * RW * 2 + 2 * otx;
-    const bool o_ok = o_act && oy < H && ox < W;
+    const int Ho = FUSED ? a.Ho : H, Wo = FUSED ? a.Wo : W;
+    const bool o_ok = o_act && oy < Ho && ox < Wo;
+    const bool finish = FUSED && gridDim.z == 1;      // bias + activation here unless wino_ysum_kernel still has to add slabs
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
         if (i > 0) __syncthreads();
@@ -314,23 +363,34 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
                     z[w][0] = ex[((w * NR * 4 + oj * 4 + r) * 2 + 0) * 64 + lane];
                     z[w][1] = ex[((w * NR * 4 + oj * 4 + r) * 2 + 1) * 64 + lane];
                 }
-                float* dst = yout + (((size_t)ob * a.M + m) * H + oy) * W + ox;
-                *reinterpret_cast<f2w*>(dst) = f2w{z[0][0] + z[1][0] + z[2][0], z[0][1] + z[1][1] + z[2][1]};
-                if (oy + 1 < H)
-                    *reinterpret_cast<f2w*>(dst + W) = f2w{z[1][0] - z[2][0] - z[3][0], z[1][1] - z[2][1] - z[3][1]};
+                float y00 = z[0][0] + z[1][0] + z[2][0], y01 = z[0][1] + z[1][1] + z[2][1];
+                float y10 = z[1][0] - z[2][0] - z[3][0], y11 = z[1][1] - z[2][1] - z[3][1];
+                if (finish) {
+                    const float bv = a.bias ? a.bias[m] : 0.f;
+                    y00 = act_fwd(y00 + bv, a.act); y01 = act_fwd(y01 + bv, a.act);
+                    y10 = act_fwd(y10 + bv, a.act); y11 = act_fwd(y11 + bv, a.act);
+                }
+                float* dst = yout + (((size_t)ob * a.M + m) * Ho + oy) * Wo + ox;
+                *reinterpret_cast<f2w*>(dst) = f2w{y00, y01};
+                if (oy + 1 < Ho) *reinterpret_cast<f2w*>(dst + Wo) = f2w{y10, y11};
             }
         }
     }
 }
 
-// y = sum of the K-split slabs, fixed order
+// y = act(sum of the K-split slabs (fixed order) + bias)
 __global__ __launch_bounds__(256) void wino_ysum_kernel(const float* __restrict__ slabs, float* __restrict__ y, size_t n4,
-                                                        size_t stride4, int ksplit) {
+                                                        size_t stride4, int ksplit, const float* __restrict__ bias, int act,
+                                                        int plane4, int M) {
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256ull) {
         float4 v = reinterpret_cast<const float4*>(slabs)[i];
         for (int s = 1; s < ksplit; ++s) {
             const float4 t = reinterpret_cast<const float4*>(slabs)[i + (size_t)s * stride4];
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (bias || act != ACT_NONE) {
+            const float bv = bias ? bias[(i / plane4) % M] : 0.f;
+            v.x = act_fwd(v.x + bv, act); v.y = act_fwd(v.y + bv, act); v.z = act_fwd(v.z + bv, act); v.w = act_fwd(v.w + bv, act);
         }
         reinterpret_cast<float4*>(y)[i] = v;
     }
@@ -353,23 +413,36 @@ static inline size_t wino_uhat_bytes(int Ci, int Co) {
     const size_t a = (size_t)ceil_div(Ci, 32) * 32, b = (size_t)ceil_div(Co, 32) * 32;
     return wino_al256(a * b * 16 * sizeof(float));
 }
-constexpr int WINO_MAX_KSPLIT = 4;
 
 #ifdef WINO_DIAG
 static unsigned long long* g_wino_diag = nullptr;
 extern "C" void dc_wino_set_diag(void* p) { g_wino_diag = (unsigned long long*)p; }
 #endif
 
-static int wino_run_ps(const float* x, const float* w, float* y, void* ws, int B, int Ci, int Co, int H, int W, bool dgrad,
-                       hipStream_t st) {
-    const int K = dgrad ? Co : Ci, M = dgrad ? Ci : Co;
+// One convolution launch: reduction over K = C0 + C1 source channels, M output channels.
+struct WinoLaunch {
+    const float* src0; int C0; int up0; const float* src1; int C1;     // input = cat(up2?(src0), src1), maps H x W
+    const float* weight; int Co, Ci; bool dgrad;                         // nn.Conv2d weight (Co,Ci,3,3) and the transform
+    const float* bias; int act, pad, P;                                  // FUSED options (P: 1 same, 2 full correlation)
+    float* out; void* ws;
+    int B, H, W, M;
+    bool fused;
+};
+
+static int wino_launch(const WinoLaunch& d, hipStream_t st) {
+    const int K = d.C0 + d.C1, M = d.M, H = d.H, W = d.W;
+    const int Ho = H + 2 * d.P - 2, Wo = W + 2 * d.P - 2;
+    const size_t b0 = (size_t)d.B * d.C0 * (H >> d.up0) * (W >> d.up0) * 4, b1 = (size_t)d.B * d.C1 * H * W * 4;
+    if (b0 >= 0x7fffffffull || b1 >= 0x7fffffffull) return DC_EINVAL;      // 32-bit buffer offsets
     WinoPsArgs a{};
-    a.x = x; a.uhat = (const float*)ws; a.B = B; a.K = K; a.M = M; a.H = H; a.W = W;
-    const int TH = ceil_div(H, 2), TW = W / 2;
+    a.x = d.src0; a.x1 = d.src1; a.uhat = (const float*)d.ws; a.bias = d.bias;
+    a.B = d.B; a.K = K; a.M = M; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+    a.C0 = d.C0; a.up0 = d.up0; a.pad = d.pad; a.P = d.P; a.act = d.act;
+    a.xbytes = (unsigned)b0; a.x1bytes = (unsigned)b1;
+    const int TH = ceil_div(Ho, 2), TW = Wo / 2;
     wino_ps_pick_region(TH, TW, a.RH, a.RW, a.RS);
     a.SUBS = (2 * a.RH + 2) * a.RS;
-    a.regs_x = ceil_div(TW, a.RW); a.regs_y = ceil_div(TH, a.RH); a.nsub = a.regs_x * a.regs_y * B;
-    a.xbytes = (unsigned)((size_t)B * K * H * W * 4);
+    a.regs_x = ceil_div(TW, a.RW); a.regs_y = ceil_div(TH, a.RH); a.nsub = a.regs_x * a.regs_y * d.B;
     a.nchunks = ceil_div(K, PSK);
     // 32 channels x 64 tiles per block while that fills 256 CUs x 2; otherwise 16 x 32, and on the deepest layers
     // (few tiles, many channels) the reduction is split as well (measured per trunk shape, tools/bench_wino.py)
@@ -377,41 +450,76 @@ static int wino_run_ps(const float* x, const float* w, float* y, void* ws, int B
     const int MT = small ? 16 : 32, G = small ? 1 : 2;
     const int Mp = ceil_div(M, MT) * MT, Kp = a.nchunks * PSK;
     const int blocks = ceil_div(a.nsub, G) * (Mp / MT);
-    const int ksplit = (blocks < 512 && a.nchunks >= 8) ? 2 : 1;
+    const size_t nout = (size_t)d.B * M * Ho * Wo;
+    const int ksplit = (blocks < 512 && a.nchunks >= 8 && (Ho * Wo) % 4 == 0) ? 2 : 1;
     a.chunks_per_split = ceil_div(a.nchunks, ksplit);
-    const size_t nout = (size_t)B * M * H * W;
-    float* slabs = (float*)((char*)ws + wino_uhat_bytes(Ci, Co));
-    a.y = ksplit > 1 ? slabs : y;
+    float* slabs = (float*)((char*)d.ws + wino_uhat_bytes(d.Ci, d.Co));
+    a.y = ksplit > 1 ? slabs : d.out;
     a.slab_stride = ksplit > 1 ? nout : 0;
-    if (dgrad)
-        hipLaunchKernelGGL((wino_weights_kernel<true>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, w, (float*)ws, Co, Ci, MT, Mp, Kp, PSK);
+    if (d.dgrad)
+        hipLaunchKernelGGL((wino_weights_kernel<true>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, d.weight, (float*)d.ws, d.Co, d.Ci, MT, Mp, Kp, PSK);
     else
-        hipLaunchKernelGGL((wino_weights_kernel<false>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, w, (float*)ws, Co, Ci, MT, Mp, Kp, PSK);
+        hipLaunchKernelGGL((wino_weights_kernel<false>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, d.weight, (float*)d.ws, d.Co, d.Ci, MT, Mp, Kp, PSK);
     DC_CHECK_LAUNCH();
 #ifdef WINO_DIAG
     a.diag = g_wino_diag;
 #endif
     a.tblocks = ceil_div(a.nsub, G); a.mblocks = Mp / MT;
-    a.m_fast = (size_t)B * H * W >= (size_t)M * 16 ? 1 : 0;       // x stream (per reduction channel) vs U stream
+    a.m_fast = (size_t)d.B * H * W >= (size_t)M * 16 ? 1 : 0;     // x stream (per reduction channel) vs U stream
     const dim3 grid(a.tblocks * a.mblocks, 1, ksplit);
-    if (small) hipLaunchKernelGGL((wino_ps_kernel<1, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wino_ps_kernel<2, 4>), grid, dim3(256), 0, st, a);
+    if (d.fused) {
+        if (small) hipLaunchKernelGGL((wino_ps_kernel<1, 2, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wino_ps_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
+    } else {
+        if (small) hipLaunchKernelGGL((wino_ps_kernel<1, 2, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wino_ps_kernel<2, 4, false>), grid, dim3(256), 0, st, a);
+    }
     DC_CHECK_LAUNCH();
     if (ksplit > 1) {
-        if (nout % 4) return DC_EINVAL;      // (W even and H*W*... : guarded by the caller's shape check below)
         const size_t n4 = nout / 4;
-        hipLaunchKernelGGL(wino_ysum_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, slabs, y, n4, n4, ksplit);
+        hipLaunchKernelGGL(wino_ysum_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, slabs,
+                           d.out, n4, n4, ksplit, d.fused ? d.bias : (const float*)nullptr, d.fused ? d.act : (int)ACT_NONE,
+                           Ho * Wo / 4, M);
         DC_CHECK_LAUNCH();
     }
     return DC_OK;
 }
 
+size_t wino_conv_ws_bytes(int B, int Ci, int Co, int H, int W) {
+    // transformed weights + the reduction-split slabs of the larger of {forward output, full-correlation data gradient}
+    const size_t fwd = (size_t)B * Co * H * W, full = (size_t)B * Ci * (H + 2) * (W + 2);
+    return wino_uhat_bytes(Ci, Co) + wino_al256(2 * std::max(fwd, full) * sizeof(float));
+}
+
+bool wino_conv_eligible(int C0, int C1, int H, int W) {
+    return W >= 2 && !(W & 1) && H >= 2 && (C1 == 0 || C0 % PSK == 0);
+}
+
+int wino_conv_fused_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight, const float* bias, float* y,
+                        void* ws, int B, int Co, int H, int W, int act, int pad, hipStream_t st) {
+    WinoLaunch d{};
+    d.src0 = x0; d.C0 = C0; d.up0 = up0; d.src1 = x1; d.C1 = C1; d.weight = weight; d.Co = Co; d.Ci = C0 + C1; d.dgrad = false;
+    d.bias = bias; d.act = act; d.pad = pad; d.P = 1; d.out = y; d.ws = ws; d.B = B; d.H = H; d.W = W; d.M = Co; d.fused = true;
+    return wino_launch(d, st);
+}
+
+// dxpad (B,Ci,H+2,W+2) = full correlation of gp (B,Co,H,W) with the rotated, transposed weights
+int wino_conv_full_dgrad(const float* gp, const float* weight, float* dxpad, void* ws, int B, int Ci, int Co, int H, int W,
+                         hipStream_t st) {
+    WinoLaunch d{};
+    d.src0 = gp; d.C0 = Co; d.up0 = 0; d.src1 = nullptr; d.C1 = 0; d.weight = weight; d.Co = Co; d.Ci = Ci; d.dgrad = true;
+    d.bias = nullptr; d.act = ACT_NONE; d.pad = PAD_ZERO; d.P = 2; d.out = dxpad; d.ws = ws; d.B = B; d.H = H; d.W = W; d.M = Ci;
+    d.fused = true;
+    return wino_launch(d, st);
+}
+
 static int wino_run(const float* x, const float* w, float* y, void* ws, int B, int Ci, int Co, int H, int W, bool dgrad,
                     hipStream_t st) {
     if (!x || !w || !y || !ws || B <= 0 || Ci <= 0 || Co <= 0 || H < 1 || W < 2 || (W & 1)) return DC_EINVAL;
-    const size_t xb = (size_t)B * (dgrad ? Co : Ci) * H * W * 4;
-    if (xb >= 0x7fffffffull) return DC_EINVAL;      // 32-bit buffer offsets
-    return wino_run_ps(x, w, y, ws, B, Ci, Co, H, W, dgrad, st);
+    WinoLaunch d{};
+    d.src0 = x; d.C0 = dgrad ? Co : Ci; d.weight = w; d.Co = Co; d.Ci = Ci; d.dgrad = dgrad; d.act = ACT_NONE; d.pad = PAD_ZERO;
+    d.P = 1; d.out = y; d.ws = ws; d.B = B; d.H = H; d.W = W; d.M = dgrad ? Ci : Co; d.fused = false;
+    return wino_launch(d, st);
 }
 
 }  // namespace dc
@@ -420,7 +528,7 @@ using namespace dc;
 
 extern "C" size_t dc_wino3x3_workspace(int B, int Ci, int Co, int H, int W) {
     if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;
-    return wino_uhat_bytes(Ci, Co) + wino_al256((size_t)WINO_MAX_KSPLIT * B * std::max(Ci, Co) * H * W * sizeof(float));
+    return wino_uhat_bytes(Ci, Co) + wino_al256((size_t)2 * B * std::max(Ci, Co) * H * W * sizeof(float));
 }
 
 extern "C" int dc_wino3x3_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int H, int W,

@@ -23,6 +23,7 @@
 //     G^T.  Deterministic.
 // Requires even W; H arbitrary.
 #include "dc_common.h"
+#include "wino.h"
 
 #include <algorithm>
 
@@ -41,12 +42,17 @@ constexpr int WG_SLAB = 4 * WG_MR * WG_KR * 4 * 3 * 64;   // floats one block wr
 struct WinoWgArgs {
     const float* x; const float* gy; float* slab;
     int B, K, M, H, W;
+    // FUSED only: x = cat(up2?(x), x1) along channels (C0 + C1 = K) under ReflectionPad2d(1) or zero padding
+    const float* x1;
+    int C0, up0, pad;
+    unsigned x1bytes;
     int RH, RW, GRS, XRS;             // sub-region shape in tiles; LDS row strides of the gy and x slabs
     int regs_x, regs_y, nsub;
     int splits, kblocks;
     unsigned xbytes, gbytes;
 };
 
+template <bool FUSED>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     constexpr int MR = WG_MR, KR = WG_KR;
     __shared__ float gl[2][WG_MT * WG_GPS];
@@ -59,6 +65,10 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     const unsigned plane = (unsigned)(H * W) * 4u;
     const wrsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), (short)0, (int)a.gbytes, 0x00020000);
     const wrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
+    const wrsrc_t x1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FUSED ? a.x1 : a.x), (short)0,
+                                                          (int)(FUSED ? a.x1bytes : a.xbytes), 0x00020000);
+    const int C0 = FUSED ? a.C0 : a.K, up0 = FUSED ? a.up0 : 0;
+    const unsigned plane0 = up0 ? (unsigned)((H >> 1) * (W >> 1)) * 4u : plane;
 
     // ---- staging roles
     // gy: 32 pair slots per channel (rows 2RH x column pairs RW), thread -> (slot, channels cg + 8q)
@@ -87,12 +97,34 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
                 pg[q] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(gr, (int)vo, (int)((unsigned)(8 * q) * plane), 0));
         }
         {
+            // same source mapping as the forward staging (wino.hip): reflection redirects the border rows / pairs,
+            // nearest-2x upsampling reads x0[y>>1][x>>1] once and duplicates it
             const int y = Y0 - 1 + xrow, xx = X0 - 2 + 2 * xcp;
-            const bool ok = x_in && y >= 0 && y < H && xx >= 0 && xx < W;
-            const unsigned vo = ok ? ((unsigned)(b * a.K + kb * WG_KT + xcg) * plane + (unsigned)(y * W + xx) * 4u) : 0x80000000u;
+            int sy = y, sx = xx;
+            if (FUSED && a.pad == PAD_REFLECT) {
+                sy = y == -1 ? 1 : (y == H ? H - 2 : y);
+                sx = xx == -2 ? 0 : (xx == W ? W - 2 : xx);
+            }
+            const bool ok = x_in && sy >= 0 && sy < H && sx >= 0 && sx < W;
+            const unsigned pix0 = (up0 ? (unsigned)((sy >> 1) * (W >> 1) + (sx >> 1)) : (unsigned)(sy * W + sx)) * 4u;
+            const unsigned pix1 = (unsigned)(sy * W + sx) * 4u;
+            const int chb = kb * WG_KT + xcg;               // wave-uniform: xcg = wave
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                px[q] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)vo, (int)((unsigned)(4 * q) * plane), 0));
+            for (int q = 0; q < 8; ++q) {
+                const int ch = chb + 4 * q;
+                if (!FUSED || ch < C0) {
+                    const unsigned vo = ok ? (unsigned)(b * C0 + ch) * plane0 + pix0 : 0x80000000u;
+                    if (FUSED && up0) {
+                        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)vo, 0, 0));
+                        px[q] = f2w{v, v};
+                    } else {
+                        px[q] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)vo, 0, 0));
+                    }
+                } else {
+                    const unsigned vo = ok ? (unsigned)(b * (a.K - C0) + (ch - C0)) * plane + pix1 : 0x80000000u;
+                    px[q] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(x1r, (int)vo, 0, 0));
+                }
+            }
         }
     };
     auto commit = [&](int buf) {
@@ -297,33 +329,49 @@ static WgPlan wg_plan(int B, int Ci, int Co, int H, int W) {
     return p;
 }
 
+static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, int pad, bool fused, const float* gy, float* dweight,
+                     void* ws, int B, int Co, int H, int W, hipStream_t st) {
+    const int Ci = C0 + C1;
+    const size_t b0 = (size_t)B * C0 * (H >> up0) * (W >> up0) * 4, b1 = (size_t)B * C1 * H * W * 4, gb = (size_t)B * Co * H * W * 4;
+    if (b0 >= 0x7fffffffull || b1 >= 0x7fffffffull || gb >= 0x7fffffffull) return DC_EINVAL;      // 32-bit buffer offsets
+    const WgPlan p = wg_plan(B, Ci, Co, H, W);
+    WinoWgArgs a{};
+    a.x = x0; a.x1 = x1; a.gy = gy; a.slab = (float*)ws; a.B = B; a.K = Ci; a.M = Co; a.H = H; a.W = W;
+    a.C0 = C0; a.up0 = up0; a.pad = pad;
+    a.RH = p.RH; a.RW = p.RW; a.GRS = p.GRS; a.XRS = p.XRS;
+    a.regs_x = p.regs_x; a.regs_y = p.regs_y; a.nsub = p.nsub; a.splits = p.splits; a.kblocks = p.kblocks;
+    a.xbytes = (unsigned)b0; a.x1bytes = (unsigned)b1; a.gbytes = (unsigned)gb;
+    const int nmk = p.mblocks * p.kblocks;
+    if (fused) hipLaunchKernelGGL(wino_wgrad_kernel<true>, dim3(p.splits, nmk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wino_wgrad_kernel<false>, dim3(p.splits, nmk), dim3(256), 0, st, a);
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wino_wreduce_kernel, dim3(nmk * WG_MR * WG_KR * 4), dim3(64 * std::min(WR_GROUPS, std::max(1, p.splits / 2))), 0, st,
+                       (const float*)ws, dweight, p.splits, nmk, p.kblocks, Co, Ci);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+size_t wino_wgrad_ws_bytes(int B, int Ci, int Co, int H, int W) {
+    const WgPlan p = wg_plan(B, Ci, Co, H, W);
+    return (size_t)p.splits * p.mblocks * p.kblocks * WG_SLAB * sizeof(float);
+}
+
+int wino_wgrad_fused(const float* x0, int C0, int up0, const float* x1, int C1, int pad, const float* gp, float* dweight, void* ws,
+                     int B, int Co, int H, int W, hipStream_t st) {
+    return wg_launch(x0, C0, up0, x1, C1, pad, true, gp, dweight, ws, B, Co, H, W, st);
+}
+
 }  // namespace dc
 
 using namespace dc;
 
 extern "C" size_t dc_wino3x3_wgrad_workspace(int B, int Ci, int Co, int H, int W) {
     if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W < 2 || (W & 1)) return 0;
-    const WgPlan p = wg_plan(B, Ci, Co, H, W);
-    return (size_t)p.splits * p.mblocks * p.kblocks * WG_SLAB * sizeof(float);
+    return wino_wgrad_ws_bytes(B, Ci, Co, H, W);
 }
 
 extern "C" int dc_wino3x3_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int H, int W,
                                 void* stream) {
     if (!x || !gy || !dweight || !ws || B <= 0 || Ci <= 0 || Co <= 0 || H < 1 || W < 2 || (W & 1)) return DC_EINVAL;
-    const size_t xb = (size_t)B * Ci * H * W * 4, gb = (size_t)B * Co * H * W * 4;
-    if (xb >= 0x7fffffffull || gb >= 0x7fffffffull) return DC_EINVAL;      // 32-bit buffer offsets
-    hipStream_t st = (hipStream_t)stream;
-    const WgPlan p = wg_plan(B, Ci, Co, H, W);
-    WinoWgArgs a{};
-    a.x = x; a.gy = gy; a.slab = (float*)ws; a.B = B; a.K = Ci; a.M = Co; a.H = H; a.W = W;
-    a.RH = p.RH; a.RW = p.RW; a.GRS = p.GRS; a.XRS = p.XRS;
-    a.regs_x = p.regs_x; a.regs_y = p.regs_y; a.nsub = p.nsub; a.splits = p.splits; a.kblocks = p.kblocks;
-    a.xbytes = (unsigned)xb; a.gbytes = (unsigned)gb;
-    const int nmk = p.mblocks * p.kblocks;
-    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(p.splits, nmk), dim3(256), 0, st, a);
-    DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wino_wreduce_kernel, dim3(nmk * WG_MR * WG_KR * 4), dim3(64 * std::min(WR_GROUPS, std::max(1, p.splits / 2))), 0, st, (const float*)ws, dweight,
-                       p.splits, nmk, p.kblocks, Co, Ci);
-    DC_CHECK_LAUNCH();
-    return DC_OK;
+    return wg_launch(x, Ci, 0, nullptr, 0, PAD_ZERO, false, gy, dweight, ws, B, Co, H, W, (hipStream_t)stream);
 }

@@ -78,7 +78,7 @@ def _sig(lib):
         "dc_photo_fwd": (i, [POINTER(PhotoDesc), p]),
         "dc_photo_bwd": (i, [POINTER(PhotoDesc), p]),
         "dc_photo_algorithmic_bytes": (c_double, [POINTER(PhotoDesc), i]),
-        "dc_conv3x3_fwd_workspace": (z, [i, i, i]),
+        "dc_conv3x3_fwd_workspace": (z, [i, i, i, i, i, i]),
         "dc_conv3x3_fwd": (i, [p, i, i, p, i, p, p, p, p, i, i, i, i, i, i, p]),
         "dc_conv3x3_bwd_workspace": (z, [i, i, i, i, i, i]),
         "dc_conv3x3_bwd": (i, [p, i, i, p, i, p, p, p, p, p, p, p, p, i, i, i, i, i, i, p]),

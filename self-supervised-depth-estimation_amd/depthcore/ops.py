@@ -449,7 +449,7 @@ class _Conv3x3(torch.autograd.Function):
         if a1 is not None and tuple(a1.shape) != (B, C1, H, W):
             raise _lib.DepthcoreError("skip tensor %s must be %s" % (tuple(a1.shape), (B, C1, H, W)))
         y = torch.empty(B, Co, H, W, dtype=torch.float32, device=a0.device)
-        ws = torch.empty(L.dc_conv3x3_fwd_workspace(C0, C1, Co), dtype=torch.uint8, device=a0.device)
+        ws = torch.empty(L.dc_conv3x3_fwd_workspace(C0, C1, B, Co, H, W), dtype=torch.uint8, device=a0.device)
         check(L.dc_conv3x3_fwd(ptr(a0), C0, int(up0), ptr(a1), C1, ptr(w), ptr(bs), ptr(y), ws.data_ptr(), B, Co, H, W,
                                int(act), int(pad), stream()), "dc_conv3x3_fwd")
         ctx.save_for_backward(a0, a1, w, y)

@@ -34,7 +34,7 @@ def rot_from_axisangle(vec):
     return _ops.pose_matrix(vec, torch.zeros_like(vec), False)
 
 
-FUSED_CONV_MIN_PIXELS = 48 * 160     # output pixels per image from which the fused MFMA block is used
+FUSED_CONV_MIN_PIXELS = 0     # output pixels per image from which dc_conv3x3 is used (0: every layer; CPU tensors never)
 
 
 class Conv3x3(nn.Module):
@@ -52,9 +52,7 @@ class Conv3x3(nn.Module):
         H, W = (x.shape[2] * 2, x.shape[3] * 2) if up else (x.shape[2], x.shape[3])
         if H * W >= FUSED_CONV_MIN_PIXELS:
             return _ops.conv3x3_block(x, skip, self.conv.weight, self.conv.bias, up, act, self._pad_mode)
-        # Small maps with wide channels (decoder levels 4-3: 6x20 .. 24x80) are dense contractions whose 16x16
-        # pixel tiles would be mostly padding; they take the library GEMM path until the batched-N variant of
-        # the MFMA kernel lands.  Same arithmetic, separate launches.
+        # comparison path for tools/time_decoder.py (DC_MIN_PIXELS): the same arithmetic as separate library launches
         if up:
             x = F.interpolate(x, scale_factor=2, mode="nearest")
         if skip is not None:
