@@ -10,8 +10,11 @@ One "step" = reference trainer.py:233-237 on one synthetic KITTI-shaped batch: p
 Workload = BASELINE.json configs[1]: resnet18, 192x640, per-GPU batch 12, fp32.  Weak scaling.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the fused photometric backward kernel: SURVEY 8d algorithmic bytes per launch /
-                  its mean duration from hipEvents recorded on the launch stream inside the timed region;
+  roofline     -- the dominant kernel of the step, dc::wino_ps_kernel (Winograd F(2x2,3x3) forward / data gradient of
+                  the trunk and decoder convolutions, ~30 % of the step): SURVEY 8d algorithmic FLOPs (2 MAC of the
+                  direct convolution) per launch / its mean duration from hipEvents recorded on the launch stream
+                  inside the timed region, against the fp32 matrix peak.  The HBM-bound fused photometric kernels
+                  (BASELINE metric 2) are reported the same way under roofline.photometric;
   cpu_baseline -- the CPU oracle's full training step timed on this host's cores (N=1 only).
 """
 import argparse
@@ -27,6 +30,7 @@ sys.path.insert(0, os.path.join(REPO, "self-supervised-depth-estimation_amd"))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD @2.4 GHz)
 
 
 def host_cores():
@@ -126,6 +130,9 @@ def main():
         _, losses = tr.train_step(inputs)
         loss0 = losses["loss"] if loss0 is None else loss0
     ops.profile_enable(args.steps + 8)
+    # every 7th conv launch carries an event pair (7 is coprime with the 78 + 32 launches per step, so all layers are
+    # sampled over the timed region); bracketing every launch costs ~4 % of the step
+    ops.conv_profile_enable((args.steps + 2) * 24, 7)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -134,6 +141,8 @@ def main():
     dt = time.perf_counter() - t0
     prof = ops.profile_collect()
     ops.profile_enable(0)
+    cprof, wprof = ops.conv_profile_collect(0), ops.conv_profile_collect(1)
+    ops.conv_profile_enable(0, 1)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     lossv = losses["loss"].detach().clone().reshape(1)
     if world > 1:
@@ -160,14 +169,18 @@ def main():
         # HBM bytes per launch from the PMC counters: collected in separate `rocprofv3 --pmc FETCH_SIZE` /
         # `--pmc WRITE_SIZE` passes by tools/pmc_traffic.sh (FETCH_SIZE x2.0 per the gfx950 calibration on a
         # known-byte dword kernel in the same run, WRITE_SIZE x1.0) and committed under profiles/.
-        traffic, traffic_src = None, None
+        traffic = {}
         tf = os.path.join(REPO, "profiles", "round1_traffic.json")
-        if os.path.exists(tf) and (args.batch, args.height, args.width) == (12, 192, 640):
+        if os.path.exists(tf) and (args.batch, args.height, args.width, args.num_layers) == (12, 192, 640, 18):
             try:
-                traffic = round(json.load(open(tf))["dc::photo_bwd_kernel"]["hbm_bytes_calibrated"], 0)
-                traffic_src = "profiles/round1_traffic.json"
+                tj = json.load(open(tf))
+                traffic = {k: round(v["hbm_bytes_calibrated"], 0) for k, v in tj.items() if "hbm_bytes_calibrated" in v}
             except Exception:
-                traffic = None
+                traffic = {}
+        c_ms = cprof["ms"] / max(cprof["launches"], 1)
+        c_tf = cprof["flops"] / (cprof["ms"] * 1e-3) / 1e12 if cprof["ms"] > 0 else 0.0
+        c_ex = cprof["executed_flops"] / (cprof["ms"] * 1e-3) / 1e12 if cprof["ms"] > 0 else 0.0
+        w_tf = wprof["flops"] / (wprof["ms"] * 1e-3) / 1e12 if wprof["ms"] > 0 else 0.0
         out = {
             "metric": "training images/sec at %dx%d bs%d (resnet%d depth+pose, 4-scale photometric+smoothness)"
                       % (args.height, args.width, args.batch, args.num_layers),
@@ -186,15 +199,33 @@ def main():
                                       args.num_layers, args.height, args.width, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "tiebreak_noise": "cpu-randn+h2d" if args.cpu_noise else "on-device counter RNG"},
-            "roofline": {"kernel": "dc::photo_bwd_kernel (fused warp+SSIM+L1+automask backward, 4 scales x 2 frames)",
-                         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "limiter": "VALU issue, not HBM: 92 M wave-level VALU instructions per launch (SQ_INSTS_VALU)",
-                         "algorithmic_bytes_per_launch": bytes_bwd, "avg_kernel_ms": round(bwd_ms, 4),
-                         "launches": prof["bwd_launches"],
-                         "fwd_kernel": {"kernel": "dc::photo_fwd_kernel", "algorithmic_bytes_per_launch": bytes_fwd,
-                                        "avg_kernel_ms": round(fwd_ms, 4),
-                                        "achieved": round(bytes_fwd / (fwd_ms * 1e-3) / 1e9, 1) if fwd_ms > 0 else 0.0}},
+            "roofline": {"kernel": "dc::wino_ps_kernel (Winograd F(2x2,3x3) fp32-MFMA convolution: forward + data gradient of "
+                                   "the trunk and decoder 3x3 convolutions)",
+                         "bound": "mfma", "achieved": round(c_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(c_tf / MFMA_F32_PEAK_TFLOPS, 4),
+                         "traffic": traffic.get("dc::wino_ps_kernel"), "traffic_source": "profiles/round1_traffic.json (mean per launch)"
+                         if traffic.get("dc::wino_ps_kernel") else None,
+                         "flops_definition": "SURVEY 8d algorithmic: 2 MAC of the direct 3x3 convolution, summed over the launches",
+                         "algorithmic_flops_per_launch": round(cprof["flops"] / max(cprof["launches"], 1), 0),
+                         "avg_kernel_ms": round(c_ms, 4), "launches_timed": cprof["launches"], "launch_sampling": "every 7th",
+                         "note": "Winograd issues 16/36 of the algorithmic MACs to the matrix cores: `frac` follows the SURVEY 8d "
+                                 "definition, `issued_frac_of_peak` is the fraction of the fp32 MFMA peak actually used",
+                         "issued_to_matrix_cores_tflops": round(c_ex, 2),
+                         "issued_frac_of_peak": round(c_ex / MFMA_F32_PEAK_TFLOPS, 4),
+                         "wgrad_kernel": {"kernel": "dc::wino_wgrad_kernel", "achieved": round(w_tf, 2),
+                                          "frac": round(w_tf / MFMA_F32_PEAK_TFLOPS, 4), "launches_timed": wprof["launches"],
+                                          "issued_frac_of_peak": round(wprof["executed_flops"] / (wprof["ms"] * 1e-3) / 1e12 /
+                                                                       MFMA_F32_PEAK_TFLOPS, 4) if wprof["ms"] > 0 else 0.0,
+                                          "avg_kernel_ms": round(wprof["ms"] / max(wprof["launches"], 1), 4)},
+                         "photometric": {"kernel": "dc::photo_bwd_kernel (fused warp+SSIM+L1+automask backward, 4 scales x 2 frames)",
+                                         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get("dc::photo_bwd_kernel"),
+                                         "limiter": "VALU issue, not HBM: 92 M wave-level VALU instructions per launch (SQ_INSTS_VALU)",
+                                         "algorithmic_bytes_per_launch": bytes_bwd, "avg_kernel_ms": round(bwd_ms, 4),
+                                         "launches": prof["bwd_launches"],
+                                         "fwd_kernel": {"kernel": "dc::photo_fwd_kernel", "algorithmic_bytes_per_launch": bytes_fwd,
+                                                        "avg_kernel_ms": round(fwd_ms, 4),
+                                                        "achieved": round(bytes_fwd / (fwd_ms * 1e-3) / 1e9, 1) if fwd_ms > 0 else 0.0}}},
             "loss_first": round(float(loss0.detach()), 6), "loss_last": round(loss_last, 6),
             "grad_bytes_allreduced_per_step": tr.buckets.nbytes if world > 1 else 0,
         }

@@ -33,6 +33,7 @@
 #include "wino.h"
 
 #include <algorithm>
+#include <vector>
 
 namespace dc {
 
@@ -419,6 +420,29 @@ static unsigned long long* g_wino_diag = nullptr;
 extern "C" void dc_wino_set_diag(void* p) { g_wino_diag = (unsigned long long*)p; }
 #endif
 
+// ---- measurement hook ---------------------------------------------------------------------------------
+namespace {
+struct ConvProf {
+    std::vector<hipEvent_t> e0, e1;
+    int used = 0;
+    double flops = 0.0, exec = 0.0;
+};
+ConvProf g_cprof[2];
+int g_cprof_cap = 0, g_cprof_every = 1;
+unsigned g_cprof_seen[2] = {0, 0};
+}  // namespace
+
+hipEvent_t conv_prof_begin(int kind, double algorithmic_flops, double executed_flops, hipStream_t st) {
+    ConvProf& d = g_cprof[kind];
+    if (g_cprof_cap == 0 || (g_cprof_seen[kind]++ % (unsigned)g_cprof_every) != 0 || d.used >= g_cprof_cap) return nullptr;
+    d.flops += algorithmic_flops; d.exec += executed_flops;
+    (void)hipEventRecord(d.e0[d.used], st);
+    return d.e1[d.used++];
+}
+void conv_prof_end(hipEvent_t e, hipStream_t st) {
+    if (e) (void)hipEventRecord(e, st);
+}
+
 // One convolution launch: reduction over K = C0 + C1 source channels, M output channels.
 struct WinoLaunch {
     const float* src0; int C0; int up0; const float* src1; int C1;     // input = cat(up2?(src0), src1), maps H x W
@@ -467,6 +491,9 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     a.tblocks = ceil_div(a.nsub, G); a.mblocks = Mp / MT;
     a.m_fast = (size_t)d.B * H * W >= (size_t)M * 16 ? 1 : 0;     // x stream (per reduction channel) vs U stream
     const dim3 grid(a.tblocks * a.mblocks, 1, ksplit);
+    // algorithmic = 2 MAC of the direct convolution; executed = the 16 Winograd-domain GEMMs incl. tile padding
+    hipEvent_t pe = conv_prof_begin(0, 2.0 * d.B * (double)M * K * 9.0 * H * W,
+                                    2.0 * 16.0 * (double)a.nsub * 32.0 * (double)Mp * Kp, st);
     if (d.fused) {
         if (small) hipLaunchKernelGGL((wino_ps_kernel<1, 2, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wino_ps_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
@@ -474,6 +501,7 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
         if (small) hipLaunchKernelGGL((wino_ps_kernel<1, 2, false>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wino_ps_kernel<2, 4, false>), grid, dim3(256), 0, st, a);
     }
+    conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     if (ksplit > 1) {
         const size_t n4 = nout / 4;
@@ -525,6 +553,42 @@ static int wino_run(const float* x, const float* w, float* y, void* ws, int B, i
 }  // namespace dc
 
 using namespace dc;
+
+extern "C" int dc_conv_profile_enable(int max_launches, int every) {
+    g_cprof_every = every > 0 ? every : 1;
+    g_cprof_seen[0] = g_cprof_seen[1] = 0;
+    for (auto& d : g_cprof) {
+        for (auto e : d.e0) (void)hipEventDestroy(e);
+        for (auto e : d.e1) (void)hipEventDestroy(e);
+        d.e0.clear(); d.e1.clear(); d.used = 0; d.flops = d.exec = 0.0;
+    }
+    g_cprof_cap = 0;
+    if (max_launches <= 0) return DC_OK;
+    for (auto& d : g_cprof) {
+        d.e0.resize(max_launches); d.e1.resize(max_launches);
+        for (int i = 0; i < max_launches; ++i)
+            if (hipEventCreate(&d.e0[i]) != hipSuccess || hipEventCreate(&d.e1[i]) != hipSuccess) return DC_ELAUNCH;
+    }
+    g_cprof_cap = max_launches;
+    return DC_OK;
+}
+
+extern "C" int dc_conv_profile_collect(int kind, double* ms, double* algorithmic_flops, double* executed_flops, int* launches) {
+    if (kind < 0 || kind > 1) return DC_EINVAL;
+    ConvProf& d = g_cprof[kind];
+    double tot = 0.0;
+    for (int i = 0; i < d.used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(d.e1[i]) != hipSuccess || hipEventElapsedTime(&t, d.e0[i], d.e1[i]) != hipSuccess) return DC_ELAUNCH;
+        tot += t;
+    }
+    if (ms) *ms = tot;
+    if (algorithmic_flops) *algorithmic_flops = d.flops;
+    if (executed_flops) *executed_flops = d.exec;
+    if (launches) *launches = d.used;
+    d.used = 0; d.flops = d.exec = 0.0;
+    return DC_OK;
+}
 
 extern "C" size_t dc_wino3x3_workspace(int B, int Ci, int Co, int H, int W) {
     if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;

@@ -342,8 +342,11 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
     a.regs_x = p.regs_x; a.regs_y = p.regs_y; a.nsub = p.nsub; a.splits = p.splits; a.kblocks = p.kblocks;
     a.xbytes = (unsigned)b0; a.x1bytes = (unsigned)b1; a.gbytes = (unsigned)gb;
     const int nmk = p.mblocks * p.kblocks;
+    hipEvent_t pe = conv_prof_begin(1, 2.0 * B * (double)Co * Ci * 9.0 * H * W,
+                                    2.0 * 16.0 * (double)p.nsub * 16.0 * (double)(p.mblocks * WG_MT) * (p.kblocks * WG_KT), st);
     if (fused) hipLaunchKernelGGL(wino_wgrad_kernel<true>, dim3(p.splits, nmk), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wino_wgrad_kernel<false>, dim3(p.splits, nmk), dim3(256), 0, st, a);
+    conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(wino_wreduce_kernel, dim3(nmk * WG_MR * WG_KR * 4), dim3(64 * std::min(WR_GROUPS, std::max(1, p.splits / 2))), 0, st,
                        (const float*)ws, dweight, p.splits, nmk, p.kblocks, Co, Ci);

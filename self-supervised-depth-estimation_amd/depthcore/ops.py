@@ -424,6 +424,21 @@ def profile_collect():
     return {"fwd_ms": fm.value, "fwd_launches": fn.value, "bwd_ms": bm.value, "bwd_launches": bn.value}
 
 
+def conv_profile_enable(max_launches, every=1):
+    """hipEvent pairs around every `every`-th Winograd conv launch of each kind (0 launches: disable and free)."""
+    check(_lib.lib().dc_conv_profile_enable(int(max_launches), int(every)), "dc_conv_profile_enable")
+
+
+def conv_profile_collect(kind):
+    """kind 0: wino_ps_kernel (conv forward / data gradient), 1: wino_wgrad_kernel.
+    -> dict(ms, flops (SURVEY 8d algorithmic), executed_flops (issued to the matrix cores), launches)."""
+    ms, fl, ex = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+    n = ctypes.c_int(0)
+    check(_lib.lib().dc_conv_profile_collect(int(kind), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ex), ctypes.byref(n)),
+          "dc_conv_profile_collect")
+    return {"ms": ms.value, "flops": fl.value, "executed_flops": ex.value, "launches": n.value}
+
+
 # ----------------------------------------------------------------------------------------------
 # a2/a3 fused decoder block: act(conv3x3(pad1(cat(up2?(x0), x1))) + bias)
 #                                   (reference layers.py:106-136,196-199; networks/depth_decoder.py:50-66)
