@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--cpu-noise", action="store_true", help="reference-style CPU randn tie-break noise + H2D copy")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--channels-last", action="store_true", help="run the ResNet trunks in NHWC")
+    ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,7 +112,7 @@ def main():
     import trainer as T
 
     opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
-                            cpu_tiebreak_noise=args.cpu_noise)
+                            cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     tr = T.Trainer(opt, device=device, rank=rank, world_size=world)
     if args.channels_last:

@@ -6,6 +6,8 @@ asynchronously from the autograd hook of its last-arriving gradient, so the exch
 branch overlaps the backward of the depth branch.  Buckets are sized for xGMI (point-to-point links:
 few large messages rather than many small ones).
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -35,6 +37,8 @@ class GradBuckets:
         if cur:
             self.buckets.append(cur)
         self.flat, self.views, self.pending, self.handles, self.launched = [], [], [], [], []
+        self.streams = []       # streams on which gradients are produced besides the current one (Trainer.overlap_streams)
+        self.comm = None        # communication stream (created on first use)
         self.nbytes = sum(p.numel() * 4 for plist in self.buckets for p in plist)
         if self.world == 1:
             return
@@ -53,12 +57,30 @@ class GradBuckets:
 
     def _launch(self, bi):
         plist = self.buckets[bi]
-        have = [i for i, p in enumerate(plist) if p.grad is not None]
-        if len(have) != len(plist):
-            self.flat[bi].zero_()
-        if have:
-            torch._foreach_copy_([self.views[bi][i] for i in have], [plist[i].grad for i in have])
-        self.handles.append(dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        flat = self.flat[bi]
+        if flat.is_cuda:
+            # Pack and exchange on a dedicated communication stream that waits for every stream gradients are produced
+            # on (with Trainer.overlap_streams a bucket may hold gradients of both branches; all of them have been
+            # *enqueued* by now, since this runs from the hook of the last one).  The producing streams are not blocked.
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(flat.device)
+            cur = torch.cuda.current_stream(flat.device)
+            self.comm.wait_stream(cur)
+            for st in self.streams:
+                self.comm.wait_stream(st)
+            ctx = torch.cuda.stream(self.comm)
+        else:
+            ctx = contextlib.nullcontext()
+        with ctx:
+            have = [i for i, p in enumerate(plist) if p.grad is not None]
+            if len(have) != len(plist):
+                flat.zero_()
+            if have:
+                torch._foreach_copy_([self.views[bi][i] for i in have], [plist[i].grad for i in have])
+                if flat.is_cuda:
+                    for i in have:
+                        plist[i].grad.record_stream(self.comm)
+            self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         self.launched[bi] = True
 
     def _make_hook(self, bi):
@@ -86,6 +108,8 @@ class GradBuckets:
                 self._launch(bi)
         for h in self.handles:
             h.wait()
+        if self.comm is not None:
+            torch.cuda.current_stream(self.flat[0].device).wait_stream(self.comm)
         inv = 1.0 / self.world
         for bi, plist in enumerate(self.buckets):
             self.flat[bi].mul_(inv)

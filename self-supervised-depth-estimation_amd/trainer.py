@@ -32,7 +32,8 @@ def default_options(**kw):
         frame_ids=[0, -1, 1], batch_size=12, learning_rate=1e-4, scheduler_step_size=15, num_layers=18,
         weights_init="scratch", pose_model_type="separate_resnet", pose_model_input="pairs",
         v1_multiscale=False, avg_reprojection=False, disable_automasking=False, predictive_mask=False,
-        no_ssim=False, fused_loss=True, cpu_tiebreak_noise=False, materialize_logs=False, bucket_mb=32)
+        no_ssim=False, fused_loss=True, cpu_tiebreak_noise=False, materialize_logs=False, bucket_mb=32,
+        overlap_streams=True)
     for k, v in kw.items():
         setattr(o, k, v)
     return o
@@ -79,6 +80,7 @@ class Trainer:
             self.backproject_depth[s] = BackprojectDepth(self.opt.batch_size, h, w).to(self.device)
             self.project_3d[s] = Project3D(self.opt.batch_size, h, w).to(self.device)
         self.step = 0
+        self._side_stream = None
 
     def set_train(self):
         for m in self.models.values():
@@ -93,9 +95,28 @@ class Trainer:
         for key, ipt in inputs.items():
             if ipt.device != self.device:
                 inputs[key] = ipt.to(self.device)
-        features = self.models["encoder"](inputs[("color_aug", 0, 0)])
-        outputs = dict(self.models["depth"](features))
-        outputs.update(self.predict_poses(inputs, features))
+        if getattr(self.opt, "overlap_streams", False) and self.device.type == "cuda":
+            # The pose network (pose encoder + decoder) and the depth network are independent until the loss: run them
+            # on two HIP streams so that one branch's kernels fill the other's tails and small launches.  Autograd
+            # replays each backward op on its forward stream, so the backward overlaps the same way.
+            main = torch.cuda.current_stream(self.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(self.device)
+                self.buckets.streams = [main, self._side_stream]
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pose_out = self.predict_poses(inputs, None)
+            features = self.models["encoder"](inputs[("color_aug", 0, 0)])
+            outputs = dict(self.models["depth"](features))
+            main.wait_stream(side)
+            for t in pose_out.values():
+                t.record_stream(main)
+            outputs.update(pose_out)
+        else:
+            features = self.models["encoder"](inputs[("color_aug", 0, 0)])
+            outputs = dict(self.models["depth"](features))
+            outputs.update(self.predict_poses(inputs, features))
         if self.opt.fused_loss:
             losses = self.fused_losses(inputs, outputs)
         else:
