@@ -229,6 +229,7 @@ def main():
                          if traffic.get("dc::wino_ps_kernel") else None,
                          "flops_definition": "SURVEY 8d algorithmic: 2 MAC of the direct 3x3 convolution, summed over the launches",
                          "algorithmic_flops_per_launch": round(cprof["flops"] / max(cprof["launches"], 1), 0),
+                         "algorithmic_bytes_per_launch": round(cprof["bytes"] / max(cprof["launches"], 1), 0),
                          "avg_kernel_ms": round(c_ms, 4), "launches_timed": cprof["launches"], "measured_in": roof_src,
                          "avg_kernel_ms_in_timed_region": round(cprof_c["ms"] / max(cprof_c["launches"], 1), 4),
                          "timed_region_note": "two-stream overlap: a launch shares the GPU with the other branch's kernels "

@@ -222,10 +222,12 @@ int dc_wino3x3_dgrad(const float* gy, const float* weight, float* gx, void* ws, 
  * main kernel with hipEvents on the launch stream.  kind 0 = wino_ps_kernel (forward / data gradient of the trunk and
  * decoder convolutions), 1 = wino_wgrad_kernel.  collect returns the summed kernel milliseconds, the summed
  * algorithmic FLOPs (2 MAC of the direct convolution), the FLOPs actually issued to the matrix cores
- * (16 Winograd-domain GEMMs including tile padding) and the launch count since the last enable / collect.
+ * (16 Winograd-domain GEMMs including tile padding), the algorithmic bytes (each operand and the result once) and the
+ * launch count since the last enable / collect.
  * `every` > 1 samples every n-th launch of a kind only (an event pair per launch costs ~4 % of a training step). */
 int dc_conv_profile_enable(int max_launches, int every);
-int dc_conv_profile_collect(int kind, double* ms, double* algorithmic_flops, double* executed_flops, int* launches);
+int dc_conv_profile_collect(int kind, double* ms, double* algorithmic_flops, double* executed_flops,
+                            double* algorithmic_bytes, int* launches);
 
 /* Weight gradient of the same convolution, also in the Winograd domain (16 GEMMs reduced over all 2x2 tiles of the
  * batch, split over blocks and summed in fixed order -- deterministic, no atomics).  x (B,Ci,H,W), gy (B,Co,H,W)

@@ -20,7 +20,7 @@ int wino_wgrad_fused(const float* x0, int C0, int up0, const float* x1, int C1, 
 
 // measurement hook (dc_conv_profile_*): hipEvent pair around the main kernel of a Winograd launch.
 // kind 0: wino_ps_kernel (forward / data gradient), 1: wino_wgrad_kernel.  Returns the end event or nullptr.
-hipEvent_t conv_prof_begin(int kind, double algorithmic_flops, double executed_flops, hipStream_t st);
+hipEvent_t conv_prof_begin(int kind, double algorithmic_flops, double executed_flops, double algorithmic_bytes, hipStream_t st);
 void conv_prof_end(hipEvent_t e, hipStream_t st);
 
 }  // namespace dc

@@ -425,17 +425,17 @@ namespace {
 struct ConvProf {
     std::vector<hipEvent_t> e0, e1;
     int used = 0;
-    double flops = 0.0, exec = 0.0;
+    double flops = 0.0, exec = 0.0, bytes = 0.0;
 };
 ConvProf g_cprof[2];
 int g_cprof_cap = 0, g_cprof_every = 1;
 unsigned g_cprof_seen[2] = {0, 0};
 }  // namespace
 
-hipEvent_t conv_prof_begin(int kind, double algorithmic_flops, double executed_flops, hipStream_t st) {
+hipEvent_t conv_prof_begin(int kind, double algorithmic_flops, double executed_flops, double algorithmic_bytes, hipStream_t st) {
     ConvProf& d = g_cprof[kind];
     if (g_cprof_cap == 0 || (g_cprof_seen[kind]++ % (unsigned)g_cprof_every) != 0 || d.used >= g_cprof_cap) return nullptr;
-    d.flops += algorithmic_flops; d.exec += executed_flops;
+    d.flops += algorithmic_flops; d.exec += executed_flops; d.bytes += algorithmic_bytes;
     (void)hipEventRecord(d.e0[d.used], st);
     return d.e1[d.used++];
 }
@@ -493,7 +493,8 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     const dim3 grid(a.tblocks * a.mblocks, 1, ksplit);
     // algorithmic = 2 MAC of the direct convolution; executed = the 16 Winograd-domain GEMMs incl. tile padding
     hipEvent_t pe = conv_prof_begin(0, 2.0 * d.B * (double)M * K * 9.0 * H * W,
-                                    2.0 * 16.0 * (double)a.nsub * 32.0 * (double)Mp * Kp, st);
+                                    2.0 * 16.0 * (double)a.nsub * 32.0 * (double)Mp * Kp,
+                                    (double)b0 + (double)b1 + 4.0 * (double)nout + 36.0 * d.Co * d.Ci, st);
     if (d.fused) {
         if (small) hipLaunchKernelGGL((wino_ps_kernel<1, 2, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wino_ps_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
@@ -560,7 +561,7 @@ extern "C" int dc_conv_profile_enable(int max_launches, int every) {
     for (auto& d : g_cprof) {
         for (auto e : d.e0) (void)hipEventDestroy(e);
         for (auto e : d.e1) (void)hipEventDestroy(e);
-        d.e0.clear(); d.e1.clear(); d.used = 0; d.flops = d.exec = 0.0;
+        d.e0.clear(); d.e1.clear(); d.used = 0; d.flops = d.exec = d.bytes = 0.0;
     }
     g_cprof_cap = 0;
     if (max_launches <= 0) return DC_OK;
@@ -573,7 +574,8 @@ extern "C" int dc_conv_profile_enable(int max_launches, int every) {
     return DC_OK;
 }
 
-extern "C" int dc_conv_profile_collect(int kind, double* ms, double* algorithmic_flops, double* executed_flops, int* launches) {
+extern "C" int dc_conv_profile_collect(int kind, double* ms, double* algorithmic_flops, double* executed_flops,
+                                       double* algorithmic_bytes, int* launches) {
     if (kind < 0 || kind > 1) return DC_EINVAL;
     ConvProf& d = g_cprof[kind];
     double tot = 0.0;
@@ -585,8 +587,9 @@ extern "C" int dc_conv_profile_collect(int kind, double* ms, double* algorithmic
     if (ms) *ms = tot;
     if (algorithmic_flops) *algorithmic_flops = d.flops;
     if (executed_flops) *executed_flops = d.exec;
+    if (algorithmic_bytes) *algorithmic_bytes = d.bytes;
     if (launches) *launches = d.used;
-    d.used = 0; d.flops = d.exec = 0.0;
+    d.used = 0; d.flops = d.exec = d.bytes = 0.0;
     return DC_OK;
 }
 

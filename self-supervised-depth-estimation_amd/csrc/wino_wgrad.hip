@@ -343,7 +343,8 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
     a.xbytes = (unsigned)b0; a.x1bytes = (unsigned)b1; a.gbytes = (unsigned)gb;
     const int nmk = p.mblocks * p.kblocks;
     hipEvent_t pe = conv_prof_begin(1, 2.0 * B * (double)Co * Ci * 9.0 * H * W,
-                                    2.0 * 16.0 * (double)p.nsub * 16.0 * (double)(p.mblocks * WG_MT) * (p.kblocks * WG_KT), st);
+                                    2.0 * 16.0 * (double)p.nsub * 16.0 * (double)(p.mblocks * WG_MT) * (p.kblocks * WG_KT),
+                                    (double)b0 + (double)b1 + (double)gb + 36.0 * Co * Ci, st);
     if (fused) hipLaunchKernelGGL(wino_wgrad_kernel<true>, dim3(p.splits, nmk), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wino_wgrad_kernel<false>, dim3(p.splits, nmk), dim3(256), 0, st, a);
     conv_prof_end(pe, st);

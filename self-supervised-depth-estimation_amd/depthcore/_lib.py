@@ -91,7 +91,7 @@ def _sig(lib):
         "dc_wino3x3_fwd": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_wino3x3_dgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_conv_profile_enable": (i, [i, i]),
-        "dc_conv_profile_collect": (i, [i, p, p, p, p]),
+        "dc_conv_profile_collect": (i, [i, p, p, p, p, p]),
         "dc_wino3x3_wgrad_workspace": (z, [i, i, i, i, i]),
         "dc_wino3x3_wgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_profile_enable": (i, [i]),

@@ -431,12 +431,12 @@ def conv_profile_enable(max_launches, every=1):
 
 def conv_profile_collect(kind):
     """kind 0: wino_ps_kernel (conv forward / data gradient), 1: wino_wgrad_kernel.
-    -> dict(ms, flops (SURVEY 8d algorithmic), executed_flops (issued to the matrix cores), launches)."""
-    ms, fl, ex = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+    -> dict(ms, flops (SURVEY 8d algorithmic), executed_flops (issued to the matrix cores), bytes (algorithmic), launches)."""
+    ms, fl, ex, by = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
     n = ctypes.c_int(0)
-    check(_lib.lib().dc_conv_profile_collect(int(kind), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ex), ctypes.byref(n)),
-          "dc_conv_profile_collect")
-    return {"ms": ms.value, "flops": fl.value, "executed_flops": ex.value, "launches": n.value}
+    check(_lib.lib().dc_conv_profile_collect(int(kind), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(ex), ctypes.byref(by),
+                                             ctypes.byref(n)), "dc_conv_profile_collect")
+    return {"ms": ms.value, "flops": fl.value, "executed_flops": ex.value, "bytes": by.value, "launches": n.value}
 
 
 # ----------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Workload for the HBM-traffic PMC passes: a calibration kernel with a KNOWN dword-access byte count
 (dc_disp_to_depth_fwd on 64 Mi floats: reads 256 MiB, writes 512 MiB) followed by the fused photometric
-forward + backward at BASELINE config 2.  Run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+forward + backward at BASELINE config 2 and two full training steps (Winograd convolution kernels).  Run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
 (separate passes); tools/pmc_traffic.sh prints calibrated bytes per launch."""
 import os
 import sys
@@ -10,6 +10,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "self-supervised-depth-estimation_amd"))
+sys.path.insert(0, REPO)
 from depthcore import ops  # noqa: E402
 from depthcore.synthetic import synthetic_batch  # noqa: E402
 
@@ -40,6 +41,13 @@ def main():
         big.mul_(1.0)
         l = ops.photometric_loss(cfg, T[0], T[1], disps)
         l[4].backward()
+    torch.cuda.synchronize()
+    # two full training steps: the Winograd convolution kernels (mean HBM bytes per launch over all layers)
+    import trainer as T
+    tr = T.Trainer(T.default_options(batch_size=B, overlap_streams=False), device=dev)
+    tr.set_train()
+    for _ in range(2):
+        tr.train_step(inp)
     torch.cuda.synchronize()
 
 

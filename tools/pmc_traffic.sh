@@ -11,7 +11,9 @@ def load(d):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        n = n.split("<")[0] if "wino_" in n else n          # all instantiations of a Winograd kernel together
+        agg[n].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 fe, wr = load(sys.argv[1] + "/fetch"), load(sys.argv[1] + "/write")
 cal = [k for k in fe if "d2d_fwd" in k][0]
@@ -19,7 +21,7 @@ known_r, known_w = 256.0 * 2**20, 512.0 * 2**20
 kr, kw = known_r / (fe[cal] * 1024.0), known_w / (wr[cal] * 1024.0)
 out = {"calibration": {"kernel": cal, "FETCH_SIZE_KB": fe[cal], "WRITE_SIZE_KB": wr[cal], "read_factor": kr, "write_factor": kw}}
 for k in fe:
-    if "photo_" in k or "identity" in k or "disp_grad" in k:
+    if "photo_" in k or "identity" in k or "disp_grad" in k or "wino_" in k:
         out[k] = {"FETCH_SIZE_KB": fe[k], "WRITE_SIZE_KB": wr.get(k, 0.0),
                   "read_bytes_calibrated": fe[k] * 1024 * kr, "write_bytes_calibrated": wr.get(k, 0.0) * 1024 * kw,
                   "hbm_bytes_calibrated": fe[k] * 1024 * kr + wr.get(k, 0.0) * 1024 * kw}
