@@ -63,3 +63,27 @@ def test_wino_deterministic():
         outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(12, 64, 48, 160), (24, 128, 24, 80), (24, 512, 6, 20)])
+def test_wino_full_size_adjoint_and_linearity(B, C, H, W):
+    """BASELINE-size trunk shapes, checked through size-independent properties instead of a CPU convolution:
+    <conv(x), g> = <x, dgrad(g)> = <w, wgrad(x, g)> (the three kernels are mutually adjoint) and linearity in x."""
+    from depthcore import ops
+    g0 = torch.Generator().manual_seed(7)
+    x = torch.randn(B, C, H, W, generator=g0).cuda().requires_grad_(True)
+    x2 = torch.randn(B, C, H, W, generator=g0).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g0) * (2.0 / (9 * C)) ** 0.5).cuda().requires_grad_(True)
+    g = torch.randn(B, C, H, W, generator=g0).cuda()
+    y = ops.wino_conv3x3(x, w)
+    y.backward(g)
+    lhs = (y.detach().double() * g.double()).sum().item()
+    via_dx = (x.detach().double() * x.grad.double()).sum().item()
+    via_dw = (w.detach().double() * w.grad.double()).sum().item()
+    scale = (y.detach().double().abs() * g.double().abs()).sum().item()
+    assert abs(lhs - via_dx) <= 1e-6 * scale and abs(lhs - via_dw) <= 1e-6 * scale, (lhs, via_dx, via_dw, scale)
+    with torch.no_grad():
+        y12 = ops.wino_conv3x3(x.detach() + 0.5 * x2, w.detach())
+        y2 = ops.wino_conv3x3(x2, w.detach())
+        err = (y12 - (y.detach() + 0.5 * y2)).abs().max().item()
+    assert err <= 2e-5 * y.detach().abs().max().item()
