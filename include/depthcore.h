@@ -165,10 +165,11 @@ int dc_profile_enable(int max_launches);
 int dc_profile_collect(double* fwd_ms, int* fwd_launches, double* bwd_ms, int* bwd_launches);
 
 /* ------------------------------------------------------------------ a2/a3 decoder blocks */
-/* layers.py:106-136 + 196-199 and networks/depth_decoder.py:50-66 as ONE fp32-MFMA implicit GEMM:
+/* layers.py:106-136 + 196-199 and networks/depth_decoder.py:50-66 (and the 3x3 conv + ReLU pairs of
+ * networks/pose_decoder.py:27-29,45-48) as ONE fused convolution (Winograd F(2x2,3x3) on even widths, else direct):
  *   y = act( conv3x3( pad1( cat( up2?(x0), x1 ) ) ) + bias )
  * x0 (B,C0,H>>up0,W>>up0) nearest-upsampled x2 on the fly when up0=1, x1 (B,C1,H,W) nullable skip,
- * weight (Co,C0+C1,3,3), bias nullable; act: 0 none, 1 ELU, 2 sigmoid; pad_mode: 0 ReflectionPad2d(1),
+ * weight (Co,C0+C1,3,3), bias nullable; act: 0 none, 1 ELU, 2 sigmoid, 3 ReLU; pad_mode: 0 ReflectionPad2d(1),
  * 1 ZeroPad2d(1).  Output (B,Co,H,W).  ws: dc_conv3x3_fwd_workspace bytes. */
 size_t dc_conv3x3_fwd_workspace(int C0, int C1, int B, int Co, int H, int W);
 int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,

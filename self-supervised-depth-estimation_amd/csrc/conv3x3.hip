@@ -852,7 +852,7 @@ extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1,
     if (!x0 || C0 <= 0 || (C1 > 0 && !x1) || C1 < 0 || !weight || !y || !ws || B <= 0 || Co <= 0 || H < 2 || W < 2)
         return DC_EINVAL;
     if (up0 && ((H | W) & 1)) return DC_EINVAL;
-    if (act < 0 || act > 2 || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
+    if (act < 0 || act > 3 || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
     const int Cin = C0 + C1;
     // even widths: fused Winograd F(2x2,3x3) (wino.hip); otherwise the direct implicit GEMM below
     if (wino_fwd(C0, C1, Co, H, W))
@@ -901,7 +901,7 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     if (!x0 || C0 <= 0 || (C1 > 0 && !x1) || C1 < 0 || !weight || !y || !gy || !ws || B <= 0 || Co <= 0 || H < 2 || W < 2)
         return DC_EINVAL;
     if (up0 && ((H | W) & 1)) return DC_EINVAL;
-    if (act < 0 || act > 2 || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
+    if (act < 0 || act > 3 || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
     const int Cin = C0 + C1;
     const size_t nW = (size_t)Co * Cin * 9;
     const int split = pick_split(B, H, W, Co, Cin);

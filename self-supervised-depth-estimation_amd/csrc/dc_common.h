@@ -91,18 +91,20 @@ __device__ __forceinline__ Bilin bilin_setup(float x, float y, int H, int W) {
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- fused conv block options (include/depthcore.h: dc_conv3x3_*) ---------------------------------
-enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2 };
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2, ACT_RELU = 3 };
 enum { PAD_REFLECT = 0, PAD_ZERO = 1 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
     if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
     return v;
 }
 // derivative expressed through the activated output y
 __device__ __forceinline__ float act_bwd(float y, int act) {
     if (act == ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
     if (act == ACT_SIGMOID) return y * (1.f - y);
+    if (act == ACT_RELU) return y > 0.f ? 1.f : 0.f;
     return 1.f;
 }
 

@@ -443,7 +443,7 @@ def conv_profile_collect(kind):
 # a2/a3 fused decoder block: act(conv3x3(pad1(cat(up2?(x0), x1))) + bias)
 #                                   (reference layers.py:106-136,196-199; networks/depth_decoder.py:50-66)
 # ----------------------------------------------------------------------------------------------
-ACT_NONE, ACT_ELU, ACT_SIGMOID = 0, 1, 2
+ACT_NONE, ACT_ELU, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3
 PAD_REFLECT, PAD_ZERO = 0, 1
 
 

@@ -5,6 +5,8 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from depthcore import ops as _ops
+
 
 class PoseDecoder(nn.Module):
     def __init__(self, num_ch_enc, num_input_features, num_frames_to_predict_for=None, stride=1):
@@ -26,7 +28,12 @@ class PoseDecoder(nn.Module):
         last = [f[-1] for f in input_features]
         out = torch.cat([self.relu(self.convs["squeeze"](f)) for f in last], 1)
         for i in range(3):
-            out = self.convs[("pose", i)](out)
+            conv = self.convs[("pose", i)]
+            if i != 2 and out.is_cuda and conv.stride == (1, 1) and out.shape[-1] % 2 == 0:
+                # 3x3 conv (zero padding) + bias + ReLU as one fused depthcore launch (dc_conv3x3_fwd/bwd)
+                out = _ops.conv3x3_block(out, None, conv.weight, conv.bias, False, _ops.ACT_RELU, _ops.PAD_ZERO)
+                continue
+            out = conv(out)
             if i != 2:
                 out = self.relu(out)
         out = out.mean(3).mean(2)

@@ -20,7 +20,7 @@ def oracle_block(x0, x1, w, b, up, act, pad):
         x = torch.cat([x, x1], 1)
     xp = R._reflect_pad1(x) if pad == 0 else F.pad(x, (1, 1, 1, 1))
     y = F.conv2d(xp, w, b)
-    return F.elu(y) if act == 1 else (torch.sigmoid(y) if act == 2 else y)
+    return F.elu(y) if act == 1 else (torch.sigmoid(y) if act == 2 else (F.relu(y) if act == 3 else y))
 
 
 CASES = [
@@ -39,6 +39,9 @@ CASES = [
     (1, 40, 0, 36, 48, 80, False, 0, 1),
     (2, 8, 0, 1, 32, 32, False, 2, 0),
     (1, 16, 32, 16, 20, 16, False, 1, 0),
+    # pose decoder: zero padding + ReLU (networks/pose_decoder.py), Winograd in all three passes and the direct path
+    (4, 256, 0, 256, 6, 20, False, 3, 1),
+    (2, 40, 0, 24, 7, 9, False, 3, 1),
 ]
 
 
