@@ -14,6 +14,7 @@
 // Exact fp32: v_mfma_f32_16x16x4_f32 (k-ordered fmaf chain), so parity with the fp32 reference holds to
 // summation order.
 #include "dc_common.h"
+#include "dispconv.h"
 #include "wino.h"
 
 #include <cstdlib>
@@ -854,6 +855,9 @@ extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1,
     if (up0 && ((H | W) & 1)) return DC_EINVAL;
     if (act < 0 || act > 3 || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
     const int Cin = C0 + C1;
+    // single-channel heads: plain-FMA kernels (dispconv.hip)
+    if (wino_enabled() && dispconv_eligible(C0, C1, up0 ? 1 : 0, Co, H, W))
+        return dispconv_fwd(x0, weight, bias, y, B, C0, H, W, act, pad_mode, ST);
     // even widths: fused Winograd F(2x2,3x3) (wino.hip); otherwise the direct implicit GEMM below
     if (wino_fwd(C0, C1, Co, H, W))
         return wino_conv_fused_fwd(x0, C0, up0 ? 1 : 0, x1, C1, weight, bias, y, ws, B, Co, H, W, act, pad_mode, ST);
@@ -927,7 +931,11 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
         DC_CHECK_LAUNCH();
         gp = gpbuf;
     }
-    if (w_dx) {
+    if (dx0 && wino_enabled() && dispconv_eligible(C0, C1, up0 ? 1 : 0, Co, H, W)) {
+        // thin single-channel head: folded-window data gradient, no padded scratch / fold pass (dispconv.hip)
+        const int rc = dispconv_dx(weight, y, gy, dx0, B, C0, H, W, act, pad_mode, ST);
+        if (rc != DC_OK) return rc;
+    } else if (w_dx) {
         // full correlation of g' with the rotated weights in the Winograd domain, then the same fold as below
         const int rc = wino_conv_full_dgrad(gp, weight, dxpad, wws, B, Cin, Co, H, W, ST);
         if (rc != DC_OK) return rc;

@@ -1,0 +1,14 @@
+// Internal interface of the disparity-head kernels (dispconv.hip) used by the fused conv block (conv3x3.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace dc {
+
+bool dispconv_eligible(int C0, int C1, int up0, int Co, int H, int W);
+int dispconv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int act, int pad,
+                 hipStream_t st);
+int dispconv_dx(const float* w, const float* y, const float* gy, float* dx, int B, int C, int H, int W, int act, int pad,
+                hipStream_t st);
+
+}  // namespace dc
