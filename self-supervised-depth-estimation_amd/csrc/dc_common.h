@@ -90,6 +90,15 @@ __device__ __forceinline__ Bilin bilin_setup(float x, float y, int H, int W) {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// ---- XCD-aware block order ---------------------------------------------------------------------------
+// The hardware hands consecutive workgroup ids to the 8 XCDs round-robin, and every XCD has its own L2.  This maps the
+// flat workgroup id to a logical index such that CONSECUTIVE logical indices run on the SAME XCD (a bijection on
+// [0, nblocks)): blocks that share an operand are given adjacent logical indices and so find it in their L2.
+__device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
+    return x * q + min(x, r) + (bid >> 3);
+}
+
 // ---- fused conv block options (include/depthcore.h: dc_conv3x3_*) ---------------------------------
 enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2, ACT_RELU = 3 };
 enum { PAD_REFLECT = 0, PAD_ZERO = 1 };

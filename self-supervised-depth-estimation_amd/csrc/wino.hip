@@ -119,9 +119,10 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
     const int H = a.H, W = a.W, RH = a.RH, RW = a.RW, RS = a.RS, SUBS = a.SUBS;
     const int CPS = G * SUBS;                         // channel plane stride in the slab
     // block -> (tile block, channel block): the faster index is the one whose operand is the larger stream, so that
-    // its second reader finds it in L2
-    const int mblk = a.m_fast ? blockIdx.x % a.mblocks : blockIdx.x / a.tblocks;
-    const int tblk = a.m_fast ? blockIdx.x / a.mblocks : blockIdx.x % a.tblocks;
+    // its other readers find it in L2
+    const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);       // neighbours in this order share an XCD (one L2)
+    const int mblk = a.m_fast ? lbid % a.mblocks : lbid / a.tblocks;
+    const int tblk = a.m_fast ? lbid / a.mblocks : lbid % a.tblocks;
     const int per_img = a.regs_x * a.regs_y;
     const int c_begin = blockIdx.z * a.chunks_per_split;
     const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);

@@ -48,7 +48,7 @@ struct WinoWgArgs {
     unsigned x1bytes;
     int RH, RW, GRS, XRS;             // sub-region shape in tiles; LDS row strides of the gy and x slabs
     int regs_x, regs_y, nsub;
-    int splits, kblocks;
+    int splits, kblocks, mblocks;
     unsigned xbytes, gbytes;
 };
 
@@ -60,7 +60,12 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, tq = lane >> 4;          // channel within a 16-block, tile within a k-step
     const int H = a.H, W = a.W, RH = a.RH, RW = a.RW, GRS = a.GRS, XRS = a.XRS;
-    const int mb = blockIdx.y / a.kblocks, kb = blockIdx.y - mb * a.kblocks;
+    // flat grid, XCD-aware: the nmk = mblocks * kblocks blocks of one split (same sub-regions: gy shared across the k-blocks,
+    // x across the m-blocks) get adjacent logical indices, i.e. one XCD and its L2
+    const int nmk = a.mblocks * a.kblocks;
+    const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int split0 = lbid / nmk, mk = lbid - split0 * nmk;
+    const int mb = mk / a.kblocks, kb = mk - mb * a.kblocks;
     const int per_img = a.regs_x * a.regs_y;
     const unsigned plane = (unsigned)(H * W) * 4u;
     const wrsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), (short)0, (int)a.gbytes, 0x00020000);
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     };
 
     // ---- reduction over this block's sub-regions: split, split + splits, ...
-    int sub = blockIdx.x;
+    int sub = split0;
     if (sub < a.nsub) {
         prefetch(sub);
         commit(0);
@@ -234,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     }
 
     // ---- q[a][.] = (sigma dU)[a][.] G and the slab write (lane-contiguous):
-    // slab[((((blk*4 + a)*MR + i)*KR + j)*4 + r)*3 + qq][lane],  blk = blockIdx.x * gridDim.y + blockIdx.y
+    // slab[((((blk*4 + a)*MR + i)*KR + j)*4 + r)*3 + qq][lane],  blk = split * nmk + mk
     const float sa = wave == 3 ? -1.f : 1.f;
-    float* dst = a.slab + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (MR * KR * 4 * 3 * 64) + lane;
+    float* dst = a.slab + ((size_t)(split0 * nmk + mk) * 4 + wave) * (MR * KR * 4 * 3 * 64) + lane;
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -339,14 +344,14 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
     a.x = x0; a.x1 = x1; a.gy = gy; a.slab = (float*)ws; a.B = B; a.K = Ci; a.M = Co; a.H = H; a.W = W;
     a.C0 = C0; a.up0 = up0; a.pad = pad;
     a.RH = p.RH; a.RW = p.RW; a.GRS = p.GRS; a.XRS = p.XRS;
-    a.regs_x = p.regs_x; a.regs_y = p.regs_y; a.nsub = p.nsub; a.splits = p.splits; a.kblocks = p.kblocks;
+    a.regs_x = p.regs_x; a.regs_y = p.regs_y; a.nsub = p.nsub; a.splits = p.splits; a.kblocks = p.kblocks; a.mblocks = p.mblocks;
     a.xbytes = (unsigned)b0; a.x1bytes = (unsigned)b1; a.gbytes = (unsigned)gb;
     const int nmk = p.mblocks * p.kblocks;
     hipEvent_t pe = conv_prof_begin(1, 2.0 * B * (double)Co * Ci * 9.0 * H * W,
                                     2.0 * 16.0 * (double)p.nsub * 16.0 * (double)(p.mblocks * WG_MT) * (p.kblocks * WG_KT),
                                     (double)b0 + (double)b1 + (double)gb + 36.0 * Co * Ci, st);
-    if (fused) hipLaunchKernelGGL(wino_wgrad_kernel<true>, dim3(p.splits, nmk), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wino_wgrad_kernel<false>, dim3(p.splits, nmk), dim3(256), 0, st, a);
+    if (fused) hipLaunchKernelGGL(wino_wgrad_kernel<true>, dim3(p.splits * nmk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wino_wgrad_kernel<false>, dim3(p.splits * nmk), dim3(256), 0, st, a);
     conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(wino_wreduce_kernel, dim3(nmk * WG_MR * WG_KR * 4), dim3(64 * std::min(WR_GROUPS, std::max(1, p.splits / 2))), 0, st,
