@@ -16,16 +16,13 @@ from depthcore import ops as _ops
 
 
 def _bn_act(x, bn, res=None, relu=True, groups=1):
-    """BatchNorm2d (+ residual) (+ ReLU): one fused depthcore launch chain in training mode on the GPU;
-    eval mode (running statistics, not on the training hot path) uses the stock functional ops.
+    """BatchNorm2d (+ residual) (+ ReLU).  Training mode (the hot path) is one fused depthcore launch chain and has no
+    fallback: a CPU tensor raises DepthcoreError.  Eval mode (running statistics; validation / export, not on the
+    training path) uses the stock functional ops.
     `groups`: number of independent sub-batches stacked along dim 0 (statistics per sub-batch)."""
-    if bn.training and x.is_cuda:
+    if bn.training:
         return _ops.bn_relu(x, bn, res, relu, groups)
-    if bn.training and groups > 1:
-        y = torch.cat([F.batch_norm(c, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum or 0.1,
-                                    bn.eps) for c in x.chunk(groups)])
-    else:
-        y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum or 0.1, bn.eps)
+    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, bn.momentum or 0.1, bn.eps)
     if res is not None:
         y = y + res
     return F.relu(y) if relu else y
