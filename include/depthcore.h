@@ -237,6 +237,17 @@ size_t dc_wino3x3_wgrad_workspace(int B, int Ci, int Co, int H, int W);
 int dc_wino3x3_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int H, int W,
                      void* stream);
 
+/* 1x1 convolution without bias, stride 1 or 2 (the trunks' `downsample` branches and Bottleneck conv1 / conv3,
+ * networks/resnet_encoder.py:74-98 via torchvision), as an fp32-MFMA GEMM on the NCHW tensors: x (B,Ci,Hi,Wi),
+ * weight (Co,Ci), y / gy (B,Co,Hi/stride,Wi/stride).  stride 2 needs even Hi, Wi.  dgrad writes every element of dx
+ * (zeros where the stride skips).  wgrad: split reduction, fixed-order sum, ws = dc_conv1x1_wgrad_workspace bytes. */
+int dc_conv1x1_fwd(const float* x, const float* weight, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride, void* stream);
+int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                     void* stream);
+size_t dc_conv1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride);
+int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,10 @@ def _sig(lib):
         "dc_wino3x3_workspace": (z, [i, i, i, i, i]),
         "dc_wino3x3_fwd": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_wino3x3_dgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
+        "dc_conv1x1_fwd": (i, [p, p, p, i, i, i, i, i, i, p]),
+        "dc_conv1x1_dgrad": (i, [p, p, p, i, i, i, i, i, i, p]),
+        "dc_conv1x1_wgrad_workspace": (z, [i, i, i, i, i, i]),
+        "dc_conv1x1_wgrad": (i, [p, p, p, p, i, i, i, i, i, i, p]),
         "dc_conv_profile_enable": (i, [i, i]),
         "dc_conv_profile_collect": (i, [i, p, p, p, p, p]),
         "dc_wino3x3_wgrad_workspace": (z, [i, i, i, i, i]),

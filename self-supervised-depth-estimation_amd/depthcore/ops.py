@@ -614,3 +614,43 @@ class _WinoConv(torch.autograd.Function):
 def wino_conv3x3(x, weight):
     """F.conv2d(x, weight, None, 1, 1) for 3x3 kernels on even-width maps (fused Winograd on the matrix cores)."""
     return _WinoConv.apply(x, weight)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1 trunk 1x1 convolutions (stride 1 / 2, no bias): MFMA GEMMs on the NCHW tensors
+# ----------------------------------------------------------------------------------------------
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride):
+        L = _lib.lib()
+        xx, ww = _c(x.detach()), _c(weight.detach())
+        B, Ci, Hi, Wi = xx.shape
+        Co = ww.shape[0]
+        y = torch.empty(B, Co, Hi // stride, Wi // stride, dtype=torch.float32, device=xx.device)
+        check(L.dc_conv1x1_fwd(ptr(xx), ptr(ww), ptr(y), B, Ci, Co, Hi, Wi, int(stride), stream()), "dc_conv1x1_fwd")
+        ctx.save_for_backward(xx, ww)
+        ctx.stride = int(stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        xx, ww = ctx.saved_tensors
+        B, Ci, Hi, Wi = xx.shape
+        Co, s_ = ww.shape[0], ctx.stride
+        g_c = _c(gy)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(xx)
+            check(L.dc_conv1x1_dgrad(ptr(g_c), ptr(ww), ptr(gx), B, Ci, Co, Hi, Wi, s_, stream()), "dc_conv1x1_dgrad")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(ww)
+            ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
+            check(L.dc_conv1x1_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream()),
+                  "dc_conv1x1_wgrad")
+        return gx, gw, None
+
+
+def conv1x1(x, weight, stride=1):
+    """F.conv2d(x, weight, None, stride) for (Co,Ci,1,1) weights; stride 2 needs even H, W."""
+    return _Conv1x1.apply(x, weight, stride)

@@ -28,6 +28,7 @@ def _bn_act(x, bn, res=None, relu=True, groups=1):
     return F.relu(y) if relu else y
 
 
+GEMM_1X1 = True       # 1x1 (stride 1 / 2) trunk convolutions on depthcore's NCHW MFMA GEMM (GPU)
 WINO_TRUNK = True     # stride-1 3x3 trunk convolutions on depthcore's fused Winograd kernel (GPU, even widths)
 
 
@@ -38,6 +39,10 @@ def _conv(conv, x):
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and x.shape[-1] % 2 == 0
             and x.dtype == torch.float32):
         return _ops.wino_conv3x3(x, conv.weight)
+    if (GEMM_1X1 and x.is_cuda and conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.bias is None and conv.stride in ((1, 1), (2, 2)) and x.dtype == torch.float32
+            and (conv.stride == (1, 1) or (x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0))):
+        return _ops.conv1x1(x, conv.weight, conv.stride[0])       # dc_conv1x1_*: the downsample / bottleneck 1x1 convolutions
     return conv(x)
 
 
@@ -56,7 +61,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         g = self._g[0]
-        idt = x if self.downsample is None else _bn_act(self.downsample[0](x), self.downsample[1], relu=False, groups=g)
+        idt = x if self.downsample is None else _bn_act(_conv(self.downsample[0], x), self.downsample[1], relu=False, groups=g)
         out = _bn_act(_conv(self.conv1, x), self.bn1, groups=g)
         return _bn_act(_conv(self.conv2, out), self.bn2, res=idt, groups=g)   # relu(bn2(conv2) + identity), one pass
 
@@ -78,10 +83,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         g = self._g[0]
-        idt = x if self.downsample is None else _bn_act(self.downsample[0](x), self.downsample[1], relu=False, groups=g)
-        out = _bn_act(self.conv1(x), self.bn1, groups=g)
+        idt = x if self.downsample is None else _bn_act(_conv(self.downsample[0], x), self.downsample[1], relu=False, groups=g)
+        out = _bn_act(_conv(self.conv1, x), self.bn1, groups=g)
         out = _bn_act(_conv(self.conv2, out), self.bn2, groups=g)
-        return _bn_act(self.conv3(out), self.bn3, res=idt, groups=g)
+        return _bn_act(_conv(self.conv3, out), self.bn3, res=idt, groups=g)
 
 
 _CFG = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3)),
