@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
 """Library (MIOpen) times of the trunk convolutions that are NOT on depthcore kernels: 7x7/2 stem, stride-2 3x3,
 1x1/2 downsample.  fwd / dgrad / wgrad separately."""
+import os
 import sys
 
 import torch
 import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "self-supervised-depth-estimation_amd"))
+from depthcore import ops  # noqa: E402
 
 
 def timed(fn, n=50):
@@ -41,8 +46,18 @@ def main():
                                                                 [False, True, False]))
         tot += t_f + t_d + t_w
         gmac = B * Co * Ci * k * k * y.shape[2] * y.shape[3] / 1e9
-        print("%-11s B=%2d %3d->%3d %3dx%3d k%d s%d: fwd %6.1f  dgrad %6.1f  wgrad %6.1f us  (%.2f GMAC)"
-              % (name, B, Ci, Co, H, W, k, s, t_f, t_d, t_w, gmac), flush=True)
+        mine = ""
+        if k == 1:
+            xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(False)
+            yg = ops.conv1x1(xg, wg, s)
+            m_f = timed(lambda: ops.conv1x1(x, w, s))
+            m_d = timed(lambda: yg.backward(gy, retain_graph=True))
+            xg2, wg2 = x.clone().requires_grad_(False), w.clone().requires_grad_(True)
+            yg2 = ops.conv1x1(xg2, wg2, s)
+            m_w = timed(lambda: yg2.backward(gy, retain_graph=True))
+            mine = "  | depthcore fwd %5.1f dgrad %5.1f wgrad %5.1f" % (m_f, m_d, m_w)
+        print("%-11s B=%2d %3d->%3d %3dx%3d k%d s%d: fwd %6.1f  dgrad %6.1f  wgrad %6.1f us  (%.2f GMAC)%s"
+              % (name, B, Ci, Co, H, W, k, s, t_f, t_d, t_w, gmac, mine), flush=True)
     print("total %.1f us per step" % tot)
 
 
