@@ -12,6 +12,9 @@ for p in (REPO, PKG, os.path.join(REPO, "tests", "golden")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle works on small tensors: a GPU box's 100+ hardware threads only add scheduling overhead
+    import torch
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
 
 
 @pytest.fixture(scope="session")
