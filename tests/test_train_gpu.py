@@ -50,8 +50,10 @@ def test_process_batch_and_step_vs_oracle():
     assert agree > 0.97, agree
 
 
-def test_fused_equals_layerwise_path():
-    B, H, W = 2, 64, 96
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (12, 192, 640)])
+def test_fused_equals_layerwise_path(B, H, W):
+    """The fused photometric op against the layer-by-layer sequence of independent kernels, on the same networks; the
+    second case is the full BASELINE configs[1] size (a property check in place of a CPU run of that size)."""
     tr, state, inputs = _setup(B, H, W)
     dev_in = {k: v.to(DEV) for k, v in inputs.items()}
     res = []
