@@ -10,23 +10,24 @@
 //
 // Mapping to CDNA4 (wino_ps_kernel)
 //   * v_mfma_f32_16x16x4_f32: rows = 16 output channels, cols = 16 tiles, K = 4 reduction channels.
-//   * a block = 4 waves = the 4 ROWS of the 4x4 Winograd domain; all waves share one LDS slab of the raw input and
-//     one chunk of transformed weights.  Row a of V = B^T d B needs two raw patch rows per tile (2 ds_read2_b64,
-//     4 fma + 4 add -> the wave's four B operands); nothing transformed ever touches HBM.
-//   * the transformed weights U are produced once per call by wino_weights_kernel in exactly the order the
-//     block stages them: [m-block][k-chunk][k][row][m][col], so staging is a linear 128-bit copy and a wave's A
-//     operands for its 4 positions arrive with one conflict-free ds_read_b128 per 16 channels and k-step.
+//   * a block = 4 waves = the 4 ROWS of the 4x4 Winograd domain; all waves share one LDS slab of the raw input.
+//     Row a of V = B^T d B needs two raw patch rows per tile (2 ds_read2_b64, 4 fma + 4 add -> the wave's four B
+//     operands); nothing transformed ever touches HBM.
+//   * the transformed weights U are produced once per call by wino_weights_kernel as [m-block][k-chunk][k][row][m][col].
+//     The four waves need DISJOINT quarters of a chunk (row = wave), so U bypasses LDS: a lane loads the 16 bytes that
+//     are its A operands for the 4 positions of one k-step and 16-channel block straight into registers (256-byte rows
+//     per 16 lanes, L2 hits for every tile block but the first of an XCD), one chunk ahead.
 //   * a wave keeps 4*MR*NR accumulator tiles (MR,NR = 2,4: 32 output channels x 64 tiles per block, 128 VGPRs);
 //     the four rows are combined at the end through LDS (Y = A^T M A is linear in the rows of M), 8-byte stores.
 //   * tiles are grouped in sub-regions of <= 32 (RH x RW chosen per map so that it divides evenly: 4x8, 2x16,
 //     3x10, 8x4); a block takes NR/2 consecutive sub-regions, which may lie in different images.
-//   * pipeline: U and the slab are double-buffered in LDS (one barrier per chunk of 8 channels); while chunk c is
+//   * pipeline: the slab is double-buffered in LDS (one barrier per chunk of 8 channels); while chunk c is
 //     multiplied, U of c+1 and x of c+1 and c+2 are in flight in registers (x comes from HBM on first touch).
-//   * block order puts the two readers of the larger stream (x across channel blocks, or U across tile blocks)
-//     next to each other so that the second read is an L2 hit; small maps split the reduction over gridDim.z and
-//     sum the partial outputs in fixed order (wino_ysum_kernel).
-// Measured phase split (-DWINO_DIAG build, tools/diag_wino.sh, B=24 256->64 48x160): MFMA phase 61 %, LDS commit
-// incl. load wait 15 %, load issue 14 %, barrier 4 % of the loop; MFMA pipe 74 % busy inside the loop.
+//   * block order puts the readers of the larger stream (x across channel blocks, or U across tile blocks) next to
+//     each other ON ONE XCD (xcd_logical_block) so that the re-reads are L2 hits; small maps split the reduction
+//     over gridDim.z and sum the partial outputs in fixed order (wino_ysum_kernel).
+// Measured phase split of the previous revision, which staged U through LDS (-DWINO_DIAG build, tools/diag_wino.sh,
+// B=24 256->64 48x160): MFMA phase 61 %, LDS commit incl. load wait 15 %, load issue 14 %, barrier 4 % of the loop.
 // dgrad is the same kernel on the 180-degree-rotated, transposed weights (wino_weights_kernel<DGRAD>).
 // Requires even W (8-byte row alignment); H arbitrary.
 #include "dc_common.h"
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 // per wave and Winograd position; gridDim.z > 1 splits the reduction channels into slabs.
 // ------------------------------------------------------------------------------------------------
 constexpr int PSK = 8;                // reduction channels per staged chunk
-constexpr int PSUB = 240;             // floats per (channel, sub-region) plane, max over the shapes
+constexpr int PSUB = 256;             // floats per (channel, sub-region) plane: >= 240 (4x8 shape); 256 makes the slab pair big enough for the row exchange
 
 struct WinoPsArgs {
     const float* x; const float* uhat; float* y;
@@ -110,9 +111,8 @@ struct WinoPsArgs {
 template <int MR, int NR, bool FUSED>
 __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
     constexpr int MT = 16 * MR, G = NR / 2;
-    constexpr int UF4 = PSK * 4 * MT, NU = UF4 / 256;
-    static_assert(NR % 2 == 0 && NR <= 2 * MR && NU >= 1, "exchange buffer aliases the U double buffer");
-    __shared__ f4 ul[2][UF4];
+    constexpr int UF4 = PSK * 4 * MT;                 // f4 items of one U chunk in global memory
+    static_assert(NR % 2 == 0 && NR * 2048 <= 2 * PSK * G * PSUB, "the row exchange aliases the slab double buffer");
     __shared__ float xl[2][PSK * G * PSUB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kk = lane >> 4;
@@ -188,13 +188,19 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
             for (int q = 0; q < 4; ++q) acc[i][j][q] = f4{0.f, 0.f, 0.f, 0.f};
 
     f2w px[2][PSK];                                  // x of chunk c lives in px[(c - c_begin) & 1], two chunks in flight
-    f4 pu[NU];
+    // A operands: the four waves need DISJOINT quarters of a U chunk (wave = Winograd row = pq), so U never goes through
+    // LDS: each lane loads its own 16 bytes per k-step and 16-channel block straight into the registers the MFMAs read,
+    // one chunk ahead (16 lanes x 16 B = 256-byte rows; the other tile blocks of this channel block find them in L2)
+    f4 ureg[2][PSK / 4][MR];
     const wrsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.uhat) + (size_t)mblk * a.nchunks * UF4 * 4, (short)0, (int)((size_t)a.nchunks * UF4 * 16), 0x00020000);
-    auto load_u = [&](int c) {
+    const int uoff = ((kk * 4 + wave) * MT + n) * 16;
+    auto load_u = [&](int c, f4 (*dst)[MR]) {
 #pragma unroll
-        for (int j = 0; j < NU; ++j)
-            pu[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ur, (tid + j * 256) * 16, c * (UF4 * 16), 0));
+        for (int ks = 0; ks < PSK / 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                dst[ks][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ur, uoff + (ks * 16 * MT + i * 16) * 16, c * (UF4 * 16), 0));
     };
     auto load_x = [&](int c, f2w* dst) {
         if (G == 2 || wave < 2) {
@@ -226,10 +232,6 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
             }
         }
     };
-    auto commit_u = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < NU; ++j) ul[buf][tid + j * 256] = pu[j];
-    };
     auto commit_x = [&](int buf, const f2w* src) {
         if (swr) {
             float* xw = xl[buf];
@@ -241,10 +243,8 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
         }
     };
 
-    auto compute = [&](int buf) {
-        const f4* up = ul[buf] + (kk * 4 + wave) * MT + n;
+    auto compute = [&](int buf, const f4 (*ua)[MR]) {
         const float* xs = xl[buf];
-        f4 ua[2][MR];
         f2w raw[2][4];                               // [buffer][row a lo, row a hi, row b lo, row b hi]
         auto read_raw = [&](int s, f2w* dst) {       // step s = ks * NR + j
             const int ks = s / NR, j = s % NR;
@@ -254,20 +254,12 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
             dst[2] = *reinterpret_cast<const f2w*>(base + offB[j & 1]);
             dst[3] = *reinterpret_cast<const f2w*>(base + offB[j & 1] + 2);
         };
-        auto read_u = [&](int ks, f4* dst) {
-#pragma unroll
-            for (int i = 0; i < MR; ++i) dst[i] = up[ks * 16 * MT + i * 16];
-        };
         constexpr int STEPS = (PSK / 4) * NR;
-        read_u(0, ua[0]);
         read_raw(0, raw[0]);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int ks = s / NR, j = s % NR;
-            if (s + 1 < STEPS) {
-                read_raw(s + 1, raw[(s + 1) & 1]);
-                if ((s + 1) % NR == 0) read_u(ks + 1, ua[(ks + 1) & 1]);
-            }
+            if (s + 1 < STEPS) read_raw(s + 1, raw[(s + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
             const f2w* rw = raw[s & 1];
             const float t0 = fmaf(rw[2].x, sgn, rw[0].x), t1 = fmaf(rw[2].y, sgn, rw[0].y);
@@ -275,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
             const float v0 = t0 - t2, v1 = t1 + t2, v2 = t2 - t1, v3 = t1 - t3;
 #pragma unroll
             for (int i = 0; i < MR; ++i) {
-                const f4 u = ua[ks & 1][i];
+                const f4 u = ua[ks][i];
                 acc[i][j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, v0, acc[i][j][0], 0, 0, 0);
                 acc[i][j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, v1, acc[i][j][1], 0, 0, 0);
                 acc[i][j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v2, acc[i][j][2], 0, 0, 0);
@@ -285,16 +277,14 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
         }
     };
 
-    // U and the slab are double-buffered in LDS (one barrier per chunk).  In flight while chunk c is multiplied:
-    // U of c+1 (L2-resident, short latency) and x of c+1 and c+2 (first touch comes from HBM).
+    // The slab is double-buffered in LDS (one barrier per chunk), U lives in registers.  In flight while chunk c is
+    // multiplied: U of c+1 (L2-resident) and x of c+1 and c+2 (first touch comes from HBM).
     const int nloc = c_end - c_begin;
     if (nloc > 0) {
-        load_u(c_begin);
+        load_u(c_begin, ureg[0]);
         load_x(c_begin, px[0]);
         if (nloc > 1) load_x(c_begin + 1, px[1]);
-        commit_u(0);
         commit_x(0, px[0]);
-        if (nloc > 1) load_u(c_begin + 1);
         if (nloc > 2) load_x(c_begin + 2, px[0]);
     }
     __syncthreads();
@@ -307,17 +297,18 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
 #define DIAG_T(k, stmt) { stmt; }
 #define DIAG_WAIT()
 #endif
-    auto step = [&](int i, f2w* pxn) {               // pxn holds x of chunk i+1
-        DIAG_T(0, compute(i & 1));
+    auto step = [&](int i, f2w* pxn, f4 (*ucur)[MR], f4 (*unxt)[MR]) {   // pxn holds x of chunk i+1
+        if (i + 1 < nloc) load_u(c_begin + i + 1, unxt);
+        DIAG_T(0, compute(i & 1, ucur));
         if (i + 1 < nloc) {
-            DIAG_T(1, commit_u((i + 1) & 1); commit_x((i + 1) & 1, pxn); DIAG_WAIT());
-            DIAG_T(2, if (i + 2 < nloc) load_u(c_begin + i + 2); if (i + 3 < nloc) load_x(c_begin + i + 3, pxn));
+            DIAG_T(1, commit_x((i + 1) & 1, pxn); DIAG_WAIT());
+            DIAG_T(2, if (i + 3 < nloc) load_x(c_begin + i + 3, pxn));
         }
         DIAG_T(3, __syncthreads());
     };
     for (int i = 0; i < nloc; i += 2) {
-        step(i, px[1]);
-        if (i + 1 < nloc) step(i + 1, px[0]);
+        step(i, px[1], ureg[0], ureg[1]);
+        if (i + 1 < nloc) step(i + 1, px[0], ureg[1], ureg[0]);
     }
 
 #ifdef WINO_DIAG
@@ -326,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
         for (int q = 0; q < 5; ++q) a.diag[(size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 5 + q] = dg[q];
 #endif
     // ---- combine the four rows: wave a contributes z[a][jj] = sum_b M[a][b] A[b][jj]; Y[0] = z0+z1+z2, Y[1] = z1-z2-z3
-    float* ex = reinterpret_cast<float*>(&ul[0][0]);             // [wave][(j*4 + r)*2 + jj][lane]
+    float* ex = &xl[0][0];                                       // [wave][(j*4 + r)*2 + jj][lane]  (the slabs are dead now)
     float* yout = a.y + (size_t)blockIdx.z * a.slab_stride;
     // the (sub-region, tile) this lane stores in the exchange round: slot j = wave
     const int oj = wave < NR ? wave : 0;
