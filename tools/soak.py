@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Soak: N training steps at the BASELINE config on changing synthetic batches; reports loss trend, NaNs and allocator growth."""
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "self-supervised-depth-estimation_amd"))
+import trainer as T  # noqa: E402
+from depthcore.synthetic import synthetic_batch  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    dev = torch.device("cuda:0")
+    tr = T.Trainer(T.default_options(batch_size=12), device=dev)
+    tr.set_train()
+    batches = [synthetic_batch(12, 192, 640, dev, seed=s) for s in range(4)]
+    losses = []
+    mem0 = None
+    for i in range(n):
+        _, l = tr.train_step(batches[i % 4])
+        if i % 25 == 0 or i == n - 1:
+            v = float(l["loss"].detach())
+            losses.append(v)
+            if not v == v:
+                raise SystemExit("NaN at step %d" % i)
+        if i == 20:
+            torch.cuda.synchronize()
+            mem0 = torch.cuda.memory_reserved()
+    torch.cuda.synchronize()
+    print("steps %d: loss %.5f -> %.5f (every 25th: %s)" % (n, losses[0], losses[-1], " ".join("%.4f" % v for v in losses)))
+    print("reserved memory after 20 steps %.2f GB, at the end %.2f GB, peak allocated %.2f GB"
+          % (mem0 / 2**30, torch.cuda.memory_reserved() / 2**30, torch.cuda.max_memory_allocated() / 2**30))
+
+
+if __name__ == "__main__":
+    main()
