@@ -192,14 +192,19 @@ int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, co
  * and running-stat updates of calling the module once per sub-batch in order; it lets the two pose pairs of
  * trainer.py:404-405 share one encoder pass.  ws: dc_bn_workspace(N,C,HW) bytes. */
 size_t dc_bn_workspace(int N, int C, int HW);
+/* relu_mask (nullable, dc_bn_mask_bytes(N,C,HW) bytes; 0 = not available for this shape): when relu=1 the forward also
+ * stores [y > 0] as one bit per element (wave ballots), which the backward reads instead of y -- 1/32 of the bytes, in
+ * each of its two passes. */
+size_t dc_bn_mask_bytes(int N, int C, int HW);
 int dc_bn_relu_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                    float* save_mean, float* save_invstd, float* running_mean, float* running_var, void* ws,
-                   int N, int C, int HW, float eps, float momentum, int relu, int groups, void* stream);
-/* gy is the gradient wrt y; the ReLU mask is taken from y (required when relu=1).  dres (nullable) receives
- * the gradient of the residual input; dgamma, dbeta nullable. */
+                   void* relu_mask, int N, int C, int HW, float eps, float momentum, int relu, int groups, void* stream);
+/* gy is the gradient wrt y; the ReLU mask is taken from relu_mask (as written by the forward) or, when that is NULL,
+ * from y (one of the two is required when relu=1).  dres (nullable) receives the gradient of the residual input;
+ * dgamma, dbeta nullable. */
 int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
                    const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, void* ws,
-                   int N, int C, int HW, int relu, int groups, void* stream);
+                   const void* relu_mask, int N, int C, int HW, int relu, int groups, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) of the ResNet stem (networks/resnet_encoder.py:93).  x (NC planes of HxW) ->
  * y (NC planes of Ho x Wo, Ho = (H-1)/2+1) and `code` (one byte per output: window position of the first

@@ -64,7 +64,8 @@ __device__ __forceinline__ void bn_reduce_partials(const float* part, int c, int
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* res, const float* part,
                                                        float* mean, float* invstd, float* run_mean, float* run_var,
                                                        const float* gamma, const float* beta, float* y, int C, int HW,
-                                                       int relu, int n_per_group, int groups, float eps, float momentum) {
+                                                       int relu, int n_per_group, int groups, float eps, float momentum,
+                                                       unsigned long long* mask) {
     __shared__ float sm[4];
     const int c = blockIdx.y, n = blockIdx.z, N = gridDim.z;
     const int nparts = N * gridDim.x, per = nparts / groups;
@@ -99,7 +100,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
                 const float4 r = *reinterpret_cast<const float4*>(res + base + i);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (relu) {
+                if (mask) {
+                    // ReLU mask for the backward as bits: the 256 elements of this wave iteration -> 4 ballots (one per
+                    // float4 component), 32 bytes instead of the 1 KiB of y the backward kernels would re-read twice
+                    const unsigned long long b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f),
+                                             b3 = __ballot(v.w > 0.f);
+                    if ((threadIdx.x & 63) == 0) {
+                        unsigned long long* mw = mask + (((size_t)n * C + c) * ((HW + 255) >> 8) + (i >> 8)) * 4;
+                        mw[0] = b0; mw[1] = b1; mw[2] = b2; mw[3] = b3;
+                    }
+                }
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
             *reinterpret_cast<float4*>(y + base + i) = v;
         }
     } else {
@@ -111,10 +124,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
     }
 }
 
+// the masked gradient of one float4: bits from the forward's ballots (lane bit of the wave-iteration's 4 words) or y > 0
+__device__ __forceinline__ float4 bn_mask_grad(float4 g, const unsigned long long* mask, const float* y, size_t plane, int C_unused,
+                                               int HW, size_t base, int i) {
+    if (mask) {
+        const unsigned long long* mw = mask + (plane * ((HW + 255) >> 8) + (i >> 8)) * 4;
+        const int l = threadIdx.x & 63;
+        g.x = ((mw[0] >> l) & 1ull) ? g.x : 0.f; g.y = ((mw[1] >> l) & 1ull) ? g.y : 0.f;
+        g.z = ((mw[2] >> l) & 1ull) ? g.z : 0.f; g.w = ((mw[3] >> l) & 1ull) ? g.w : 0.f;
+    } else {
+        const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    return g;
+}
+
 // backward stats: partial {sum g, sum g*x_hat}, g = gy*[y>0] when relu
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const float* y, const float* gy,
                                                            const float* mean, const float* invstd, float* part, int C,
-                                                           int HW, int relu, int n_per_group) {
+                                                           int HW, int relu, int n_per_group, const unsigned long long* mask) {
     __shared__ float sm[4];
     const int c = blockIdx.y, n = blockIdx.z;
     const size_t base = ((size_t)n * C + c) * HW;
@@ -126,10 +154,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const
         for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
             const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
             float4 g = *reinterpret_cast<const float4*>(gy + base + i);
-            if (relu) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
-                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
-            }
+            if (relu) g = bn_mask_grad(g, mask, y, (size_t)n * C + c, C, HW, base, i);
             s += (g.x + g.y) + (g.z + g.w);
             q += (g.x * (xv.x - m) + g.y * (xv.y - m)) + (g.z * (xv.z - m) + g.w * (xv.w - m));
         }
@@ -154,7 +179,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
                                                            const float* mean, const float* invstd, const float* gamma,
                                                            const float* part, float* dgamma, float* dbeta, float* dx,
                                                            float* dres, int C, int HW, int relu, int n_per_group,
-                                                           int groups) {
+                                                           int groups, const unsigned long long* mask) {
     __shared__ float sm[4];
     const int c = blockIdx.y, n = blockIdx.z, N = gridDim.z;
     const int nparts = N * gridDim.x, per = nparts / groups;
@@ -182,10 +207,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
         for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
             const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
             float4 g = *reinterpret_cast<const float4*>(gy + base + i);
-            if (relu) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
-                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
-            }
+            if (relu) g = bn_mask_grad(g, mask, y, (size_t)n * C + c, C, HW, base, i);
             if (dres) *reinterpret_cast<float4*>(dres + base + i) = g;
             float4 d;
             d.x = k * (g.x - a - (xv.x - m) * bq); d.y = k * (g.y - a - (xv.y - m) * bq);
@@ -212,9 +234,15 @@ extern "C" size_t dc_bn_workspace(int N, int C, int HW) {
     return ((size_t)C * N * ceil_div(HW, BN_CHUNK) * 2 + 2 * (size_t)C * N) * sizeof(float);   // partials + per-group means
 }
 
+extern "C" size_t dc_bn_mask_bytes(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0 || (HW & 3)) return 0;            // the bit mask exists for the float4 path only
+    return (size_t)N * C * ((HW + 255) >> 8) * 4 * sizeof(unsigned long long);
+}
+
 extern "C" int dc_bn_relu_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                               float* save_mean, float* save_invstd, float* running_mean, float* running_var, void* ws,
-                              int N, int C, int HW, float eps, float momentum, int relu, int groups, void* stream) {
+                              void* relu_mask, int N, int C, int HW, float eps, float momentum, int relu, int groups,
+                              void* stream) {
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || N <= 0 || C <= 0 || HW <= 0) return DC_EINVAL;
     if (groups < 1 || N % groups) return DC_EINVAL;
     const int chunks = ceil_div(HW, BN_CHUNK);
@@ -222,24 +250,27 @@ extern "C" int dc_bn_relu_fwd(const float* x, const float* res, const float* gam
     hipLaunchKernelGGL(bn_stats_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, part, C, HW);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, res, (const float*)part, save_mean,
-                       save_invstd, running_mean, running_var, gamma, beta, y, C, HW, relu, N / groups, groups, eps, momentum);
+                       save_invstd, running_mean, running_var, gamma, beta, y, C, HW, relu, N / groups, groups, eps, momentum,
+                       (HW & 3) ? (unsigned long long*)nullptr : (unsigned long long*)relu_mask);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
 
 extern "C" int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, const float* gamma,
                               const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dgamma,
-                              float* dbeta, void* ws, int N, int C, int HW, int relu, int groups, void* stream) {
+                              float* dbeta, void* ws, const void* relu_mask, int N, int C, int HW, int relu, int groups,
+                              void* stream) {
     if (!x || !gy || !gamma || !save_mean || !save_invstd || !dx || !ws || N <= 0 || C <= 0 || HW <= 0) return DC_EINVAL;
-    if (relu && !y) return DC_EINVAL;
+    const unsigned long long* mk = (HW & 3) ? nullptr : (const unsigned long long*)relu_mask;
+    if (relu && !y && !mk) return DC_EINVAL;
     if (groups < 1 || N % groups) return DC_EINVAL;
     const int chunks = ceil_div(HW, BN_CHUNK);
     float* part = (float*)ws;
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, part, C,
-                       HW, relu, N / groups);
+                       HW, relu, N / groups, mk);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, gamma,
-                       (const float*)part, dgamma, dbeta, dx, dres, C, HW, relu, N / groups, groups);
+                       (const float*)part, dgamma, dbeta, dx, dres, C, HW, relu, N / groups, groups, mk);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }

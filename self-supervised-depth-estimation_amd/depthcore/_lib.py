@@ -83,8 +83,9 @@ def _sig(lib):
         "dc_conv3x3_bwd_workspace": (z, [i, i, i, i, i, i]),
         "dc_conv3x3_bwd": (i, [p, i, i, p, i, p, p, p, p, p, p, p, p, i, i, i, i, i, i, p]),
         "dc_bn_workspace": (z, [i, i, i]),
-        "dc_bn_relu_fwd": (i, [p, p, p, p, p, p, p, p, p, p, i, i, i, f, f, i, i, p]),
-        "dc_bn_relu_bwd": (i, [p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, i, p]),
+        "dc_bn_mask_bytes": (z, [i, i, i]),
+        "dc_bn_relu_fwd": (i, [p, p, p, p, p, p, p, p, p, p, p, i, i, i, f, f, i, i, p]),
+        "dc_bn_relu_bwd": (i, [p, p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, i, p]),
         "dc_maxpool3x3s2_fwd": (i, [p, p, p, i, i, i, p]),
         "dc_maxpool3x3s2_bwd": (i, [p, p, p, i, i, i, p]),
         "dc_wino3x3_workspace": (z, [i, i, i, i, i]),

@@ -510,17 +510,19 @@ class _BNReLU(torch.autograd.Function):
         mean = torch.empty(groups * C, dtype=torch.float32, device=xx.device)
         invstd = torch.empty(groups * C, dtype=torch.float32, device=xx.device)
         ws = torch.empty(L.dc_bn_workspace(N, C, H * W), dtype=torch.uint8, device=xx.device)
+        nmask = L.dc_bn_mask_bytes(N, C, H * W) if relu else 0
+        mask = torch.empty(nmask, dtype=torch.uint8, device=xx.device) if nmask else None      # [y > 0] as bits
         check(L.dc_bn_relu_fwd(ptr(xx), ptr(rr), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(invstd),
-                               ptr(running_mean), ptr(running_var), ws.data_ptr(), N, C, H * W, float(eps),
-                               float(momentum), int(relu), int(groups), stream()), "dc_bn_relu_fwd")
-        ctx.save_for_backward(xx, y, g, mean, invstd)
+                               ptr(running_mean), ptr(running_var), ws.data_ptr(), mask.data_ptr() if nmask else None,
+                               N, C, H * W, float(eps), float(momentum), int(relu), int(groups), stream()), "dc_bn_relu_fwd")
+        ctx.save_for_backward(xx, y, g, mean, invstd, mask)
         ctx.cfg = (int(relu), res is not None, int(groups))
         return y
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.lib()
-        xx, y, g, mean, invstd = ctx.saved_tensors
+        xx, y, g, mean, invstd, mask = ctx.saved_tensors
         relu, has_res, groups = ctx.cfg
         N, C, H, W = xx.shape
         g_c = _c(gy)
@@ -530,7 +532,8 @@ class _BNReLU(torch.autograd.Function):
         dbeta = torch.empty_like(g)
         ws = torch.empty(L.dc_bn_workspace(N, C, H * W), dtype=torch.uint8, device=xx.device)
         check(L.dc_bn_relu_bwd(ptr(xx), ptr(y), ptr(g_c), ptr(g), ptr(mean), ptr(invstd), ptr(dx), ptr(dres), ptr(dgamma),
-                               ptr(dbeta), ws.data_ptr(), N, C, H * W, relu, groups, stream()), "dc_bn_relu_bwd")
+                               ptr(dbeta), ws.data_ptr(), mask.data_ptr() if mask is not None else None, N, C, H * W, relu,
+                               groups, stream()), "dc_bn_relu_bwd")
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 
