@@ -150,5 +150,12 @@ def ptr(t, dtype=torch.float32):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of the current PyTorch stream (the raw accessor is ~30x cheaper than torch.cuda.current_stream(),
+    which costs ~9 us and is needed once per launch)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""cProfile of the host side of Trainer.train_step (Python + launch work), top functions by own time."""
+import cProfile
+import os
+import pstats
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "self-supervised-depth-estimation_amd"))
+import trainer as T  # noqa: E402
+from depthcore.synthetic import synthetic_batch  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    tr = T.Trainer(T.default_options(batch_size=12), device=dev)
+    tr.set_train()
+    inputs = synthetic_batch(12, 192, 640, dev, seed=1)
+    for _ in range(5):
+        tr.train_step(inputs)
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(10):
+        tr.train_step(inputs)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(28)
+
+
+if __name__ == "__main__":
+    main()
