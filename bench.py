@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: training images/s of the self-supervised depth step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = reference trainer.py:233-237 on one synthetic KITTI-shaped batch: process_batch
-(resnet18 depth encoder + decoder on frame 0, pose encoder + decoder on the pairs (-1,0),(0,+1),
-4-scale fused warp + SSIM/L1 + automask + smoothness loss) -> backward -> (RCCL all-reduce) -> Adam.
-Workload = BASELINE.json configs[1]: resnet18, 192x640, per-GPU batch 12, fp32.  Weak scaling.
+N = 1 runs in this process.  N > 1 and no WORLD_SIZE in the environment: this process becomes a launcher that never
+touches the GPU; it starts N fresh child processes of this script (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays rank 0's JSON line and exits with the worst child exit code.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (WORLD_SIZE already set) it is a rank.  If the
+box has fewer than N GPUs the launcher refuses (exit code 2) instead of printing a mislabelled 1-GPU line.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel of the step, dc::wino_ps_kernel (Winograd F(2x2,3x3) forward / data gradient of
-                  the trunk and decoder convolutions, ~30 % of the step): SURVEY 8d algorithmic FLOPs (2 MAC of the
-                  direct convolution) per launch / its mean duration from hipEvents recorded on the launch stream
-                  inside the timed region, against the fp32 matrix peak.  The HBM-bound fused photometric kernels
-                  (BASELINE metric 2) are reported the same way under roofline.photometric;
-  cpu_baseline -- the CPU oracle's full training step timed on this host's cores (N=1 only).
+One "step" = reference trainer.py:233-237 on one synthetic KITTI-shaped batch: process_batch (ResNet depth encoder +
+decoder on frame 0, pose encoder + decoder on the pairs (-1,0),(0,+1), 4-scale fused warp + SSIM/L1 + automask +
+smoothness loss) -> backward -> (RCCL all-reduce of the gradient buckets) -> Adam.  Default workload = BASELINE.json
+configs[1]: resnet18, 192x640, per-GPU batch 12, fp32; `--num-layers 50 --height 320 --width 1024 --batch 8` is
+configs[2] per rank.  Weak scaling: every rank processes its own batch.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline     -- the dominant kernel of the step (Winograd fp32-MFMA convolution): SURVEY 8d algorithmic FLOPs per launch /
+                  its mean duration from hipEvents on the launch stream, against the fp32 matrix peak; the HBM-bound fused
+                  photometric kernels (BASELINE metric 2) the same way under roofline.photometric, backward chain as a whole;
+  phases_ms    -- forward / backward / exposed gradient exchange / Adam wall split of a step (N > 1: what scaling costs);
+  cpu_baseline -- the CPU oracle's full training step timed on this host's cores (N=1 only; SURVEY 8d protocol).
+
+Rehearsal switches (not measurements, flagged in the line): DC_DIST_BACKEND=gloo exchanges over gloo instead of RCCL;
+`--oversubscribe` lets several ranks share one GPU; `--rehearse` replaces the GPU step by a CPU stand-in so that the
+launcher, the rendezvous, the bucketed exchange and the max-over-ranks timing can be exercised on a machine without GPUs.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -31,27 +43,86 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD @2.4 GHz)
+VALU_LANE_OPS_PEAK = 78.6e12   # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: wave-level VALU instructions x 64 lanes per second
 
 
-def host_cores():
+# ------------------------------------------------------------------------------------------------ launcher (N > 1)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(args, argv):
+    """Parent of an N-rank run.  Must not initialise the GPU: torch.cuda.device_count() does not (task statement)."""
+    n = args.gpus
+    if not args.rehearse:
+        have = torch.cuda.device_count()
+        if have < n and not args.oversubscribe:
+            print("bench.py: --gpus %d but this machine exposes %d GPU(s); refusing to print a mislabelled line "
+                  "(rehearsal on fewer GPUs: DC_DIST_BACKEND=gloo python bench.py --gpus %d --oversubscribe)" % (n, have, n),
+                  file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                       # exactly the child we started
+            rcs.append(p.wait())
+    for line in out0.decode().splitlines():       # libraries (gloo) chat on stdout: only the JSON line is relayed there
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    if bad:
+        print("bench.py: rank exit codes %r" % rcs, file=sys.stderr)
+        return bad[0] if bad[0] > 0 else 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def host_info():
+    model = "unknown"
     try:
-        n = len(os.sched_getaffinity(0))
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
     except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, os.cpu_count() or n, 64))
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or usable, usable
 
 
-def cpu_baseline(opt, trainer, seconds_budget=25.0):
-    """Time the CPU oracle (oracle/train_step.py, "port") on a BOUNDED sample of the same workload:
-    a B=1 paging step, a timed B=2 probe step, then one timed step at the largest batch <= opt.batch_size
-    that the probe predicts fits in ~seconds_budget.  images/s = sample batch / step time."""
+def cpu_baseline(opt, trainer, seconds_budget=45.0):
+    """SURVEY 8d protocol on a BOUNDED sample: the CPU oracle (oracle/train_step.py, kind "port") runs the same step
+    (fwd + bwd + Adam) from the GPU trainer's weights on the same kind of synthetic batch.  All usable cores: one warm-up
+    step, then >= 3 timed steps at the largest batch <= opt.batch_size a timed B=2 probe predicts to fit the budget
+    (the full batch on the GPU box) -> median and min.  1 thread: one timed B=1 step."""
     from oracle import ref_cpu as R
     from oracle.train_step import CpuTrainer
-    cores = host_cores()
-    torch.set_num_threads(cores)
+    model, logical, usable = host_info()
+    # torch's intra-op pool stops scaling long before 100+ threads on these convolutions; the thread count used is stated
+    threads = max(1, min(usable, 64))
     state = {k: {n: t.detach().cpu() for n, t in m.state_dict().items()} for k, m in trainer.models.items()}
-    ct = CpuTrainer(state, R.Opt(height=opt.height, width=opt.width), opt.num_layers, opt.learning_rate)
     H, W = opt.height, opt.width
+    ct = CpuTrainer(state, R.Opt(height=H, width=W), opt.num_layers, opt.learning_rate)
 
     def step(b, seed):
         inputs = R.synthetic_inputs(b, H, W, seed=seed)
@@ -60,52 +131,130 @@ def cpu_baseline(opt, trainer, seconds_budget=25.0):
         ct.train_step(inputs, noise)
         return time.perf_counter() - t0
 
-    step(1, 2)
+    torch.set_num_threads(threads)
+    step(1, 2)                                      # pages the oracle in
     t2 = step(2, 1)
-    print("cpu_baseline: %d threads, B=2 probe step %.2f s" % (cores, t2), file=sys.stderr, flush=True)
-    bs = int(max(1, min(opt.batch_size, seconds_budget / (t2 / 2.0))))
-    t = step(bs, 0) if bs != 2 else t2
-    print("cpu_baseline: B=%d step %.2f s" % (bs, t), file=sys.stderr, flush=True)
-    return {"value": round(bs / t, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "one full training step (fwd+bwd+Adam) of the CPU oracle at B=%d (of %d), %dx%d, resnet%d, "
-                      "fp32, torch %d threads, after a B=1 and a B=2 step" % (bs, opt.batch_size, H, W,
-                                                                             opt.num_layers, cores)}
+    nsteps = 3
+    bs = int(max(1, min(opt.batch_size, seconds_budget / nsteps / (t2 / 2.0))))
+    print("cpu_baseline: %s, %d logical / %d usable cores, %d threads; B=2 probe %.2f s -> B=%d x %d timed steps"
+          % (model, logical, usable, threads, t2, bs, nsteps), file=sys.stderr, flush=True)
+    step(bs, 3)                                     # warm-up at the timed size
+    ts = [step(bs, 10 + i) for i in range(nsteps)]
+    torch.set_num_threads(1)
+    t1 = step(1, 4)
+    torch.set_num_threads(threads)
+    med, best = statistics.median(ts), min(ts)
+    print("cpu_baseline: steps %s s; 1 thread B=1 %.2f s" % (["%.2f" % t for t in ts], t1), file=sys.stderr, flush=True)
+    return {"value": round(bs / med, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "value_best": round(bs / best, 4), "step_seconds_median": round(med, 3), "step_seconds_min": round(best, 3),
+            "timed_steps": nsteps, "sample_batch": bs, "cpu_model": model, "host_logical_cores": logical,
+            "host_usable_cores": usable, "one_thread": {"value": round(1.0 / t1, 4), "unit": "images/s", "cores": 1,
+                                                         "sample": "one B=1 step"},
+            "sample": "%d timed full training steps (fwd+bwd+Adam; median) of the CPU oracle at B=%d (of %d), %dx%d, "
+                      "resnet%d, fp32, torch intra-op threads = %d, after a B=1, a B=2 and one B=%d warm-up step"
+                      % (nsteps, bs, opt.batch_size, H, W, opt.num_layers, threads, bs)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=12)
-    ap.add_argument("--height", type=int, default=192)
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--num-layers", type=int, default=18)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-noise", action="store_true", help="reference-style CPU randn tie-break noise + H2D copy")
-    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
-    ap.add_argument("--channels-last", action="store_true", help="run the ResNet trunks in NHWC")
-    ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ rehearsal stand-in
+def rehearse(args, world, rank):
+    """CPU stand-in for the GPU step: same process layout, rendezvous, bucketed exchange (depthcore/ddp.py over gloo),
+    barrier + max-over-ranks timing and JSON relay -- NOT a measurement of anything."""
+    import torch.distributed as dist
+    import torch.nn as nn
+    from depthcore.ddp import GradBuckets, broadcast_parameters
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(3, 16, 3, padding=1), nn.ReLU(), nn.Conv2d(16, 16, 3, padding=1), nn.ReLU(),
+                        nn.Conv2d(16, 1, 3, padding=1))
+    if world > 1:
+        broadcast_parameters([net], 0)
+    gb = GradBuckets([("net." + n, p) for n, p in net.named_parameters()], 0.001, world)
+    optim = torch.optim.Adam(net.parameters(), 1e-4)
+    x = torch.rand(args.batch, 3, 32, 64, generator=torch.Generator().manual_seed(100 + rank))
 
+    def step():
+        loss = net(x).square().mean()
+        gb.zero()
+        loss.backward()
+        gb.finish()
+        optim.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    wsum = torch.stack([p.detach().double().sum() for p in net.parameters()])
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        lo, hi = wsum.clone(), wsum.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if float((hi - lo).abs().max()) > 1e-9 * float(hi.abs().max() + 1):
+            raise SystemExit("replicas diverged")
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL (CPU stand-in step, not a measurement)", "value": round(world * args.batch * args.steps / float(dt), 3),
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(dt) / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rehearsal": True,
+                          "config": {"workload": "rehearsal stand-in", "global_batch": world * args.batch, "parallelism": "dp%d" % world},
+                          "grad_bytes_allreduced_per_step": gb.nbytes if world > 1 else 0, "loss_last": round(float(loss), 6)}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ a rank
+def _traffic_for(cfg_key):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc
+    WRITE_SIZE` runs, tools/pmc_traffic.sh; FETCH_SIZE x2.0 per the gfx950 calibration, WRITE_SIZE x1.0).  They are
+    CITED, not measured in this run: a PMC pass serialises the step and cannot share a process with the timed region."""
+    for name in ("round2_traffic_%s.json" % cfg_key, "round1_traffic.json" if cfg_key == "c2" else None):
+        if not name:
+            continue
+        tf = os.path.join(REPO, "profiles", name)
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                return {k: v for k, v in tj.items() if isinstance(v, dict)}, "cited from profiles/%s" % name
+            except Exception:
+                pass
+    return {}, None
+
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch `python bench.py --gpus N` or torchrun with "
+                         "--nproc-per-node N)" % (args.gpus, world))
+    if args.rehearse:
+        return rehearse(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    local = local % torch.cuda.device_count()          # (rehearsals with several ranks on one GPU)
+    ndev = torch.cuda.device_count()
+    if world > ndev and not args.oversubscribe:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) (add --oversubscribe for a rehearsal)" % (world, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
+    backend = os.environ.get("DC_DIST_BACKEND", "nccl")         # "nccl" is RCCL on ROCm; gloo only for rehearsal
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("DC_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for rehearsal
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
 
     from depthcore import ops
     from depthcore.synthetic import synthetic_batch
@@ -115,9 +264,6 @@ def main():
                             cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     tr = T.Trainer(opt, device=device, rank=rank, world_size=world)
-    if args.channels_last:
-        for k in ("encoder", "pose_encoder"):
-            tr.models[k].to(memory_format=torch.channels_last)
     tr.set_train()
     inputs = synthetic_batch(args.batch, args.height, args.width, device, seed=100 + rank)
 
@@ -129,21 +275,44 @@ def main():
     loss0 = None
     for _ in range(args.warmup):
         _, losses = tr.train_step(inputs)
-        loss0 = losses["loss"] if loss0 is None else loss0
+        loss0 = losses["loss"].detach().clone() if loss0 is None else loss0
     ops.profile_enable(args.steps + 8)
-    # every 7th conv launch carries an event pair (7 is coprime with the 78 + 32 launches per step, so all layers are
+    # every 7th conv launch carries an event pair (7 is coprime with the launches per step, so all layers are
     # sampled over the timed region); bracketing every launch costs ~4 % of the step
-    ops.conv_profile_enable((args.steps + 2) * 24, 7)
+    ops.conv_profile_enable((args.steps + 2) * 40, 7)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         _, losses = tr.train_step(inputs)
     sync()
     dt = time.perf_counter() - t0
+    loss_last = float(losses["loss"].detach())
+    del losses, _                       # drop the autograd graph before the stream layout changes below
     prof = ops.profile_collect()
     ops.profile_enable(0)
     cprof_c, wprof_c = ops.conv_profile_collect(0), ops.conv_profile_collect(1)
     ops.conv_profile_enable(0, 1)
+
+    # ---- wall split of a step: forward / backward / exposed exchange / Adam (host-synchronised, after the timed region)
+    PH = 4
+    ph = [0.0, 0.0, 0.0, 0.0]
+    for _ in range(PH):
+        ts = [time.perf_counter()]
+
+        def mark():
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter())
+        outputs, losses = tr.process_batch(inputs); mark()
+        tr.buckets.zero()
+        losses["loss"].backward(); mark()
+        tr.buckets.finish(); mark()
+        tr.model_optimizer.step(); mark()
+        tr.step += 1
+        for i in range(4):
+            ph[i] += (ts[i + 1] - ts[i]) * 1e3 / PH
+        del outputs, losses
+    packed = tr.buckets.packed
+
     # In the timed region the pose and the depth network run on two HIP streams, so a launch's event pair also spans
     # the time it shares the GPU with a kernel of the other stream.  The kernel's own duration (what rocprofv3, which
     # serialises dispatches, reports) is taken from SERIAL_STEPS single-stream steps run right after the timed region
@@ -152,7 +321,7 @@ def main():
     if tr.opt.overlap_streams:
         tr.opt.overlap_streams = False
         ops.profile_enable(SERIAL_STEPS + 2)
-        ops.conv_profile_enable((SERIAL_STEPS + 1) * 160, 1)
+        ops.conv_profile_enable((SERIAL_STEPS + 1) * 260, 1)
         for _ in range(SERIAL_STEPS):
             tr.train_step(inputs)
         torch.cuda.synchronize()
@@ -166,43 +335,45 @@ def main():
         cprof, wprof = cprof_c, wprof_c
         roof_src = "timed region, every 7th launch"
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    lossv = losses["loss"].detach().clone().reshape(1)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        # replicas must stay in lock-step: after K identical Adam steps on averaged gradients the weights agree
-        wsum = torch.stack([p.detach().double().sum() for p in tr.parameters_to_train[:8]])
+        # replicas must stay in lock-step: after K identical Adam steps on averaged gradients ALL weights agree
+        wsum = torch.stack([p.detach().double().sum() for p in tr.parameters_to_train])
         wmax, wmin = wsum.clone(), wsum.clone()
         dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(wmin, op=dist.ReduceOp.MIN)
         if float((wmax - wmin).abs().max()) > 1e-6 * float(wmax.abs().max() + 1):
-            raise SystemExit("replicas diverged: %r vs %r" % (wmax.tolist(), wmin.tolist()))
+            bad = int((wmax - wmin).abs().argmax())
+            raise SystemExit("replicas diverged at parameter %d: %r vs %r" % (bad, float(wmax[bad]), float(wmin[bad])))
     dt = float(tmax.item())
-    loss_last = float(losses["loss"].detach())
     if not (loss_last == loss_last):
         raise SystemExit("loss is NaN")
 
     if rank == 0:
+        cfg = (args.num_layers, args.height, args.width, args.batch)
+        cfg_key = {(18, 192, 640, 12): "c2", (50, 320, 1024, 8): "c3"}.get(cfg, "other")
+        label = {"c2": "BASELINE configs[1]: ", "c3": "BASELINE configs[2] (per rank): "}.get(cfg_key, "")
         N = args.batch * args.height * args.width
         bytes_fwd = sum(36.0 * N + 16.0 * (N >> (2 * s)) for s in range(4))
         bytes_bwd = sum(36.0 * N + 20.0 * (N >> (2 * s)) for s in range(4))
-        bwd_ms = prof["bwd_ms"] / max(prof["bwd_launches"], 1)
-        fwd_ms = prof["fwd_ms"] / max(prof["fwd_launches"], 1)
-        ach = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC counters: collected in separate `rocprofv3 --pmc FETCH_SIZE` /
-        # `--pmc WRITE_SIZE` passes by tools/pmc_traffic.sh (FETCH_SIZE x2.0 per the gfx950 calibration on a
-        # known-byte dword kernel in the same run, WRITE_SIZE x1.0) and committed under profiles/.
-        traffic = {}
-        tf = os.path.join(REPO, "profiles", "round1_traffic.json")
-        if os.path.exists(tf) and (args.batch, args.height, args.width, args.num_layers) == (12, 192, 640, 18):
-            try:
-                tj = json.load(open(tf))
-                traffic = {k: round(v["hbm_bytes_calibrated"], 0) for k, v in tj.items() if "hbm_bytes_calibrated" in v}
-            except Exception:
-                traffic = {}
+        nb, nf = max(prof["bwd_launches"], 1), max(prof["fwd_launches"], 1)
+        bwd_ms, fwd_ms = prof["bwd_ms"] / nb, prof["fwd_ms"] / nf
+        bwd_chain_ms, fwd_chain_ms = prof["bwd_chain_ms"] / nb, prof["fwd_chain_ms"] / nf
+        ach = bytes_bwd / (bwd_chain_ms * 1e-3) / 1e9 if bwd_chain_ms > 0 else 0.0
+        traffic, traffic_src = _traffic_for(cfg_key)
+
+        def tr_bytes(k):
+            v = traffic.get(k)
+            return round(v["hbm_bytes_calibrated"], 0) if v and "hbm_bytes_calibrated" in v else None
+
+        def valu(k):
+            v = traffic.get(k)
+            return v.get("sq_insts_valu") if v else None
         c_ms = cprof["ms"] / max(cprof["launches"], 1)
         c_tf = cprof["flops"] / (cprof["ms"] * 1e-3) / 1e12 if cprof["ms"] > 0 else 0.0
         c_ex = cprof["executed_flops"] / (cprof["ms"] * 1e-3) / 1e12 if cprof["ms"] > 0 else 0.0
         w_tf = wprof["flops"] / (wprof["ms"] * 1e-3) / 1e12 if wprof["ms"] > 0 else 0.0
+        vb = valu("dc::photo_bwd_kernel")
         out = {
             "metric": "training images/sec at %dx%d bs%d (resnet%d depth+pose, 4-scale photometric+smoothness)"
                       % (args.height, args.width, args.batch, args.num_layers),
@@ -214,19 +385,14 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%sresnet%d depth+pose, %dx%d, per-GPU batch %d, 4 scales, "
                                    "frames {0,-1,+1}, automasking, Adam lr 1e-4; random-init weights"
-                                   % ("BASELINE configs[1]: " if (args.num_layers, args.height, args.width, args.batch)
-                                      == (18, 192, 640, 12) else
-                                      "BASELINE configs[2] (per-rank): " if (args.num_layers, args.height, args.width,
-                                                                             args.batch) == (50, 320, 1024, 8) else "",
-                                      args.num_layers, args.height, args.width, args.batch),
+                                   % (label, args.num_layers, args.height, args.width, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "tiebreak_noise": "cpu-randn+h2d" if args.cpu_noise else "on-device counter RNG"},
             "roofline": {"kernel": "dc::wino_ps_kernel (Winograd F(2x2,3x3) fp32-MFMA convolution: forward + data gradient of "
                                    "the trunk and decoder 3x3 convolutions)",
                          "bound": "mfma", "achieved": round(c_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(c_tf / MFMA_F32_PEAK_TFLOPS, 4),
-                         "traffic": traffic.get("dc::wino_ps_kernel"), "traffic_source": "profiles/round1_traffic.json (mean per launch)"
-                         if traffic.get("dc::wino_ps_kernel") else None,
+                         "traffic": tr_bytes("dc::wino_ps_kernel"), "traffic_source": traffic_src,
                          "flops_definition": "SURVEY 8d algorithmic: 2 MAC of the direct 3x3 convolution, summed over the launches",
                          "algorithmic_flops_per_launch": round(cprof["flops"] / max(cprof["launches"], 1), 0),
                          "algorithmic_bytes_per_launch": round(cprof["bytes"] / max(cprof["launches"], 1), 0),
@@ -243,25 +409,69 @@ def main():
                                           "issued_frac_of_peak": round(wprof["executed_flops"] / (wprof["ms"] * 1e-3) / 1e12 /
                                                                        MFMA_F32_PEAK_TFLOPS, 4) if wprof["ms"] > 0 else 0.0,
                                           "avg_kernel_ms": round(wprof["ms"] / max(wprof["launches"], 1), 4)},
-                         "photometric": {"kernel": "dc::photo_bwd_kernel (fused warp+SSIM+L1+automask backward, 4 scales x 2 frames)",
+                         "photometric": {"kernel": "fused warp+SSIM+L1+automask+smoothness BACKWARD, whole chain of a step "
+                                                   "(dc::photo_bwd_kernel + disp_grad_kernel + pose_grad_kernel; 4 scales x 2 frames)",
                                          "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get("dc::photo_bwd_kernel"),
-                                         "limiter": "VALU issue, not HBM: 92 M wave-level VALU instructions per launch (SQ_INSTS_VALU)",
-                                         "algorithmic_bytes_per_launch": bytes_bwd, "avg_kernel_ms": round(bwd_ms, 4),
-                                         "launches": prof["bwd_launches"],
-                                         "fwd_kernel": {"kernel": "dc::photo_fwd_kernel", "algorithmic_bytes_per_launch": bytes_fwd,
-                                                        "avg_kernel_ms": round(fwd_ms, 4),
-                                                        "achieved": round(bytes_fwd / (fwd_ms * 1e-3) / 1e9, 1) if fwd_ms > 0 else 0.0}}},
-            "loss_first": round(float(loss0.detach()), 6), "loss_last": round(loss_last, 6),
+                                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr_bytes("dc::photo_bwd_kernel"),
+                                         "traffic_source": traffic_src,
+                                         "algorithmic_bytes_per_launch": bytes_bwd, "avg_chain_ms": round(bwd_chain_ms, 4),
+                                         "avg_kernel_ms": round(bwd_ms, 4), "launches": prof["bwd_launches"],
+                                         "dominant_kernel_frac": round(bytes_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                         if bwd_ms > 0 else 0.0,
+                                         "limiter": "VALU issue, not HBM (SQ_INSTS_VALU per launch under valu_wave_insts)",
+                                         "valu_wave_insts": vb,
+                                         "valu_frac_of_peak": round(vb * 64.0 / (bwd_ms * 1e-3) / VALU_LANE_OPS_PEAK, 4)
+                                         if vb and bwd_ms > 0 else None,
+                                         "fwd_chain": {"kernel": "identity + smooth + dc::photo_fwd_kernel + finalize",
+                                                       "algorithmic_bytes_per_launch": bytes_fwd,
+                                                       "avg_chain_ms": round(fwd_chain_ms, 4), "avg_kernel_ms": round(fwd_ms, 4),
+                                                       "achieved": round(bytes_fwd / (fwd_chain_ms * 1e-3) / 1e9, 1)
+                                                       if fwd_chain_ms > 0 else 0.0,
+                                                       "frac": round(bytes_fwd / (fwd_chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                       if fwd_chain_ms > 0 else 0.0}}},
+            "phases_ms": {"forward": round(ph[0], 3), "backward_incl_overlapped_exchange": round(ph[1], 3),
+                          "exposed_exchange_wait": round(ph[2], 3), "adam": round(ph[3], 3),
+                          "note": "host-synchronised between phases (slower than the pipelined step); %d steps after the "
+                                  "timed region" % PH},
+            "loss_first": round(float(loss0), 6), "loss_last": round(loss_last, 6),
             "grad_bytes_allreduced_per_step": tr.buckets.nbytes if world > 1 else 0,
+            "grad_buckets": len(tr.buckets.buckets) if world > 1 else 0,
+            "grads_packed_by_copy_per_step": packed if world > 1 else 0,
+            "dist_backend": (backend if world > 1 else None),
         }
+        if world > 1 and (backend != "nccl" or args.oversubscribe):
+            out["rehearsal"] = "backend %s%s: not an RCCL/xGMI measurement" % (backend, ", ranks share GPUs" if args.oversubscribe else "")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opt, tr)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--num-layers", type=int, default=18)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-noise", action="store_true", help="reference-style CPU randn tie-break noise + H2D copy")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
+    ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")
+    ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: let ranks share GPUs (use with DC_DIST_BACKEND=gloo)")
+    ap.add_argument("--rehearse", action="store_true", help="rehearsal: CPU stand-in step over gloo (launcher / exchange plumbing only)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch(args, sys.argv[1:])
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

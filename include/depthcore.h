@@ -157,12 +157,16 @@ int dc_photo_bwd(const dc_photo_desc* d, void* stream);
 double dc_photo_algorithmic_bytes(const dc_photo_desc* d, int backward);
 
 /* Measurement hook (bench.py `roofline`): when enabled, dc_photo_fwd / dc_photo_bwd bracket their
- * dominant kernel (photo_fwd_kernel / photo_bwd_kernel) with hipEvents on the launch stream.
- * dc_profile_enable(n) allocates n event pairs per direction (0 disables and frees);
- * dc_profile_collect synchronises on the recorded events and returns summed kernel milliseconds and
- * launch counts since the last enable/collect. */
+ * dominant kernel (photo_fwd_kernel / photo_bwd_kernel) AND their whole launch chain (forward: identity + smoothness +
+ * photo_fwd + finalize; backward: photo_bwd + disp_grad + pose_grad) with hipEvents on the launch stream.
+ * dc_profile_enable(n) allocates n event pairs per bracket (0 disables and frees);
+ * dc_profile_collect synchronises on the recorded events and returns summed milliseconds and launch counts since the
+ * last enable/collect (any output pointer may be NULL).
+ * The compute entry points of this library are stateless and re-entrant; these hooks and dc_conv_profile_* are the
+ * only process-global mutable state (event pools guarded by a mutex) and are meant for one measuring thread. */
 int dc_profile_enable(int max_launches);
-int dc_profile_collect(double* fwd_ms, int* fwd_launches, double* bwd_ms, int* bwd_launches);
+int dc_profile_collect(double* fwd_ms, int* fwd_launches, double* bwd_ms, int* bwd_launches,
+                       double* fwd_chain_ms, double* bwd_chain_ms);
 
 /* ------------------------------------------------------------------ a2/a3 decoder blocks */
 /* layers.py:106-136 + 196-199 and networks/depth_decoder.py:50-66 (and the 3x3 conv + ReLU pairs of

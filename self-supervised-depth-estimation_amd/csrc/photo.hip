@@ -12,6 +12,7 @@
 //   * backward recomputes the warp (halo 2) instead of saving it, routes the min() gradient by the
 //     1-byte argmin map the forward wrote, and reduces the pose gradient per wave -> per block ->
 //     fixed-order final sum (no float atomics, bitwise reproducible).
+#include <mutex>
 #include <vector>
 
 #include "dc_common.h"
@@ -1099,8 +1100,9 @@ struct ProfDir {
     std::vector<hipEvent_t> e0, e1;
     int used = 0;
 };
-ProfDir g_prof[2];
+ProfDir g_prof[4];     // 0 / 1: photo_fwd_kernel / photo_bwd_kernel alone; 2 / 3: the whole forward / backward launch chain
 int g_prof_cap = 0;
+std::mutex g_prof_mu;  // the hooks are the library's only process-global state (include/depthcore.h)
 
 void prof_free() {
     for (auto& d : g_prof) {
@@ -1122,6 +1124,7 @@ inline void prof_end(hipEvent_t e, hipStream_t st) {
 }  // namespace
 
 extern "C" int dc_profile_enable(int max_launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     prof_free();
     if (max_launches <= 0) return DC_OK;
     for (auto& d : g_prof) {
@@ -1134,10 +1137,12 @@ extern "C" int dc_profile_enable(int max_launches) {
     return DC_OK;
 }
 
-extern "C" int dc_profile_collect(double* fwd_ms, int* fwd_launches, double* bwd_ms, int* bwd_launches) {
-    double* ms[2] = {fwd_ms, bwd_ms};
-    int* cnt[2] = {fwd_launches, bwd_launches};
-    for (int dir = 0; dir < 2; ++dir) {
+extern "C" int dc_profile_collect(double* fwd_ms, int* fwd_launches, double* bwd_ms, int* bwd_launches,
+                                  double* fwd_chain_ms, double* bwd_chain_ms) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double* ms[4] = {fwd_ms, bwd_ms, fwd_chain_ms, bwd_chain_ms};
+    int* cnt[4] = {fwd_launches, bwd_launches, nullptr, nullptr};
+    for (int dir = 0; dir < 4; ++dir) {
         ProfDir& d = g_prof[dir];
         double tot = 0.0;
         for (int i = 0; i < d.used; ++i) {
@@ -1164,6 +1169,7 @@ extern "C" int dc_photo_fwd(const dc_photo_desc* d, void* stream) {
     int rc = fill_args(d, a, c, false);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    hipEvent_t pc = prof_begin(2, st);
     // identity losses + the pixel-interleaved image copies the gather kernels read (forward AND backward)
     if (!(a.flags & DC_OPT_NO_AUTOMASK))
         hipLaunchKernelGGL(identity_kernel<true>, dim3(c.strips_f, ceil_div(a.H, ID_ROWS), a.B), dim3(64), 0, st, a);
@@ -1182,6 +1188,7 @@ extern "C" int dc_photo_fwd(const dc_photo_desc* d, void* stream) {
     prof_end(pe, st);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, a);
+    prof_end(pc, st);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -1193,6 +1200,7 @@ extern "C" int dc_photo_bwd(const dc_photo_desc* d, void* stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)a.ns * BWD_LDS_PER_WAVE * sizeof(float);
+    hipEvent_t pc = prof_begin(3, st);
     hipEvent_t pe = prof_begin(1, st);
     hipLaunchKernelGGL(photo_bwd_kernel, dim3(c.strips_b, c.rowblocks, a.B), dim3(64 * a.ns), lds, st, a);
     prof_end(pe, st);
@@ -1207,6 +1215,7 @@ extern "C" int dc_photo_bwd(const dc_photo_desc* d, void* stream) {
     }
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(pose_grad_kernel, dim3(a.B, 2), dim3(64), 0, st, a);
+    prof_end(pc, st);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }

@@ -100,7 +100,8 @@ def _sig(lib):
         "dc_wino3x3_wgrad_workspace": (z, [i, i, i, i, i]),
         "dc_wino3x3_wgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_profile_enable": (i, [i]),
-        "dc_profile_collect": (i, [POINTER(c_double), POINTER(c_int), POINTER(c_double), POINTER(c_int)]),
+        "dc_profile_collect": (i, [POINTER(c_double), POINTER(c_int), POINTER(c_double), POINTER(c_int), POINTER(c_double),
+                                   POINTER(c_double)]),
     }
     missing = []
     for name, (res, args) in S.items():
@@ -150,12 +151,23 @@ def ptr(t, dtype=torch.float32):
     return t.data_ptr()
 
 
-_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # private accessor: optional, see stream()
+_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
-def stream():
-    """hipStream_t of the current PyTorch stream (the raw accessor is ~30x cheaper than torch.cuda.current_stream(),
-    which costs ~9 us and is needed once per launch)."""
+def stream(t=None):
+    """hipStream_t of the current PyTorch stream of the CURRENT device.
+
+    `t` is a tensor the launch reads or writes: the kernels are launched on the calling thread's current HIP device,
+    so a tensor that lives on another device is refused here (a stream of device 0 with pointers of device 1 is a
+    memory fault or silent unordered peer access) -- wrap the call in `torch.cuda.device(t.device)` or call
+    `torch.cuda.set_device` first (Trainer.__init__ does).
+    The raw accessor is ~30x cheaper than torch.cuda.current_stream() (~9 us, needed once per launch); when a torch
+    build lacks it the public API is used."""
+    dev = _get_device()
+    if t is not None and t.device.index != dev:
+        raise DepthcoreError("tensor on %s but the current device is cuda:%d; there is no cross-device launch -- "
+                             "use torch.cuda.set_device / torch.cuda.device(...)" % (t.device, dev))
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
-    return torch.cuda.current_stream().cuda_stream
+        return _raw_stream(dev)
+    return torch.cuda.current_stream(dev).cuda_stream

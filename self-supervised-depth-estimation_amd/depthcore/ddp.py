@@ -1,10 +1,24 @@
 """Data-parallel gradient exchange over RCCL/xGMI (torch.distributed backend "nccl" on ROCm).
 
-One process per GPU, full replica, per-rank batch = opt.batch_size.  Gradients live in
-a few flat fp32 buckets (parameters' .grad are views into them); a bucket's all-reduce is launched
-asynchronously from the autograd hook of its last-arriving gradient, so the exchange of the pose
-branch overlaps the backward of the depth branch.  Buckets are sized for xGMI (point-to-point links:
-few large messages rather than many small ones).
+One process per GPU, full replica, per-rank batch = opt.batch_size (the reference itself has no data
+parallelism).  Gradients live in a few flat fp32 buckets sized for xGMI (point-to-point links: few large messages
+rather than many small ones):
+
+  * every parameter owns a slice of a bucket (`GradSlot`); the depthcore autograd ops write a parameter gradient
+    straight INTO that slice (ops._grad_dst), autograd adopts the slice as `.grad` without a copy, so for the kernels of
+    this package there is no pack pass and no unpack pass.  Gradients produced by stock torch ops (the few library
+    convolutions left) are packed with one multi-tensor copy per bucket;
+  * a bucket's all-reduce is launched asynchronously from the autograd hook of its last-arriving gradient (in bucket
+    order, so every rank issues the same sequence of collectives), on a dedicated communication stream, so the
+    exchange of the branch that finishes first overlaps the backward of the other;
+  * the mean is taken by the collective itself (ReduceOp.AVG on RCCL; gloo, used only for CPU rehearsal, has no AVG and
+    gets SUM + one scale pass).
+
+Semantics shared with torch's DistributedDataParallel: a parameter that received no gradient on this rank contributes
+zeros and ends the step with the mean of the other ranks' gradients (possibly all zeros) as `.grad` -- at world size 1
+its `.grad` stays None.  `encoder.fc.*` never gets a gradient on any rank (reference networks/resnet_encoder.py:82 keeps
+it for checkpoint compatibility) and is excluded from the buckets.  BatchNorm running statistics are per rank, as in
+the reference (no SyncBN); checkpoints are written by rank 0.
 """
 import contextlib
 
@@ -12,42 +26,67 @@ import torch
 import torch.distributed as dist
 
 
+class GradSlot:
+    """A parameter's slice of its flat bucket.  `armed` is set by GradBuckets.zero() and cleared by the first backward
+    op that takes the slice as its output, so a parameter used twice in one graph gets an ordinary second gradient
+    that autograd accumulates into the slice."""
+    __slots__ = ("view", "armed")
+
+    def __init__(self, view):
+        self.view = view
+        self.armed = False
+
+    def take(self):
+        self.armed = False
+        return self.view.detach()       # a fresh tensor object on the same memory: autograd may adopt it as .grad
+
+
 class GradBuckets:
-    """Single GPU: gradients stay where autograd puts them (no copies at all).
-    Multi GPU: when the last gradient of a bucket has been produced, the bucket is packed with ONE
-    multi-tensor copy, all-reduced asynchronously (overlapping the rest of backward), and unpacked
-    (one multi-tensor copy) in finish()."""
+    """Single GPU: gradients stay where autograd puts them (no buckets, no copies).
+    Multi GPU: see the module docstring."""
 
     def __init__(self, named_params, bucket_mb=32, world_size=1, process_group=None):
         self.world = world_size
         self.pg = process_group
-        # reverse registration order ~ order in which backward produces gradients
+        named_params = list(named_params)
+        # reverse of the order given ~ order in which backward produces gradients: pass the modules in the order the
+        # forward runs them (Trainer does), so that the in-order exchange below starts as early as possible
         params = [(n, p) for n, p in named_params if p.requires_grad and ".fc." not in n]  # fc never gets a grad
         self.all_params = [p for _, p in named_params]
         params = params[::-1]
-        self.buckets = []
-        cur, cur_n = [], 0
+        self.buckets, self.names = [], []
+        cur, cur_names, cur_n = [], [], 0
         limit = bucket_mb * (1 << 20) // 4
         for n, p in params:
             if cur and cur_n + p.numel() > limit:
                 self.buckets.append(cur)
-                cur, cur_n = [], 0
+                self.names.append(cur_names)
+                cur, cur_names, cur_n = [], [], 0
             cur.append(p)
+            cur_names.append(n)
             cur_n += p.numel()
         if cur:
             self.buckets.append(cur)
+            self.names.append(cur_names)
         self.flat, self.views, self.pending, self.handles, self.launched = [], [], [], [], []
+        self.launch_order = []  # bucket indices in the order their collectives were issued this step (identical on all ranks)
+        self.next = 0           # next bucket to exchange
+        self.packed = 0         # gradients that had to be copied into their slice this step (0 on the all-depthcore path)
         self.streams = []       # streams on which gradients are produced besides the current one (Trainer.overlap_streams)
         self.comm = None        # communication stream (created on first use)
         self.nbytes = sum(p.numel() * 4 for plist in self.buckets for p in plist)
         if self.world == 1:
             return
+        backend = dist.get_backend(process_group)
+        self.avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
         for bi, plist in enumerate(self.buckets):
             n = sum(p.numel() for p in plist)
             flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
             off, views = 0, []
             for p in plist:
-                views.append(flat[off:off + p.numel()].view_as(p))
+                v = flat[off:off + p.numel()].view_as(p)
+                views.append(v)
+                p._dc_grad_slot = GradSlot(v)
                 off += p.numel()
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
             self.flat.append(flat)
@@ -59,7 +98,7 @@ class GradBuckets:
         plist = self.buckets[bi]
         flat = self.flat[bi]
         if flat.is_cuda:
-            # Pack and exchange on a dedicated communication stream that waits for every stream gradients are produced
+            # Exchange on a dedicated communication stream that waits for every stream gradients are produced
             # on (with Trainer.overlap_streams a bucket may hold gradients of both branches; all of them have been
             # *enqueued* by now, since this runs from the hook of the last one).  The producing streams are not blocked.
             if self.comm is None:
@@ -72,52 +111,69 @@ class GradBuckets:
         else:
             ctx = contextlib.nullcontext()
         with ctx:
-            have = [i for i, p in enumerate(plist) if p.grad is not None]
-            if len(have) != len(plist):
-                flat.zero_()
-            if have:
-                torch._foreach_copy_([self.views[bi][i] for i in have], [plist[i].grad for i in have])
+            views = self.views[bi]
+            missing = [i for i, p in enumerate(plist) if p.grad is None]
+            if missing:          # no gradient on this rank this step: contributes zeros (module docstring)
+                torch._foreach_zero_([views[i] for i in missing])
+            stray = [i for i, p in enumerate(plist)
+                     if p.grad is not None and p.grad.data_ptr() != views[i].data_ptr()]
+            if stray:            # produced by a stock torch op (or not adopted by autograd): pack
+                torch._foreach_copy_([views[i] for i in stray], [plist[i].grad for i in stray])
                 if flat.is_cuda:
-                    for i in have:
+                    for i in stray:
                         plist[i].grad.record_stream(self.comm)
-            self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self.packed += len(stray)
+            op = self.avg_op if self.avg_op is not None else dist.ReduceOp.SUM
+            self.handles.append(dist.all_reduce(flat, op=op, group=self.pg, async_op=True))
         self.launched[bi] = True
+        self.launch_order.append(bi)
 
     def _make_hook(self, bi):
         def hook(param):
             self.pending[bi] -= 1
-            if self.pending[bi] == 0:
-                self._launch(bi)
+            # Collectives are issued strictly in bucket order, whatever order the gradients arrive in: every rank then
+            # issues the same sequence even if a parameter gets no gradient on one of them (finish() issues the rest).
+            while self.next < len(self.flat) and self.pending[self.next] == 0:
+                self._launch(self.next)
+                self.next += 1
         return hook
 
     def zero(self):
-        """model_optimizer.zero_grad(set_to_none=True) + reset of the bucket state."""
+        """model_optimizer.zero_grad(set_to_none=True) + reset of the bucket state (arms the gradient slots)."""
         for p in self.all_params:
             p.grad = None
         for bi in range(len(self.flat)):
             self.pending[bi] = len(self.buckets[bi])
             self.launched[bi] = False
+            for p in self.buckets[bi]:
+                p._dc_grad_slot.armed = True
         self.handles = []
+        self.launch_order = []
+        self.packed = 0
+        self.next = 0
 
     def finish(self):
-        """Wait for the exchanges and turn sums into means (call before optimizer.step)."""
+        """Wait for the exchanges; afterwards every bucketed parameter's `.grad` is its (averaged) slice.
+        Call between backward() and optimizer.step()."""
         if self.world == 1:
             return
-        for bi in range(len(self.flat)):      # buckets with a parameter that got no gradient this step
-            if not self.launched[bi]:
-                self._launch(bi)
+        while self.next < len(self.flat):     # buckets holding a parameter that got no gradient this step
+            self._launch(self.next)
+            self.next += 1
         for h in self.handles:
             h.wait()
         if self.comm is not None:
             torch.cuda.current_stream(self.flat[0].device).wait_stream(self.comm)
-        inv = 1.0 / self.world
+        if self.avg_op is None:
+            torch._foreach_mul_(self.flat, 1.0 / self.world)
         for bi, plist in enumerate(self.buckets):
-            self.flat[bi].mul_(inv)
             for p, v in zip(plist, self.views[bi]):
-                p.grad = v
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
 
 
 def broadcast_parameters(modules, src=0, process_group=None):
+    """Initial weights AND buffers from rank `src` (afterwards BatchNorm statistics evolve per rank)."""
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
             dist.broadcast(t.data, src=src, group=process_group)

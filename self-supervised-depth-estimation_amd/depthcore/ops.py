@@ -15,6 +15,19 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _slot(param):
+    """forward(): the parameter's slice of its flat DDP gradient bucket, if depthcore.ddp.GradBuckets gave it one."""
+    return getattr(param, "_dc_grad_slot", None)
+
+
+def _grad_dst(slot, like):
+    """backward(): where a parameter gradient is written -- the armed bucket slice (autograd adopts it as `.grad`, so the
+    gradient exchange needs no pack copy) or, at world size 1 / on a second use of the parameter, a fresh tensor."""
+    if slot is not None and slot.armed:
+        return slot.take()
+    return torch.empty_like(like) if like is not None else None
+
+
 # ----------------------------------------------------------------------------------------------
 # fused photometric loss  (reference trainer.py:465-622)
 # ----------------------------------------------------------------------------------------------
@@ -114,7 +127,7 @@ class _PhotoLoss(torch.autograd.Function):
                     d.color[s][f] = ptr(ex["color"][s][f])
                 if automask:
                     d.identity_selection[s] = ptr(ex["identity_selection"][s])
-        check(L.dc_photo_fwd(ctypes.byref(d), stream()), "dc_photo_fwd")
+        check(L.dc_photo_fwd(ctypes.byref(d), stream(cfg.target)), "dc_photo_fwd")
         cfg.extras = ex
         ctx.cfg, ctx.ws, ctx.argmin = cfg, ws, argmin
         ctx.save_for_backward(T0, T1, *disps)
@@ -135,7 +148,7 @@ class _PhotoLoss(torch.autograd.Function):
             d.argmin[s] = ctx.argmin[s].data_ptr()
             d.d_disp[s] = ptr(d_disp[s])
         d.d_T[0], d.d_T[1] = ptr(dT[0]), ptr(dT[1])
-        check(L.dc_photo_bwd(ctypes.byref(d), stream()), "dc_photo_bwd")
+        check(L.dc_photo_bwd(ctypes.byref(d), stream(cfg.target)), "dc_photo_bwd")
         return (None, dT[0], dT[1], *d_disp)
 
 
@@ -160,7 +173,7 @@ class _PoseMatrix(torch.autograd.Function):
         tr = _c(translation.detach().reshape(-1, 3))
         B = aa.shape[0]
         M = torch.empty(B, 4, 4, dtype=torch.float32, device=aa.device)
-        check(L.dc_pose_matrix_fwd(ptr(aa), ptr(tr), int(bool(invert)), ptr(M), B, stream()), "dc_pose_matrix_fwd")
+        check(L.dc_pose_matrix_fwd(ptr(aa), ptr(tr), int(bool(invert)), ptr(M), B, stream(aa)), "dc_pose_matrix_fwd")
         ctx.save_for_backward(aa, tr)
         ctx.invert = int(bool(invert))
         ctx.shapes = (axisangle.shape, translation.shape)
@@ -173,7 +186,7 @@ class _PoseMatrix(torch.autograd.Function):
         B = aa.shape[0]
         daa, dtr = torch.empty_like(aa), torch.empty_like(tr)
         g_c = _c(gM)      # named: stays alive until the launch is enqueued
-        check(L.dc_pose_matrix_bwd(ptr(aa), ptr(tr), ctx.invert, ptr(g_c), ptr(daa), ptr(dtr), B, stream()),
+        check(L.dc_pose_matrix_bwd(ptr(aa), ptr(tr), ctx.invert, ptr(g_c), ptr(daa), ptr(dtr), B, stream(aa)),
               "dc_pose_matrix_bwd")
         return daa.reshape(ctx.shapes[0]), dtr.reshape(ctx.shapes[1]), None
 
@@ -192,7 +205,7 @@ class _DispToDepth(torch.autograd.Function):
         d = _c(disp.detach())
         scaled, depth = torch.empty_like(d), torch.empty_like(d)
         check(L.dc_disp_to_depth_fwd(ptr(d), ptr(scaled), ptr(depth), d.numel(), float(min_depth), float(max_depth),
-                                     stream()), "dc_disp_to_depth_fwd")
+                                     stream(d)), "dc_disp_to_depth_fwd")
         ctx.save_for_backward(d)
         ctx.lim = (float(min_depth), float(max_depth))
         return scaled, depth
@@ -207,7 +220,7 @@ class _DispToDepth(torch.autograd.Function):
         gs_c = _c(gs) if gs is not None else None
         gd_c = _c(gd) if gd is not None else None
         check(L.dc_disp_to_depth_bwd(ptr(d), ptr(gs_c), ptr(gd_c), ptr(out), d.numel(), ctx.lim[0], ctx.lim[1],
-                                     stream()), "dc_disp_to_depth_bwd")
+                                     stream(d)), "dc_disp_to_depth_bwd")
         return out, None, None
 
 
@@ -221,7 +234,7 @@ def disp_to_depth(disp, min_depth, max_depth):
 def pix_coords(B, H, W, device):
     L = _lib.lib()
     pc = torch.empty(B, 3, H * W, dtype=torch.float32, device=device)
-    check(L.dc_pix_coords(ptr(pc), B, H, W, stream()), "dc_pix_coords")
+    check(L.dc_pix_coords(ptr(pc), B, H, W, stream(pc)), "dc_pix_coords")
     return pc
 
 
@@ -232,7 +245,7 @@ class _Backproject(torch.autograd.Function):
         d, ik = _c(depth.detach()), _c(inv_K.detach())
         B, _, H, W = d.shape
         cam = torch.empty(B, 4, H * W, dtype=torch.float32, device=d.device)
-        check(L.dc_backproject_fwd(ptr(d), ptr(ik), ptr(cam), B, H, W, stream()), "dc_backproject_fwd")
+        check(L.dc_backproject_fwd(ptr(d), ptr(ik), ptr(cam), B, H, W, stream(d)), "dc_backproject_fwd")
         ctx.save_for_backward(ik)
         ctx.shape = d.shape
         return cam
@@ -244,7 +257,7 @@ class _Backproject(torch.autograd.Function):
         B, _, H, W = ctx.shape
         dd = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
         g_c = _c(g)      # named: stays alive until the launch is enqueued
-        check(L.dc_backproject_bwd(ptr(g_c), ptr(ik), ptr(dd), B, H, W, stream()), "dc_backproject_bwd")
+        check(L.dc_backproject_bwd(ptr(g_c), ptr(ik), ptr(dd), B, H, W, stream(g_c)), "dc_backproject_bwd")
         return dd, None
 
 
@@ -262,7 +275,7 @@ class _Project3D(torch.autograd.Function):
         p, k, t = _c(points.detach()), _c(K.detach()), _c(T.detach())
         B = p.shape[0]
         grid = torch.empty(B, H, W, 2, dtype=torch.float32, device=p.device)
-        check(L.dc_project3d_fwd(ptr(p), ptr(k), ptr(t), ptr(grid), B, H, W, float(eps), stream()), "dc_project3d_fwd")
+        check(L.dc_project3d_fwd(ptr(p), ptr(k), ptr(t), ptr(grid), B, H, W, float(eps), stream(p)), "dc_project3d_fwd")
         ctx.save_for_backward(p, k, t)
         ctx.dims = (B, H, W, float(eps))
         return grid
@@ -276,7 +289,7 @@ class _Project3D(torch.autograd.Function):
         ws = torch.empty(L.dc_project3d_bwd_workspace(B, H, W), dtype=torch.uint8, device=p.device)
         g_c = _c(g)      # named: stays alive until the launch is enqueued
         check(L.dc_project3d_bwd(ptr(p), ptr(k), ptr(t), ptr(g_c), ptr(dp), ptr(dT), ws.data_ptr(), B, H, W, eps,
-                                 stream()), "dc_project3d_bwd")
+                                 stream(p)), "dc_project3d_bwd")
         return dp, None, dT, None, None, None
 
 
@@ -295,7 +308,7 @@ class _GridSample(torch.autograd.Function):
         B, C, H, W = im.shape
         Ho, Wo = g.shape[1], g.shape[2]
         out = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=im.device)
-        check(L.dc_grid_sample_fwd(ptr(im), ptr(g), ptr(out), B, C, H, W, Ho, Wo, int(bool(align_corners)), stream()),
+        check(L.dc_grid_sample_fwd(ptr(im), ptr(g), ptr(out), B, C, H, W, Ho, Wo, int(bool(align_corners)), stream(im)),
               "dc_grid_sample_fwd")
         ctx.save_for_backward(im, g)
         ctx.ac = int(bool(align_corners))
@@ -309,7 +322,7 @@ class _GridSample(torch.autograd.Function):
         Ho, Wo = g.shape[1], g.shape[2]
         dg = torch.empty_like(g)
         g_c = _c(go)      # named: stays alive until the launch is enqueued
-        check(L.dc_grid_sample_bwd(ptr(im), ptr(g), ptr(g_c), ptr(dg), B, C, H, W, Ho, Wo, ctx.ac, stream()),
+        check(L.dc_grid_sample_bwd(ptr(im), ptr(g), ptr(g_c), ptr(dg), B, C, H, W, Ho, Wo, ctx.ac, stream(im)),
               "dc_grid_sample_bwd")
         return None, dg, None       # images are leaves without grad on this path
 
@@ -328,7 +341,7 @@ class _UpsampleBilinear(torch.autograd.Function):
         xx = _c(x.detach())
         B, C, h, w = xx.shape
         out = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=xx.device)
-        check(L.dc_upsample_bilinear_fwd(ptr(xx), ptr(out), B * C, h, w, Ho, Wo, stream()), "dc_upsample_bilinear_fwd")
+        check(L.dc_upsample_bilinear_fwd(ptr(xx), ptr(out), B * C, h, w, Ho, Wo, stream(xx)), "dc_upsample_bilinear_fwd")
         ctx.dims = (B, C, h, w, Ho, Wo)
         return out
 
@@ -338,7 +351,7 @@ class _UpsampleBilinear(torch.autograd.Function):
         B, C, h, w, Ho, Wo = ctx.dims
         dx = torch.empty(B, C, h, w, dtype=torch.float32, device=go.device)
         g_c = _c(go)      # named: stays alive until the launch is enqueued
-        check(L.dc_upsample_bilinear_bwd(ptr(g_c), ptr(dx), B * C, h, w, Ho, Wo, stream()), "dc_upsample_bilinear_bwd")
+        check(L.dc_upsample_bilinear_bwd(ptr(g_c), ptr(dx), B * C, h, w, Ho, Wo, stream(g_c)), "dc_upsample_bilinear_bwd")
         return dx, None, None
 
 
@@ -356,7 +369,7 @@ class _SSIM(torch.autograd.Function):
         xx, yy = _c(x.detach()), _c(y.detach())
         B, C, H, W = xx.shape
         out = torch.empty_like(xx)
-        check(L.dc_ssim_fwd(ptr(xx), ptr(yy), ptr(out), B * C, H, W, stream()), "dc_ssim_fwd")
+        check(L.dc_ssim_fwd(ptr(xx), ptr(yy), ptr(out), B * C, H, W, stream(xx)), "dc_ssim_fwd")
         ctx.save_for_backward(xx, yy)
         return out
 
@@ -368,7 +381,7 @@ class _SSIM(torch.autograd.Function):
         dx = torch.empty_like(xx) if ctx.needs_input_grad[0] else None
         dy = torch.empty_like(yy) if ctx.needs_input_grad[1] else None
         g_c = _c(go)      # named: stays alive until the launch is enqueued
-        check(L.dc_ssim_bwd(ptr(xx), ptr(yy), ptr(g_c), ptr(dx), ptr(dy), B * C, H, W, stream()), "dc_ssim_bwd")
+        check(L.dc_ssim_bwd(ptr(xx), ptr(yy), ptr(g_c), ptr(dx), ptr(dy), B * C, H, W, stream(xx)), "dc_ssim_bwd")
         return dx, dy
 
 
@@ -388,7 +401,7 @@ class _Smooth(torch.autograd.Function):
         C = im.shape[1]
         out = torch.empty(1, dtype=torch.float32, device=d.device)
         ws = torch.empty(L.dc_smooth_workspace(B, h, w), dtype=torch.uint8, device=d.device)
-        check(L.dc_smooth_fwd(ptr(d), ptr(im), ptr(out), ws.data_ptr(), B, C, h, w, stream()), "dc_smooth_fwd")
+        check(L.dc_smooth_fwd(ptr(d), ptr(im), ptr(out), ws.data_ptr(), B, C, h, w, stream(d)), "dc_smooth_fwd")
         ctx.save_for_backward(d, im)
         return out.reshape(())
 
@@ -399,7 +412,7 @@ class _Smooth(torch.autograd.Function):
         B, _, h, w = d.shape
         dd = torch.empty_like(d)
         g_c = _c(g.reshape(1))      # named: stays alive until the launch is enqueued
-        check(L.dc_smooth_bwd(ptr(d), ptr(im), ptr(g_c), ptr(dd), B, im.shape[1], h, w, stream()),
+        check(L.dc_smooth_bwd(ptr(d), ptr(im), ptr(g_c), ptr(dd), B, im.shape[1], h, w, stream(d)),
               "dc_smooth_bwd")
         return dd, None
 
@@ -416,12 +429,14 @@ def profile_enable(max_launches):
 
 
 def profile_collect():
-    """-> dict(fwd_ms, fwd_launches, bwd_ms, bwd_launches); synchronises on the recorded events."""
-    fm, bm = ctypes.c_double(0), ctypes.c_double(0)
+    """-> dict(fwd_ms, fwd_launches, bwd_ms, bwd_launches, fwd_chain_ms, bwd_chain_ms): the dominant kernel of each
+    direction and the whole launch chain of each direction; synchronises on the recorded events."""
+    fm, bm, fc, bc = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
     fn, bn = ctypes.c_int(0), ctypes.c_int(0)
-    check(_lib.lib().dc_profile_collect(ctypes.byref(fm), ctypes.byref(fn), ctypes.byref(bm), ctypes.byref(bn)),
-          "dc_profile_collect")
-    return {"fwd_ms": fm.value, "fwd_launches": fn.value, "bwd_ms": bm.value, "bwd_launches": bn.value}
+    check(_lib.lib().dc_profile_collect(ctypes.byref(fm), ctypes.byref(fn), ctypes.byref(bm), ctypes.byref(bn),
+                                        ctypes.byref(fc), ctypes.byref(bc)), "dc_profile_collect")
+    return {"fwd_ms": fm.value, "fwd_launches": fn.value, "bwd_ms": bm.value, "bwd_launches": bn.value,
+            "fwd_chain_ms": fc.value, "bwd_chain_ms": bc.value}
 
 
 def conv_profile_enable(max_launches, every=1):
@@ -466,9 +481,10 @@ class _Conv3x3(torch.autograd.Function):
         y = torch.empty(B, Co, H, W, dtype=torch.float32, device=a0.device)
         ws = torch.empty(L.dc_conv3x3_fwd_workspace(C0, C1, B, Co, H, W), dtype=torch.uint8, device=a0.device)
         check(L.dc_conv3x3_fwd(ptr(a0), C0, int(up0), ptr(a1), C1, ptr(w), ptr(bs), ptr(y), ws.data_ptr(), B, Co, H, W,
-                               int(act), int(pad), stream()), "dc_conv3x3_fwd")
+                               int(act), int(pad), stream(a0)), "dc_conv3x3_fwd")
         ctx.save_for_backward(a0, a1, w, y)
         ctx.cfg = (int(up0), int(act), int(pad), bias is not None)
+        ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
         return y
 
     @staticmethod
@@ -482,12 +498,16 @@ class _Conv3x3(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx0 = torch.empty_like(a0) if need[0] else None
         dx1 = torch.empty_like(a1) if (a1 is not None and need[1]) else None
-        dw = torch.empty_like(w) if need[2] else None
-        db = torch.empty(Co, dtype=torch.float32, device=y.device) if (has_bias and need[3]) else None
+        dw = _grad_dst(ctx.slots[0], w) if need[2] else None
+        db = None
+        if has_bias and need[3]:
+            db = _grad_dst(ctx.slots[1], None)
+            if db is None:
+                db = torch.empty(Co, dtype=torch.float32, device=y.device)
         ws = torch.empty(L.dc_conv3x3_bwd_workspace(C0, C1, B, Co, H, W), dtype=torch.uint8, device=y.device)
         g_c = _c(gy)      # named: stays alive until the launch is enqueued
         check(L.dc_conv3x3_bwd(ptr(a0), C0, up0, ptr(a1), C1, ptr(w), ptr(y), ptr(g_c), ptr(dx0), ptr(dx1), ptr(dw),
-                               ptr(db), ws.data_ptr(), B, Co, H, W, act, pad, stream()), "dc_conv3x3_bwd")
+                               ptr(db), ws.data_ptr(), B, Co, H, W, act, pad, stream(a0)), "dc_conv3x3_bwd")
         return dx0, dx1, dw, db, None, None, None
 
 
@@ -514,9 +534,10 @@ class _BNReLU(torch.autograd.Function):
         mask = torch.empty(nmask, dtype=torch.uint8, device=xx.device) if nmask else None      # [y > 0] as bits
         check(L.dc_bn_relu_fwd(ptr(xx), ptr(rr), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(invstd),
                                ptr(running_mean), ptr(running_var), ws.data_ptr(), mask.data_ptr() if nmask else None,
-                               N, C, H * W, float(eps), float(momentum), int(relu), int(groups), stream()), "dc_bn_relu_fwd")
+                               N, C, H * W, float(eps), float(momentum), int(relu), int(groups), stream(xx)), "dc_bn_relu_fwd")
         ctx.save_for_backward(xx, y, g, mean, invstd, mask)
         ctx.cfg = (int(relu), res is not None, int(groups))
+        ctx.slots = (_slot(gamma), _slot(beta))
         return y
 
     @staticmethod
@@ -528,12 +549,12 @@ class _BNReLU(torch.autograd.Function):
         g_c = _c(gy)
         dx = torch.empty_like(xx)
         dres = torch.empty_like(xx) if (has_res and ctx.needs_input_grad[1]) else None
-        dgamma = torch.empty_like(g)
-        dbeta = torch.empty_like(g)
+        dgamma = _grad_dst(ctx.slots[0], g)
+        dbeta = _grad_dst(ctx.slots[1], g)
         ws = torch.empty(L.dc_bn_workspace(N, C, H * W), dtype=torch.uint8, device=xx.device)
         check(L.dc_bn_relu_bwd(ptr(xx), ptr(y), ptr(g_c), ptr(g), ptr(mean), ptr(invstd), ptr(dx), ptr(dres), ptr(dgamma),
                                ptr(dbeta), ws.data_ptr(), mask.data_ptr() if mask is not None else None, N, C, H * W, relu,
-                               groups, stream()), "dc_bn_relu_bwd")
+                               groups, stream(xx)), "dc_bn_relu_bwd")
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -557,7 +578,7 @@ class _MaxPool(torch.autograd.Function):
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         y = torch.empty(N, C, Ho, Wo, dtype=torch.float32, device=xx.device)
         code = torch.empty(N, C, Ho, Wo, dtype=torch.uint8, device=xx.device)
-        check(L.dc_maxpool3x3s2_fwd(ptr(xx), ptr(y), code.data_ptr(), N * C, H, W, stream()), "dc_maxpool3x3s2_fwd")
+        check(L.dc_maxpool3x3s2_fwd(ptr(xx), ptr(y), code.data_ptr(), N * C, H, W, stream(xx)), "dc_maxpool3x3s2_fwd")
         ctx.save_for_backward(code)
         ctx.dims = (N, C, H, W)
         return y
@@ -569,7 +590,7 @@ class _MaxPool(torch.autograd.Function):
         N, C, H, W = ctx.dims
         g_c = _c(gy)
         dx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
-        check(L.dc_maxpool3x3s2_bwd(ptr(g_c), code.data_ptr(), ptr(dx), N * C, H, W, stream()), "dc_maxpool3x3s2_bwd")
+        check(L.dc_maxpool3x3s2_bwd(ptr(g_c), code.data_ptr(), ptr(dx), N * C, H, W, stream(g_c)), "dc_maxpool3x3s2_bwd")
         return dx
 
 
@@ -589,8 +610,9 @@ class _WinoConv(torch.autograd.Function):
         Co = ww.shape[0]
         y = torch.empty(B, Co, H, W, dtype=torch.float32, device=xx.device)
         ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
-        check(L.dc_wino3x3_fwd(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, stream()), "dc_wino3x3_fwd")
+        check(L.dc_wino3x3_fwd(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, stream(xx)), "dc_wino3x3_fwd")
         ctx.save_for_backward(xx, ww)
+        ctx.slot = _slot(weight)
         return y
 
     @staticmethod
@@ -604,12 +626,12 @@ class _WinoConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xx)
             ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
-            check(L.dc_wino3x3_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), B, Ci, Co, H, W, stream()),
+            check(L.dc_wino3x3_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), B, Ci, Co, H, W, stream(g_c)),
                   "dc_wino3x3_dgrad")
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(ww)
+            gw = _grad_dst(ctx.slot, ww)
             ws = torch.empty(L.dc_wino3x3_wgrad_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
-            check(L.dc_wino3x3_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, H, W, stream()),
+            check(L.dc_wino3x3_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, H, W, stream(xx)),
                   "dc_wino3x3_wgrad")
         return gx, gw
 
@@ -630,9 +652,10 @@ class _Conv1x1(torch.autograd.Function):
         B, Ci, Hi, Wi = xx.shape
         Co = ww.shape[0]
         y = torch.empty(B, Co, Hi // stride, Wi // stride, dtype=torch.float32, device=xx.device)
-        check(L.dc_conv1x1_fwd(ptr(xx), ptr(ww), ptr(y), B, Ci, Co, Hi, Wi, int(stride), stream()), "dc_conv1x1_fwd")
+        check(L.dc_conv1x1_fwd(ptr(xx), ptr(ww), ptr(y), B, Ci, Co, Hi, Wi, int(stride), stream(xx)), "dc_conv1x1_fwd")
         ctx.save_for_backward(xx, ww)
         ctx.stride = int(stride)
+        ctx.slot = _slot(weight)
         return y
 
     @staticmethod
@@ -645,11 +668,11 @@ class _Conv1x1(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xx)
-            check(L.dc_conv1x1_dgrad(ptr(g_c), ptr(ww), ptr(gx), B, Ci, Co, Hi, Wi, s_, stream()), "dc_conv1x1_dgrad")
+            check(L.dc_conv1x1_dgrad(ptr(g_c), ptr(ww), ptr(gx), B, Ci, Co, Hi, Wi, s_, stream(g_c)), "dc_conv1x1_dgrad")
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(ww)
+            gw = _grad_dst(ctx.slot, ww)
             ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
-            check(L.dc_conv1x1_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream()),
+            check(L.dc_conv1x1_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream(xx)),
                   "dc_conv1x1_wgrad")
         return gx, gw, None
 

@@ -43,6 +43,10 @@ class Trainer:
     def __init__(self, options, device="cuda:0", rank=0, world_size=1, process_group=None, seed=0):
         self.opt = options
         self.device = torch.device(device)
+        if self.device.type == "cuda":
+            # the dc_* kernels launch on the calling thread's current HIP device (depthcore._lib.stream refuses tensors
+            # of another one): the reference pins each model to a fixed cuda:N as well (trainer.py:43-50)
+            torch.cuda.set_device(self.device)
         self.rank, self.world_size = rank, world_size
         assert self.opt.height % 32 == 0 and self.opt.width % 32 == 0      # trainer.py:37-38
         assert self.opt.frame_ids[0] == 0
@@ -67,7 +71,12 @@ class Trainer:
             self.parameters_to_train += list(m.parameters())     # trainer.py:69-113: one Adam group
         if world_size > 1:
             broadcast_parameters(self.models.values(), 0, process_group)
-        named = [(k + "." + n, p) for k, m in self.models.items() for n, p in m.named_parameters()]
+        # in the order the forward runs the modules (GradBuckets exchanges in the reverse of it): with overlap_streams
+        # the pose branch is issued first (process_batch), so its gradients are the last ones backward produces
+        order = (("pose_encoder", "pose", "encoder", "depth") if getattr(self.opt, "overlap_streams", False)
+                 else ("encoder", "depth", "pose_encoder", "pose"))
+        order = list(order) + [k for k in self.models if k not in order]
+        named = [(k + "." + n, p) for k in order for n, p in self.models[k].named_parameters()]
         self.buckets = GradBuckets(named, self.opt.bucket_mb, world_size, process_group)
         self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate,
                                           fused=self.device.type == "cuda")

@@ -1,5 +1,7 @@
 """The N>1 gradient exchange (depthcore/ddp.py) on CPU: 2 gloo ranks must end with the mean of
-the per-rank gradients, including a parameter that receives no gradient on one step."""
+the per-rank gradients -- including a (non-fc) parameter that receives no gradient on ONE rank, gradients written
+straight into their bucket slice by an op that uses ops._grad_dst (no pack copy), and the same sequence of collectives
+on every rank."""
 import os
 import socket
 
@@ -17,15 +19,38 @@ def _free_port():
     return p
 
 
+class _ScaleFn(torch.autograd.Function):
+    """y = x * w (w: per-channel) whose backward writes dw where the depthcore ops do: ops._grad_dst."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from depthcore import ops
+        ctx.save_for_backward(x, w)
+        ctx.slot = ops._slot(w)
+        return x * w.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from depthcore import ops
+        x, w = ctx.saved_tensors
+        dw = ops._grad_dst(ctx.slot, w)
+        torch.sum(g * x, dim=(0, 2, 3), out=dw)
+        return g * w.view(1, -1, 1, 1), dw
+
+
 class _Net(nn.Module):
     def __init__(self):
         super().__init__()
         self.c1 = nn.Conv2d(3, 8, 3, padding=1)
+        self.scale = nn.Parameter(torch.ones(8))
         self.c2 = nn.Conv2d(8, 4, 3, padding=1)
+        self.aux = nn.Conv2d(8, 4, 1)      # used on rank 0 only: no gradient on the other rank
         self.fc = nn.Linear(4, 2)          # never used, like encoder.fc
 
-    def forward(self, x):
-        return self.c2(torch.relu(self.c1(x)))
+    def forward(self, x, use_aux=True):
+        h = _ScaleFn.apply(torch.relu(self.c1(x)), self.scale)
+        y = self.c2(h)
+        return y + self.aux(h) if use_aux else y
 
 
 def _make_model():
@@ -49,9 +74,15 @@ def _worker(rank, world, port, q):
         torch.manual_seed(100 + rank + 10 * step)
         x = torch.randn(2, 3, 8, 8)
         gb.zero()
-        m(x).square().mean().backward()
+        m(x, use_aux=(rank == 0)).square().mean().backward()
         gb.finish()
-    q.put((rank, [p.grad.numpy().copy() for n, p in m.named_parameters() if not n.startswith("fc.")]))
+        # the op that writes into its slice was not packed; every other gradient (stock torch ops) was
+        nb = sum(len(b) for b in gb.buckets)
+        assert gb.packed == nb - 1 - (2 if rank else 0), (gb.packed, nb)
+        assert m.scale.grad.data_ptr() == m.scale._dc_grad_slot.view.data_ptr()
+    assert all(p.grad.data_ptr() == p._dc_grad_slot.view.data_ptr() for b in gb.buckets for p in b)
+    assert m.fc.weight.grad is None
+    q.put((rank, [p.grad.numpy().copy() for n, p in m.named_parameters() if not n.startswith("fc.")], list(gb.launch_order)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,7 +95,10 @@ def test_two_rank_gradient_mean():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
+    got = [q.get(timeout=120) for _ in range(world)]
+    res = {r: g for r, g, _ in got}
+    orders = [o for _, _, o in got]
+    assert orders[0] == orders[1] == sorted(orders[0]) and len(orders[0]) > 1      # same collective sequence everywhere
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -75,8 +109,9 @@ def test_two_rank_gradient_mean():
         torch.manual_seed(100 + rank + 10)
         x = torch.randn(2, 3, 8, 8)
         m.zero_grad()
-        m(x).square().mean().backward()
-        g = [p.grad.clone() for n, p in m.named_parameters() if not n.startswith("fc.")]
+        m(x, use_aux=(rank == 0)).square().mean().backward()
+        g = [(p.grad.clone() if p.grad is not None else torch.zeros_like(p))       # no gradient = zeros in the mean
+             for n, p in m.named_parameters() if not n.startswith("fc.")]
         want = g if want is None else [a + b for a, b in zip(want, g)]
     want = [w / world for w in want]
     for rank in range(world):

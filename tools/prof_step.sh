@@ -4,7 +4,7 @@ set -e
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/ps_$TAG
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 4 --no-cpu-baseline "$@" > $OUT.json 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 4 --no-cpu-baseline "$@" > $OUT.json 2> $OUT.err || { tail -20 $OUT.err; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
