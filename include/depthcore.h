@@ -249,13 +249,26 @@ int dc_wino3x3_wgrad(const float* x, const float* gy, float* dweight, void* ws, 
 /* 1x1 convolution without bias, stride 1 or 2 (the trunks' `downsample` branches and Bottleneck conv1 / conv3,
  * networks/resnet_encoder.py:74-98 via torchvision), as an fp32-MFMA GEMM on the NCHW tensors: x (B,Ci,Hi,Wi),
  * weight (Co,Ci), y / gy (B,Co,Hi/stride,Wi/stride).  stride 2 needs even Hi, Wi.  dgrad writes every element of dx
- * (zeros where the stride skips).  wgrad: split reduction, fixed-order sum, ws = dc_conv1x1_wgrad_workspace bytes. */
+ * (zeros where the stride skips).  wgrad: split reduction, fixed-order sum, ws = dc_conv1x1_wgrad_workspace bytes.
+ * Shapes with Ci % 4 == 0 and (Hi/stride * Wi/stride) % 4 == 0 (stride 2: also Wi/stride % 4 == 0) run on tiled
+ * kernels (up to 128 x 128 outputs per block, 16-byte staging, pixels flattened over the batch); others on a general
+ * 64 x 64 kernel.  All variants are deterministic. */
 int dc_conv1x1_fwd(const float* x, const float* weight, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride, void* stream);
 int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride,
                      void* stream);
 size_t dc_conv1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride);
 int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
                      void* stream);
+
+/* The same convolution with bias and activation fused into the epilogue: y = act(conv1x1(x) + bias), act as in
+ * dc_conv3x3_fwd (0 none, 1 ELU, 2 sigmoid, 3 ReLU); bias may be NULL.  This is `relu(squeeze(f))` and the final
+ * `pose_2` convolution of networks/pose_decoder.py:25,30,40-48.
+ * Backward: dc_bias_act_bwd turns gy into the gradient of the pre-activation, gpre = gy * act'(y) (gpre may alias gy, or
+ * be NULL when only dbias is wanted), and reduces dbias[c] = sum_{b,p} gpre (fixed-order, deterministic; dbias may be
+ * NULL); gpre then feeds dc_conv1x1_dgrad / dc_conv1x1_wgrad.  y, gy, gpre: (B,C,P). */
+int dc_conv1x1_bias_act_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi, int Wi,
+                            int stride, int act, void* stream);
+int dc_bias_act_bwd(const float* y, const float* gy, float* gpre, float* dbias, int B, int C, int P, int act, void* stream);
 
 #ifdef __cplusplus
 }

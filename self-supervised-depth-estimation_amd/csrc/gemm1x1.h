@@ -1,0 +1,13 @@
+// Tiled 1x1-convolution GEMMs (gemm1x1.hip) behind the dc_conv1x1_* entry points of pointwise.hip.
+#pragma once
+#include <stddef.h>
+
+extern "C" {
+int dc_gemm1x1_supported(int B, int Ci, int Co, int Hi, int Wi, int stride);
+int dc_gemm1x1_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                   int act, void* stream);
+int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride, void* stream);
+size_t dc_gemm1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride);
+int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                     void* stream);
+}

@@ -1,0 +1,567 @@
+// 1x1 convolutions as tiled fp32-MFMA GEMMs straight on the NCHW tensors: the Bottleneck conv1 / conv3 and `downsample`
+// convolutions of the ResNet-50+ trunks (reference networks/resnet_encoder.py:70-98 via torchvision: about half of the
+// trunk's multiplies at BASELINE configs[2]) and the 1x1 convolutions of the pose decoder (networks/pose_decoder.py:25,30).
+//
+//   forward        y[b,m,p]          = act( sum_k w[m,k] * x[b,k,s*py,s*px] + bias[m] )
+//   data gradient  dx[b,k,s*py,s*px] = sum_m w[m,k] * gy[b,m,p]        (0 at the positions the stride skips)
+//   weight grad    dw[m,k]           = sum_{b,p} gy[b,m,p] * x[b,k,s*py,s*px]    split over blocks, fixed-order reduce
+//
+// One block = 4 waves (2 x 2) = (32 MT) x (32 NT) outputs, MT, NT in {2, 4}; a wave keeps MT x NT accumulator tiles of
+// v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation).  The pixel dimension is flattened over the batch
+// (n = b * P + p), so small maps (10 x 32 at layer4) still fill 128-wide tiles.
+//
+// No operand is ever transposed, neither in HBM nor on the way into LDS: both operands are copied global -> registers
+// -> LDS as 16-byte vectors in the layout they have in memory, and the *reading* pattern adapts:
+//   * an operand whose GEMM row/column index is contiguous in memory (x and gy as B operand: pixels; w as A operand of the
+//     data gradient: input channels) lives in LDS as [reduction][index]; a lane reads MT (NT) consecutive floats with one
+//     ds_read_b128 / b64 and uses them for its MT (NT) tiles -- tile t of lane i covers index i * MT + t;
+//   * an operand whose *reduction* index is contiguous in memory (w as A operand of the forward: input channels; gy and x
+//     in the weight gradient: pixels) lives in LDS as [index][reduction (+4 pad)]; a lane reads two consecutive reduction
+//     elements with one ds_read_b64 and uses them in two successive MFMA steps.
+// Both patterns are bank-conflict free (strides chosen per MI355X_MICROARCH.md's LDS table: b128 rows = 0 mod 64 dwords,
+// b64 index-major rows = 4 * odd dwords).  The reduction order inside a chunk of 8 is permuted identically for A and B
+// (element 2 k' + s of the chunk goes to MFMA step s, k-lane k'), which changes nothing in the sum.
+//
+// Pipeline: LDS double-buffered, one barrier per reduction chunk of KC; the global loads of chunk c+1 are issued before
+// the MFMAs of chunk c and committed to LDS after them.  ~110 VGPRs -> several blocks per CU cover each other's waits.
+// Block order: m-tiles of one pixel tile are adjacent and, through xcd_logical_block, on the same XCD: the activation
+// tile is fetched from HBM once per XCD pass and re-served by that XCD's L2; the weights are L2-resident.
+#include "dc_common.h"
+#include "gemm1x1.h"
+
+#include <algorithm>
+
+namespace dc {
+
+using gf4 = __attribute__((ext_vector_type(4))) float;
+using gf2 = __attribute__((ext_vector_type(2))) float;
+
+constexpr int GKC = 16;                // reduction chunk (forward / data gradient)
+constexpr int GKW = 32;                // reduction chunk of the weight gradient (pixels: 128-byte row segments)
+
+struct G1Args {
+    const float* w;       // (Co, Ci)
+    const float* x;       // (B, Ci, Hi, Wi)
+    const float* gy;      // (B, Co, Ho, Wo)           (backward)
+    const float* bias;    // (Co) or null               (forward)
+    float* out;           // y / dx / slab-or-dw
+    int B, Co, Ci, Hi, Wi, Ho, Wo, s;
+    int act;              // forward epilogue
+    int mtiles, ntiles;   // tile grid
+    int splits, chunks;   // weight gradient: reduction chunks in total, blocks along the reduction
+};
+
+// ---- LDS strides -------------------------------------------------------------------------------------
+// index-contiguous image [KC][W]: row stride so that the MT-wide reads of a 16-lane k-group are conflict-free
+// (a k-group pair of one 32-lane read group sits two reduction rows apart: element 2 k' + s)
+template <int T, int W>
+struct IdxStride { static constexpr int v = (T == 4) ? W : W + 16; };
+
+// ---- operand reads: fill a[t][s] for the two MFMA steps s of reduction octet q ---------------------------------
+// index-contiguous image: S[(red)][stride], tile t of lane i <-> index base + i * T + t
+template <int T, int STRIDE>
+__device__ __forceinline__ void read_idx(const float* S, int base, int q, int lane, float (&a)[4][2]) {
+    const int i = lane & 15, kp = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float* p = S + (q * 8 + 2 * kp + s) * STRIDE + base + i * T;
+        if constexpr (T == 4) {
+            const gf4 v = *reinterpret_cast<const gf4*>(p);
+            a[0][s] = v.x; a[1][s] = v.y; a[2][s] = v.z; a[3][s] = v.w;
+        } else {
+            const gf2 v = *reinterpret_cast<const gf2*>(p);
+            a[0][s] = v.x; a[1][s] = v.y;
+        }
+    }
+}
+// reduction-contiguous image: S[(index)][KC + 4], tile t of lane i <-> index base + t * 16 + i
+template <int T, int KC>
+__device__ __forceinline__ void read_red(const float* S, int base, int q, int lane, float (&a)[4][2]) {
+    const int i = lane & 15, kp = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const gf2 v = *reinterpret_cast<const gf2*>(S + (base + t * 16 + i) * (KC + 4) + q * 8 + 2 * kp);
+        a[t][0] = v.x; a[t][1] = v.y;
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void mma_octet(const float (&a)[4][2], const float (&b)[4][2], gf4 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+}
+
+// ---- pixel addressing of a 4-pixel group of the flattened (b, p) dimension --------------------------------------
+struct PixGroup {
+    size_t off;      // element offset of (b, channel 0, pixel) in the strided tensor
+    bool ok;
+};
+// n: first of 4 consecutive output pixels (P % 4 == 0, for stride 2 also Wo % 4 == 0: the group lies in one row)
+__device__ __forceinline__ PixGroup pix_group(int n, int N, int P, int Wo, int C, int Hi, int Wi, int s) {
+    PixGroup g;
+    g.ok = n < N;
+    const int nn = g.ok ? n : 0;
+    const int b = nn / P, p = nn - b * P;
+    if (s == 1) {
+        g.off = (size_t)b * C * P + p;
+    } else {
+        const int py = p / Wo, px = p - py * Wo;
+        g.off = (size_t)b * C * Hi * Wi + (size_t)(py * s) * Wi + px * s;
+    }
+    return g;
+}
+// 4 output pixels of one channel plane (stride-2: every other element of 8 consecutive ones)
+__device__ __forceinline__ gf4 load_pix4(const float* plane_ptr, int s) {
+    if (s == 1) return *reinterpret_cast<const gf4*>(plane_ptr);
+    const gf4 u = *reinterpret_cast<const gf4*>(plane_ptr), v = *reinterpret_cast<const gf4*>(plane_ptr + 4);
+    return gf4{u.x, u.z, v.x, v.z};
+}
+
+// =====================================================================================================================
+// forward.  A = w [co][ci] (reduction-contiguous), B = x [ci][n] (index-contiguous)
+// =====================================================================================================================
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
+    constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SB = IdxStride<NT, BN>::v;
+    constexpr int NA = BM * KC / 1024, NB = KC * BN / 1024;          // float4 per thread per chunk
+    __shared__ float As[2][BM * (KC + 4)];
+    __shared__ float Bs[2][KC * SB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int m0 = (lb % a.mtiles) * BM, n0 = (lb / a.mtiles) * BN;
+    const int P = a.Ho * a.Wo, N = a.B * P;
+    const size_t plane = (size_t)a.Hi * a.Wi;
+
+    // staging roles
+    int arow[NA], akq[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int idx = tid + j * 256;
+        arow[j] = idx / (KC / 4); akq[j] = idx % (KC / 4);
+    }
+    int bk[NB], bc4[NB];
+    PixGroup bg[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int idx = tid + j * 256;
+        bk[j] = idx / (BN / 4); bc4[j] = idx % (BN / 4);
+        bg[j] = pix_group(n0 + bc4[j] * 4, N, P, a.Wo, a.Ci, a.Hi, a.Wi, a.s);
+    }
+    gf4 ra[NA], rb[NB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int m = m0 + arow[j], k = k0 + akq[j] * 4;
+            ra[j] = (m < a.Co && k < a.Ci) ? *reinterpret_cast<const gf4*>(a.w + (size_t)m * a.Ci + k) : gf4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int k = k0 + bk[j];
+            rb[j] = (bg[j].ok && k < a.Ci) ? load_pix4(a.x + bg[j].off + (size_t)k * plane, a.s) : gf4{0, 0, 0, 0};
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) *reinterpret_cast<gf4*>(&As[buf][arow[j] * (KC + 4) + akq[j] * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<gf4*>(&Bs[buf][bk[j] * SB + bc4[j] * 4]) = rb[j];
+    };
+
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
+
+    const int nchunk = (a.Ci + KC - 1) / KC;
+    gload(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload((c + 1) * KC);
+#pragma unroll
+        for (int q = 0; q < KC / 8; ++q) {
+            float av[4][2], bv[4][2];
+            read_red<MT, KC>(As[buf], wm * 16 * MT, q, lane, av);
+            read_idx<NT, SB>(Bs[buf], wn * 16 * NT, q, lane, bv);
+            mma_octet<MT, NT>(av, bv, acc);
+        }
+        if (c + 1 < nchunk) commit(buf ^ 1);
+        __syncthreads();
+    }
+    // D: row r' = (lane >> 4) * 4 + r of tile mt <-> m = m0 + wm*16MT + mt*16 + r';  col j = lane & 15 of tile nt <-> n = .. + j*NT + nt
+    const int j = lane & 15;
+    const int n = n0 + wn * 16 * NT + j * NT;
+    if (n < N) {
+        const int b = n / P, p = n - b * P;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
+                if (m >= a.Co) continue;
+                const float bsv = a.bias ? a.bias[m] : 0.f;
+                float* dst = a.out + ((size_t)b * a.Co + m) * P + p;
+                if constexpr (NT == 4) {
+                    *reinterpret_cast<gf4*>(dst) = gf4{act_fwd(acc[mt][0][r] + bsv, a.act), act_fwd(acc[mt][1][r] + bsv, a.act),
+                                                       act_fwd(acc[mt][2][r] + bsv, a.act), act_fwd(acc[mt][3][r] + bsv, a.act)};
+                } else {
+                    *reinterpret_cast<gf2*>(dst) = gf2{act_fwd(acc[mt][0][r] + bsv, a.act), act_fwd(acc[mt][1][r] + bsv, a.act)};
+                }
+            }
+    }
+}
+
+// =====================================================================================================================
+// data gradient.  rows = input channels ci, reduction = co.  A = w [co][ci] (index-contiguous), B = gy [co][n] (index-cont.)
+// =====================================================================================================================
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
+    constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SA = IdxStride<MT, BM>::v, SB = IdxStride<NT, BN>::v;
+    constexpr int NA = KC * BM / 1024, NB = KC * BN / 1024;
+    __shared__ float As[2][KC * SA];
+    __shared__ float Bs[2][KC * SB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int m0 = (lb % a.mtiles) * BM, n0 = (lb / a.mtiles) * BN;
+    const int P = a.Ho * a.Wo, N = a.B * P;
+
+    int ak[NA], ac4[NA], bk[NB], bc4[NB];
+    PixGroup bg[NB];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int idx = tid + j * 256;
+        ak[j] = idx / (BM / 4); ac4[j] = idx % (BM / 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int idx = tid + j * 256;
+        bk[j] = idx / (BN / 4); bc4[j] = idx % (BN / 4);
+        bg[j] = pix_group(n0 + bc4[j] * 4, N, P, a.Wo, a.Co, a.Ho, a.Wo, 1);
+    }
+    gf4 ra[NA], rb[NB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int k = k0 + ak[j], m = m0 + ac4[j] * 4;
+            ra[j] = (k < a.Co && m < a.Ci) ? *reinterpret_cast<const gf4*>(a.w + (size_t)k * a.Ci + m) : gf4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int k = k0 + bk[j];
+            rb[j] = (bg[j].ok && k < a.Co) ? *reinterpret_cast<const gf4*>(a.gy + bg[j].off + (size_t)k * P) : gf4{0, 0, 0, 0};
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) *reinterpret_cast<gf4*>(&As[buf][ak[j] * SA + ac4[j] * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<gf4*>(&Bs[buf][bk[j] * SB + bc4[j] * 4]) = rb[j];
+    };
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
+    const int nchunk = (a.Co + KC - 1) / KC;
+    gload(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload((c + 1) * KC);
+#pragma unroll
+        for (int q = 0; q < KC / 8; ++q) {
+            float av[4][2], bv[4][2];
+            read_idx<MT, SA>(As[buf], wm * 16 * MT, q, lane, av);
+            read_idx<NT, SB>(Bs[buf], wn * 16 * NT, q, lane, bv);
+            mma_octet<MT, NT>(av, bv, acc);
+        }
+        if (c + 1 < nchunk) commit(buf ^ 1);
+        __syncthreads();
+    }
+    // row r' of tile mt <-> ci = m0 + wm*16MT + r'*MT + mt;  col j of tile nt <-> n = .. + j*NT + nt
+    const int j = lane & 15;
+    const int n = n0 + wn * 16 * NT + j * NT;
+    if (n >= N) return;
+    const int b = n / P, p = n - b * P;
+    const size_t plane = (size_t)a.Hi * a.Wi;
+    size_t pix;
+    if (a.s == 1) {
+        pix = p;
+    } else {
+        const int py = p / a.Wo, px = p - py * a.Wo;
+        pix = (size_t)(py * 2) * a.Wi + px * 2;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = m0 + wm * 16 * MT + ((lane >> 4) * 4 + r) * MT + mt;
+            if (ci >= a.Ci) continue;
+            float* dst = a.out + ((size_t)b * a.Ci + ci) * plane + pix;
+            if (a.s == 1) {
+                if constexpr (NT == 4)
+                    *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                else
+                    *reinterpret_cast<gf2*>(dst) = gf2{acc[mt][0][r], acc[mt][1][r]};
+            } else {                         // the 2 x (2 NT) cell block of these NT output pixels: values and the zeros
+                if constexpr (NT == 4) {
+                    *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], 0.f, acc[mt][1][r], 0.f};
+                    *reinterpret_cast<gf4*>(dst + 4) = gf4{acc[mt][2][r], 0.f, acc[mt][3][r], 0.f};
+                    *reinterpret_cast<gf4*>(dst + a.Wi) = gf4{0, 0, 0, 0};
+                    *reinterpret_cast<gf4*>(dst + a.Wi + 4) = gf4{0, 0, 0, 0};
+                } else {
+                    *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], 0.f, acc[mt][1][r], 0.f};
+                    *reinterpret_cast<gf4*>(dst + a.Wi) = gf4{0, 0, 0, 0};
+                }
+            }
+        }
+}
+
+// =====================================================================================================================
+// weight gradient.  rows = co, cols = ci, reduction = flattened pixels n.  A = gy [co][n], B = x [ci][n]: both
+// reduction-contiguous.  blockIdx.y = split: takes chunks split, split + splits, ...; writes slab[split][co][ci]
+// (or dw itself when there is one split).
+// =====================================================================================================================
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
+    constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKW;
+    constexpr int NA = BM * KC / 1024, NB = BN * KC / 1024;
+    extern __shared__ float g1_smem[];                       // As[2][BM][KC+4], Bs[2][BN][KC+4]
+    constexpr int ASZ = BM * (KC + 4), BSZ = BN * (KC + 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = (blockIdx.x % a.mtiles) * BM, c0 = (blockIdx.x / a.mtiles) * BN;
+    const int P = a.Ho * a.Wo, N = a.B * P;
+    const size_t plane = (size_t)a.Hi * a.Wi;
+    const int kq = tid % (KC / 4), row0 = tid / (KC / 4);    // the same 4-pixel group for all of a thread's loads
+    gf4 ra[NA], rb[NB];
+    auto gload = [&](int ch) {           // chunk ch = KC consecutive flattened pixels; a 4-pixel group lies in one image row
+        const int n = ch * KC + kq * 4;
+        const bool ok = n < N;
+        const int b = ok ? n / P : 0, p = ok ? n - b * P : 0;
+        size_t pix;
+        if (a.s == 1) {
+            pix = p;
+        } else {
+            const int py = p / a.Wo, px = p - py * a.Wo;
+            pix = (size_t)(py * 2) * a.Wi + px * 2;
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int m = m0 + row0 + j * (1024 / KC);
+            ra[j] = (ok && m < a.Co) ? *reinterpret_cast<const gf4*>(a.gy + ((size_t)b * a.Co + m) * P + p) : gf4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int ci = c0 + row0 + j * (1024 / KC);
+            rb[j] = (ok && ci < a.Ci) ? load_pix4(a.x + ((size_t)b * a.Ci + ci) * plane + pix, a.s) : gf4{0, 0, 0, 0};
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            *reinterpret_cast<gf4*>(g1_smem + buf * ASZ + (row0 + j * (1024 / KC)) * (KC + 4) + kq * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            *reinterpret_cast<gf4*>(g1_smem + 2 * ASZ + buf * BSZ + (row0 + j * (1024 / KC)) * (KC + 4) + kq * 4) = rb[j];
+    };
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
+    // split blockIdx.y owns a contiguous range of chunks (its successive 128-byte row segments stay in one L2)
+    const int per = (a.chunks + a.splits - 1) / a.splits;
+    const int ch0 = blockIdx.y * per, ch1 = min(ch0 + per, a.chunks);
+    if (ch0 < ch1) {
+        gload(ch0);
+        commit(0);
+    }
+    __syncthreads();
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int buf = (ch - ch0) & 1;
+        const bool more = ch + 1 < ch1;
+        if (more) gload(ch + 1);
+#pragma unroll
+        for (int q = 0; q < KC / 8; ++q) {
+            float av[4][2], bv[4][2];
+            read_red<MT, KC>(g1_smem + buf * ASZ, wm * 16 * MT, q, lane, av);
+            read_red<NT, KC>(g1_smem + 2 * ASZ + buf * BSZ, wn * 16 * NT, q, lane, bv);
+            mma_octet<MT, NT>(av, bv, acc);
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+    }
+    float* slab = a.out + (size_t)blockIdx.y * a.Co * a.Ci;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
+                const int ci = c0 + wn * 16 * NT + nt * 16 + (lane & 15);
+                if (m < a.Co && ci < a.Ci) slab[(size_t)m * a.Ci + ci] = acc[mt][nt][r];
+            }
+}
+
+// dw = sum of the slabs in fixed order (float4 per thread; slabs are L2-hot)
+__global__ __launch_bounds__(256) void g1_wreduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int n4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    gf4 t = reinterpret_cast<const gf4*>(slab)[i];
+    for (int s = 1; s < splits; ++s) t += reinterpret_cast<const gf4*>(slab + (size_t)s * n4 * 4)[i];
+    reinterpret_cast<gf4*>(dw)[i] = t;
+}
+
+// ---- bias + activation backward of the 1x1 convolutions that have them (pose decoder): g' = gy * act'(y), dbias = sum g'
+// one block per channel; deterministic (fixed-order tree)
+__global__ __launch_bounds__(256) void g1_bias_act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                                             float* __restrict__ gpre, float* __restrict__ dbias, int B, int C, int P,
+                                                             int act) {
+    __shared__ float sm[256];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B * P; i += 256) {
+        const int b = i / P, p = i - b * P;
+        const size_t o = ((size_t)b * C + c) * P + p;
+        const float g = gy[o] * act_bwd(y[o], act);
+        if (gpre) gpre[o] = g;
+        s += g;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && dbias) dbias[c] = sm[0];
+}
+
+// ---- tile choice: the largest tile that still gives the chip ~2 blocks per CU -------------------------------------------
+struct G1Tile { int mt, nt; };
+static G1Tile g1_pick(int M, int N) {
+    auto blocks = [&](int mt, int nt) { return (long)ceil_div(M, 32 * mt) * ceil_div(N, 32 * nt); };
+    if (M > 64 && blocks(4, 4) >= 440) return {4, 4};
+    if (blocks(2, 4) >= 440 || N >= 8 * M) return {2, 4};
+    return {2, 2};
+}
+static int g1_wsplits(int M, int K, int chunks, G1Tile t) {
+    const int tiles = ceil_div(M, 32 * t.mt) * ceil_div(K, 32 * t.nt);
+    return std::max(1, std::min({chunks, ceil_div(768, tiles), 512}));
+}
+static G1Tile g1_wpick(int M, int K) {
+    if (M > 64 && K > 64 && (long)ceil_div(M, 128) * ceil_div(K, 128) >= 32) return {4, 4};
+    return {2, 2};
+}
+
+}  // namespace dc
+
+using namespace dc;
+
+// fast path: float4 along the pixels (P % 4; stride 2 needs Wo % 4 and even input sizes), float4 along the channels of w
+extern "C" int dc_gemm1x1_supported(int B, int Ci, int Co, int Hi, int Wi, int stride) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || Hi <= 0 || Wi <= 0) return 0;
+    if (stride != 1 && stride != 2) return 0;
+    if (stride == 2 && ((Hi & 1) || (Wi & 1))) return 0;
+    const int Ho = Hi / stride, Wo = Wi / stride;
+    if (stride == 2 && (Wo & 3)) return 0;
+    if ((Ho * Wo) & 3) return 0;
+    if (Ci & 3) return 0;
+    if ((size_t)B * std::max(Ci, Co) * Hi * Wi >= (1ull << 31)) return 0;
+    return 1;
+}
+
+static void g1_fill(G1Args& a, int B, int Ci, int Co, int Hi, int Wi, int stride) {
+    a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;
+}
+
+extern "C" int dc_gemm1x1_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi, int Wi,
+                              int stride, int act, void* stream) {
+    if (!x || !weight || !y || !dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride) || act < 0 || act > 3) return DC_EINVAL;
+    G1Args a{};
+    g1_fill(a, B, Ci, Co, Hi, Wi, stride);
+    a.w = weight; a.x = x; a.bias = bias; a.out = y; a.act = act;
+    const int N = B * a.Ho * a.Wo;
+    const G1Tile t = g1_pick(Co, N);
+    a.mtiles = ceil_div(Co, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
+    const dim3 grid(a.mtiles * a.ntiles);
+    hipStream_t st = (hipStream_t)stream;
+    if (t.mt == 4) hipLaunchKernelGGL((g1_fwd_kernel<4, 4>), grid, dim3(256), 0, st, a);
+    else if (t.nt == 4) hipLaunchKernelGGL((g1_fwd_kernel<2, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((g1_fwd_kernel<2, 2>), grid, dim3(256), 0, st, a);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                                void* stream) {
+    if (!gy || !weight || !dx || !dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    G1Args a{};
+    g1_fill(a, B, Ci, Co, Hi, Wi, stride);
+    a.w = weight; a.gy = gy; a.out = dx;
+    const int N = B * a.Ho * a.Wo;
+    const G1Tile t = g1_pick(Ci, N);
+    a.mtiles = ceil_div(Ci, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
+    const dim3 grid(a.mtiles * a.ntiles);
+    hipStream_t st = (hipStream_t)stream;
+    if (t.mt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<4, 4>), grid, dim3(256), 0, st, a);
+    else if (t.nt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<2, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((g1_dgrad_kernel<2, 2>), grid, dim3(256), 0, st, a);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" size_t dc_gemm1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride) {
+    if (!dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride)) return 0;
+    const int chunks = ceil_div(B * (Hi / stride) * (Wi / stride), GKW);
+    const G1Tile t = g1_wpick(Co, Ci);
+    const int splits = g1_wsplits(Co, Ci, chunks, t);
+    return splits > 1 ? (size_t)splits * Co * Ci * sizeof(float) : 16;
+}
+
+extern "C" int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,
+                                int stride, void* stream) {
+    if (!x || !gy || !dweight || !ws || !dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    G1Args a{};
+    g1_fill(a, B, Ci, Co, Hi, Wi, stride);
+    a.x = x; a.gy = gy;
+    a.chunks = ceil_div(B * a.Ho * a.Wo, GKW);
+    const G1Tile t = g1_wpick(Co, Ci);
+    a.splits = g1_wsplits(Co, Ci, a.chunks, t);
+    a.splits = ceil_div(a.chunks, ceil_div(a.chunks, a.splits));      // no empty split: every slab gets written
+    a.out = a.splits > 1 ? (float*)ws : dweight;
+    a.mtiles = ceil_div(Co, 32 * t.mt); a.ntiles = ceil_div(Ci, 32 * t.nt);
+    const dim3 grid(a.mtiles * a.ntiles, a.splits);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)2 * 32 * (t.mt + t.nt) * (GKW + 4) * sizeof(float);
+    if (t.mt == 4) {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)g1_wgrad_kernel<4, 4>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * (GKW + 4) * 4);
+        if (attr != hipSuccess) return DC_ELAUNCH;
+        hipLaunchKernelGGL((g1_wgrad_kernel<4, 4>), grid, dim3(256), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((g1_wgrad_kernel<2, 2>), grid, dim3(256), lds, st, a);
+    }
+    DC_CHECK_LAUNCH();
+    if (a.splits > 1) {
+        const int n4 = Co * Ci / 4;
+        hipLaunchKernelGGL(g1_wreduce_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, st, (const float*)ws, dweight, a.splits, n4);
+        DC_CHECK_LAUNCH();
+    }
+    return DC_OK;
+}
+
+extern "C" int dc_bias_act_bwd(const float* y, const float* gy, float* gpre, float* dbias, int B, int C, int P, int act, void* stream) {
+    if (!y || !gy || B <= 0 || C <= 0 || P <= 0 || act < 0 || act > 3) return DC_EINVAL;
+    hipLaunchKernelGGL(g1_bias_act_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, y, gy, gpre, dbias, B, C, P, act);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}

@@ -7,7 +7,12 @@
 //   data gradient  dx[b,k,s*py,s*px] = sum_m w[m,k] * gy[b,m,p]      (0 at the positions the stride skips)
 //   weight grad    dw[m,k]           = sum_{b,p} gy[b,m,p] * x[b,k,s*py,s*px]   split over blocks, fixed-order reduce
 // v_mfma_f32_16x16x4_f32, block = 4 waves = 64 outputs x 64 columns, reduction staged through LDS in chunks of 16.
+//
+// These are the GENERAL kernels (any shape, scalar staging).  Shapes whose pixel count and channel count allow 16-byte
+// staging -- every Bottleneck / downsample / pose-decoder convolution at the BASELINE sizes -- are dispatched to the tiled
+// kernels of gemm1x1.hip by the entry points at the bottom of this file.
 #include "dc_common.h"
+#include "gemm1x1.h"
 
 #include <algorithm>
 
@@ -26,6 +31,8 @@ struct PwArgs {
     int B, M, K;       // conv channels: M = Co, K = Ci
     int Hi, Wi, Ho, Wo, s;
     int splits;        // wgrad
+    const float* bias; // forward epilogue: y = act(y + bias[m])   (null: none)
+    int act;
 };
 
 // ---- shared MFMA core: acc[nt] += A(16 rows of this wave x PK) * B(PK x 64 columns)
@@ -89,7 +96,8 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(PwArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + wave * 16 + (lane >> 4) * 4 + r, p = p0 + nt * 16 + (lane & 15);
-            if (m < a.M && p < P) a.out[((size_t)b * a.M + m) * P + p] = acc[nt][r];
+            if (m < a.M && p < P)
+                a.out[((size_t)b * a.M + m) * P + p] = act_fwd(acc[nt][r] + (a.bias ? a.bias[m] : 0.f), a.act);
         }
 }
 
@@ -220,22 +228,32 @@ static bool pw_shape_ok(int B, int Ci, int Co, int Hi, int Wi, int s) {
 
 extern "C" size_t dc_conv1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride) {
     if (!pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return 0;
+    if (dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride)) return dc_gemm1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, stride);
     return (size_t)pw_splits(B, Hi / stride, Wi / stride, Co, Ci) * Co * Ci * sizeof(float);
 }
 
-extern "C" int dc_conv1x1_fwd(const float* x, const float* weight, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride,
-                              void* stream) {
-    if (!x || !weight || !y || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+extern "C" int dc_conv1x1_bias_act_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi,
+                                       int Wi, int stride, int act, void* stream) {
+    if (!x || !weight || !y || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride) || act < 0 || act > 3) return DC_EINVAL;
+    if (dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride))
+        return dc_gemm1x1_fwd(x, weight, bias, y, B, Ci, Co, Hi, Wi, stride, act, stream);
     PwArgs a{};
+    a.bias = bias; a.act = act;
     a.a = weight; a.b = x; a.out = y; a.B = B; a.M = Co; a.K = Ci; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;
     hipLaunchKernelGGL(pw_fwd_kernel, dim3(ceil_div(a.Ho * a.Wo, PT), ceil_div(Co, PT), B), dim3(256), 0, (hipStream_t)stream, a);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
 
+extern "C" int dc_conv1x1_fwd(const float* x, const float* weight, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                              void* stream) {
+    return dc_conv1x1_bias_act_fwd(x, weight, nullptr, y, B, Ci, Co, Hi, Wi, stride, ACT_NONE, stream);
+}
+
 extern "C" int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride,
                                 void* stream) {
     if (!gy || !weight || !dx || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    if (dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride)) return dc_gemm1x1_dgrad(gy, weight, dx, B, Ci, Co, Hi, Wi, stride, stream);
     PwArgs a{};
     a.a = weight; a.b = gy; a.out = dx; a.B = B; a.M = Co; a.K = Ci; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;
     hipLaunchKernelGGL(pw_dgrad_kernel, dim3(ceil_div(a.Ho * a.Wo, PT), ceil_div(Ci, PT), B), dim3(256), 0, (hipStream_t)stream, a);
@@ -246,6 +264,8 @@ extern "C" int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx,
 extern "C" int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,
                                 int stride, void* stream) {
     if (!x || !gy || !dweight || !ws || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    if (dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride))
+        return dc_gemm1x1_wgrad(x, gy, dweight, ws, B, Ci, Co, Hi, Wi, stride, stream);
     PwArgs a{};
     a.a = gy; a.b = x; a.out = (float*)ws; a.B = B; a.M = Co; a.K = Ci; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;
     a.splits = pw_splits(B, a.Ho, a.Wo, Co, Ci);

@@ -642,41 +642,57 @@ def wino_conv3x3(x, weight):
 
 
 # ----------------------------------------------------------------------------------------------
-# a1 trunk 1x1 convolutions (stride 1 / 2, no bias): MFMA GEMMs on the NCHW tensors
+# a1 / a4  1x1 convolutions (stride 1 / 2; optional bias + activation): MFMA GEMMs on the NCHW tensors
 # ----------------------------------------------------------------------------------------------
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, stride):
+    def forward(ctx, x, weight, bias, stride, act):
         L = _lib.lib()
         xx, ww = _c(x.detach()), _c(weight.detach())
+        bs = _c(bias.detach()) if bias is not None else None
         B, Ci, Hi, Wi = xx.shape
         Co = ww.shape[0]
+        if ww.numel() != Co * Ci or (bs is not None and bs.numel() != Co):
+            raise _lib.DepthcoreError("1x1 weight %s / bias do not match %d input channels" % (tuple(ww.shape), Ci))
         y = torch.empty(B, Co, Hi // stride, Wi // stride, dtype=torch.float32, device=xx.device)
-        check(L.dc_conv1x1_fwd(ptr(xx), ptr(ww), ptr(y), B, Ci, Co, Hi, Wi, int(stride), stream(xx)), "dc_conv1x1_fwd")
-        ctx.save_for_backward(xx, ww)
-        ctx.stride = int(stride)
-        ctx.slot = _slot(weight)
+        check(L.dc_conv1x1_bias_act_fwd(ptr(xx), ptr(ww), ptr(bs), ptr(y), B, Ci, Co, Hi, Wi, int(stride), int(act), stream(xx)),
+              "dc_conv1x1_bias_act_fwd")
+        plain = bias is None and act == ACT_NONE
+        ctx.save_for_backward(xx, ww, None if plain else y)
+        ctx.cfg = (int(stride), int(act), bias is not None)
+        ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.lib()
-        xx, ww = ctx.saved_tensors
+        xx, ww, y = ctx.saved_tensors
         B, Ci, Hi, Wi = xx.shape
-        Co, s_ = ww.shape[0], ctx.stride
+        s_, act, has_bias = ctx.cfg
+        Co = ww.shape[0]
         g_c = _c(gy)
-        gx = gw = None
+        gx = gw = gb = None
+        if y is not None:      # gradient of the pre-activation (+ bias gradient), one pass
+            P = (Hi // s_) * (Wi // s_)
+            gpre = torch.empty_like(g_c) if act != ACT_NONE else None
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = _grad_dst(ctx.slots[1], None)
+                if gb is None:
+                    gb = torch.empty(Co, dtype=torch.float32, device=xx.device)
+            check(L.dc_bias_act_bwd(ptr(y), ptr(g_c), ptr(gpre), ptr(gb), B, Co, P, act, stream(xx)), "dc_bias_act_bwd")
+            if gpre is not None:
+                g_c = gpre
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xx)
-            check(L.dc_conv1x1_dgrad(ptr(g_c), ptr(ww), ptr(gx), B, Ci, Co, Hi, Wi, s_, stream(g_c)), "dc_conv1x1_dgrad")
+            check(L.dc_conv1x1_dgrad(ptr(g_c), ptr(ww), ptr(gx), B, Ci, Co, Hi, Wi, s_, stream(xx)), "dc_conv1x1_dgrad")
         if ctx.needs_input_grad[1]:
-            gw = _grad_dst(ctx.slot, ww)
+            gw = _grad_dst(ctx.slots[0], ww)
             ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
             check(L.dc_conv1x1_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream(xx)),
                   "dc_conv1x1_wgrad")
-        return gx, gw, None
+        return gx, gw, gb, None, None
 
 
-def conv1x1(x, weight, stride=1):
-    """F.conv2d(x, weight, None, stride) for (Co,Ci,1,1) weights; stride 2 needs even H, W."""
-    return _Conv1x1.apply(x, weight, stride)
+def conv1x1(x, weight, stride=1, bias=None, act=ACT_NONE):
+    """act(F.conv2d(x, weight, bias, stride)) for (Co,Ci,1,1) weights; stride 2 needs even H, W."""
+    return _Conv1x1.apply(x, weight, bias, stride, act)

@@ -25,17 +25,26 @@ class PoseDecoder(nn.Module):
         self.net = nn.ModuleList(list(self.convs.values()))
 
     def forward(self, input_features):
+        """networks/pose_decoder.py:40-54.  On the GPU every convolution is a depthcore launch with its bias and ReLU in
+        the epilogue (dc_conv1x1_bias_act_fwd, dc_conv3x3_fwd); there is no library convolution on this path."""
         last = [f[-1] for f in input_features]
-        out = torch.cat([self.relu(self.convs["squeeze"](f)) for f in last], 1)
-        for i in range(3):
-            conv = self.convs[("pose", i)]
-            if i != 2 and out.is_cuda and conv.stride == (1, 1) and out.shape[-1] % 2 == 0:
-                # 3x3 conv (zero padding) + bias + ReLU as one fused depthcore launch (dc_conv3x3_fwd/bwd)
+        if last[0].is_cuda:
+            sq = self.convs["squeeze"]
+            out = [_ops.conv1x1(f, sq.weight, 1, sq.bias, _ops.ACT_RELU) for f in last]
+            out = out[0] if len(out) == 1 else torch.cat(out, 1)
+            for i in range(2):
+                conv = self.convs[("pose", i)]
+                if conv.stride != (1, 1):
+                    raise NotImplementedError("PoseDecoder stride != 1 is not on the hot path (the reference never sets it)")
                 out = _ops.conv3x3_block(out, None, conv.weight, conv.bias, False, _ops.ACT_RELU, _ops.PAD_ZERO)
-                continue
-            out = conv(out)
-            if i != 2:
-                out = self.relu(out)
+            fin = self.convs[("pose", 2)]
+            out = _ops.conv1x1(out, fin.weight, 1, fin.bias, _ops.ACT_NONE)
+        else:               # CPU: module bookkeeping / export only, not a compute path of this package
+            out = torch.cat([self.relu(self.convs["squeeze"](f)) for f in last], 1)
+            for i in range(3):
+                out = self.convs[("pose", i)](out)
+                if i != 2:
+                    out = self.relu(out)
         out = out.mean(3).mean(2)
         out = 0.01 * out.view(-1, self.num_frames_to_predict_for, 1, 6)
         return out[..., :3], out[..., 3:]

@@ -40,11 +40,10 @@ def _conv(conv, x):
             and x.dtype == torch.float32):
         return _ops.wino_conv3x3(x, conv.weight)
     if (GEMM_1X1 and x.is_cuda and conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
-            and conv.bias is None and conv.stride == (2, 2) and x.dtype == torch.float32
-            and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0 and conv.in_channels * conv.out_channels <= 131072):
-        # the stride-2 `downsample` branches of the ResNet-18/34 widths: small GEMMs that the library wraps in layout transposes (dc_conv1x1_*).
-        # The large 1x1 convolutions of the Bottleneck trunks stay on the library (measured: C3 127 vs 93 img/s)
-        return _ops.conv1x1(x, conv.weight, 2)
+            and conv.bias is None and conv.stride in ((1, 1), (2, 2)) and x.dtype == torch.float32
+            and (conv.stride == (1, 1) or (x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0))):
+        # Bottleneck conv1 / conv3 and every `downsample` branch: NCHW fp32-MFMA GEMMs (dc_conv1x1_*), no layout transposes
+        return _ops.conv1x1(x, conv.weight, conv.stride[0])
     return conv(x)
 
 

@@ -135,3 +135,38 @@ def test_decoder_full_size_determinism(min_pixels, monkeypatch):
         for a, b in zip(*res):
             assert torch.equal(a, b)          # split-K slabs reduced in fixed order: bitwise reproducible
     assert o[("disp", 0)].shape == (4, 1, 192, 640)
+
+
+@pytest.mark.parametrize("fixture", ["2x3", "4x8"])
+def test_pose_decoder_golden(golden, fixture):
+    """a4: networks.PoseDecoder on the GPU (squeeze / pose_2 on dc_conv1x1_bias_act_fwd, the 3x3 pairs on dc_conv3x3_fwd)
+    against the reference decoder's outputs and gradients.  "2x3" is the round-1 fixture (odd width: general kernels),
+    "4x8" the round-2 one (tiled 1x1 GEMMs, Winograd 3x3)."""
+    import networks
+    import make_golden_r2 as MG2
+    nce = np.array([64, 64, 128, 256, 512])
+    pose = networks.PoseDecoder(nce, num_input_features=1, num_frames_to_predict_for=2).to(DEV)
+    assert list(pose.state_dict().keys()) == list(golden["decoders"]["pose_keys"])
+    pose.load_state_dict(pose_state(nce, 5))
+    if fixture == "2x3":
+        g = golden["decoders"]
+        key = lambda k: "pose_" + k                  # noqa: E731
+        f4 = T(g["pose_feat"])
+    else:
+        g = golden["pose_even"]
+        key = lambda k: k                            # noqa: E731
+        f4, _ = MG2.pose_even_feature()
+    f4 = f4.to(DEV).requires_grad_()
+    a, t = pose([[f4]])
+    close(a, g[key("aa")], rtol=1e-3, atol=1e-6)
+    close(t, g[key("tr")], rtol=1e-3, atol=1e-6)
+    names = [n for n, _ in pose.named_parameters()]
+    gr = torch.autograd.grad((a * T(g[key("cot_aa")]).to(DEV)).sum() + (t * T(g[key("cot_tr")]).to(DEV)).sum(),
+                             [f4] + [p for _, p in pose.named_parameters()])
+    want = g[key("gfeat")]
+    got = gr[0].cpu() if want.ndim == 4 else torch.from_numpy(MG.summ(gr[0]))
+    close(got, want, rtol=2e-3, atol=1e-6 if want.ndim == 4 else 1e-5)
+    for j, k in enumerate(names):
+        gk = gr[1 + j].cpu()
+        got = gk if gk.numel() <= 4096 else torch.from_numpy(MG.summ(gk))
+        close(got, g[key("g_" + k)], rtol=3e-3, atol=2e-4)

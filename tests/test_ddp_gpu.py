@@ -2,9 +2,10 @@
 of Trainer.overlap_streams, the dedicated communication stream, finish() and the optimiser step.
 
 One GPU box has one GPU, so the process group has a single rank; the Trainer is told world_size = 2, which turns the
-bucket machinery on (pack -> all_reduce over the 1-rank group -> x 1/2 -> unpack into .grad views).  Adam is invariant
-to a uniform scale of the gradients (up to eps), so after one step the weights must match those of the plain
-single-GPU trainer started from the same state -- any lost, stale or misrouted gradient would show."""
+bucket machinery on (gradients produced inside their bucket slices -> ReduceOp.AVG over the 1-rank group -> .grad =
+slices).  The mean over a 1-rank group is the local gradient, so every gradient must equal the plain single-GPU
+trainer's from the same state -- any lost, stale or misrouted gradient would show -- and only the gradients of the
+library convolutions may have needed a pack copy."""
 import os
 import socket
 

@@ -1,0 +1,71 @@
+"""a1 at network level: networks.ResnetEncoder (resnet18 and resnet50, bn_groups 1 and 2) forward AND backward on the HIP
+path against the oracle's functional ResNet (oracle/resnet_ref.py) evaluated in fp64.
+
+Every feature map, every parameter gradient and the input gradient are compared by relative L2 norm.  The bound is
+stated against the fp64 result and calibrated in the test itself: the HIP path may be at most 3x as far from fp64 as
+the oracle's own fp32 evaluation is (training-mode BatchNorm on small maps amplifies rounding differences, so a fixed
+number would either be loose for the stem or flaky for layer4), with a floor of 2e-5."""
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _oracle(state, x, cots, num_layers, groups, dtype):
+    from oracle.resnet_ref import resnet_encoder_forward
+    st = {k: (v.to(dtype).requires_grad_() if v.is_floating_point() and "running" not in k else
+              (v.to(dtype) if v.is_floating_point() else v)) for k, v in state.items()}
+    xr = x.to(dtype).requires_grad_()
+    n = x.shape[0] // groups
+    parts = [resnet_encoder_forward(st, xr[g * n:(g + 1) * n], num_layers, training=True) for g in range(groups)]
+    feats = [torch.cat([p[i] for p in parts], 0) for i in range(5)]
+    loss = sum((f * c.to(dtype)).sum() for f, c in zip(feats, cots))
+    names = [k for k, v in st.items() if v.requires_grad and ".fc." not in k]
+    grads = torch.autograd.grad(loss, [st[k] for k in names] + [xr])
+    return feats, dict(zip(names, grads[:-1])), grads[-1]
+
+
+@pytest.mark.parametrize("num_layers,groups,nimg,B,H,W", [
+    (18, 1, 1, 4, 64, 128),
+    (18, 2, 2, 4, 64, 128),          # the pose encoder's stacked pairs (6 channels, per-pair BN statistics)
+    (50, 1, 1, 4, 64, 128),
+    (50, 2, 2, 4, 96, 128),
+    (18, 1, 1, 1, 192, 640),         # BASELINE configs[0] shape (C1: a single 192x640 frame)
+])
+def test_encoder_forward_and_all_gradients_vs_fp64_oracle(num_layers, groups, nimg, B, H, W):
+    import networks
+    torch.manual_seed(0)
+    enc = networks.ResnetEncoder(num_layers, False, num_input_images=nimg).to(DEV)
+    enc.train()
+    state = {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(B, 3 * nimg, H, W, generator=g)
+    xh = x.to(DEV).requires_grad_()
+    got = enc(xh, bn_groups=groups)
+    cots = [torch.randn(f.shape, generator=g) / f[0].numel() ** 0.5 for f in got]
+    loss = sum((f * c.to(DEV)).sum() for f, c in zip(got, cots))
+    params = {"encoder." + n: p for n, p in enc.encoder.named_parameters() if not n.startswith("fc.")}
+    gh = torch.autograd.grad(loss, list(params.values()) + [xh])
+    gh_p, gh_x = dict(zip(params.keys(), gh[:-1])), gh[-1]
+
+    f64, g64, gx64 = _oracle(state, x, cots, num_layers, groups, torch.float64)
+    f32, g32, gx32 = _oracle(state, x, cots, num_layers, groups, torch.float32)
+
+    def bound(e32):
+        return max(3.0 * e32, 2e-5)
+
+    worst = 0.0
+    for i in range(5):
+        e, e32 = rel_l2(got[i], f64[i]), rel_l2(f32[i], f64[i])
+        assert e <= bound(e32), ("feature %d" % i, e, e32)
+    assert set(g64) == set(gh_p)
+    for k in g64:
+        e, e32 = rel_l2(gh_p[k], g64[k]), rel_l2(g32[k], g64[k])
+        worst = max(worst, e)
+        assert e <= bound(e32), (k, e, e32)
+    e, e32 = rel_l2(gh_x, gx64), rel_l2(gx32, gx64)
+    assert e <= bound(e32), ("input gradient", e, e32)
+    assert worst < 1e-3            # north-star tolerance as the outer bound on every parameter gradient

@@ -245,3 +245,23 @@ def test_decoders(golden):
         gk = gr[1 + j]
         got = gk if gk.numel() <= 4096 else torch.from_numpy(MG.summ(gk))
         close(got, g["pose_g_" + k], rtol=2e-3, atol=1e-4)
+
+
+def test_pose_decoder_even_fixture(golden):
+    """Round-2 fixture (tests/golden/make_golden_r2.py): the reference PoseDecoder on an even-sized (4x8) feature map."""
+    import make_golden_r2 as MG2
+    from self_check_shapes import pose_state
+    g = golden["pose_even"]
+    nce = np.array([64, 64, 128, 256, 512])
+    ps = {k: v.requires_grad_() for k, v in pose_state(nce, 5).items()}
+    f4, _ = MG2.pose_even_feature()
+    f4.requires_grad_()
+    a, t = R.pose_decoder_forward(ps, [[f4]], 2)
+    close(a, g["aa"], rtol=1e-4, atol=1e-6); close(t, g["tr"], rtol=1e-4, atol=1e-6)
+    pn = list(ps)
+    gr = torch.autograd.grad((a * T(g["cot_aa"])).sum() + (t * T(g["cot_tr"])).sum(), [f4] + [ps[k] for k in pn])
+    close(MG.summ(gr[0]), g["gfeat"], rtol=1e-3, atol=1e-6)
+    for j, k in enumerate(pn):
+        gk = gr[1 + j]
+        got = gk if gk.numel() <= 4096 else torch.from_numpy(MG.summ(gk))
+        close(got, g["g_" + k], rtol=2e-3, atol=1e-4)

@@ -119,11 +119,63 @@ def test_full_size_c2_vs_oracle():
         assert rel_l2(gT[f][:, :3, :], ogT[f][:, :3, :]) < 2e-2
 
 
-def test_properties_full_size():
-    """Size-independent properties at the bench size: determinism (bitwise), loss-gradient
-    linearity in the upstream gradient, zero gradient for scales that receive none."""
-    from depthcore import ops
+@pytest.mark.parametrize("shape", [(1, 192, 640), (2, 160, 512), (1, 320, 1024)])
+def test_vs_oracle_c1_and_c3_shapes(shape):
+    """BASELINE configs[0] (a single 192x640 triplet) and the 320x1024 frame of configs[2] (one full-size frame and a
+    half-size batch of the same aspect), 4 scales, against the CPU oracle."""
+    b, h, w = shape
+    inputs = R.synthetic_inputs(b, h, w, seed=4)
+    g = torch.Generator().manual_seed(10)
+    disps = [torch.rand(b, 1, h >> s, w >> s, generator=g) for s in range(4)]
+    Ts = random_poses(b, 8)
+    noise = R.tiebreak_noise(b, h, w)
+    opt = R.Opt(height=h, width=w)
+    ol, oo, ogd, ogT = oracle_photo(inputs, disps, Ts, opt, noise)
+    losses, ex, gd, gT = hip_photo(inputs, disps, Ts, noise)
+    close(losses[4], ol["loss"], rtol=1e-3, atol=0)
+    for s in range(4):
+        close(losses[s], ol["loss/%d" % s], rtol=1e-3, atol=0)
+        sel = (ex["argmin"][s] >= 2).cpu()
+        assert (sel != oo["identity_selection/%d" % s].bool()).float().mean() < 1e-3
+        assert rel_l2(gd[s], ogd[s]) < 2e-2
+    for f in range(2):
+        assert rel_l2(gT[f][:, :3, :], ogT[f][:, :3, :]) < 2e-2
+
+
+def test_gradient_error_is_the_conditioning_of_the_fp32_problem():
+    """Why the gradient budgets above are 2e-2 and not 1e-3: the photometric gradient is ill-conditioned in fp32
+    (E[x^2]-mu^2 cancellation over C2 = 9e-4, floor/argmin/clamp switching).  At the full configs[1] size the oracle is
+    evaluated in fp64 and in fp32; the HIP path (fp32) must be no further from the fp64 gradients than twice the
+    oracle's own fp32 evaluation is -- i.e. its error is the problem's, not the kernels'."""
     b, h, w = 12, 192, 640
+    inputs = R.synthetic_inputs(b, h, w, seed=0)
+    g = torch.Generator().manual_seed(77)
+    disps = [torch.rand(b, 1, h >> s, w >> s, generator=g) for s in range(4)]
+    Ts = random_poses(b, 6)
+    noise = R.tiebreak_noise(b, h, w)
+    opt = R.Opt()
+    l64, _, gd64, gT64 = oracle_photo(inputs, disps, Ts, opt, noise, dtype=torch.float64)
+    l32, _, gd32, gT32 = oracle_photo(inputs, disps, Ts, opt, noise)
+    losses, ex, gd, gT = hip_photo(inputs, disps, Ts, noise)
+    assert abs(float(losses[4]) - float(l64["loss"])) <= 1e-4 * abs(float(l64["loss"]))
+    report = []
+    for s in range(4):
+        e_hip, e_32 = rel_l2(gd[s], gd64[s]), rel_l2(gd32[s], gd64[s])
+        report.append(("gdisp%d" % s, e_hip, e_32))
+        assert e_hip <= 2.0 * e_32 + 1e-4, report
+    for f in range(2):
+        e_hip, e_32 = rel_l2(gT[f][:, :3, :], gT64[f][:, :3, :]), rel_l2(gT32[f][:, :3, :], gT64[f][:, :3, :])
+        report.append(("dT%d" % f, e_hip, e_32))
+        assert e_hip <= 2.0 * e_32 + 1e-4, report
+    print("conditioning (name, |hip-f64|/|f64|, |f32-f64|/|f64|):", report)
+
+
+@pytest.mark.parametrize("shape", [(12, 192, 640), (8, 320, 1024)])
+def test_properties_full_size(shape):
+    """Size-independent properties at the bench sizes (configs[1] and configs[2] per rank): determinism (bitwise),
+    finite gradients, loss = mean of the scale losses, on-device tie-break noise only breaks ties."""
+    from depthcore import ops
+    b, h, w = shape
     inputs = R.synthetic_inputs(b, h, w, seed=1)
     g = torch.Generator().manual_seed(2)
     disps = [torch.rand(b, 1, h >> s, w >> s, generator=g) for s in range(4)]
