@@ -173,7 +173,7 @@ int dc_profile_collect(double* fwd_ms, int* fwd_launches, double* bwd_ms, int* b
  * networks/pose_decoder.py:27-29,45-48) as ONE fused convolution (Winograd F(2x2,3x3) on even widths, else direct):
  *   y = act( conv3x3( pad1( cat( up2?(x0), x1 ) ) ) + bias )
  * x0 (B,C0,H>>up0,W>>up0) nearest-upsampled x2 on the fly when up0=1, x1 (B,C1,H,W) nullable skip,
- * weight (Co,C0+C1,3,3), bias nullable; act: 0 none, 1 ELU, 2 sigmoid, 3 ReLU; pad_mode: 0 ReflectionPad2d(1),
+ * weight (Co,C0+C1,3,3), bias nullable; act: 0 none, 1 ELU, 2 sigmoid, 3 ReLU, 4 tanh; pad_mode: 0 ReflectionPad2d(1),
  * 1 ZeroPad2d(1).  Output (B,Co,H,W).  ws: dc_conv3x3_fwd_workspace bytes. */
 size_t dc_conv3x3_fwd_workspace(int C0, int C1, int B, int Co, int H, int W);
 int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
@@ -250,9 +250,10 @@ int dc_wino3x3_wgrad(const float* x, const float* gy, float* dweight, void* ws, 
  * networks/resnet_encoder.py:74-98 via torchvision), as an fp32-MFMA GEMM on the NCHW tensors: x (B,Ci,Hi,Wi),
  * weight (Co,Ci), y / gy (B,Co,Hi/stride,Wi/stride).  stride 2 needs even Hi, Wi.  dgrad writes every element of dx
  * (zeros where the stride skips).  wgrad: split reduction, fixed-order sum, ws = dc_conv1x1_wgrad_workspace bytes.
- * Shapes with Ci % 4 == 0 and (Hi/stride * Wi/stride) % 4 == 0 (stride 2: also Wi/stride % 4 == 0) run on tiled
- * kernels (up to 128 x 128 outputs per block, 16-byte staging, pixels flattened over the batch); others on a general
- * 64 x 64 kernel.  All variants are deterministic. */
+ * Shapes with Ci % 4 == 0 and (Hi/stride * Wi/stride) % 4 == 0 (stride 2: also Wi/stride % 4 == 0) whose reduction
+ * extent (forward: Ci, data gradient: Co, weight gradient: B * pixels) is a multiple of 32 run on tiled kernels (up to
+ * 128 x 128 outputs per block, 16-byte staging, pixels flattened over the batch); others on a general 64 x 64 kernel.
+ * All variants are deterministic. */
 int dc_conv1x1_fwd(const float* x, const float* weight, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride, void* stream);
 int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride,
                      void* stream);
@@ -261,7 +262,7 @@ int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, 
                      void* stream);
 
 /* The same convolution with bias and activation fused into the epilogue: y = act(conv1x1(x) + bias), act as in
- * dc_conv3x3_fwd (0 none, 1 ELU, 2 sigmoid, 3 ReLU); bias may be NULL.  This is `relu(squeeze(f))` and the final
+ * dc_conv3x3_fwd (0 none, 1 ELU, 2 sigmoid, 3 ReLU, 4 tanh); bias may be NULL.  This is `relu(squeeze(f))` and the final
  * `pose_2` convolution of networks/pose_decoder.py:25,30,40-48.
  * Backward: dc_bias_act_bwd turns gy into the gradient of the pre-activation, gpre = gy * act'(y) (gpre may alias gy, or
  * be NULL when only dbias is wanted), and reduces dbias[c] = sum_{b,p} gpre (fixed-order, deterministic; dbias may be
@@ -269,6 +270,44 @@ int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, 
 int dc_conv1x1_bias_act_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi, int Wi,
                             int stride, int act, void* stream);
 int dc_bias_act_bwd(const float* y, const float* gy, float* gpre, float* dbias, int B, int C, int P, int act, void* stream);
+
+/* ------------------------------------------------------------------ f1 Fusion_v3 front-end */
+/* AttentionConv of networks/fusion_v2.py:46-98 as instantiated by ResidualAttentionUnit (:101-137): kernel 3, stride 1,
+ * padding 1, groups 1, bias=True, C = 2 or 4 channels.  One fused kernel per direction (no q / k / v / unfold / softmax
+ * tensors in HBM):
+ *   r = relu_in ? relu(x) : x;   q = Wq r + bq;   k, v = 1x1 convolutions of the zero-padded r;
+ *   y[c] = sum_t softmax_t( q[c] * (k_t[c] + rel_t[c]) ) * v_t[c]   (+ res, or relu(res) when relu_res)
+ * rel_t = rel_h[dy] for c < C/2, rel_w[dx] otherwise.  relu_in / relu_res reproduce the unit's in-place ReLUs
+ * (fusion_v2.py:130-136: the skip connection adds the ReLU'd input).
+ * Weights are (C,C) row-major [out][in] (the (C,C,1,1) conv weights), biases (C), rel_h / rel_w 3 floats.
+ *
+ * The input channels are GATHERED from up to C tensors through a dc_attn_map, so the `torch.cat`s of
+ * FeatureFusionBlock_v3.forward (fusion_v2.py:309-313) and the PixelShuffle of UpscalePS (:226-236) never exist in memory:
+ * channel c of pixel (b, y, x) is ptr[c][b * batch_stride[c] + y * W + x] (DC_ATTN_PLAIN: ptr[c] = that channel's plane of
+ * batch element 0), or, for DC_ATTN_PIXEL_SHUFFLE2, element ((y&1)*2 + (x&1), y>>1, x>>1) of a (4, H/2, W/2) block at
+ * ptr[c] + b * batch_stride[c] (the pre-shuffle output of UpscalePS's convolution; H, W even).  y and gy are plain
+ * contiguous (B,C,H,W).
+ * Backward: the gradient of input channel c is stored through the map `dx` (same addressing; every element written once),
+ * after adding dx_add (plain (B,C,H,W), nullable: the gradient that reaches the same input through the unit's skip
+ * connection); `dres` (nullable / ptr[0] NULL) receives gy masked by relu_res;
+ * dparams = dc_attnconv_param_count(C) floats laid out [dWq (C*C), dbq (C), dWk, dbk, dWv, dbv, drel_h (3), drel_w (3)],
+ * overwritten; deterministic (per-block partial rows in ws, summed in fixed order).  ws: dc_attnconv_bwd_workspace bytes. */
+enum { DC_ATTN_PLAIN = 0, DC_ATTN_PIXEL_SHUFFLE2 = 1 };
+typedef struct dc_attn_map {
+    const float* ptr[4];
+    long long batch_stride[4];   /* elements */
+    int mode[4];
+} dc_attn_map;
+typedef struct dc_attn_params {
+    const float *wq, *bq, *wk, *bk, *wv, *bv, *rel_h, *rel_w;
+} dc_attn_params;
+int dc_attnconv_fwd(const dc_attn_map* x, const dc_attn_params* p, const dc_attn_map* res, float* y, int B, int C, int H, int W,
+                    int relu_in, int relu_res, void* stream);
+int dc_attnconv_param_count(int C);
+size_t dc_attnconv_bwd_workspace(int B, int C, int H, int W);
+int dc_attnconv_bwd(const dc_attn_map* x, const dc_attn_params* p, const dc_attn_map* res, const float* gy, const dc_attn_map* dx,
+                    const float* dx_add, const dc_attn_map* dres, float* dparams, void* ws, int B, int C, int H, int W, int relu_in,
+                    int relu_res, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,13 @@ def upscale_ps(x, w, b, scale=2):
     return y.reshape(B, c, H * scale, W * scale)
 
 
+def upscale_ps_shuffle_only(y, scale=2):
+    """nn.PixelShuffle(scale) alone (the second half of UpscalePS)."""
+    B, C, H, W = y.shape
+    c = C // (scale * scale)
+    return y.view(B, c, scale, scale, H, W).permute(0, 1, 4, 2, 5, 3).reshape(B, c, H * scale, W * scale)
+
+
 def fusion_block_v3(dt, upt, dt_1, dt_2, st, p, init_scale):
     """networks/fusion_v2.py:304-320."""
     if init_scale:

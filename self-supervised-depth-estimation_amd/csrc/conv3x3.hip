@@ -853,7 +853,7 @@ extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1,
     if (!x0 || C0 <= 0 || (C1 > 0 && !x1) || C1 < 0 || !weight || !y || !ws || B <= 0 || Co <= 0 || H < 2 || W < 2)
         return DC_EINVAL;
     if (up0 && ((H | W) & 1)) return DC_EINVAL;
-    if (act < 0 || act > 3 || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
+    if (act < 0 || act > ACT_LAST || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
     const int Cin = C0 + C1;
     // single-channel heads: plain-FMA kernels (dispconv.hip)
     if (wino_enabled() && dispconv_eligible(C0, C1, up0 ? 1 : 0, Co, H, W))
@@ -905,7 +905,7 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     if (!x0 || C0 <= 0 || (C1 > 0 && !x1) || C1 < 0 || !weight || !y || !gy || !ws || B <= 0 || Co <= 0 || H < 2 || W < 2)
         return DC_EINVAL;
     if (up0 && ((H | W) & 1)) return DC_EINVAL;
-    if (act < 0 || act > 3 || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
+    if (act < 0 || act > ACT_LAST || pad_mode < 0 || pad_mode > 1) return DC_EINVAL;
     const int Cin = C0 + C1;
     const size_t nW = (size_t)Co * Cin * 9;
     const int split = pick_split(B, H, W, Co, Cin);

@@ -100,13 +100,14 @@ __device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
 }
 
 // ---- fused conv block options (include/depthcore.h: dc_conv3x3_*) ---------------------------------
-enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2, ACT_RELU = 3 };
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_SIGMOID = 2, ACT_RELU = 3, ACT_TANH = 4, ACT_LAST = ACT_TANH };
 enum { PAD_REFLECT = 0, PAD_ZERO = 1 };
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;
     if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
     if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_TANH) return tanhf(v);
     return v;
 }
 // derivative expressed through the activated output y
@@ -114,6 +115,7 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
     if (act == ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
     if (act == ACT_SIGMOID) return y * (1.f - y);
     if (act == ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == ACT_TANH) return 1.f - y * y;
     return 1.f;
 }
 

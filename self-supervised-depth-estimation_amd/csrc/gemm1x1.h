@@ -3,7 +3,10 @@
 #include <stddef.h>
 
 extern "C" {
-int dc_gemm1x1_supported(int B, int Ci, int Co, int Hi, int Wi, int stride);
+/* per pass: 16-byte staging possible and the reduction extent a multiple of the 32-wide chunk */
+int dc_gemm1x1_fwd_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);
+int dc_gemm1x1_dgrad_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);
+int dc_gemm1x1_wgrad_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);
 int dc_gemm1x1_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride,
                    int act, void* stream);
 int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride, void* stream);

@@ -22,8 +22,11 @@
 // b64 index-major rows = 4 * odd dwords).  The reduction order inside a chunk of 8 is permuted identically for A and B
 // (element 2 k' + s of the chunk goes to MFMA step s, k-lane k'), which changes nothing in the sum.
 //
-// Pipeline: LDS double-buffered, one barrier per reduction chunk of KC; the global loads of chunk c+1 are issued before
-// the MFMAs of chunk c and committed to LDS after them.  ~110 VGPRs -> several blocks per CU cover each other's waits.
+// Main loop: reduction chunks of 32 (128 MFMAs per wave between barriers at 128 x 128), LDS double-buffered with ONE
+// barrier per chunk; the global loads of chunk c+1 are issued before the MFMAs of chunk c and committed to LDS after
+// them.  The loop has no bounds branches: the reduction extent is a multiple of the chunk (checked on the host, other
+// shapes take the general kernels of pointwise.hip), and rows / columns past the edge of the matrix are CLAMPED to the
+// last valid row / pixel group -- they compute garbage that is never stored.
 // Block order: m-tiles of one pixel tile are adjacent and, through xcd_logical_block, on the same XCD: the activation
 // tile is fetched from HBM once per XCD pass and re-served by that XCD's L2; the weights are L2-resident.
 #include "dc_common.h"
@@ -36,8 +39,7 @@ namespace dc {
 using gf4 = __attribute__((ext_vector_type(4))) float;
 using gf2 = __attribute__((ext_vector_type(2))) float;
 
-constexpr int GKC = 16;                // reduction chunk (forward / data gradient)
-constexpr int GKW = 32;                // reduction chunk of the weight gradient (pixels: 128-byte row segments)
+constexpr int GKC = 32;                // reduction chunk
 
 struct G1Args {
     const float* w;       // (Co, Ci)
@@ -96,24 +98,14 @@ __device__ __forceinline__ void mma_octet(const float (&a)[4][2], const float (&
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
 }
 
-// ---- pixel addressing of a 4-pixel group of the flattened (b, p) dimension --------------------------------------
-struct PixGroup {
-    size_t off;      // element offset of (b, channel 0, pixel) in the strided tensor
-    bool ok;
-};
-// n: first of 4 consecutive output pixels (P % 4 == 0, for stride 2 also Wo % 4 == 0: the group lies in one row)
-__device__ __forceinline__ PixGroup pix_group(int n, int N, int P, int Wo, int C, int Hi, int Wi, int s) {
-    PixGroup g;
-    g.ok = n < N;
-    const int nn = g.ok ? n : 0;
+// ---- pixel addressing: element offset of (b, channel 0, first pixel) of a 4-pixel group of the flattened (b, p) dimension.
+// n is clamped to the last valid group (P % 4 == 0; stride 2: Wo % 4 == 0, so a group lies in one row).
+__device__ __forceinline__ size_t pix_group_off(int n, int N, int P, int Wo, int C, int Hi, int Wi, int s) {
+    const int nn = min(n, N - 4);
     const int b = nn / P, p = nn - b * P;
-    if (s == 1) {
-        g.off = (size_t)b * C * P + p;
-    } else {
-        const int py = p / Wo, px = p - py * Wo;
-        g.off = (size_t)b * C * Hi * Wi + (size_t)(py * s) * Wi + px * s;
-    }
-    return g;
+    if (s == 1) return (size_t)b * C * P + p;
+    const int py = p / Wo, px = p - py * Wo;
+    return (size_t)b * C * Hi * Wi + (size_t)(py * s) * Wi + px * s;
 }
 // 4 output pixels of one channel plane (stride-2: every other element of 8 consecutive ones)
 __device__ __forceinline__ gf4 load_pix4(const float* plane_ptr, int s) {
@@ -122,54 +114,53 @@ __device__ __forceinline__ gf4 load_pix4(const float* plane_ptr, int s) {
     return gf4{u.x, u.z, v.x, v.z};
 }
 
+extern __shared__ float g1_smem[];
+
 // =====================================================================================================================
-// forward.  A = w [co][ci] (reduction-contiguous), B = x [ci][n] (index-contiguous)
+// forward.  A = w [co][ci] (reduction-contiguous), B = x [ci][n] (index-contiguous).  Ci % KC == 0.
 // =====================================================================================================================
-template <int MT, int NT>
+template <int MT, int NT, bool EPI>
 __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
     constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SB = IdxStride<NT, BN>::v;
     constexpr int NA = BM * KC / 1024, NB = KC * BN / 1024;          // float4 per thread per chunk
-    __shared__ float As[2][BM * (KC + 4)];
-    __shared__ float Bs[2][KC * SB];
+    constexpr int ASZ = BM * (KC + 4), BSZ = KC * SB;
+    float* const As = g1_smem;                 // [2][ASZ]
+    float* const Bs = g1_smem + 2 * ASZ;       // [2][BSZ]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
     const int m0 = (lb % a.mtiles) * BM, n0 = (lb / a.mtiles) * BN;
     const int P = a.Ho * a.Wo, N = a.B * P;
     const size_t plane = (size_t)a.Hi * a.Wi;
 
-    // staging roles
-    int arow[NA], akq[NA];
+    // staging roles: global source pointers (advance by the chunk) and LDS destinations, fixed for the whole loop
+    const float* asrc[NA];
+    int adst[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int idx = tid + j * 256;
-        arow[j] = idx / (KC / 4); akq[j] = idx % (KC / 4);
+        const int idx = tid + j * 256, row = idx / (KC / 4), kq = idx % (KC / 4);
+        asrc[j] = a.w + (size_t)min(m0 + row, a.Co - 1) * a.Ci + kq * 4;
+        adst[j] = row * (KC + 4) + kq * 4;
     }
-    int bk[NB], bc4[NB];
-    PixGroup bg[NB];
+    const float* bsrc[NB];
+    int bdst[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int idx = tid + j * 256;
-        bk[j] = idx / (BN / 4); bc4[j] = idx % (BN / 4);
-        bg[j] = pix_group(n0 + bc4[j] * 4, N, P, a.Wo, a.Ci, a.Hi, a.Wi, a.s);
+        const int idx = tid + j * 256, k = idx / (BN / 4), c4 = idx % (BN / 4);
+        bsrc[j] = a.x + pix_group_off(n0 + c4 * 4, N, P, a.Wo, a.Ci, a.Hi, a.Wi, a.s) + (size_t)k * plane;
+        bdst[j] = k * SB + c4 * 4;
     }
     gf4 ra[NA], rb[NB];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int m = m0 + arow[j], k = k0 + akq[j] * 4;
-            ra[j] = (m < a.Co && k < a.Ci) ? *reinterpret_cast<const gf4*>(a.w + (size_t)m * a.Ci + k) : gf4{0, 0, 0, 0};
-        }
+        for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j] + k0);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int k = k0 + bk[j];
-            rb[j] = (bg[j].ok && k < a.Ci) ? load_pix4(a.x + bg[j].off + (size_t)k * plane, a.s) : gf4{0, 0, 0, 0};
-        }
+        for (int j = 0; j < NB; ++j) rb[j] = load_pix4(bsrc[j] + (size_t)k0 * plane, a.s);
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) *reinterpret_cast<gf4*>(&As[buf][arow[j] * (KC + 4) + akq[j] * 4]) = ra[j];
+        for (int j = 0; j < NA; ++j) *reinterpret_cast<gf4*>(As + buf * ASZ + adst[j]) = ra[j];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) *reinterpret_cast<gf4*>(&Bs[buf][bk[j] * SB + bc4[j] * 4]) = rb[j];
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<gf4*>(Bs + buf * BSZ + bdst[j]) = rb[j];
     };
 
     gf4 acc[MT][NT];
@@ -178,7 +169,7 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
 
-    const int nchunk = (a.Ci + KC - 1) / KC;
+    const int nchunk = a.Ci / KC;
     gload(0);
     commit(0);
     __syncthreads();
@@ -188,8 +179,8 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
 #pragma unroll
         for (int q = 0; q < KC / 8; ++q) {
             float av[4][2], bv[4][2];
-            read_red<MT, KC>(As[buf], wm * 16 * MT, q, lane, av);
-            read_idx<NT, SB>(Bs[buf], wn * 16 * NT, q, lane, bv);
+            read_red<MT, KC>(As + buf * ASZ, wm * 16 * MT, q, lane, av);
+            read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, bv);
             mma_octet<MT, NT>(av, bv, acc);
         }
         if (c + 1 < nchunk) commit(buf ^ 1);
@@ -206,70 +197,71 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
                 if (m >= a.Co) continue;
-                const float bsv = a.bias ? a.bias[m] : 0.f;
-                float* dst = a.out + ((size_t)b * a.Co + m) * P + p;
-                if constexpr (NT == 4) {
-                    *reinterpret_cast<gf4*>(dst) = gf4{act_fwd(acc[mt][0][r] + bsv, a.act), act_fwd(acc[mt][1][r] + bsv, a.act),
-                                                       act_fwd(acc[mt][2][r] + bsv, a.act), act_fwd(acc[mt][3][r] + bsv, a.act)};
-                } else {
-                    *reinterpret_cast<gf2*>(dst) = gf2{act_fwd(acc[mt][0][r] + bsv, a.act), act_fwd(acc[mt][1][r] + bsv, a.act)};
+                float v[4];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt][r];
+                if constexpr (EPI) {
+                    const float bsv = a.bias ? a.bias[m] : 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) v[nt] = act_fwd(v[nt] + bsv, a.act);
                 }
+                float* dst = a.out + ((size_t)b * a.Co + m) * P + p;
+                if constexpr (NT == 4) *reinterpret_cast<gf4*>(dst) = gf4{v[0], v[1], v[2], v[3]};
+                else *reinterpret_cast<gf2*>(dst) = gf2{v[0], v[1]};
             }
     }
 }
 
 // =====================================================================================================================
 // data gradient.  rows = input channels ci, reduction = co.  A = w [co][ci] (index-contiguous), B = gy [co][n] (index-cont.)
+// Co % KC == 0.
 // =====================================================================================================================
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
     constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SA = IdxStride<MT, BM>::v, SB = IdxStride<NT, BN>::v;
     constexpr int NA = KC * BM / 1024, NB = KC * BN / 1024;
-    __shared__ float As[2][KC * SA];
-    __shared__ float Bs[2][KC * SB];
+    constexpr int ASZ = KC * SA, BSZ = KC * SB;
+    float* const As = g1_smem;
+    float* const Bs = g1_smem + 2 * ASZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
     const int m0 = (lb % a.mtiles) * BM, n0 = (lb / a.mtiles) * BN;
     const int P = a.Ho * a.Wo, N = a.B * P;
 
-    int ak[NA], ac4[NA], bk[NB], bc4[NB];
-    PixGroup bg[NB];
+    const float* asrc[NA];
+    const float* bsrc[NB];
+    int adst[NA], bdst[NB];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int idx = tid + j * 256;
-        ak[j] = idx / (BM / 4); ac4[j] = idx % (BM / 4);
+        const int idx = tid + j * 256, k = idx / (BM / 4), c4 = idx % (BM / 4);
+        asrc[j] = a.w + (size_t)k * a.Ci + min(m0 + c4 * 4, a.Ci - 4);
+        adst[j] = k * SA + c4 * 4;
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int idx = tid + j * 256;
-        bk[j] = idx / (BN / 4); bc4[j] = idx % (BN / 4);
-        bg[j] = pix_group(n0 + bc4[j] * 4, N, P, a.Wo, a.Co, a.Ho, a.Wo, 1);
+        const int idx = tid + j * 256, k = idx / (BN / 4), c4 = idx % (BN / 4);
+        bsrc[j] = a.gy + pix_group_off(n0 + c4 * 4, N, P, a.Wo, a.Co, a.Ho, a.Wo, 1) + (size_t)k * P;
+        bdst[j] = k * SB + c4 * 4;
     }
     gf4 ra[NA], rb[NB];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int k = k0 + ak[j], m = m0 + ac4[j] * 4;
-            ra[j] = (k < a.Co && m < a.Ci) ? *reinterpret_cast<const gf4*>(a.w + (size_t)k * a.Ci + m) : gf4{0, 0, 0, 0};
-        }
+        for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j] + (size_t)k0 * a.Ci);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int k = k0 + bk[j];
-            rb[j] = (bg[j].ok && k < a.Co) ? *reinterpret_cast<const gf4*>(a.gy + bg[j].off + (size_t)k * P) : gf4{0, 0, 0, 0};
-        }
+        for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const gf4*>(bsrc[j] + (size_t)k0 * P);
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) *reinterpret_cast<gf4*>(&As[buf][ak[j] * SA + ac4[j] * 4]) = ra[j];
+        for (int j = 0; j < NA; ++j) *reinterpret_cast<gf4*>(As + buf * ASZ + adst[j]) = ra[j];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) *reinterpret_cast<gf4*>(&Bs[buf][bk[j] * SB + bc4[j] * 4]) = rb[j];
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<gf4*>(Bs + buf * BSZ + bdst[j]) = rb[j];
     };
     gf4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
-    const int nchunk = (a.Co + KC - 1) / KC;
+    const int nchunk = a.Co / KC;
     gload(0);
     commit(0);
     __syncthreads();
@@ -279,8 +271,8 @@ __global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
 #pragma unroll
         for (int q = 0; q < KC / 8; ++q) {
             float av[4][2], bv[4][2];
-            read_idx<MT, SA>(As[buf], wm * 16 * MT, q, lane, av);
-            read_idx<NT, SB>(Bs[buf], wn * 16 * NT, q, lane, bv);
+            read_idx<MT, SA>(As + buf * ASZ, wm * 16 * MT, q, lane, av);
+            read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, bv);
             mma_octet<MT, NT>(av, bv, acc);
         }
         if (c + 1 < nchunk) commit(buf ^ 1);
@@ -326,26 +318,30 @@ __global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
 }
 
 // =====================================================================================================================
-// weight gradient.  rows = co, cols = ci, reduction = flattened pixels n.  A = gy [co][n], B = x [ci][n]: both
-// reduction-contiguous.  blockIdx.y = split: takes chunks split, split + splits, ...; writes slab[split][co][ci]
-// (or dw itself when there is one split).
+// weight gradient.  rows = co, cols = ci, reduction = flattened pixels n (N % KC == 0).  A = gy [co][n], B = x [ci][n]: both
+// reduction-contiguous.  blockIdx.y = split: a contiguous range of chunks (its successive 128-byte row segments stay in one
+// L2); writes slab[split][co][ci] (or dw itself when there is one split).
 // =====================================================================================================================
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
-    constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKW;
+    constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC;
     constexpr int NA = BM * KC / 1024, NB = BN * KC / 1024;
-    extern __shared__ float g1_smem[];                       // As[2][BM][KC+4], Bs[2][BN][KC+4]
     constexpr int ASZ = BM * (KC + 4), BSZ = BN * (KC + 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = (blockIdx.x % a.mtiles) * BM, c0 = (blockIdx.x / a.mtiles) * BN;
-    const int P = a.Ho * a.Wo, N = a.B * P;
+    const int P = a.Ho * a.Wo;
     const size_t plane = (size_t)a.Hi * a.Wi;
     const int kq = tid % (KC / 4), row0 = tid / (KC / 4);    // the same 4-pixel group for all of a thread's loads
+    // rows past the matrix edge are clamped (their products are never stored)
+    size_t arow[NA], brow[NB];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) arow[j] = (size_t)min(m0 + row0 + j * (1024 / KC), a.Co - 1) * P;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) brow[j] = (size_t)min(c0 + row0 + j * (1024 / KC), a.Ci - 1) * plane;
     gf4 ra[NA], rb[NB];
     auto gload = [&](int ch) {           // chunk ch = KC consecutive flattened pixels; a 4-pixel group lies in one image row
         const int n = ch * KC + kq * 4;
-        const bool ok = n < N;
-        const int b = ok ? n / P : 0, p = ok ? n - b * P : 0;
+        const int b = n / P, p = n - b * P;
         size_t pix;
         if (a.s == 1) {
             pix = p;
@@ -353,16 +349,12 @@ __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
             const int py = p / a.Wo, px = p - py * a.Wo;
             pix = (size_t)(py * 2) * a.Wi + px * 2;
         }
+        const float* ga = a.gy + (size_t)b * a.Co * P + p;
+        const float* xb = a.x + (size_t)b * a.Ci * plane + pix;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int m = m0 + row0 + j * (1024 / KC);
-            ra[j] = (ok && m < a.Co) ? *reinterpret_cast<const gf4*>(a.gy + ((size_t)b * a.Co + m) * P + p) : gf4{0, 0, 0, 0};
-        }
+        for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const gf4*>(ga + arow[j]);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int ci = c0 + row0 + j * (1024 / KC);
-            rb[j] = (ok && ci < a.Ci) ? load_pix4(a.x + ((size_t)b * a.Ci + ci) * plane + pix, a.s) : gf4{0, 0, 0, 0};
-        }
+        for (int j = 0; j < NB; ++j) rb[j] = load_pix4(xb + brow[j], a.s);
     };
     auto commit = [&](int buf) {
 #pragma unroll
@@ -377,7 +369,6 @@ __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
-    // split blockIdx.y owns a contiguous range of chunks (its successive 128-byte row segments stay in one L2)
     const int per = (a.chunks + a.splits - 1) / a.splits;
     const int ch0 = blockIdx.y * per, ch1 = min(ch0 + per, a.chunks);
     if (ch0 < ch1) {
@@ -445,38 +436,70 @@ __global__ __launch_bounds__(256) void g1_bias_act_bwd_kernel(const float* __res
     if (threadIdx.x == 0 && dbias) dbias[c] = sm[0];
 }
 
-// ---- tile choice: the largest tile that still gives the chip ~2 blocks per CU -------------------------------------------
+// ---- tile choice ---------------------------------------------------------------------------------------------------
+// Estimated time of a tile shape = rounds the grid needs on the chip x cost of one block, where the cost per block grows
+// with its MFMA count and the smaller tiles pay more operand traffic per MFMA.  Blocks resident per CU: LDS-limited.
 struct G1Tile { int mt, nt; };
-static G1Tile g1_pick(int M, int N) {
-    auto blocks = [&](int mt, int nt) { return (long)ceil_div(M, 32 * mt) * ceil_div(N, 32 * nt); };
-    if (M > 64 && blocks(4, 4) >= 440) return {4, 4};
-    if (blocks(2, 4) >= 440 || N >= 8 * M) return {2, 4};
-    return {2, 2};
-}
-static int g1_wsplits(int M, int K, int chunks, G1Tile t) {
-    const int tiles = ceil_div(M, 32 * t.mt) * ceil_div(K, 32 * t.nt);
-    return std::max(1, std::min({chunks, ceil_div(768, tiles), 512}));
+static size_t g1_lds_fwd(G1Tile t) { return (size_t)2 * (32 * t.mt * (GKC + 4) + GKC * (t.nt == 4 ? 128 : 80)) * sizeof(float); }
+static size_t g1_lds_dgrad(G1Tile t) { return (size_t)2 * GKC * ((t.mt == 4 ? 128 : 80) + (t.nt == 4 ? 128 : 80)) * sizeof(float); }
+static size_t g1_lds_wgrad(G1Tile t) { return (size_t)2 * 32 * (t.mt + t.nt) * (GKC + 4) * sizeof(float); }
+static G1Tile g1_pick(int M, int N, size_t (*lds)(G1Tile)) {
+    const G1Tile cand[3] = {{4, 4}, {2, 4}, {2, 2}};
+    const double penalty[3] = {1.0, 1.12, 1.3};          // relative cost per MFMA (operand re-reads, shorter MFMA runs)
+    double best = 1e300;
+    G1Tile pick = cand[2];
+    for (int i = 0; i < 3; ++i) {
+        if (cand[i].mt == 4 && M <= 64) continue;
+        const long blocks = (long)ceil_div(M, 32 * cand[i].mt) * ceil_div(N, 32 * cand[i].nt);
+        const int per_cu = std::max(1, std::min(4, (int)((size_t)(150 << 10) / lds(cand[i]))));
+        const long slots = 256L * per_cu;
+        const long rounds = (blocks + slots - 1) / slots;
+        // a chip filled to less than half hides no latency: charge that more than proportionally
+        const double fill = (double)blocks / (double)(rounds * slots);
+        const double t = (double)rounds * per_cu * cand[i].mt * cand[i].nt * penalty[i] * (fill < 0.5 && rounds == 1 ? 0.5 + fill : 1.0);
+        if (t < best) { best = t; pick = cand[i]; }
+    }
+    return pick;
 }
 static G1Tile g1_wpick(int M, int K) {
     if (M > 64 && K > 64 && (long)ceil_div(M, 128) * ceil_div(K, 128) >= 32) return {4, 4};
     return {2, 2};
+}
+static int g1_wsplits(int M, int K, int chunks, G1Tile t) {
+    const int tiles = ceil_div(M, 32 * t.mt) * ceil_div(K, 32 * t.nt);
+    int s = std::max(1, std::min({chunks, ceil_div(768, tiles), 512}));
+    return ceil_div(chunks, ceil_div(chunks, s));        // no empty split: every slab gets written
+}
+
+template <typename K>
+static bool g1_set_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 
 }  // namespace dc
 
 using namespace dc;
 
-// fast path: float4 along the pixels (P % 4; stride 2 needs Wo % 4 and even input sizes), float4 along the channels of w
-extern "C" int dc_gemm1x1_supported(int B, int Ci, int Co, int Hi, int Wi, int stride) {
-    if (B <= 0 || Ci <= 0 || Co <= 0 || Hi <= 0 || Wi <= 0) return 0;
-    if (stride != 1 && stride != 2) return 0;
-    if (stride == 2 && ((Hi & 1) || (Wi & 1))) return 0;
+// ---- which shapes the tiled kernels take (the entry points of pointwise.hip ask per pass) ---------------------------------
+static bool g1_common(int B, int Ci, int Co, int Hi, int Wi, int stride) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || Hi <= 0 || Wi <= 0) return false;
+    if (stride != 1 && stride != 2) return false;
+    if (stride == 2 && ((Hi & 1) || (Wi & 1))) return false;
     const int Ho = Hi / stride, Wo = Wi / stride;
-    if (stride == 2 && (Wo & 3)) return 0;
-    if ((Ho * Wo) & 3) return 0;
-    if (Ci & 3) return 0;
-    if ((size_t)B * std::max(Ci, Co) * Hi * Wi >= (1ull << 31)) return 0;
-    return 1;
+    if (stride == 2 && (Wo & 3)) return false;
+    if ((Ho * Wo) & 3) return false;                    // 16-byte pixel groups never straddle images
+    if (Ci & 3) return false;                           // 16-byte groups along the channels of w
+    if ((size_t)B * std::max(Ci, Co) * Hi * Wi >= (1ull << 31)) return false;
+    return true;
+}
+extern "C" int dc_gemm1x1_fwd_ok(int B, int Ci, int Co, int Hi, int Wi, int stride) {
+    return g1_common(B, Ci, Co, Hi, Wi, stride) && Ci % GKC == 0;
+}
+extern "C" int dc_gemm1x1_dgrad_ok(int B, int Ci, int Co, int Hi, int Wi, int stride) {
+    return g1_common(B, Ci, Co, Hi, Wi, stride) && Co % GKC == 0;
+}
+extern "C" int dc_gemm1x1_wgrad_ok(int B, int Ci, int Co, int Hi, int Wi, int stride) {
+    return g1_common(B, Ci, Co, Hi, Wi, stride) && ((size_t)B * (Hi / stride) * (Wi / stride)) % GKC == 0;
 }
 
 static void g1_fill(G1Args& a, int B, int Ci, int Co, int Hi, int Wi, int stride) {
@@ -485,43 +508,57 @@ static void g1_fill(G1Args& a, int B, int Ci, int Co, int Hi, int Wi, int stride
 
 extern "C" int dc_gemm1x1_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi, int Wi,
                               int stride, int act, void* stream) {
-    if (!x || !weight || !y || !dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride) || act < 0 || act > 3) return DC_EINVAL;
+    if (!x || !weight || !y || !dc_gemm1x1_fwd_ok(B, Ci, Co, Hi, Wi, stride) || act < 0 || act > ACT_LAST) return DC_EINVAL;
     G1Args a{};
     g1_fill(a, B, Ci, Co, Hi, Wi, stride);
     a.w = weight; a.x = x; a.bias = bias; a.out = y; a.act = act;
     const int N = B * a.Ho * a.Wo;
-    const G1Tile t = g1_pick(Co, N);
+    const G1Tile t = g1_pick(Co, N, g1_lds_fwd);
     a.mtiles = ceil_div(Co, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
     const dim3 grid(a.mtiles * a.ntiles);
     hipStream_t st = (hipStream_t)stream;
-    if (t.mt == 4) hipLaunchKernelGGL((g1_fwd_kernel<4, 4>), grid, dim3(256), 0, st, a);
-    else if (t.nt == 4) hipLaunchKernelGGL((g1_fwd_kernel<2, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((g1_fwd_kernel<2, 2>), grid, dim3(256), 0, st, a);
+    const size_t lds = g1_lds_fwd(t);
+    const bool epi = bias || act != ACT_NONE;
+    static const bool attr = g1_set_lds(g1_fwd_kernel<4, 4, false>, g1_lds_fwd({4, 4})) &&
+                             g1_set_lds(g1_fwd_kernel<4, 4, true>, g1_lds_fwd({4, 4}));
+    if (!attr) return DC_ELAUNCH;
+#define G1_FWD(MT, NT)                                                                            \
+    do {                                                                                          \
+        if (epi) hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, true>), grid, dim3(256), lds, st, a);  \
+        else hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, false>), grid, dim3(256), lds, st, a);     \
+    } while (0)
+    if (t.mt == 4) G1_FWD(4, 4);
+    else if (t.nt == 4) G1_FWD(2, 4);
+    else G1_FWD(2, 2);
+#undef G1_FWD
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
 
 extern "C" int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride,
                                 void* stream) {
-    if (!gy || !weight || !dx || !dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    if (!gy || !weight || !dx || !dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
     G1Args a{};
     g1_fill(a, B, Ci, Co, Hi, Wi, stride);
     a.w = weight; a.gy = gy; a.out = dx;
     const int N = B * a.Ho * a.Wo;
-    const G1Tile t = g1_pick(Ci, N);
+    const G1Tile t = g1_pick(Ci, N, g1_lds_dgrad);
     a.mtiles = ceil_div(Ci, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
     const dim3 grid(a.mtiles * a.ntiles);
     hipStream_t st = (hipStream_t)stream;
-    if (t.mt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<4, 4>), grid, dim3(256), 0, st, a);
-    else if (t.nt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<2, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((g1_dgrad_kernel<2, 2>), grid, dim3(256), 0, st, a);
+    const size_t lds = g1_lds_dgrad(t);
+    static const bool attr = g1_set_lds(g1_dgrad_kernel<4, 4>, g1_lds_dgrad({4, 4}));
+    if (!attr) return DC_ELAUNCH;
+    if (t.mt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<4, 4>), grid, dim3(256), lds, st, a);
+    else if (t.nt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<2, 4>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((g1_dgrad_kernel<2, 2>), grid, dim3(256), lds, st, a);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
 
 extern "C" size_t dc_gemm1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride) {
-    if (!dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride)) return 0;
-    const int chunks = ceil_div(B * (Hi / stride) * (Wi / stride), GKW);
+    if (!dc_gemm1x1_wgrad_ok(B, Ci, Co, Hi, Wi, stride)) return 0;
+    const int chunks = B * (Hi / stride) * (Wi / stride) / GKC;
     const G1Tile t = g1_wpick(Co, Ci);
     const int splits = g1_wsplits(Co, Ci, chunks, t);
     return splits > 1 ? (size_t)splits * Co * Ci * sizeof(float) : 16;
@@ -529,27 +566,22 @@ extern "C" size_t dc_gemm1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int 
 
 extern "C" int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,
                                 int stride, void* stream) {
-    if (!x || !gy || !dweight || !ws || !dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    if (!x || !gy || !dweight || !ws || !dc_gemm1x1_wgrad_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
     G1Args a{};
     g1_fill(a, B, Ci, Co, Hi, Wi, stride);
     a.x = x; a.gy = gy;
-    a.chunks = ceil_div(B * a.Ho * a.Wo, GKW);
+    a.chunks = B * a.Ho * a.Wo / GKC;
     const G1Tile t = g1_wpick(Co, Ci);
     a.splits = g1_wsplits(Co, Ci, a.chunks, t);
-    a.splits = ceil_div(a.chunks, ceil_div(a.chunks, a.splits));      // no empty split: every slab gets written
     a.out = a.splits > 1 ? (float*)ws : dweight;
     a.mtiles = ceil_div(Co, 32 * t.mt); a.ntiles = ceil_div(Ci, 32 * t.nt);
     const dim3 grid(a.mtiles * a.ntiles, a.splits);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)2 * 32 * (t.mt + t.nt) * (GKW + 4) * sizeof(float);
-    if (t.mt == 4) {
-        static const hipError_t attr = hipFuncSetAttribute((const void*)g1_wgrad_kernel<4, 4>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * (GKW + 4) * 4);
-        if (attr != hipSuccess) return DC_ELAUNCH;
-        hipLaunchKernelGGL((g1_wgrad_kernel<4, 4>), grid, dim3(256), lds, st, a);
-    } else {
-        hipLaunchKernelGGL((g1_wgrad_kernel<2, 2>), grid, dim3(256), lds, st, a);
-    }
+    const size_t lds = g1_lds_wgrad(t);
+    static const bool attr = g1_set_lds(g1_wgrad_kernel<4, 4>, g1_lds_wgrad({4, 4}));
+    if (!attr) return DC_ELAUNCH;
+    if (t.mt == 4) hipLaunchKernelGGL((g1_wgrad_kernel<4, 4>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((g1_wgrad_kernel<2, 2>), grid, dim3(256), lds, st, a);
     DC_CHECK_LAUNCH();
     if (a.splits > 1) {
         const int n4 = Co * Ci / 4;
@@ -560,7 +592,7 @@ extern "C" int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight,
 }
 
 extern "C" int dc_bias_act_bwd(const float* y, const float* gy, float* gpre, float* dbias, int B, int C, int P, int act, void* stream) {
-    if (!y || !gy || B <= 0 || C <= 0 || P <= 0 || act < 0 || act > 3) return DC_EINVAL;
+    if (!y || !gy || B <= 0 || C <= 0 || P <= 0 || act < 0 || act > ACT_LAST) return DC_EINVAL;
     hipLaunchKernelGGL(g1_bias_act_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, y, gy, gpre, dbias, B, C, P, act);
     DC_CHECK_LAUNCH();
     return DC_OK;

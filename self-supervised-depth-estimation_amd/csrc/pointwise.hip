@@ -228,14 +228,14 @@ static bool pw_shape_ok(int B, int Ci, int Co, int Hi, int Wi, int s) {
 
 extern "C" size_t dc_conv1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride) {
     if (!pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return 0;
-    if (dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride)) return dc_gemm1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, stride);
+    if (dc_gemm1x1_wgrad_ok(B, Ci, Co, Hi, Wi, stride)) return dc_gemm1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, stride);
     return (size_t)pw_splits(B, Hi / stride, Wi / stride, Co, Ci) * Co * Ci * sizeof(float);
 }
 
 extern "C" int dc_conv1x1_bias_act_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi,
                                        int Wi, int stride, int act, void* stream) {
-    if (!x || !weight || !y || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride) || act < 0 || act > 3) return DC_EINVAL;
-    if (dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride))
+    if (!x || !weight || !y || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride) || act < 0 || act > ACT_LAST) return DC_EINVAL;
+    if (dc_gemm1x1_fwd_ok(B, Ci, Co, Hi, Wi, stride))
         return dc_gemm1x1_fwd(x, weight, bias, y, B, Ci, Co, Hi, Wi, stride, act, stream);
     PwArgs a{};
     a.bias = bias; a.act = act;
@@ -253,7 +253,7 @@ extern "C" int dc_conv1x1_fwd(const float* x, const float* weight, float* y, int
 extern "C" int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride,
                                 void* stream) {
     if (!gy || !weight || !dx || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
-    if (dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride)) return dc_gemm1x1_dgrad(gy, weight, dx, B, Ci, Co, Hi, Wi, stride, stream);
+    if (dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) return dc_gemm1x1_dgrad(gy, weight, dx, B, Ci, Co, Hi, Wi, stride, stream);
     PwArgs a{};
     a.a = weight; a.b = gy; a.out = dx; a.B = B; a.M = Co; a.K = Ci; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;
     hipLaunchKernelGGL(pw_dgrad_kernel, dim3(ceil_div(a.Ho * a.Wo, PT), ceil_div(Ci, PT), B), dim3(256), 0, (hipStream_t)stream, a);
@@ -264,7 +264,7 @@ extern "C" int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx,
 extern "C" int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,
                                 int stride, void* stream) {
     if (!x || !gy || !dweight || !ws || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
-    if (dc_gemm1x1_supported(B, Ci, Co, Hi, Wi, stride))
+    if (dc_gemm1x1_wgrad_ok(B, Ci, Co, Hi, Wi, stride))
         return dc_gemm1x1_wgrad(x, gy, dweight, ws, B, Ci, Co, Hi, Wi, stride, stream);
     PwArgs a{};
     a.a = gy; a.b = x; a.out = (float*)ws; a.B = B; a.M = Co; a.K = Ci; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;

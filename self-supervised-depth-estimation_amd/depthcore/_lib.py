@@ -47,6 +47,18 @@ class PhotoDesc(Structure):
     ]
 
 
+class AttnMap(Structure):
+    """Mirror of `dc_attn_map`: where each input channel of an AttentionConv lives (include/depthcore.h)."""
+    _fields_ = [("ptr", _F * 4), ("batch_stride", ctypes.c_longlong * 4), ("mode", c_int32 * 4)]
+
+
+class AttnParams(Structure):
+    """Mirror of `dc_attn_params`."""
+    _fields_ = [(n, _F) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "rel_h", "rel_w")]
+
+
+ATTN_PLAIN, ATTN_PIXEL_SHUFFLE2 = 0, 1
+
 _lib = None
 
 
@@ -101,6 +113,11 @@ def _sig(lib):
         "dc_conv_profile_collect": (i, [i, p, p, p, p, p]),
         "dc_wino3x3_wgrad_workspace": (z, [i, i, i, i, i]),
         "dc_wino3x3_wgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
+        "dc_attnconv_fwd": (i, [POINTER(AttnMap), POINTER(AttnParams), POINTER(AttnMap), p, i, i, i, i, i, i, p]),
+        "dc_attnconv_param_count": (i, [i]),
+        "dc_attnconv_bwd_workspace": (z, [i, i, i, i]),
+        "dc_attnconv_bwd": (i, [POINTER(AttnMap), POINTER(AttnParams), POINTER(AttnMap), p, POINTER(AttnMap), p, POINTER(AttnMap), p,
+                                p, i, i, i, i, i, i, p]),
         "dc_profile_enable": (i, [i]),
         "dc_profile_collect": (i, [POINTER(c_double), POINTER(c_int), POINTER(c_double), POINTER(c_int), POINTER(c_double),
                                    POINTER(c_double)]),

@@ -458,7 +458,7 @@ def conv_profile_collect(kind):
 # a2/a3 fused decoder block: act(conv3x3(pad1(cat(up2?(x0), x1))) + bias)
 #                                   (reference layers.py:106-136,196-199; networks/depth_decoder.py:50-66)
 # ----------------------------------------------------------------------------------------------
-ACT_NONE, ACT_ELU, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3
+ACT_NONE, ACT_ELU, ACT_SIGMOID, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
 PAD_REFLECT, PAD_ZERO = 0, 1
 
 
@@ -696,3 +696,116 @@ class _Conv1x1(torch.autograd.Function):
 def conv1x1(x, weight, stride=1, bias=None, act=ACT_NONE):
     """act(F.conv2d(x, weight, bias, stride)) for (Co,Ci,1,1) weights; stride 2 needs even H, W."""
     return _Conv1x1.apply(x, weight, bias, stride, act)
+
+
+# ----------------------------------------------------------------------------------------------
+# f1 ResidualAttentionUnit of the Fusion_v3 front-end (reference networks/fusion_v2.py:46-137)
+# ----------------------------------------------------------------------------------------------
+PLAIN, PIXEL_SHUFFLE2 = "plain", "ps2"
+
+
+def _attn_map(tensors, kinds, H, W):
+    """dc_attn_map over a list of contiguous source tensors: `plain` (B,c,H,W) contributes c channels, `ps2`
+    (B,4,H/2,W/2) one channel read through PixelShuffle(2)."""
+    m = _lib.AttnMap()
+    c = 0
+    for t, k in zip(tensors, kinds):
+        if k == PLAIN:
+            if t.shape[2] != H or t.shape[3] != W:
+                raise _lib.DepthcoreError("attention source %s does not match %dx%d" % (tuple(t.shape), H, W))
+            for ch in range(t.shape[1]):
+                m.ptr[c] = ptr(t) + ch * H * W * 4
+                m.batch_stride[c] = t.shape[1] * H * W
+                m.mode[c] = _lib.ATTN_PLAIN
+                c += 1
+        else:
+            if tuple(t.shape[1:]) != (4, H // 2, W // 2) or (H & 1) or (W & 1):
+                raise _lib.DepthcoreError("pixel-shuffle source %s does not match %dx%d" % (tuple(t.shape), H, W))
+            m.ptr[c] = ptr(t)
+            m.batch_stride[c] = 4 * (H // 2) * (W // 2)
+            m.mode[c] = _lib.ATTN_PIXEL_SHUFFLE2
+            c += 1
+    return m, c
+
+
+def _attn_params(ps):
+    """ps: (rel_h, rel_w, wk, bk, wq, bq, wv, bv) in the reference's registration order -> dc_attn_params."""
+    a = _lib.AttnParams()
+    a.rel_h, a.rel_w, a.wk, a.bk, a.wq, a.bq, a.wv, a.bv = (ptr(t) for t in ps)
+    return a
+
+
+def _attn_param_grads(dp, C, like):
+    """dparams vector [dWq, dbq, dWk, dbk, dWv, dbv, drel_h, drel_w] -> gradients in the order/shape of `like`
+    (rel_h, rel_w, wk, bk, wq, bq, wv, bv)."""
+    cc = C * C
+    o = [0, cc, cc + C, 2 * cc + C, 2 * cc + 2 * C, 3 * cc + 2 * C, 3 * cc + 3 * C, 3 * cc + 3 * C + 3, 3 * cc + 3 * C + 6]
+    dwq, dbq, dwk, dbk, dwv, dbv, drh, drw = (dp[o[i]:o[i + 1]] for i in range(8))
+    out = (drh, drw, dwk, dbk, dwq, dbq, dwv, dbv)
+    return tuple(g.reshape(t.shape) for g, t in zip(out, like))
+
+
+class _ResidualAttentionUnit(torch.autograd.Function):
+    """atten2(relu(atten1(relu(u)))) + relu(u) with u gathered from `srcs` (no cat / pixel-shuffle tensors): two fused
+    launches forward, two backward (the unit's in-place ReLUs make the skip connection add relu(u), fusion_v2.py:130-136)."""
+
+    @staticmethod
+    def forward(ctx, kinds, nsrc, *args):
+        L = _lib.lib()
+        srcs = [_c(t.detach()) for t in args[:nsrc]]
+        p1 = [_c(t.detach()) for t in args[nsrc:nsrc + 8]]
+        p2 = [_c(t.detach()) for t in args[nsrc + 8:nsrc + 16]]
+        B = srcs[0].shape[0]
+        H, W = (srcs[0].shape[2], srcs[0].shape[3]) if kinds[0] == PLAIN else (srcs[0].shape[2] * 2, srcs[0].shape[3] * 2)
+        xm, C = _attn_map(srcs, kinds, H, W)
+        if C not in (2, 4) or p1[2].shape[0] != C:
+            raise _lib.DepthcoreError("AttentionConv kernels cover 2 and 4 channels (got %d sources channels, weights %s)"
+                                      % (C, tuple(p1[2].shape)))
+        dev = srcs[0].device
+        y1 = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+        y = torch.empty_like(y1)
+        a1, a2 = _attn_params(p1), _attn_params(p2)
+        st = stream(srcs[0])
+        check(L.dc_attnconv_fwd(ctypes.byref(xm), ctypes.byref(a1), None, ptr(y1), B, C, H, W, 1, 0, st), "dc_attnconv_fwd")
+        y1m, _ = _attn_map([y1], [PLAIN], H, W)
+        check(L.dc_attnconv_fwd(ctypes.byref(y1m), ctypes.byref(a2), ctypes.byref(xm), ptr(y), B, C, H, W, 1, 1, st),
+              "dc_attnconv_fwd")
+        ctx.save_for_backward(y1, *srcs, *p1, *p2)
+        ctx.cfg = (tuple(kinds), nsrc, B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        kinds, nsrc, B, C, H, W = ctx.cfg
+        saved = ctx.saved_tensors
+        y1, srcs, p1, p2 = saved[0], list(saved[1:1 + nsrc]), list(saved[1 + nsrc:9 + nsrc]), list(saved[9 + nsrc:17 + nsrc])
+        dev = y1.device
+        g_c = _c(gy)
+        npar = L.dc_attnconv_param_count(C)
+        dp1 = torch.empty(npar, dtype=torch.float32, device=dev)
+        dp2 = torch.empty(npar, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.dc_attnconv_bwd_workspace(B, C, H, W), dtype=torch.uint8, device=dev)
+        dy1 = torch.empty_like(y1)
+        dskip = torch.empty_like(y1)
+        xm, _ = _attn_map(srcs, kinds, H, W)
+        y1m, _ = _attn_map([y1], [PLAIN], H, W)
+        dy1m, _ = _attn_map([dy1], [PLAIN], H, W)
+        dskm, _ = _attn_map([dskip], [PLAIN], H, W)
+        a1, a2 = _attn_params(p1), _attn_params(p2)
+        st = stream(y1)
+        # second AttentionConv: input relu(y1), skip relu(u)
+        check(L.dc_attnconv_bwd(ctypes.byref(y1m), ctypes.byref(a2), ctypes.byref(xm), ptr(g_c), ctypes.byref(dy1m), None,
+                                ctypes.byref(dskm), ptr(dp2), ws.data_ptr(), B, C, H, W, 1, 1, st), "dc_attnconv_bwd")
+        # first AttentionConv: input relu(u); its input gradient + the skip gradient go straight to the sources' gradients
+        dsrcs = [torch.empty_like(t) for t in srcs]
+        dm, _ = _attn_map(dsrcs, kinds, H, W)
+        check(L.dc_attnconv_bwd(ctypes.byref(xm), ctypes.byref(a1), None, ptr(dy1), ctypes.byref(dm), ptr(dskip), None,
+                                ptr(dp1), ws.data_ptr(), B, C, H, W, 1, 0, st), "dc_attnconv_bwd")
+        return (None, None, *dsrcs, *_attn_param_grads(dp1, C, p1), *_attn_param_grads(dp2, C, p2))
+
+
+def residual_attention_unit(srcs, kinds, params1, params2):
+    """srcs / kinds: the unit's input channels as a list of tensors (`PLAIN` (B,c,H,W) or `PIXEL_SHUFFLE2` (B,4,H/2,W/2));
+    params1 / params2: (rel_h, rel_w, key w, key b, query w, query b, value w, value b) of atten1 / atten2."""
+    return _ResidualAttentionUnit.apply(tuple(kinds), len(srcs), *srcs, *params1, *params2)

@@ -1,4 +1,5 @@
-"""Drop-in for the reference's `networks` package on the hot path (networks/__init__.py:1-3)."""
+"""Drop-in for the reference's `networks` package on the hot path (networks/__init__.py:1-9)."""
 from .resnet_encoder import ResnetEncoder
 from .depth_decoder import DepthDecoder
 from .pose_decoder import PoseDecoder
+from .fusion import Fusion_v3, FeatureFusionBlock_v3, ResidualAttentionUnit, AttentionConv, UpscalePS

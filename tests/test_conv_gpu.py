@@ -20,7 +20,8 @@ def oracle_block(x0, x1, w, b, up, act, pad):
         x = torch.cat([x, x1], 1)
     xp = R._reflect_pad1(x) if pad == 0 else F.pad(x, (1, 1, 1, 1))
     y = F.conv2d(xp, w, b)
-    return F.elu(y) if act == 1 else (torch.sigmoid(y) if act == 2 else (F.relu(y) if act == 3 else y))
+    return F.elu(y) if act == 1 else (torch.sigmoid(y) if act == 2 else (F.relu(y) if act == 3 else
+                                                                          (torch.tanh(y) if act == 4 else y)))
 
 
 CASES = [
@@ -42,6 +43,13 @@ CASES = [
     # pose decoder: zero padding + ReLU (networks/pose_decoder.py), Winograd in all three passes and the direct path
     (4, 256, 0, 256, 6, 20, False, 3, 1),
     (2, 40, 0, 24, 7, 9, False, 3, 1),
+    # Fusion_v3's three tiny convolutions (networks/fusion_v2.py:290,301-302): conv_1 1->2 zero pad, conv3x3 4->1 reflect,
+    # UpscalePS 4->4 zero pad + tanh
+    (2, 1, 0, 2, 12, 20, False, 0, 1),
+    (2, 4, 0, 1, 12, 20, False, 0, 0),
+    (2, 4, 0, 4, 12, 20, False, 4, 1),
+    (3, 4, 0, 4, 24, 80, False, 4, 1),
+    (3, 4, 0, 1, 24, 80, False, 0, 0),
 ]
 
 

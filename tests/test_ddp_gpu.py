@@ -63,11 +63,15 @@ def test_bucketed_exchange_over_rccl_with_stream_overlap():
                 if n == "__loss__":
                     continue
                 g0, g1 = grads[0][n], grads[1][n]
-                # mean over "2 ranks" of a 1-rank sum = half the local gradient; the library weight gradients (stem, stride-2) use
+                # RCCL's AVG over the (1-rank) group = the local gradient; the library weight gradients (stem, stride-2) use
                 # atomics and differ run to run by up to ~1e-2 of their scale at single elements -- a lost or misrouted gradient
                 # would be off by its whole norm
-                err = float((g1 - 0.5 * g0).norm() / (0.5 * g0.norm() + 1e-30))
-                assert err <= 2e-2, (n, err)
+                err = float((g1 - g0).norm() / (g0.norm() + 1e-30))
+                assert err <= 2e-2, (n, err, float(g0.norm()), float(g1.norm()), step)
+            # gradients of depthcore ops are written straight into their slices; only stock torch ops' need the pack copy
+            nparams = sum(len(b) for b in ddp.buckets.buckets)
+            assert 0 < ddp.buckets.packed <= 16 and ddp.buckets.packed < nparams // 8, (ddp.buckets.packed, nparams)
+            assert ddp.buckets.launch_order == sorted(ddp.buckets.launch_order)
             # move on to another point of weight space for the next round (the ddp copy is re-synchronised there)
             ref.model_optimizer.step()
             ddp.model_optimizer.step()                     # also exercises the optimiser on the bucket-view gradients
