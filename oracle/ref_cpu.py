@@ -255,6 +255,7 @@ class Opt:
     v1_multiscale = False
     avg_reprojection = False
     disable_automasking = False
+    predictive_mask = False
     no_ssim = False
     align_corners = False      # installed-torch default of F.grid_sample
 
@@ -306,6 +307,13 @@ def compute_losses(inputs, outputs, opt, noise):
                                for f in (-1, 1)], 1)
             if opt.avg_reprojection:
                 ident = ident.mean(1, keepdim=True)
+        elif opt.predictive_mask:
+            # trainer.py:571-584: per-frame mask from a second decoder, pushed towards 1 by a BCE term (log clamped at -100)
+            mask = outputs["predictive_mask"][("disp", s)]
+            if not opt.v1_multiscale:
+                mask = upsample_bilinear(mask, opt.height, opt.width)
+            reproj = reproj * mask
+            loss = loss + 0.2 * (-torch.clamp(torch.log(mask), min=-100.0)).mean()
         if opt.avg_reprojection:
             reproj = reproj.mean(1, keepdim=True)
         if not opt.disable_automasking:

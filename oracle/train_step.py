@@ -8,13 +8,15 @@ over plain state dicts.  Used as the checker of the full-step parity test and as
 """
 import torch
 
+from . import fusion_ref as FR
 from . import ref_cpu as R
 from .resnet_ref import resnet_encoder_forward
 
 
 class CpuTrainer:
     def __init__(self, state, opt=None, num_layers=18, lr=1e-4):
-        """state: {"encoder": sd, "depth": sd, "pose_encoder": sd, "pose": sd} of CPU fp32 tensors."""
+        """state: {"encoder": sd, "depth": sd, "pose_encoder": sd, "pose": sd[, "fusion": sd]} of CPU tensors (fp32, or
+        fp64 for conditioning checks).  With a "fusion" entry the front-end is trainer_fusion_v3.py:311-330."""
         self.opt = opt or R.Opt()
         self.num_layers = num_layers
         self.state = {k: {n: t.detach().clone() for n, t in sd.items()} for k, sd in state.items()}
@@ -29,8 +31,14 @@ class CpuTrainer:
 
     def process_batch(self, inputs, noise):
         o = self.opt
-        feats = resnet_encoder_forward(self.state["encoder"], inputs[("color_aug", 0, 0)], self.num_layers)
-        outputs = R.depth_decoder_forward(self.state["depth"], feats, self.num_ch_enc, tuple(o.scales))
+        if "fusion" in self.state:
+            enc_input = torch.cat([inputs[("color_aug", i, 0)] for i in (-2, -1, 0)], 0)
+            feats = resnet_encoder_forward(self.state["encoder"], enc_input, self.num_layers)
+            dec = R.depth_decoder_forward(self.state["depth"], feats, self.num_ch_enc, tuple(o.scales))
+            outputs = FR.fusion_v3_forward(self.state["fusion"], dec)
+        else:
+            feats = resnet_encoder_forward(self.state["encoder"], inputs[("color_aug", 0, 0)], self.num_layers)
+            outputs = R.depth_decoder_forward(self.state["depth"], feats, self.num_ch_enc, tuple(o.scales))
         outputs.update(R.predict_poses(
             inputs,
             lambda x: resnet_encoder_forward(self.state["pose_encoder"], x, self.num_layers),

@@ -18,8 +18,9 @@
 //   * an operand whose *reduction* index is contiguous in memory (w as A operand of the forward: input channels; gy and x
 //     in the weight gradient: pixels) lives in LDS as [index][reduction (+4 pad)]; a lane reads two consecutive reduction
 //     elements with one ds_read_b64 and uses them in two successive MFMA steps.
-// Both patterns are bank-conflict free (strides chosen per MI355X_MICROARCH.md's LDS table: b128 rows = 0 mod 64 dwords,
-// b64 index-major rows = 4 * odd dwords).  The reduction order inside a chunk of 8 is permuted identically for A and B
+// Both patterns are bank-conflict free (strides chosen per MI355X_MICROARCH.md's LDS table: b128 rows = 0 mod 64 dwords;
+// index-major rows = 2 mod 32 dwords, which serves both ds_read_b64 and the ds_read2_b64 pairs the compiler forms from
+// them -- 16 lanes x 2 dwords tile the 32 banks; rows of 4 * odd dwords measured 60 % conflict cycles under read2).  The reduction order inside a chunk of 8 is permuted identically for A and B
 // (element 2 k' + s of the chunk goes to MFMA step s, k-lane k'), which changes nothing in the sum.
 //
 // Main loop: reduction chunks of 32 (128 MFMAs per wave between barriers at 128 x 128), LDS double-buffered with ONE
@@ -76,15 +77,21 @@ __device__ __forceinline__ void read_idx(const float* S, int base, int q, int la
         }
     }
 }
-// reduction-contiguous image: S[(index)][KC + 4], tile t of lane i <-> index base + t * 16 + i
+// reduction-contiguous image: S[(index)][KC + RP], tile t of lane i <-> index base + t * 16 + i
+constexpr int RP = 2;                  // row padding of the reduction-contiguous images (rows are 8-byte aligned)
 template <int T, int KC>
 __device__ __forceinline__ void read_red(const float* S, int base, int q, int lane, float (&a)[4][2]) {
     const int i = lane & 15, kp = lane >> 4;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const gf2 v = *reinterpret_cast<const gf2*>(S + (base + t * 16 + i) * (KC + 4) + q * 8 + 2 * kp);
+        const gf2 v = *reinterpret_cast<const gf2*>(S + (base + t * 16 + i) * (KC + RP) + q * 8 + 2 * kp);
         a[t][0] = v.x; a[t][1] = v.y;
     }
+}
+// 16 bytes into a reduction-contiguous image (its rows are only 8-byte aligned: two ds_write_b64)
+__device__ __forceinline__ void store_red4(float* p, gf4 v) {
+    *reinterpret_cast<gf2*>(p) = gf2{v.x, v.y};
+    *reinterpret_cast<gf2*>(p + 2) = gf2{v.z, v.w};
 }
 
 template <int MT, int NT>
@@ -123,7 +130,7 @@ template <int MT, int NT, bool EPI>
 __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
     constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SB = IdxStride<NT, BN>::v;
     constexpr int NA = BM * KC / 1024, NB = KC * BN / 1024;          // float4 per thread per chunk
-    constexpr int ASZ = BM * (KC + 4), BSZ = KC * SB;
+    constexpr int ASZ = BM * (KC + RP), BSZ = KC * SB;
     float* const As = g1_smem;                 // [2][ASZ]
     float* const Bs = g1_smem + 2 * ASZ;       // [2][BSZ]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
     for (int j = 0; j < NA; ++j) {
         const int idx = tid + j * 256, row = idx / (KC / 4), kq = idx % (KC / 4);
         asrc[j] = a.w + (size_t)min(m0 + row, a.Co - 1) * a.Ci + kq * 4;
-        adst[j] = row * (KC + 4) + kq * 4;
+        adst[j] = row * (KC + RP) + kq * 4;
     }
     const float* bsrc[NB];
     int bdst[NB];
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) *reinterpret_cast<gf4*>(As + buf * ASZ + adst[j]) = ra[j];
+        for (int j = 0; j < NA; ++j) store_red4(As + buf * ASZ + adst[j], ra[j]);
 #pragma unroll
         for (int j = 0; j < NB; ++j) *reinterpret_cast<gf4*>(Bs + buf * BSZ + bdst[j]) = rb[j];
     };
@@ -326,7 +333,7 @@ template <int MT, int NT>
 __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
     constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC;
     constexpr int NA = BM * KC / 1024, NB = BN * KC / 1024;
-    constexpr int ASZ = BM * (KC + 4), BSZ = BN * (KC + 4);
+    constexpr int ASZ = BM * (KC + RP), BSZ = BN * (KC + RP);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = (blockIdx.x % a.mtiles) * BM, c0 = (blockIdx.x / a.mtiles) * BN;
     const int P = a.Ho * a.Wo;
@@ -359,10 +366,10 @@ __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
     auto commit = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-            *reinterpret_cast<gf4*>(g1_smem + buf * ASZ + (row0 + j * (1024 / KC)) * (KC + 4) + kq * 4) = ra[j];
+            store_red4(g1_smem + buf * ASZ + (row0 + j * (1024 / KC)) * (KC + RP) + kq * 4, ra[j]);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            *reinterpret_cast<gf4*>(g1_smem + 2 * ASZ + buf * BSZ + (row0 + j * (1024 / KC)) * (KC + 4) + kq * 4) = rb[j];
+            store_red4(g1_smem + 2 * ASZ + buf * BSZ + (row0 + j * (1024 / KC)) * (KC + RP) + kq * 4, rb[j]);
     };
     gf4 acc[MT][NT];
 #pragma unroll
@@ -440,9 +447,9 @@ __global__ __launch_bounds__(256) void g1_bias_act_bwd_kernel(const float* __res
 // Estimated time of a tile shape = rounds the grid needs on the chip x cost of one block, where the cost per block grows
 // with its MFMA count and the smaller tiles pay more operand traffic per MFMA.  Blocks resident per CU: LDS-limited.
 struct G1Tile { int mt, nt; };
-static size_t g1_lds_fwd(G1Tile t) { return (size_t)2 * (32 * t.mt * (GKC + 4) + GKC * (t.nt == 4 ? 128 : 80)) * sizeof(float); }
+static size_t g1_lds_fwd(G1Tile t) { return (size_t)2 * (32 * t.mt * (GKC + RP) + GKC * (t.nt == 4 ? 128 : 80)) * sizeof(float); }
 static size_t g1_lds_dgrad(G1Tile t) { return (size_t)2 * GKC * ((t.mt == 4 ? 128 : 80) + (t.nt == 4 ? 128 : 80)) * sizeof(float); }
-static size_t g1_lds_wgrad(G1Tile t) { return (size_t)2 * 32 * (t.mt + t.nt) * (GKC + 4) * sizeof(float); }
+static size_t g1_lds_wgrad(G1Tile t) { return (size_t)2 * 32 * (t.mt + t.nt) * (GKC + RP) * sizeof(float); }
 static G1Tile g1_pick(int M, int N, size_t (*lds)(G1Tile)) {
     const G1Tile cand[3] = {{4, 4}, {2, 4}, {2, 2}};
     const double penalty[3] = {1.0, 1.12, 1.3};          // relative cost per MFMA (operand re-reads, shorter MFMA runs)

@@ -131,17 +131,34 @@ class ResNetTrunk(nn.Module):
         return nn.Sequential(*layers)
 
 
+def load_imagenet_weights(trunk, weights, num_input_images=1):
+    """networks/resnet_encoder.py:52-57: a torchvision ResNet state dict goes into the trunk with `conv1.weight` tiled over
+    the stacked input frames and divided by their number (so the stem's response to identical frames is unchanged).
+    `weights`: a state dict or the path of a torchvision `resnet{N}-*.pth` file."""
+    loaded = torch.load(weights, map_location="cpu") if isinstance(weights, (str, bytes)) or hasattr(weights, "__fspath__") \
+        else dict(weights)
+    loaded = {k: v for k, v in loaded.items()}
+    loaded["conv1.weight"] = torch.cat([loaded["conv1.weight"]] * num_input_images, 1) / num_input_images
+    trunk.load_state_dict(loaded)
+    return trunk
+
+
 class ResnetEncoder(nn.Module):
-    """networks/resnet_encoder.py:62-98.  `pretrained=True` needs a network download and is refused."""
+    """networks/resnet_encoder.py:62-98.  `pretrained`: False (scratch init), or the torchvision ImageNet weights as a
+    state dict / the path of their file (applied with the reference's tile-and-divide rule for `num_input_images` > 1).
+    `pretrained=True` would need the reference's download (model_zoo.load_url) and is refused: there is no network."""
 
     def __init__(self, num_layers, pretrained, num_input_images=1):
         super().__init__()
         if num_layers not in _CFG:
             raise ValueError("{} is not a valid number of resnet layers".format(num_layers))
-        if pretrained:
-            raise RuntimeError("pretrained ImageNet weights need a download; load a checkpoint with load_state_dict")
+        if pretrained is True:
+            raise RuntimeError("pretrained=True downloads the ImageNet weights (networks/resnet_encoder.py:53); pass the "
+                               "torchvision state dict or the path of its .pth file as `pretrained` instead")
         self.num_ch_enc = np.array([64, 64, 128, 256, 512])
         self.encoder = ResNetTrunk(num_layers, num_input_images)
+        if pretrained:
+            load_imagenet_weights(self.encoder, pretrained, num_input_images)
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
         self._nbt = None

@@ -8,7 +8,11 @@ validation) is out of scope (SURVEY 8, rows a14-a18 only).
 Two equivalent loss paths, both on hand-written gfx950 kernels:
   * fused (default): generate_images_pred + compute_losses are ONE forward op and ONE backward op
     (`depthcore.ops.photometric_loss`); log tensors are produced only when asked for;
-  * layer-by-layer (`opt.fused_loss = False`): the reference's own sequence of `layers.*` calls.
+  * layer-by-layer (`opt.fused_loss = False`): the reference's own sequence of `layers.*` calls.  The `v1_multiscale`
+    and `predictive_mask` ablations (trainer.py:471,541,571-590) always take this path.
+
+`opt.fusion = "v3"` switches the front-end to the reference's trainer_fusion_v3.py:277-330: frames [-2, -1, 0] are stacked
+through the depth encoder + decoder and fused by `networks.Fusion_v3` (BASELINE configs[4]).
 """
 import json
 import os
@@ -26,14 +30,12 @@ from depthcore.ddp import GradBuckets, broadcast_parameters
 
 
 def default_options(**kw):
-    """Hot-path defaults of the reference's options.py:100-213."""
-    o = types.SimpleNamespace(
-        height=192, width=640, scales=[0, 1, 2, 3], min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3,
-        frame_ids=[0, -1, 1], batch_size=12, learning_rate=1e-4, scheduler_step_size=15, num_layers=18,
-        weights_init="scratch", pose_model_type="separate_resnet", pose_model_input="pairs",
-        v1_multiscale=False, avg_reprojection=False, disable_automasking=False, predictive_mask=False,
-        no_ssim=False, fused_loss=True, cpu_tiebreak_noise=False, materialize_logs=False, bucket_mb=32,
-        overlap_streams=True)
+    """The reference's option set with its defaults (options.py, via options.MonodepthOptions) plus this build's knobs;
+    `weights_init` defaults to "scratch" here (no network: the ImageNet download of "pretrained" is unavailable -- a
+    torchvision checkpoint can be given to ResnetEncoder(pretrained=<path or state_dict>))."""
+    from options import MonodepthOptions
+    o = MonodepthOptions().parse([])
+    o.weights_init = "scratch"
     for k, v in kw.items():
         setattr(o, k, v)
     return o
@@ -52,8 +54,12 @@ class Trainer:
         assert self.opt.frame_ids[0] == 0
         if self.opt.pose_model_type != "separate_resnet" or self.opt.pose_model_input != "pairs":
             raise NotImplementedError("hot path covers pose_model_type=separate_resnet, pose_model_input=pairs")
-        if self.opt.predictive_mask or self.opt.v1_multiscale:
-            raise NotImplementedError("predictive_mask / v1_multiscale ablations are outside the hot path")
+        if self.opt.predictive_mask and not self.opt.disable_automasking:       # trainer.py:116-117
+            raise ValueError("When using predictive_mask, please disable automasking with disable_automasking")
+        if getattr(self.opt, "fusion", None) not in (None, "v3"):
+            raise NotImplementedError("fusion front-ends: None (trainer.py) or 'v3' (trainer_fusion_v3.py)")
+        if self.opt.fusion and -2 not in self.opt.frame_ids:
+            raise ValueError("the Fusion_v3 front-end stacks frames [-2, -1, 0]: frame_ids must be [0, -2, -1, 1]")
         self.num_scales = len(self.opt.scales)
         self.num_pose_frames = 2
 
@@ -61,10 +67,15 @@ class Trainer:
         self.models = {}
         self.models["encoder"] = networks.ResnetEncoder(self.opt.num_layers, self.opt.weights_init == "pretrained")
         self.models["depth"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, self.opt.scales)
+        if self.opt.fusion:                                      # trainer_fusion_v3.py:74
+            self.models["fusion"] = networks.Fusion_v3(attention=not self.opt.disable_attention)
         self.models["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, self.opt.weights_init == "pretrained",
                                                              num_input_images=self.num_pose_frames)
         self.models["pose"] = networks.PoseDecoder(self.models["pose_encoder"].num_ch_enc, num_input_features=1,
                                                    num_frames_to_predict_for=2)
+        if self.opt.predictive_mask:                             # trainer.py:115-125: one mask per source frame
+            self.models["predictive_mask"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, self.opt.scales,
+                                                                   num_output_channels=2)
         self.parameters_to_train = []
         for m in self.models.values():
             m.to(self.device)
@@ -73,9 +84,9 @@ class Trainer:
             broadcast_parameters(self.models.values(), 0, process_group)
         # in the order the forward runs the modules (GradBuckets exchanges in the reverse of it): with overlap_streams
         # the pose branch is issued first (process_batch), so its gradients are the last ones backward produces
-        order = (("pose_encoder", "pose", "encoder", "depth") if getattr(self.opt, "overlap_streams", False)
-                 else ("encoder", "depth", "pose_encoder", "pose"))
-        order = list(order) + [k for k in self.models if k not in order]
+        main = ["encoder", "depth"] + [k for k in ("fusion", "predictive_mask") if k in self.models]
+        order = (["pose_encoder", "pose"] + main) if getattr(self.opt, "overlap_streams", False) else (main + ["pose_encoder", "pose"])
+        order = order + [k for k in self.models if k not in order]
         named = [(k + "." + n, p) for k in order for n, p in self.models[k].named_parameters()]
         self.buckets = GradBuckets(named, self.opt.bucket_mb, world_size, process_group)
         self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate,
@@ -89,7 +100,10 @@ class Trainer:
             self.backproject_depth[s] = BackprojectDepth(self.opt.batch_size, h, w).to(self.device)
             self.project_3d[s] = Project3D(self.opt.batch_size, h, w).to(self.device)
         self.step = 0
+        self.epoch = 0
         self._side_stream = None
+        if getattr(self.opt, "load_weights_folder", None):       # trainer.py:137-138
+            self.load_model()
 
     def set_train(self):
         for m in self.models.values():
@@ -116,22 +130,34 @@ class Trainer:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 pose_out = self.predict_poses(inputs, None)
-            features = self.models["encoder"](inputs[("color_aug", 0, 0)])
-            outputs = dict(self.models["depth"](features))
+            outputs = self._depth_branch(inputs)
             main.wait_stream(side)
             for t in pose_out.values():
                 t.record_stream(main)
             outputs.update(pose_out)
         else:
-            features = self.models["encoder"](inputs[("color_aug", 0, 0)])
-            outputs = dict(self.models["depth"](features))
-            outputs.update(self.predict_poses(inputs, features))
-        if self.opt.fused_loss:
+            outputs = self._depth_branch(inputs)
+            outputs.update(self.predict_poses(inputs, None))
+        if self.opt.fused_loss and not (self.opt.predictive_mask or self.opt.v1_multiscale):
             losses = self.fused_losses(inputs, outputs)
         else:
             self.generate_images_pred(inputs, outputs)
             losses = self.compute_losses(inputs, outputs)
         return outputs, losses
+
+    def _depth_branch(self, inputs):
+        """trainer.py:276-310 (vanilla wiring) / trainer_fusion_v3.py:311-330 (frames [-2, -1, 0] stacked along the batch
+        through encoder + decoder, then Fusion_v3: the decoder output of frame -2 is the one refined -- as in the reference)."""
+        if self.opt.fusion:
+            enc_input = torch.cat([inputs[("color_aug", i, 0)] for i in (-2, -1, 0)], 0)
+            features = self.models["encoder"](enc_input)
+            outputs = dict(self.models["fusion"](self.models["depth"](features)))
+        else:
+            features = self.models["encoder"](inputs[("color_aug", 0, 0)])
+            outputs = dict(self.models["depth"](features))
+        if self.opt.predictive_mask:                             # trainer.py:307-310
+            outputs["predictive_mask"] = self.models["predictive_mask"](features)
+        return outputs
 
     # ------------------------------------------------------------------ trainer.py:378-442 (pairs mode)
     def predict_poses(self, inputs, features):
@@ -155,8 +181,10 @@ class Trainer:
     def _noise(self, B, nch):
         if not self.opt.cpu_tiebreak_noise or self.opt.disable_automasking:
             return None
-        # the reference draws on the CPU generator and copies (trainer.py:594-595)
-        return [torch.randn(B, nch, self.opt.height, self.opt.width).to(self.device) for _ in self.opt.scales]
+        # the reference draws on the CPU generator and copies (trainer.py:594-595); v1_multiscale: at each scale's size
+        v1 = self.opt.v1_multiscale
+        return [torch.randn(B, nch, self.opt.height >> (s if v1 else 0), self.opt.width >> (s if v1 else 0)).to(self.device)
+                for s in self.opt.scales]
 
     def fused_losses(self, inputs, outputs, materialize=None):
         o = self.opt
@@ -191,8 +219,11 @@ class Trainer:
     def generate_images_pred(self, inputs, outputs):
         o = self.opt
         for scale in o.scales:
-            disp = interpolate_bilinear(outputs[("disp", scale)], [o.height, o.width])
-            source_scale = 0
+            if o.v1_multiscale:                                  # trainer.py:470-472: warp at each scale's own resolution
+                disp, source_scale = outputs[("disp", scale)], scale
+            else:
+                disp = interpolate_bilinear(outputs[("disp", scale)], [o.height, o.width])
+                source_scale = 0
             _, depth = disp_to_depth(disp, o.min_depth, o.max_depth)
             outputs[("depth", 0, scale)] = depth
             for frame_id in (-1, 1):
@@ -219,13 +250,22 @@ class Trainer:
         B = inputs[("color", 0, 0)].shape[0]
         noise = self._noise(B, 1 if o.avg_reprojection else 2)
         for si, scale in enumerate(o.scales):
-            disp, color, target = outputs[("disp", scale)], inputs[("color", 0, scale)], inputs[("color", 0, 0)]
+            source_scale = scale if o.v1_multiscale else 0       # trainer.py:541-544
+            disp, color, target = outputs[("disp", scale)], inputs[("color", 0, scale)], inputs[("color", 0, source_scale)]
             reproj = torch.cat([self.compute_reprojection_loss(outputs[("color", f, scale)], target)
                                 for f in (-1, 1)], 1)
+            loss = 0
+            if o.predictive_mask:                                # trainer.py:571-584 (automasking is off here)
+                mask = outputs["predictive_mask"][("disp", scale)]
+                if not o.v1_multiscale:
+                    mask = interpolate_bilinear(mask, [o.height, o.width])
+                reproj = reproj * mask
+                # nn.BCELoss()(mask, ones): -log(mask) with the log clamped at -100, mean over all elements
+                loss = loss + 0.2 * (-torch.clamp(torch.log(mask), min=-100.0)).mean()
             if o.avg_reprojection:
                 reproj = reproj.mean(1, keepdim=True)
             if not o.disable_automasking:
-                ident = torch.cat([self.compute_reprojection_loss(inputs[("color", f, 0)], target)
+                ident = torch.cat([self.compute_reprojection_loss(inputs[("color", f, source_scale)], target)
                                    for f in (-1, 1)], 1)
                 if o.avg_reprojection:
                     ident = ident.mean(1, keepdim=True)
@@ -239,7 +279,7 @@ class Trainer:
                 to_optimise, idxs = torch.min(combined, dim=1)
                 if not o.disable_automasking:
                     outputs["identity_selection/{}".format(scale)] = (idxs > ident.shape[1] - 1).float()
-            loss = to_optimise.mean()
+            loss = loss + to_optimise.mean()
             norm_disp = disp / (disp.mean(2, True).mean(3, True) + 1e-7)
             loss = loss + o.disparity_smoothness * get_smooth_loss(norm_disp, color) / (2 ** scale)
             total_loss = total_loss + loss
@@ -248,22 +288,47 @@ class Trainer:
         return losses
 
     # ------------------------------------------------------------------ trainer.py:700-763
-    def save_model(self, folder):
-        """Reference checkpoint layout (trainer.py:711-729): `{name}.pth` = state_dict per model (the encoder's
-        additionally carries height / width / use_stereo) + `adam.pth`; options next to them as opt.json."""
+    @property
+    def log_path(self):
+        return os.path.join(self.opt.log_dir, self.opt.model_name)          # trainer.py:35
+
+    def save_opts(self, models_dir=None):
+        """trainer.py:700-709: `<log_path>/models/opt.json` with every option."""
+        models_dir = models_dir or os.path.join(self.log_path, "models")
+        os.makedirs(models_dir, exist_ok=True)
+        with open(os.path.join(models_dir, "opt.json"), "w") as f:
+            json.dump({k: v for k, v in vars(self.opt).items() if isinstance(v, (int, float, str, bool, list, type(None)))},
+                      f, indent=2)
+
+    def save_model(self, folder=None):
+        """Reference checkpoint layout (trainer.py:711-729): `<log_path>/models/weights_{epoch}/{name}.pth` = state_dict per
+        model (the encoder's additionally carries height / width / use_stereo) + `adam.pth`.  `folder` overrides the
+        location (then opt.json is written next to the weights as well)."""
+        explicit = folder is not None
+        folder = folder or os.path.join(self.log_path, "models", "weights_{}".format(getattr(self, "epoch", 0)))
         os.makedirs(folder, exist_ok=True)
         for name, model in self.models.items():
             to_save = model.state_dict()
             if name == "encoder":
-                to_save["height"], to_save["width"], to_save["use_stereo"] = self.opt.height, self.opt.width, False
+                to_save["height"], to_save["width"] = self.opt.height, self.opt.width
+                to_save["use_stereo"] = getattr(self.opt, "use_stereo", False)
             torch.save(to_save, os.path.join(folder, "{}.pth".format(name)))
         torch.save(self.model_optimizer.state_dict(), os.path.join(folder, "adam.pth"))
-        with open(os.path.join(folder, "opt.json"), "w") as f:
-            json.dump({k: v for k, v in vars(self.opt).items() if isinstance(v, (int, float, str, bool, list))}, f, indent=2)
+        self.save_opts(folder if explicit else None)
+        return folder
 
-    def load_model(self, folder, models_to_load=("encoder", "depth", "pose_encoder", "pose")):
-        """trainer.py:731-763: keep only the keys the current model has (drops height/width/use_stereo)."""
-        for name in models_to_load:
+    def load_model(self, folder=None, models_to_load=None):
+        """trainer.py:731-763: `opt.load_weights_folder` / `opt.models_to_load` by default; for every model keep only the
+        keys the current module has (drops the encoder's height / width / use_stereo entries) and leave the others at their
+        initial values.  Names of `models_to_load` that this trainer does not have (the reference's default list also names
+        `gru` and `head`) are skipped; a listed model without its file is an error, as in the reference."""
+        folder = os.path.expanduser(folder or self.opt.load_weights_folder)
+        if not os.path.isdir(folder):
+            raise FileNotFoundError("Cannot find folder {}".format(folder))
+        names = list(models_to_load if models_to_load is not None else self.opt.models_to_load)
+        for name in names[::-1]:
+            if name not in self.models:
+                continue
             path = os.path.join(folder, "{}.pth".format(name))
             model_dict = self.models[name].state_dict()
             pretrained = torch.load(path, map_location=self.device)

@@ -87,7 +87,11 @@ def test_residual_attention_unit_vs_oracle(case):
     gh = torch.autograd.grad((yh * cot.to(DEV)).sum(), sh + list(ph.values()))
     close(yh, yo, rtol=1e-4, atol=1e-5)
     names = ["src%d" % i for i in range(len(srcs))] + list(st)
+    scale = max(float(b.abs().max()) for b in go)
     for n, a, b in zip(names, gh, go):
+        if "key_conv.bias" in n:      # analytically zero (softmax is invariant to a shift of the logits' k offset times q ... sum_t dlogit_t = 0)
+            assert float(a.abs().max()) <= 1e-5 * scale and float(b.abs().max()) <= 1e-5 * scale, n
+            continue
         assert rel_l2(a, b) < 2e-4, (n, rel_l2(a, b))
 
 

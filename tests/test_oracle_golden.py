@@ -265,3 +265,44 @@ def test_pose_decoder_even_fixture(golden):
         gk = gr[1 + j]
         got = gk if gk.numel() <= 4096 else torch.from_numpy(MG.summ(gk))
         close(got, g["g_" + k], rtol=2e-3, atol=1e-4)
+
+
+def _ablation_setup(tag):
+    import make_golden_r2 as MG2
+    B, H, W = MG.B, MG.H, MG.W
+    inputs = R.synthetic_inputs(B, H, W, seed=0)
+    disp, aa, tr, mask = MG2.ablation_inputs(tag)
+    kw = dict(v1_multiscale=True) if tag == "v1ms" else dict(disable_automasking=True, predictive_mask=True)
+    opt = R.Opt(height=H, width=W, **kw)
+    torch.manual_seed(1234)          # trainer.py:594-595 draws with the default CPU generator, one tensor per scale
+    noise = None if tag == "pmask" else [torch.randn(B, 2, H >> s, W >> s) for s in range(4)]
+    return inputs, disp, aa, tr, mask, opt, noise
+
+
+@pytest.mark.parametrize("tag", ["v1ms", "pmask"])
+def test_trainer_ablations(golden, tag):
+    """a15 ablations `v1_multiscale` (trainer.py:471,541) and `predictive_mask` (:571-590) vs the reference's outputs."""
+    g = golden["trainer_ablations"]
+    inputs, disp, aa, tr, mask, opt, noise = _ablation_setup(tag)
+    leaves = [disp[s].requires_grad_() for s in range(4)] + [aa[-1].requires_grad_(), aa[1].requires_grad_(),
+                                                             tr[-1].requires_grad_(), tr[1].requires_grad_()]
+    outputs = {("disp", s): disp[s] for s in range(4)}
+    if mask is not None:
+        outputs["predictive_mask"] = {("disp", s): mask[s].requires_grad_() for s in range(4)}
+        leaves += [mask[s] for s in range(4)]
+    for f in (-1, 1):
+        outputs[("cam_T_cam", 0, f)] = R.transformation_from_parameters(aa[f], tr[f], invert=(f < 0))
+        close(outputs[("cam_T_cam", 0, f)], g[tag + "_T_%d" % f], rtol=1e-5, atol=1e-7)
+    R.generate_images_pred(inputs, outputs, opt)
+    losses = R.compute_losses(inputs, outputs, opt, noise)
+    close(losses["loss"], g[tag + "_loss"], rtol=1e-5)
+    grads = torch.autograd.grad(losses["loss"], leaves)
+    for s in range(4):
+        close(losses["loss/%d" % s], g[tag + "_loss%d" % s], rtol=1e-5)
+        close_frac(grads[s], g[tag + "_gdisp%d" % s], rtol=1e-3, atol=1e-7, bad=1e-2)
+        if mask is not None:
+            close(grads[8 + s], g[tag + "_gmask%d" % s], rtol=1e-3, atol=1e-8)
+    for j, f in enumerate((-1, 1)):
+        for k, gi in (("gaa", 4 + j), ("gtr", 6 + j)):
+            want = T(g[tag + "_%s_%d" % (k, f)])
+            assert float((grads[gi] - want).norm() / want.norm()) < 2e-2

@@ -31,7 +31,7 @@ def main():
     L = _lib.lib()
     only_dc = "--dc-only" in sys.argv
     cases = []
-    for B in (8, 16):
+    for B in ((8,) if "--b8" in sys.argv else (8, 16)):
         cases += [("l1.conv1", B, 256, 64, 80, 256, 1), ("l1.conv3", B, 64, 256, 80, 256, 1),
                   ("l2.0.conv1", B, 256, 128, 80, 256, 1), ("l2.0.down", B, 256, 512, 80, 256, 2),
                   ("l2.conv1", B, 512, 128, 40, 128, 1), ("l2.conv3", B, 128, 512, 40, 128, 1),
