@@ -11,7 +11,13 @@
 //     image exists only in registers (it is written out only when the log tensors are requested);
 //   * backward recomputes the warp (halo 2) instead of saving it, routes the min() gradient by the
 //     1-byte argmin map the forward wrote, and reduces the pose gradient per wave -> per block ->
-//     fixed-order final sum (no float atomics, bitwise reproducible).
+//     fixed-order final sum (no float atomics, bitwise reproducible);
+//   * the target image's 3x3 window statistics (mu_y, sigma_y + C2, mu_y^2 + C1 per channel) do not depend on the
+//     scale, the source frame or the direction: identity_kernel, which streams the target anyway, computes them once
+//     per step and stores them next to the target pixel (12 floats per pixel); the four scale-waves of the forward and
+//     of the backward load them instead of redoing the two 3x3 sums per channel (8x per step before);
+//   * the SSIM derivative of the backward is evaluated for ONE source frame per pixel, the one the argmin map routes the
+//     gradient to (the other frame's coefficient is exactly zero), except under avg_reprojection where both get half.
 #include <mutex>
 #include <vector>
 
@@ -19,13 +25,11 @@
 
 namespace dc {
 
-#ifndef DC_R_ROWS
-#define DC_R_ROWS 16
-#endif
 #ifndef FWD_WAVES
 #define FWD_WAVES 3
 #endif
-constexpr int R_ROWS = DC_R_ROWS;   // image rows produced per wave (even)
+constexpr int BWD_BLOCKS_PER_CU = 2;   // __launch_bounds__ of the backward / forward kernels (256-thread blocks per CU)
+constexpr int FWD_BLOCKS_PER_CU = FWD_WAVES;
 constexpr float kC1 = 0.01f * 0.01f;  // layers.py:231-232
 constexpr float kC2 = 0.03f * 0.03f;
 constexpr float k9 = 1.f / 9.f;
@@ -48,7 +52,9 @@ struct PhotoArgs {
     const float* noise[DC_MAX_SCALES];
     unsigned long long seed;
     float* idl;                        // identity losses, pixel-interleaved (B, H, W, 2|1)
-    float* pk[3];                      // pixel-interleaved RGBx copies (B,H,W,4) of target / source -1 / source +1
+    float* pk[3];                      // [0]: target + window statistics (B,H,W,3 channels x {t, mu, sig+C2, mu^2+C1});
+                                       // [1], [2]: pixel-interleaved RGBx copies (B,H,W,4) of source -1 / source +1
+    int rows_f, rows_b;                // image rows a wave produces in the forward / backward march (even)
     uint8_t* argmin[DC_MAX_SCALES];
     float* depth[DC_MAX_SCALES];
     float* sample[DC_MAX_SCALES][2];
@@ -95,6 +101,9 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 typedef int i2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f3 bload3(rsrc_t r, unsigned voff) {      // one RGB pixel of a packed image
     return __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, 0, 0));
+}
+__device__ __forceinline__ f4v bload4(rsrc_t r, unsigned voff, unsigned imm) {
+    return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)imm, 0));
 }
 __device__ __forceinline__ f2 bload2(rsrc_t r, unsigned voff) {
     return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0));
@@ -145,7 +154,8 @@ struct Ctx {   // per-wave constants (scalar registers)
     int H, W;
     unsigned plane4;        // bytes of one channel plane
     rsrc_t tg, s0, s1;      // target / source -1 / source +1 of this batch element (3 planes each)
-    rsrc_t ptg, ps0, ps1;   // their pixel-interleaved RGBx copies (16 B per pixel)
+    rsrc_t ptg;             // target pixel + its 3x3 window statistics (48 B per pixel, written by identity_kernel)
+    rsrc_t ps0, ps1;        // pixel-interleaved RGBx copies of the sources (16 B per pixel)
     rsrc_t dp;              // disparity of this (scale, batch element)
     int hs, ws;
     float ry, rx;
@@ -165,7 +175,7 @@ __device__ __forceinline__ void make_ctx(Ctx& c, const PhotoArgs& p, int b, int 
     c.tg = make_rsrc(p.target + img, 3u * c.plane4);
     c.s0 = make_rsrc(p.src[0] + img, 3u * c.plane4);
     c.s1 = make_rsrc(p.src[1] + img, 3u * c.plane4);
-    c.ptg = make_rsrc(p.pk[0] + (size_t)b * plane * 4, 4u * c.plane4);
+    c.ptg = make_rsrc(p.pk[0] + (size_t)b * plane * 12, 12u * c.plane4);
     c.ps0 = make_rsrc(p.pk[1] + (size_t)b * plane * 4, 4u * c.plane4);
     c.ps1 = make_rsrc(p.pk[2] + (size_t)b * plane * 4, 4u * c.plane4);
     c.hs = p.hs[s]; c.ws = p.ws[s];
@@ -204,7 +214,7 @@ __device__ __forceinline__ float disp_value(const DispTaps& t, const Ctx& c) {
 // ---- one pixel, both source frames: disp -> depth -> BackprojectDepth -> Project3D -> grid_sample
 // coordinates (layers.py:21-24,163-192; trainer.py:508-511), with the 3 + 12 + 12 loads left in flight.
 struct Taps {
-    f3 t;                // target pixel (RGB)
+    f4v ts[3];           // per channel: target pixel, mu_y, sig_y + C2, mu_y^2 + C1   (pk[0])
     f3 tap[2][4];        // [frame][nw, ne, sw, se] RGB pixels
     float wx1[2], wy1[2];
     float sx[2], sy[2];  // backward only: d(ix)/du, d(iy)/dv incl. the border-clamp zero
@@ -237,7 +247,12 @@ __device__ __forceinline__ TapOff tap_offsets(float x, float y, int H, int W) {
 template <int MODE, bool LOGS>
 __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, float disp, int x, int y, RowLog& lg,
                                           float* park) {
-    r.t = bload3(c.ptg, (unsigned)(y * c.W + x) * 16u);
+    {
+        const unsigned o = (unsigned)(y * c.W + x) * 48u;
+        r.ts[0] = bload4(c.ptg, o, 0);
+        r.ts[1] = bload4(c.ptg, o, 16);
+        r.ts[2] = bload4(c.ptg, o, 32);
+    }
     const float scaled = c.min_disp + c.disp_range * disp;
     const float depth = frcp(scaled);
     const float xf = (float)x, yf = (float)y;
@@ -284,9 +299,13 @@ __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, f
     r.tap[0][3] = bload3(c.ps0, to[0].o11); r.tap[1][3] = bload3(c.ps1, to[1].o11);
 }
 
+struct TStat {
+    float mu_y, sig_y_c2, mu_yy_c1;   // mu_y, sig_y + C2, mu_y^2 + C1
+};
 struct Row {   // raw values of one image row at the lane's own pixel: target + both warped frames
     float t[3];
     float w[2][3];
+    TStat st[3];   // window statistics of the target centred on this row (gather kernels: loaded, not recomputed)
 };
 
 __device__ __forceinline__ void blend_row(const Taps& r, Row& o) {
@@ -299,7 +318,10 @@ __device__ __forceinline__ void blend_row(const Taps& r, Row& o) {
             o.w[f][ch] = r.tap[f][0][ch] * wnw + r.tap[f][1][ch] * wne + r.tap[f][2][ch] * wsw + r.tap[f][3][ch] * wse;
     }
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) o.t[ch] = r.t[ch];
+    for (int ch = 0; ch < 3; ++ch) {
+        o.t[ch] = r.ts[ch].x;
+        o.st[ch].mu_y = r.ts[ch].y; o.st[ch].sig_y_c2 = r.ts[ch].z; o.st[ch].mu_yy_c1 = r.ts[ch].w;
+    }
 }
 
 // 3-tap horizontal sum across lanes: two DPP-fused adds
@@ -307,9 +329,6 @@ __device__ __forceinline__ float hsum3(float v) { return from_left(v) + v + from
 
 // Window statistics of one channel: vertical sums in-lane over the three rows held in registers, then
 // the horizontal 3-sum on the five column sums (instead of ringing five h-sums per channel and frame).
-struct TStat {
-    float mu_y, sig_y_c2, mu_yy_c1;   // mu_y, sig_y + C2, mu_y^2 + C1
-};
 __device__ __forceinline__ TStat target_stat(float a, float b, float c) {
     const float sy = hsum3(a + b + c);
     const float syy = hsum3(fmaf(a, a, fmaf(b, b, c * c)));
@@ -338,12 +357,15 @@ __device__ __forceinline__ WStat warp_stat(const TStat& ts, float xa, float xb, 
 }
 
 // 0.85 * mean_c SSIM + 0.15 * mean_c |t - w|  (trainer.py:517-529) for both frames; rows a,b,c = p-1,p,p+1
+// STORED: the centre row carries the precomputed target statistics (gather kernels); otherwise they are computed here
+// (identity_kernel, which is also where they are produced -- bit-identical by construction).
+template <bool STORED>
 __device__ __forceinline__ void reproj_values(const Row& a, const Row& b, const Row& c, bool no_ssim, float out[2]) {
     float ss[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         TStat ts;
-        if (!no_ssim) ts = target_stat(a.t[ch], b.t[ch], c.t[ch]);
+        if (!no_ssim) ts = STORED ? b.st[ch] : target_stat(a.t[ch], b.t[ch], c.t[ch]);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             l1[f] += fabsf(b.t[ch] - b.w[f][ch]);
@@ -408,18 +430,31 @@ __global__ __launch_bounds__(64) void identity_kernel(PhotoArgs p) {
         const int yy = y0 - 1 + i;
         const Row cur = nxt;
         load_row(yy + 1);   // next row flies during this row's math
-        // pixel-interleaved copies of the three images for the gather kernels (rows this wave owns)
+        // pixel-interleaved copies of the two source images for the gather kernels (rows this wave owns)
         if (i >= 1 && i <= ID_ROWS && yy < H && lane_ok) {
             const unsigned o = (unsigned)(yy * W + x) * 16u;
-            bstore4(c.ptg, o, cur.t[0], cur.t[1], cur.t[2], 0.f);
             bstore4(c.ps0, o, cur.w[0][0], cur.w[0][1], cur.w[0][2], 0.f);
             bstore4(c.ps1, o, cur.w[1][0], cur.w[1][1], cur.w[1][2], 0.f);
         }
+        // target pixel + its window statistics of row py = yy-1 (window rows yy-2, yy-1, yy), once for all scales,
+        // both source frames, forward and backward
+        Row mid = r_new;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) mid.st[ch] = target_stat(r_old.t[ch], r_new.t[ch], cur.t[ch]);
+        const int py = yy - 1;
+        const bool out_ok = i >= 2 && py < H && lane_ok;
+        if (out_ok) {
+            const unsigned o = (unsigned)(py * W + x) * 48u;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(i4, (f4v){mid.t[ch], mid.st[ch].mu_y, mid.st[ch].sig_y_c2, mid.st[ch].mu_yy_c1}), c.ptg,
+                    (int)o, ch * 16, 0);
+        }
         if (IDENT) {
             float r[2];
-            reproj_values(r_old, r_new, cur, no_ssim, r);
-            const int py = yy - 1;
-            if (i >= 2 && py < H && lane_ok) {
+            reproj_values<true>(r_old, mid, cur, no_ssim, r);
+            if (out_ok) {
                 const unsigned o = (unsigned)(py * W + x);
                 if (avg) bstore(idl, o * 4u, 0, (r[0] + r[1]) * 0.5f);
                 else bstore2(idl, o * 8u, r[0], r[1]);
@@ -444,6 +479,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
     const int x = blockIdx.x * 62 - 1 + lane;
+    const int R_ROWS = p.rows_f;
     const int y0 = blockIdx.y * R_ROWS;
     const int H = p.H, W = p.W;
     const int xr = reflect_clamp(x, W);
@@ -505,7 +541,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
             if (float* dep = p.depth[s]) dep[(size_t)b * plane + o] = lg_cur.depth;
         }
         float r[2];
-        reproj_values(r_old, r_new, cur, no_ssim, r);
+        reproj_values<true>(r_old, r_new, cur, no_ssim, r);
         const int py = yy - 1;
         if (i >= 2 && py < H && lane_ok) {
             // ---- min over [identity(-1), identity(+1), reproj(-1), reproj(+1)]  (trainer.py:592-610)
@@ -679,6 +715,7 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
     const int x = blockIdx.x * 60 - 2 + lane;
+    const int R_ROWS = p.rows_b;
     const int y0 = blockIdx.y * R_ROWS;
     const int H = p.H, W = p.W;
     const int xr = reflect_clamp(x, W);
@@ -741,7 +778,10 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
             }
         }
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) cur.t[ch] = tp.t[ch];
+        for (int ch = 0; ch < 3; ++ch) {
+            cur.t[ch] = tp.ts[ch].x;
+            cur.st[ch].mu_y = tp.ts[ch].y; cur.st[ch].sig_y_c2 = tp.ts[ch].z; cur.st[ch].mu_yy_c1 = tp.ts[ch].w;
+        }
         const int m_cur = m_in;
         // ---------------- all loads of the step: row yy+1 (taps, target, argmin) and disparity of row yy+2
         issue_row<1, false>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), nolog,
@@ -751,42 +791,72 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
 
         // ---------------- stage B: SSIM derivative coefficients at row p = yy-1 (window rows yy-2, yy-1, yy)
         float g_tmp[2][3];
-        {
-            const int py = yy - 1;
-            float gs[2] = {0.f, 0.f};
-            if (i >= 2 && py >= 0 && py < H && col_ok) {
 #pragma unroll
-                for (int f = 0; f < 2; ++f) gs[f] = (sel_all || m_new == selv[f]) ? sel_val * g_ssim : 0.f;
-            }
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) g_tmp[f][ch] = 0.f;
+        if (i >= 2) {            // (the first two steps only fill the window)
+            const int py = yy - 1;
+            const bool p_ok = py >= 0 && py < H && col_ok;
             const float fu = (yy == 1) ? 2.f : 1.f;          // fold-back for q = yy   (p = q-1)
             const float fd = (yy - 2 == H - 2) ? 2.f : 1.f;  // fold-back for q = yy-2 (p = q+1)
+            // derivative coefficients of one (channel, frame) from its window statistics
+            auto coeffs = [&](const TStat& ts, const WStat& t, float gsel, float& a, float& bb, float& cc) {
+                const float n = t.n1 * t.n2;
+                const float id = frcp(t.d1 * t.d2);
+                const float nid = n * id;
+                const float v = fmaf(-0.5f, nid, 0.5f);
+                // clamp(.,0,1) passes the gradient inclusively
+                const float G = (v >= 0.f && v <= 1.f) ? gsel : 0.f;
+                const float Gid = G * id;
+                // d/d mu_x | d/d E[xx] | d/d E[xy]   (E[.] held fixed for mu_x)
+                a = Gid * fmaf(nid * t.mu_x, t.d2 - t.d1, -ts.mu_y * (t.n2 - t.n1));
+                bb = 0.5f * Gid * nid * t.d1;
+                cc = -Gid * t.n1;
+            };
+            // transposed 3x3: along x across lanes, along y onto the pending rows q = p-1 (= yy-2), p (= yy-1), p+1 (= yy)
+            auto spread = [&](int f, int ch, float a, float bb, float cc) {
+                const float ka = fmaf(fr, from_right(a), fmaf(fl, from_left(a), a));
+                const float kb = fmaf(fr, from_right(bb), fmaf(fl, from_left(bb), bb));
+                const float kc = fmaf(fr, from_right(cc), fmaf(fl, from_left(cc), cc));
+                const float kb2 = kb + kb;
+                g_old.g[f][ch] = fmaf(fd, fmaf(r_old.t[ch], kc, fmaf(r_old.w[f][ch], kb2, ka)), g_old.g[f][ch]);
+                g_new.g[f][ch] += fmaf(r_new.t[ch], kc, fmaf(r_new.w[f][ch], kb2, ka));
+                g_tmp[f][ch] = fu * fmaf(cur.t[ch], kc, fmaf(cur.w[f][ch], kb2, ka));   // fresh accumulator of row yy
+            };
+            if (sel_all || avg) {
+                // avg_reprojection: both frames carry half of the gradient
+                float gs[2];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const TStat ts = target_stat(r_old.t[ch], r_new.t[ch], cur.t[ch]);
+                for (int f = 0; f < 2; ++f) gs[f] = (p_ok && (sel_all || m_new == selv[f])) ? sel_val * g_ssim : 0.f;
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    const WStat t = warp_stat(ts, r_old.w[f][ch], r_new.w[f][ch], cur.w[f][ch], r_old.t[ch],
-                                              r_new.t[ch], cur.t[ch]);
-                    const float n = t.n1 * t.n2;
-                    const float id = frcp(t.d1 * t.d2);
-                    const float nid = n * id;
-                    const float v = fmaf(-0.5f, nid, 0.5f);
-                    // clamp(.,0,1) passes the gradient inclusively
-                    const float G = (v >= 0.f && v <= 1.f) ? gs[f] : 0.f;
-                    const float Gid = G * id;
-                    // d/d mu_x | d/d E[xx] | d/d E[xy]   (E[.] held fixed for mu_x)
-                    const float a = Gid * fmaf(nid * t.mu_x, t.d2 - t.d1, -ts.mu_y * (t.n2 - t.n1));
-                    const float bb = 0.5f * Gid * nid * t.d1;
-                    const float cc = -Gid * t.n1;
-                    // transposed 3x3 along x ...
-                    const float ka = fmaf(fr, from_right(a), fmaf(fl, from_left(a), a));
-                    const float kb = fmaf(fr, from_right(bb), fmaf(fl, from_left(bb), bb));
-                    const float kc = fmaf(fr, from_right(cc), fmaf(fl, from_left(cc), cc));
-                    const float kb2 = kb + kb;
-                    // ... and along y: row p feeds the pending rows q = p-1 (= yy-2), p (= yy-1), p+1 (= yy)
-                    g_old.g[f][ch] = fmaf(fd, fmaf(r_old.t[ch], kc, fmaf(r_old.w[f][ch], kb2, ka)), g_old.g[f][ch]);
-                    g_new.g[f][ch] += fmaf(r_new.t[ch], kc, fmaf(r_new.w[f][ch], kb2, ka));
-                    g_tmp[f][ch] = fu * fmaf(cur.t[ch], kc, fmaf(cur.w[f][ch], kb2, ka));   // fresh accumulator of row yy
+                for (int ch = 0; ch < 3; ++ch) {
+                    const TStat ts = r_new.st[ch];
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const WStat t = warp_stat(ts, r_old.w[f][ch], r_new.w[f][ch], cur.w[f][ch], r_old.t[ch], r_new.t[ch],
+                                                  cur.t[ch]);
+                        float a, bb, cc;
+                        coeffs(ts, t, gs[f], a, bb, cc);
+                        spread(f, ch, a, bb, cc);
+                    }
+                }
+            } else {
+                // min(): the argmin map routes the gradient of pixel p to at most ONE frame; the other frame's coefficients
+                // are exactly zero, so the window statistics and the derivative are evaluated for the selected frame only
+                const bool s1 = m_new == selv[1];
+                const float gsel = (p_ok && (s1 || m_new == selv[0])) ? sel_val * g_ssim : 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const TStat ts = r_new.st[ch];
+                    const float xa = s1 ? r_old.w[1][ch] : r_old.w[0][ch];
+                    const float xb = s1 ? r_new.w[1][ch] : r_new.w[0][ch];
+                    const float xc = s1 ? cur.w[1][ch] : cur.w[0][ch];
+                    const WStat t = warp_stat(ts, xa, xb, xc, r_old.t[ch], r_new.t[ch], cur.t[ch]);
+                    float a, bb, cc;
+                    coeffs(ts, t, gsel, a, bb, cc);
+                    spread(0, ch, s1 ? 0.f : a, s1 ? 0.f : bb, s1 ? 0.f : cc);
+                    spread(1, ch, s1 ? a : 0.f, s1 ? bb : 0.f, s1 ? cc : 0.f);
                 }
             }
         }
@@ -1008,21 +1078,42 @@ static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Carve {
     size_t idl, pk[3], part_photo, part_smooth, stats, gdup[DC_MAX_SCALES], part_dP, total;
-    int nblk_f, nchunk, nblk_b_img, strips_f, strips_b, rowblocks;
+    int nblk_f, nchunk, nblk_b_img, strips_f, strips_b, rows_f, rows_b, rowblocks_f, rowblocks_b;
 };
+
+// Rows a wave marches per block.  A block costs (rows + halo) row-steps and the grid runs in ceil(blocks / slots) rounds
+// (slots = 256 CUs x resident blocks per CU): pick the row count that minimises rounds x (rows + halo) -- at 192 x 640,
+// B = 12 the 16-row blocks of round 1 needed 4 rounds of 20 row-steps in the backward, 64-row blocks need 1 round of 68.
+static int pick_rows(int H, int strips, int B, int halo, int blocks_per_cu) {
+    static const int cand[] = {16, 24, 32, 48, 64, 96, 128};
+    const long slots = 256L * blocks_per_cu;
+    int best = 16;
+    long best_cost = -1;
+    for (int r : cand) {
+        if (r > 16 && r >= 2 * H) break;
+        const long blocks = (long)strips * ceil_div(H, r) * B;
+        const long cost = ceil_div((int)blocks, (int)slots) * (long)(r + halo);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
+    }
+    return best;
+}
 
 static Carve carve(const dc_photo_desc* d) {
     Carve c;
     const size_t N = (size_t)d->B * d->H * d->W;
     c.strips_f = ceil_div(d->W, 62);
     c.strips_b = ceil_div(d->W, 60);
-    c.rowblocks = ceil_div(d->H, R_ROWS);
-    c.nblk_f = c.strips_f * c.rowblocks * d->B;
-    c.nblk_b_img = c.strips_b * c.rowblocks;
+    c.rows_f = pick_rows(d->H, c.strips_f, d->B, 2, FWD_BLOCKS_PER_CU);
+    c.rows_b = pick_rows(d->H, c.strips_b, d->B, 4, BWD_BLOCKS_PER_CU);
+    c.rowblocks_f = ceil_div(d->H, c.rows_f);
+    c.rowblocks_b = ceil_div(d->H, c.rows_b);
+    c.nblk_f = c.strips_f * c.rowblocks_f * d->B;
+    c.nblk_b_img = c.strips_b * c.rowblocks_b;
     c.nchunk = ceil_div(d->H * d->W, SM_CHUNK);
     size_t off = 0;
     c.idl = off; off += align256(N * 2 * 4);
-    for (int k = 0; k < 3; ++k) { c.pk[k] = off; off += align256(N * 16); }
+    c.pk[0] = off; off += align256(N * 48);           // target + window statistics: 3 channels x 4 floats
+    for (int k = 1; k < 3; ++k) { c.pk[k] = off; off += align256(N * 16); }
     c.part_photo = off; off += align256((size_t)d->num_scales * c.nblk_f * 4);
     c.part_smooth = off; off += align256((size_t)d->num_scales * d->B * c.nchunk * 3 * 4);
     c.stats = off; off += align256((size_t)d->num_scales * d->B * 3 * 4);
@@ -1087,6 +1178,7 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
     a.stats = (float*)(ws + c.stats);
     a.part_dP = (float*)(ws + c.part_dP);
     a.nblk_f = c.nblk_f; a.nchunk = c.nchunk; a.nblk_b_img = c.nblk_b_img;
+    a.rows_f = c.rows_f; a.rows_b = c.rows_b;
     return DC_OK;
 }
 
@@ -1182,9 +1274,9 @@ extern "C" int dc_photo_fwd(const dc_photo_desc* d, void* stream) {
     for (int s = 0; s < a.ns; ++s) logs = logs || a.depth[s] || a.sample[s][0] || a.sample[s][1] || a.color[s][0] || a.color[s][1];
     hipEvent_t pe = prof_begin(0, st);
     if (logs)
-        hipLaunchKernelGGL(photo_fwd_kernel<true>, dim3(c.strips_f, c.rowblocks, a.B), dim3(64 * a.ns), 0, st, a);
+        hipLaunchKernelGGL(photo_fwd_kernel<true>, dim3(c.strips_f, c.rowblocks_f, a.B), dim3(64 * a.ns), 0, st, a);
     else
-        hipLaunchKernelGGL(photo_fwd_kernel<false>, dim3(c.strips_f, c.rowblocks, a.B), dim3(64 * a.ns), 0, st, a);
+        hipLaunchKernelGGL(photo_fwd_kernel<false>, dim3(c.strips_f, c.rowblocks_f, a.B), dim3(64 * a.ns), 0, st, a);
     prof_end(pe, st);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, a);
@@ -1202,7 +1294,7 @@ extern "C" int dc_photo_bwd(const dc_photo_desc* d, void* stream) {
     const size_t lds = (size_t)a.ns * BWD_LDS_PER_WAVE * sizeof(float);
     hipEvent_t pc = prof_begin(3, st);
     hipEvent_t pe = prof_begin(1, st);
-    hipLaunchKernelGGL(photo_bwd_kernel, dim3(c.strips_b, c.rowblocks, a.B), dim3(64 * a.ns), lds, st, a);
+    hipLaunchKernelGGL(photo_bwd_kernel, dim3(c.strips_b, c.rowblocks_b, a.B), dim3(64 * a.ns), lds, st, a);
     prof_end(pe, st);
     DC_CHECK_LAUNCH();
     {
