@@ -271,6 +271,23 @@ int dc_conv1x1_bias_act_fwd(const float* x, const float* weight, const float* bi
                             int stride, int act, void* stream);
 int dc_bias_act_bwd(const float* y, const float* gy, float* gpre, float* dbias, int B, int C, int P, int act, void* stream);
 
+/* The strided convolutions of the trunks (networks/resnet_encoder.py:87-98 via torchvision): ksize 7 = the 7x7 / 2 stem
+ * (padding 3, Ci = 3 or 6), ksize 3 = the 3x3 / 2 first convolution of layer2-4 (padding 1); no bias.  Implicit GEMMs on
+ * the fp32 matrix cores straight on NCHW (no im2col tensor, no layout transposes), exact fp32 products, deterministic.
+ * x (B,Ci,Hi,Wi) with even Hi, Wi and (Wi/2) % 4 == 0 (dc_convs2_supported); weight (Co,Ci,k,k); y / gy
+ * (B,Co,Hi/2,Wi/2).  dgrad exists for ksize 3 (Ci % 4 == 0, Co % 32 == 0); the stem's input is the image.
+ * ws: the matching *_workspace bytes (re-laid-out weights / split-reduction slabs). */
+int dc_convs2_supported(int B, int Ci, int Co, int Hi, int Wi, int ksize);
+size_t dc_convs2_fwd_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize);
+int dc_convs2_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int Hi, int Wi, int ksize,
+                  void* stream);
+size_t dc_convs2_dgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize);
+int dc_convs2_dgrad(const float* gy, const float* weight, float* dx, void* ws, int B, int Ci, int Co, int Hi, int Wi, int ksize,
+                    void* stream);
+size_t dc_convs2_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize);
+int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int ksize,
+                    void* stream);
+
 /* ------------------------------------------------------------------ f1 Fusion_v3 front-end */
 /* AttentionConv of networks/fusion_v2.py:46-98 as instantiated by ResidualAttentionUnit (:101-137): kernel 3, stride 1,
  * padding 1, groups 1, bias=True, C = 2 or 4 channels.  One fused kernel per direction (no q / k / v / unfold / softmax

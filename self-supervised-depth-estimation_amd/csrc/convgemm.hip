@@ -1,0 +1,503 @@
+// The strided convolutions of the ResNet trunks -- the 7x7 / 2 stem (3 or 6 input channels) and the 3x3 / 2 first
+// convolution of layer2-4 (reference networks/resnet_encoder.py:87-98 via torchvision) -- as implicit GEMMs on the tiled
+// fp32-MFMA kernels of gemm_tiles.h, straight on the NCHW tensors: no im2col tensor, no NHWC transposes, exact fp32
+// products with fp32 accumulation (the library's weight gradient of the stem was measured 1 % off an fp64 reference).
+//
+//   forward   y[b,co,oy,ox]  = sum_{ci,ky,kx} w[co,ci,ky,kx] * x[b,ci,2oy+ky-p,2ox+kx-p]        p = KS/2, zero padding
+//     GEMM: M = co, N = flattened (b,oy,ox), reduction k = (ci,ky,kx) -- the (Co, Ci*KS*KS) weight matrix as it lies in
+//     memory is the A operand (rows padded to a multiple of the 32-wide chunk for the stem: K = 147 / 294); the B tile is
+//     gathered by the loader: row k of the chunk -> (ci,ky,kx), four consecutive output pixels -> four stride-2 taps.
+//   weight gradient   dw[co,(ci,ky,kx)] = sum_n gy[co,n] * x[..]: M = co, N = (ci,ky,kx), reduction = pixels, split over
+//     blocks with a fixed-order slab reduce; the B rows are gathered the same way (row -> tap fixed, pixel group per chunk).
+//   data gradient (3x3 only; the stem's input is the image)   dx[b,ci,2oy+dy,2ox+dx] = sum over the taps whose parity
+//     matches: (dy,dx) = (0,0): 1 tap, (0,1) / (1,0): 2 taps, (1,1): 4 taps -- 9 taps per 4 input pixels, nothing multiplied
+//     by a structural zero.  One block owns an output-grid pixel tile and one row parity dy and keeps BOTH column parities
+//     in registers, so it stores whole 32-byte runs of dx.  Weights are re-laid out once per call to [tap][co][ci].
+// All three are deterministic (no atomics).
+#include "dc_common.h"
+#include "gemm_tiles.h"
+
+#include <algorithm>
+
+namespace dc {
+
+struct CgArgs {
+    const float* w;       // forward: (Co, Kp) rows; dgrad: [tap][Co][Ci]
+    const float* x;       // (B, Ci, Hi, Wi)
+    const float* gy;      // (B, Co, Ho, Wo)
+    float* out;
+    int B, Co, Ci, Hi, Wi, Ho, Wo;
+    int K, Kp;            // Ci * KS * KS and its padded row length in `w`
+    int mtiles, ntiles;
+    int splits, chunks;   // weight gradient
+};
+
+// four stride-2 taps of one input row: x[ix0], x[ix0+2], x[ix0+4], x[ix0+6] with zero padding outside [0, Wi)
+__device__ __forceinline__ gf4 gather4_s2(const float* row, int ix0, int Wi, bool row_ok) {
+    gf4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row_ok) {
+        if (ix0 >= 0 && ix0 < Wi) v.x = row[ix0];
+        if (ix0 + 2 >= 0 && ix0 + 2 < Wi) v.y = row[ix0 + 2];
+        if (ix0 + 4 >= 0 && ix0 + 4 < Wi) v.z = row[ix0 + 4];
+        if (ix0 + 6 >= 0 && ix0 + 6 < Wi) v.w = row[ix0 + 6];
+    }
+    return v;
+}
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+template <int MT, int NT, int KS>
+__global__ __launch_bounds__(256) void cg_fwd_kernel(CgArgs a) {
+    constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SB = IdxStride<NT, BN>::v, T = KS * KS, PAD = KS / 2;
+    constexpr int NA = BM * KC / 1024, NB = KC * BN / 1024;
+    constexpr int ASZ = BM * (KC + RP), BSZ = KC * SB;
+    float* const As = g1_smem;
+    float* const Bs = g1_smem + 2 * ASZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int m0 = (lb % a.mtiles) * BM, n0 = (lb / a.mtiles) * BN;
+    const int P = a.Ho * a.Wo, N = a.B * P;
+    const size_t plane = (size_t)a.Hi * a.Wi;
+
+    const float* asrc[NA];
+    int adst[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int idx = tid + j * 256, row = idx / (KC / 4), kq = idx % (KC / 4);
+        asrc[j] = a.w + (size_t)min(m0 + row, a.Co - 1) * a.Kp + kq * 4;
+        adst[j] = row * (KC + RP) + kq * 4;
+    }
+    // B: all of a thread's rows share one pixel group (c4 is the same for every j: 256 % (BN/4) == 0)
+    const int c4 = tid % (BN / 4), krow0 = tid / (BN / 4);
+    const int ng = min(n0 + c4 * 4, N - 4);
+    const int b = ng / P, pp = ng - b * P, py = pp / a.Wo, px0 = pp - py * a.Wo;
+    const float* xb = a.x + (size_t)b * a.Ci * plane;
+    const int iy0 = 2 * py - PAD, ix0 = 2 * px0 - PAD;
+    gf4 ra[NA], rb[NB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j] + k0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int k = k0 + krow0 + j * (1024 / BN);
+            const int ci = k / T, tap = k - ci * T, ky = tap / KS, kx = tap - ky * KS;
+            const int iy = iy0 + ky;
+            const bool ok = k < a.K && iy >= 0 && iy < a.Hi;
+            rb[j] = gather4_s2(xb + (size_t)min(ci, a.Ci - 1) * plane + (size_t)max(min(iy, a.Hi - 1), 0) * a.Wi, ix0 + kx, a.Wi, ok);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) store_red4(As + buf * ASZ + adst[j], ra[j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<gf4*>(Bs + buf * BSZ + (krow0 + j * (1024 / BN)) * SB + c4 * 4) = rb[j];
+    };
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
+    const int nchunk = a.Kp / KC;
+    gload(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload((c + 1) * KC);
+#pragma unroll
+        for (int q = 0; q < KC / 8; ++q) {
+            float av[4][2], bv[4][2];
+            read_red<MT, KC>(As + buf * ASZ, wm * 16 * MT, q, lane, av);
+            read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, bv);
+            mma_octet<MT, NT>(av, bv, acc);
+        }
+        if (c + 1 < nchunk) commit(buf ^ 1);
+        __syncthreads();
+    }
+    const int j = lane & 15;
+    const int n = n0 + wn * 16 * NT + j * NT;
+    if (n < N) {
+        const int bo = n / P, p = n - bo * P;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
+                if (m >= a.Co) continue;
+                float* dst = a.out + ((size_t)bo * a.Co + m) * P + p;
+                if constexpr (NT == 4) *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                else *reinterpret_cast<gf2*>(dst) = gf2{acc[mt][0][r], acc[mt][1][r]};
+            }
+    }
+}
+
+// =====================================================================================================================
+// weight gradient: rows = co, cols = (ci,ky,kx), reduction = flattened output pixels (a partial last chunk contributes
+// zeros through the gy operand)
+// =====================================================================================================================
+template <int MT, int NT, int KS>
+__global__ __launch_bounds__(256) void cg_wgrad_kernel(CgArgs a) {
+    constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, T = KS * KS, PAD = KS / 2;
+    constexpr int NA = BM * KC / 1024, NB = BN * KC / 1024;
+    constexpr int ASZ = BM * (KC + RP), BSZ = BN * (KC + RP);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = (blockIdx.x % a.mtiles) * BM, c0 = (blockIdx.x / a.mtiles) * BN;
+    const int P = a.Ho * a.Wo;
+    const size_t plane = (size_t)a.Hi * a.Wi;
+    const int kq = tid % (KC / 4), row0 = tid / (KC / 4);
+    size_t arow[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) arow[j] = (size_t)min(m0 + row0 + j * (1024 / KC), a.Co - 1) * P;
+    // this thread's B rows: column r of dw <-> (ci, ky, kx), fixed for the whole loop
+    size_t bch[NB];
+    int bky[NB], bkx[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int r = min(c0 + row0 + j * (1024 / KC), a.K - 1);
+        const int ci = r / T, tap = r - ci * T;
+        bky[j] = tap / KS - PAD;
+        bkx[j] = tap - (tap / KS) * KS - PAD;
+        bch[j] = (size_t)ci * plane;
+    }
+    gf4 ra[NA], rb[NB];
+    const int Ntot = a.B * P;
+    auto gload = [&](int ch) {
+        const int n_ = ch * KC + kq * 4;
+        const bool okn = n_ < Ntot;
+        const int n = min(n_, Ntot - 4);
+        const int b = n / P, p = n - b * P, py = p / a.Wo, px0 = p - py * a.Wo;
+        const float* ga = a.gy + (size_t)b * a.Co * P + p;
+        const float* xb = a.x + (size_t)b * a.Ci * plane;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) ra[j] = okn ? *reinterpret_cast<const gf4*>(ga + arow[j]) : gf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int iy = 2 * py + bky[j];
+            const bool ok = iy >= 0 && iy < a.Hi;
+            rb[j] = gather4_s2(xb + bch[j] + (size_t)max(min(iy, a.Hi - 1), 0) * a.Wi, 2 * px0 + bkx[j], a.Wi, ok);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) store_red4(g1_smem + buf * ASZ + (row0 + j * (1024 / KC)) * (KC + RP) + kq * 4, ra[j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            store_red4(g1_smem + 2 * ASZ + buf * BSZ + (row0 + j * (1024 / KC)) * (KC + RP) + kq * 4, rb[j]);
+    };
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
+    const int per = (a.chunks + a.splits - 1) / a.splits;
+    const int ch0 = blockIdx.y * per, ch1 = min(ch0 + per, a.chunks);
+    if (ch0 < ch1) {
+        gload(ch0);
+        commit(0);
+    }
+    __syncthreads();
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int buf = (ch - ch0) & 1;
+        const bool more = ch + 1 < ch1;
+        if (more) gload(ch + 1);
+#pragma unroll
+        for (int q = 0; q < KC / 8; ++q) {
+            float av[4][2], bv[4][2];
+            read_red<MT, KC>(g1_smem + buf * ASZ, wm * 16 * MT, q, lane, av);
+            read_red<NT, KC>(g1_smem + 2 * ASZ + buf * BSZ, wn * 16 * NT, q, lane, bv);
+            mma_octet<MT, NT>(av, bv, acc);
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+    }
+    float* slab = a.out + (size_t)blockIdx.y * a.Co * a.K;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
+                const int col = c0 + wn * 16 * NT + nt * 16 + (lane & 15);
+                if (m < a.Co && col < a.K) slab[(size_t)m * a.K + col] = acc[mt][nt][r];
+            }
+}
+
+__global__ __launch_bounds__(256) void cg_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float t = slab[i];
+    for (int s = 1; s < splits; ++s) t += slab[(size_t)s * n + i];
+    dw[i] = t;
+}
+
+// =====================================================================================================================
+// data gradient of the 3x3 / 2 convolution.  rows = ci, cols = output-grid pixels n = (b,oy,ox); blockIdx.y = row parity dy.
+// Reduction chunks: (tap, 32 output channels); A = wt[tap][co][ci] (index-contiguous), B = gy[co] shifted by the tap.
+// =====================================================================================================================
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void cg_dgrad3_kernel(CgArgs a) {
+    constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SA = IdxStride<MT, BM>::v, SB = IdxStride<NT, BN>::v;
+    constexpr int NA = KC * BM / 1024, NB = KC * BN / 1024;
+    constexpr int ASZ = KC * SA, BSZ = KC * SB;
+    float* const As = g1_smem;
+    float* const Bs = g1_smem + 2 * ASZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int m0 = (lb % a.mtiles) * BM, n0 = (lb / a.mtiles) * BN;
+    const int dy = blockIdx.y;
+    const int P = a.Ho * a.Wo, N = a.B * P;
+
+    const float* asrc[NA];
+    int adst[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int idx = tid + j * 256, k = idx / (BM / 4), c4 = idx % (BM / 4);
+        asrc[j] = a.w + (size_t)k * a.Ci + min(m0 + c4 * 4, a.Ci - 4);
+        adst[j] = k * SA + c4 * 4;
+    }
+    const int c4 = tid % (BN / 4), krow0 = tid / (BN / 4);
+    const int ng = min(n0 + c4 * 4, N - 4);
+    const int b = ng / P, pp = ng - b * P, oy = pp / a.Wo, ox0 = pp - oy * a.Wo;
+    const float* gb = a.gy + (size_t)b * a.Co * P;
+    // chunk list of this row parity: dy = 0 -> ky = 1; dy = 1 -> ky = 0 (reads gy row oy+1) and ky = 2 (row oy)
+    const int nky = dy ? 2 : 1;
+    const int cpt = a.Co / KC;                 // chunks per tap
+    const int nchunk = nky * 3 * cpt;
+    gf4 ra[NA], rb[NB];
+    auto tap_of = [&](int c, int& ky, int& kx, int& co0) {
+        const int t = c / cpt;
+        co0 = (c - t * cpt) * KC;
+        ky = dy ? (t / 3) * 2 : 1;
+        kx = t % 3;
+    };
+    auto gload = [&](int c) {
+        int ky, kx, co0;
+        tap_of(c, ky, kx, co0);
+        const float* wt = a.w + (size_t)(ky * 3 + kx) * a.Co * a.Ci + (size_t)co0 * a.Ci;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j] + (wt - a.w));
+        // input pixel (2oy+dy, 2ox+dxp) takes tap (ky,kx) from gy[(2oy+dy+1-ky)/2][(2ox+dxp+1-kx)/2]
+        const int sy = (dy + 1 - ky) / 2, sx = (kx == 0) ? 1 : 0;      // kx = 1: dxp 0, shift 0; kx = 0: dxp 1, shift 1; kx = 2: dxp 1, shift 0
+        const int gyr = oy + sy;
+        const bool rok = gyr < a.Ho;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float* row = gb + (size_t)(co0 + krow0 + j * (1024 / BN)) * P + (size_t)min(gyr, a.Ho - 1) * a.Wo;
+            gf4 v = {0.f, 0.f, 0.f, 0.f};
+            if (rok) {
+                if (sx == 0) {
+                    v = *reinterpret_cast<const gf4*>(row + ox0);
+                } else {
+                    v.x = row[ox0 + 1]; v.y = row[ox0 + 2]; v.z = row[ox0 + 3];
+                    if (ox0 + 4 < a.Wo) v.w = row[ox0 + 4];
+                }
+            }
+            rb[j] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) *reinterpret_cast<gf4*>(As + buf * ASZ + adst[j]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<gf4*>(Bs + buf * BSZ + (krow0 + j * (1024 / BN)) * SB + c4 * 4) = rb[j];
+    };
+    gf4 acc[2][MT][NT];          // [column parity]
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[d][mt][nt] = gf4{0, 0, 0, 0};
+    gload(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+        int ky, kx, co0;
+        tap_of(c, ky, kx, co0);
+        if (kx == 1) {
+#pragma unroll
+            for (int q = 0; q < KC / 8; ++q) {
+                float av[4][2], bv[4][2];
+                read_idx<MT, SA>(As + buf * ASZ, wm * 16 * MT, q, lane, av);
+                read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, bv);
+                mma_octet<MT, NT>(av, bv, acc[0]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < KC / 8; ++q) {
+                float av[4][2], bv[4][2];
+                read_idx<MT, SA>(As + buf * ASZ, wm * 16 * MT, q, lane, av);
+                read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, bv);
+                mma_octet<MT, NT>(av, bv, acc[1]);
+            }
+        }
+        if (c + 1 < nchunk) commit(buf ^ 1);
+        __syncthreads();
+    }
+    const int j = lane & 15;
+    const int n = n0 + wn * 16 * NT + j * NT;
+    if (n >= N) return;
+    const int bo = n / P, p = n - bo * P, qy = p / a.Wo, qx = p - qy * a.Wo;
+    const size_t plane = (size_t)a.Hi * a.Wi;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = m0 + wm * 16 * MT + ((lane >> 4) * 4 + r) * MT + mt;
+            if (ci >= a.Ci) continue;
+            float* dst = a.out + ((size_t)bo * a.Ci + ci) * plane + (size_t)(2 * qy + dy) * a.Wi + 2 * qx;
+#pragma unroll
+            for (int h = 0; h < NT / 2; ++h)
+                *reinterpret_cast<gf4*>(dst + 4 * h) =
+                    gf4{acc[0][mt][2 * h][r], acc[1][mt][2 * h][r], acc[0][mt][2 * h + 1][r], acc[1][mt][2 * h + 1][r]};
+        }
+}
+
+// ---- weight re-layouts (once per call; a few hundred KB) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void cg_wpad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int K, int Kp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Co * Kp) return;
+    const int co = i / Kp, k = i - co * Kp;
+    wp[i] = k < K ? w[(size_t)co * K + k] : 0.f;
+}
+__global__ __launch_bounds__(256) void cg_wt3_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int Ci) {
+    const int i = blockIdx.x * 256 + threadIdx.x;        // over [tap][co][ci]
+    if (i >= 9 * Co * Ci) return;
+    const int tap = i / (Co * Ci), r = i - tap * (Co * Ci), co = r / Ci, ci = r - co * Ci;
+    wt[i] = w[((size_t)co * Ci + ci) * 9 + tap];
+}
+
+struct CgTile { int mt, nt; };
+static size_t cg_lds_fwd(CgTile t) { return (size_t)2 * (32 * t.mt * (GKC + RP) + GKC * (t.nt == 4 ? 128 : 80)) * sizeof(float); }
+static size_t cg_lds_dgrad(CgTile t) { return (size_t)2 * GKC * ((t.mt == 4 ? 128 : 80) + (t.nt == 4 ? 128 : 80)) * sizeof(float); }
+static size_t cg_lds_wgrad(CgTile t) { return (size_t)2 * 32 * (t.mt + t.nt) * (GKC + RP) * sizeof(float); }
+static CgTile cg_pick(int M, int N) {
+    auto blocks = [&](int mt, int nt) { return (long)ceil_div(M, 32 * mt) * ceil_div(N, 32 * nt); };
+    if (M > 64 && blocks(4, 4) >= 500) return {4, 4};
+    if (blocks(2, 4) >= 300 || N >= 8 * M) return {2, 4};
+    return {2, 2};
+}
+static int cg_wsplits(int tiles, int chunks) {
+    const int s = std::max(1, std::min({chunks, ceil_div(768, tiles), 512}));
+    return ceil_div(chunks, ceil_div(chunks, s));
+}
+template <typename K>
+static bool cg_set_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
+}  // namespace dc
+
+using namespace dc;
+
+static bool cg_ok(int B, int Ci, int Co, int Hi, int Wi, int ks) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || Hi <= 0 || Wi <= 0 || (ks != 3 && ks != 7)) return false;
+    if ((Hi & 1) || (Wi & 1)) return false;
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    if (Wo & 3) return false;                           // 16-byte pixel groups inside one output row
+    if ((size_t)B * std::max(Ci, Co) * Hi * Wi >= (1ull << 31)) return false;
+    return true;
+}
+static int cg_kp(int Ci, int ks) { return ceil_div(Ci * ks * ks, GKC) * GKC; }
+
+extern "C" int dc_convs2_supported(int B, int Ci, int Co, int Hi, int Wi, int ksize) { return cg_ok(B, Ci, Co, Hi, Wi, ksize) ? 1 : 0; }
+
+extern "C" size_t dc_convs2_fwd_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize) {
+    if (!cg_ok(B, Ci, Co, Hi, Wi, ksize)) return 0;
+    const int K = Ci * ksize * ksize, Kp = cg_kp(Ci, ksize);
+    return Kp == K ? 16 : (size_t)Co * Kp * sizeof(float);
+}
+
+extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int Hi, int Wi, int ksize,
+                             void* stream) {
+    if (!x || !weight || !y || !ws || !cg_ok(B, Ci, Co, Hi, Wi, ksize)) return DC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    CgArgs a{};
+    a.x = x; a.out = y; a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
+    a.K = Ci * ksize * ksize; a.Kp = cg_kp(Ci, ksize);
+    if (a.Kp != a.K) {       // stem: rows of 147 / 294 floats are neither 16-byte aligned nor a multiple of the chunk
+        hipLaunchKernelGGL(cg_wpad_kernel, dim3(ceil_div(Co * a.Kp, 256)), dim3(256), 0, st, weight, (float*)ws, Co, a.K, a.Kp);
+        DC_CHECK_LAUNCH();
+        a.w = (const float*)ws;
+    } else {
+        a.w = weight;
+    }
+    const int N = B * a.Ho * a.Wo;
+    const CgTile t = cg_pick(Co, N);
+    a.mtiles = ceil_div(Co, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
+    const dim3 grid(a.mtiles * a.ntiles);
+    const size_t lds = cg_lds_fwd(t);
+    static const bool attr = cg_set_lds(cg_fwd_kernel<4, 4, 3>, cg_lds_fwd({4, 4})) && cg_set_lds(cg_fwd_kernel<4, 4, 7>, cg_lds_fwd({4, 4}));
+    if (!attr) return DC_ELAUNCH;
+#define CG_FWD(KS)                                                                                  \
+    do {                                                                                            \
+        if (t.mt == 4) hipLaunchKernelGGL((cg_fwd_kernel<4, 4, KS>), grid, dim3(256), lds, st, a);  \
+        else if (t.nt == 4) hipLaunchKernelGGL((cg_fwd_kernel<2, 4, KS>), grid, dim3(256), lds, st, a); \
+        else hipLaunchKernelGGL((cg_fwd_kernel<2, 2, KS>), grid, dim3(256), lds, st, a);            \
+    } while (0)
+    if (ksize == 3) CG_FWD(3); else CG_FWD(7);
+#undef CG_FWD
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" size_t dc_convs2_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize) {
+    if (!cg_ok(B, Ci, Co, Hi, Wi, ksize)) return 0;
+    const int K = Ci * ksize * ksize;
+    const int tiles = ceil_div(Co, 64) * ceil_div(K, 64);
+    const int splits = cg_wsplits(tiles, ceil_div(B * (Hi / 2) * (Wi / 2), GKC));
+    return splits > 1 ? (size_t)splits * Co * K * sizeof(float) : 16;
+}
+
+extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,
+                               int ksize, void* stream) {
+    if (!x || !gy || !dweight || !ws || !cg_ok(B, Ci, Co, Hi, Wi, ksize)) return DC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    CgArgs a{};
+    a.x = x; a.gy = gy; a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
+    a.K = Ci * ksize * ksize; a.Kp = a.K;
+    a.chunks = ceil_div(B * a.Ho * a.Wo, GKC);
+    a.mtiles = ceil_div(Co, 64); a.ntiles = ceil_div(a.K, 64);
+    a.splits = cg_wsplits(a.mtiles * a.ntiles, a.chunks);
+    a.out = a.splits > 1 ? (float*)ws : dweight;
+    const dim3 grid(a.mtiles * a.ntiles, a.splits);
+    const size_t lds = cg_lds_wgrad({2, 2});
+    if (ksize == 3) hipLaunchKernelGGL((cg_wgrad_kernel<2, 2, 3>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((cg_wgrad_kernel<2, 2, 7>), grid, dim3(256), lds, st, a);
+    DC_CHECK_LAUNCH();
+    if (a.splits > 1) {
+        const int n = Co * a.K;
+        hipLaunchKernelGGL(cg_slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, (const float*)ws, dweight, a.splits, n);
+        DC_CHECK_LAUNCH();
+    }
+    return DC_OK;
+}
+
+extern "C" size_t dc_convs2_dgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize) {
+    if (!cg_ok(B, Ci, Co, Hi, Wi, ksize) || ksize != 3 || (Ci & 3) || Co % GKC) return 0;
+    return (size_t)9 * Co * Ci * sizeof(float);
+}
+
+extern "C" int dc_convs2_dgrad(const float* gy, const float* weight, float* dx, void* ws, int B, int Ci, int Co, int Hi, int Wi,
+                               int ksize, void* stream) {
+    if (!gy || !weight || !dx || !ws || !dc_convs2_dgrad_workspace(B, Ci, Co, Hi, Wi, ksize)) return DC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cg_wt3_kernel, dim3(ceil_div(9 * Co * Ci, 256)), dim3(256), 0, st, weight, (float*)ws, Co, Ci);
+    DC_CHECK_LAUNCH();
+    CgArgs a{};
+    a.w = (const float*)ws; a.gy = gy; a.out = dx; a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
+    const int N = B * a.Ho * a.Wo;
+    // both column parities live in registers: 2 x (MT x NT) accumulator tiles -> 64 x 128 and 64 x 64 blocks only
+    const CgTile t = ((long)ceil_div(Ci, 64) * ceil_div(N, 128) * 2 >= 300) ? CgTile{2, 4} : CgTile{2, 2};
+    a.mtiles = ceil_div(Ci, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
+    const dim3 grid(a.mtiles * a.ntiles, 2);
+    const size_t lds = cg_lds_dgrad(t);
+    if (t.nt == 4) hipLaunchKernelGGL((cg_dgrad3_kernel<2, 4>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((cg_dgrad3_kernel<2, 2>), grid, dim3(256), lds, st, a);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}

@@ -32,15 +32,11 @@
 // tile is fetched from HBM once per XCD pass and re-served by that XCD's L2; the weights are L2-resident.
 #include "dc_common.h"
 #include "gemm1x1.h"
+#include "gemm_tiles.h"
 
 #include <algorithm>
 
 namespace dc {
-
-using gf4 = __attribute__((ext_vector_type(4))) float;
-using gf2 = __attribute__((ext_vector_type(2))) float;
-
-constexpr int GKC = 32;                // reduction chunk
 
 struct G1Args {
     const float* w;       // (Co, Ci)
@@ -53,57 +49,6 @@ struct G1Args {
     int mtiles, ntiles;   // tile grid
     int splits, chunks;   // weight gradient: reduction chunks in total, blocks along the reduction
 };
-
-// ---- LDS strides -------------------------------------------------------------------------------------
-// index-contiguous image [KC][W]: row stride so that the MT-wide reads of a 16-lane k-group are conflict-free
-// (a k-group pair of one 32-lane read group sits two reduction rows apart: element 2 k' + s)
-template <int T, int W>
-struct IdxStride { static constexpr int v = (T == 4) ? W : W + 16; };
-
-// ---- operand reads: fill a[t][s] for the two MFMA steps s of reduction octet q ---------------------------------
-// index-contiguous image: S[(red)][stride], tile t of lane i <-> index base + i * T + t
-template <int T, int STRIDE>
-__device__ __forceinline__ void read_idx(const float* S, int base, int q, int lane, float (&a)[4][2]) {
-    const int i = lane & 15, kp = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const float* p = S + (q * 8 + 2 * kp + s) * STRIDE + base + i * T;
-        if constexpr (T == 4) {
-            const gf4 v = *reinterpret_cast<const gf4*>(p);
-            a[0][s] = v.x; a[1][s] = v.y; a[2][s] = v.z; a[3][s] = v.w;
-        } else {
-            const gf2 v = *reinterpret_cast<const gf2*>(p);
-            a[0][s] = v.x; a[1][s] = v.y;
-        }
-    }
-}
-// reduction-contiguous image: S[(index)][KC + RP], tile t of lane i <-> index base + t * 16 + i
-constexpr int RP = 2;                  // row padding of the reduction-contiguous images (rows are 8-byte aligned)
-template <int T, int KC>
-__device__ __forceinline__ void read_red(const float* S, int base, int q, int lane, float (&a)[4][2]) {
-    const int i = lane & 15, kp = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const gf2 v = *reinterpret_cast<const gf2*>(S + (base + t * 16 + i) * (KC + RP) + q * 8 + 2 * kp);
-        a[t][0] = v.x; a[t][1] = v.y;
-    }
-}
-// 16 bytes into a reduction-contiguous image (its rows are only 8-byte aligned: two ds_write_b64)
-__device__ __forceinline__ void store_red4(float* p, gf4 v) {
-    *reinterpret_cast<gf2*>(p) = gf2{v.x, v.y};
-    *reinterpret_cast<gf2*>(p + 2) = gf2{v.z, v.w};
-}
-
-template <int MT, int NT>
-__device__ __forceinline__ void mma_octet(const float (&a)[4][2], const float (&b)[4][2], gf4 (&acc)[MT][NT]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
-}
 
 // ---- pixel addressing: element offset of (b, channel 0, first pixel) of a 4-pixel group of the flattened (b, p) dimension.
 // n is clamped to the last valid group (P % 4 == 0; stride 2: Wo % 4 == 0, so a group lies in one row).
@@ -120,8 +65,6 @@ __device__ __forceinline__ gf4 load_pix4(const float* plane_ptr, int s) {
     const gf4 u = *reinterpret_cast<const gf4*>(plane_ptr), v = *reinterpret_cast<const gf4*>(plane_ptr + 4);
     return gf4{u.x, u.z, v.x, v.z};
 }
-
-extern __shared__ float g1_smem[];
 
 // =====================================================================================================================
 // forward.  A = w [co][ci] (reduction-contiguous), B = x [ci][n] (index-contiguous).  Ci % KC == 0.

@@ -341,10 +341,17 @@ __device__ __forceinline__ TStat target_stat(float a, float b, float c) {
 struct WStat {
     float mu_x, n1, n2, d1, d2;
 };
-__device__ __forceinline__ WStat warp_stat(const TStat& ts, float xa, float xb, float xc, float ya, float yb, float yc) {
-    const float sx = hsum3(xa + xb + xc);
-    const float sxx = hsum3(fmaf(xa, xa, fmaf(xb, xb, xc * xc)));
-    const float sxy = hsum3(fmaf(xa, ya, fmaf(xb, yb, xc * yc)));
+struct WSums {
+    float sx, sxx, sxy;      // 3x3 window sums of x, x*x, x*y
+};
+__device__ __forceinline__ WSums warp_sums(float xa, float xb, float xc, float ya, float yb, float yc) {
+    WSums w;
+    w.sx = hsum3(xa + xb + xc);
+    w.sxx = hsum3(fmaf(xa, xa, fmaf(xb, xb, xc * xc)));
+    w.sxy = hsum3(fmaf(xa, ya, fmaf(xb, yb, xc * yc)));
+    return w;
+}
+__device__ __forceinline__ WStat warp_from_sums(const TStat& ts, float sx, float sxx, float sxy) {
     WStat s;
     s.mu_x = sx * k9;
     const float sig_x = fmaf(sxx, k9, -s.mu_x * s.mu_x);
@@ -354,6 +361,10 @@ __device__ __forceinline__ WStat warp_stat(const TStat& ts, float xa, float xb, 
     s.d1 = fmaf(s.mu_x, s.mu_x, ts.mu_yy_c1);
     s.d2 = sig_x + ts.sig_y_c2;
     return s;
+}
+__device__ __forceinline__ WStat warp_stat(const TStat& ts, float xa, float xb, float xc, float ya, float yb, float yc) {
+    const WSums w = warp_sums(xa, xb, xc, ya, yb, yc);
+    return warp_from_sums(ts, w.sx, w.sxx, w.sxy);
 }
 
 // 0.85 * mean_c SSIM + 0.15 * mean_c |t - w|  (trainer.py:517-529) for both frames; rows a,b,c = p-1,p,p+1
@@ -843,16 +854,16 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
                 }
             } else {
                 // min(): the argmin map routes the gradient of pixel p to at most ONE frame; the other frame's coefficients
-                // are exactly zero, so the window statistics and the derivative are evaluated for the selected frame only
+                // are exactly zero.  The window sums are taken for both frames (a pixel's window spans lanes that may have
+                // chosen the other frame), the statistics and the derivative only for the selected one.
                 const bool s1 = m_new == selv[1];
                 const float gsel = (p_ok && (s1 || m_new == selv[0])) ? sel_val * g_ssim : 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     const TStat ts = r_new.st[ch];
-                    const float xa = s1 ? r_old.w[1][ch] : r_old.w[0][ch];
-                    const float xb = s1 ? r_new.w[1][ch] : r_new.w[0][ch];
-                    const float xc = s1 ? cur.w[1][ch] : cur.w[0][ch];
-                    const WStat t = warp_stat(ts, xa, xb, xc, r_old.t[ch], r_new.t[ch], cur.t[ch]);
+                    const WSums w0 = warp_sums(r_old.w[0][ch], r_new.w[0][ch], cur.w[0][ch], r_old.t[ch], r_new.t[ch], cur.t[ch]);
+                    const WSums w1 = warp_sums(r_old.w[1][ch], r_new.w[1][ch], cur.w[1][ch], r_old.t[ch], r_new.t[ch], cur.t[ch]);
+                    const WStat t = warp_from_sums(ts, s1 ? w1.sx : w0.sx, s1 ? w1.sxx : w0.sxx, s1 ? w1.sxy : w0.sxy);
                     float a, bb, cc;
                     coeffs(ts, t, gsel, a, bb, cc);
                     spread(0, ch, s1 ? 0.f : a, s1 ? 0.f : bb, s1 ? 0.f : cc);
@@ -1081,19 +1092,20 @@ struct Carve {
     int nblk_f, nchunk, nblk_b_img, strips_f, strips_b, rows_f, rows_b, rowblocks_f, rowblocks_b;
 };
 
-// Rows a wave marches per block.  A block costs (rows + halo) row-steps and the grid runs in ceil(blocks / slots) rounds
-// (slots = 256 CUs x resident blocks per CU): pick the row count that minimises rounds x (rows + halo) -- at 192 x 640,
-// B = 12 the 16-row blocks of round 1 needed 4 rounds of 20 row-steps in the backward, 64-row blocks need 1 round of 68.
+// Rows a wave marches per block.  Taller blocks spend fewer steps on the halo rows (a block costs rows + halo row-steps),
+// but the kernels are VALU-bound and need about two resident waves per SIMD: the tallest candidate that still leaves at
+// least 1.5 blocks per resident slot (256 CUs x blocks per CU) keeps the chip full for most of the launch.  (Measured at
+// 192 x 640, B = 12: 64-row blocks -- 396 blocks on 512 slots -- dropped the VALU pipe from 90 % to 67 % busy.)
 static int pick_rows(int H, int strips, int B, int halo, int blocks_per_cu) {
-    static const int cand[] = {16, 24, 32, 48, 64, 96, 128};
+    static const int cand[] = {16, 24, 32, 48, 64};
     const long slots = 256L * blocks_per_cu;
     int best = 16;
-    long best_cost = -1;
+    long best_work = (long)strips * ceil_div(H, 16) * B * (16 + halo);
     for (int r : cand) {
-        if (r > 16 && r >= 2 * H) break;
         const long blocks = (long)strips * ceil_div(H, r) * B;
-        const long cost = ceil_div((int)blocks, (int)slots) * (long)(r + halo);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
+        if (2 * blocks < 3 * slots) continue;
+        const long work = blocks * (r + halo);
+        if (work < best_work) { best_work = work; best = r; }
     }
     return best;
 }

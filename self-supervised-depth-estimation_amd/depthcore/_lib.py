@@ -113,6 +113,13 @@ def _sig(lib):
         "dc_conv_profile_collect": (i, [i, p, p, p, p, p]),
         "dc_wino3x3_wgrad_workspace": (z, [i, i, i, i, i]),
         "dc_wino3x3_wgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
+        "dc_convs2_supported": (i, [i, i, i, i, i, i]),
+        "dc_convs2_fwd_workspace": (z, [i, i, i, i, i, i]),
+        "dc_convs2_fwd": (i, [p, p, p, p, i, i, i, i, i, i, p]),
+        "dc_convs2_dgrad_workspace": (z, [i, i, i, i, i, i]),
+        "dc_convs2_dgrad": (i, [p, p, p, p, i, i, i, i, i, i, p]),
+        "dc_convs2_wgrad_workspace": (z, [i, i, i, i, i, i]),
+        "dc_convs2_wgrad": (i, [p, p, p, p, i, i, i, i, i, i, p]),
         "dc_attnconv_fwd": (i, [POINTER(AttnMap), POINTER(AttnParams), POINTER(AttnMap), p, i, i, i, i, i, i, p]),
         "dc_attnconv_param_count": (i, [i]),
         "dc_attnconv_bwd_workspace": (z, [i, i, i, i]),

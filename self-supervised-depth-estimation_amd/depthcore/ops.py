@@ -699,6 +699,58 @@ def conv1x1(x, weight, stride=1, bias=None, act=ACT_NONE):
 
 
 # ----------------------------------------------------------------------------------------------
+# a1 strided trunk convolutions: 7x7 / 2 stem and 3x3 / 2 (no bias), implicit GEMMs on the matrix cores
+# ----------------------------------------------------------------------------------------------
+def conv_s2_supported(x, weight):
+    B, Ci, Hi, Wi = x.shape
+    return bool(_lib.lib().dc_convs2_supported(B, Ci, weight.shape[0], Hi, Wi, weight.shape[-1]))
+
+
+class _ConvS2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        L = _lib.lib()
+        xx, ww = _c(x.detach()), _c(weight.detach())
+        B, Ci, Hi, Wi = xx.shape
+        Co, ks = ww.shape[0], ww.shape[-1]
+        if tuple(ww.shape) != (Co, Ci, ks, ks) or not L.dc_convs2_supported(B, Ci, Co, Hi, Wi, ks):
+            raise _lib.DepthcoreError("strided convolution %s on input %s is outside dc_convs2_* (3x3 / 7x7, stride 2, even "
+                                      "sizes, output width %% 4 == 0)" % (tuple(ww.shape), tuple(xx.shape)))
+        y = torch.empty(B, Co, Hi // 2, Wi // 2, dtype=torch.float32, device=xx.device)
+        ws = torch.empty(L.dc_convs2_fwd_workspace(B, Ci, Co, Hi, Wi, ks), dtype=torch.uint8, device=xx.device)
+        check(L.dc_convs2_fwd(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, Hi, Wi, ks, stream(xx)), "dc_convs2_fwd")
+        ctx.save_for_backward(xx, ww)
+        ctx.slot = _slot(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        xx, ww = ctx.saved_tensors
+        B, Ci, Hi, Wi = xx.shape
+        Co, ks = ww.shape[0], ww.shape[-1]
+        g_c = _c(gy)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            n = L.dc_convs2_dgrad_workspace(B, Ci, Co, Hi, Wi, ks)
+            if not n:
+                raise _lib.DepthcoreError("no data gradient for this strided convolution (the 7x7 stem reads the image)")
+            gx = torch.empty_like(xx)
+            ws = torch.empty(n, dtype=torch.uint8, device=xx.device)
+            check(L.dc_convs2_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), B, Ci, Co, Hi, Wi, ks, stream(xx)), "dc_convs2_dgrad")
+        if ctx.needs_input_grad[1]:
+            gw = _grad_dst(ctx.slot, ww)
+            ws = torch.empty(L.dc_convs2_wgrad_workspace(B, Ci, Co, Hi, Wi, ks), dtype=torch.uint8, device=xx.device)
+            check(L.dc_convs2_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, ks, stream(xx)), "dc_convs2_wgrad")
+        return gx, gw
+
+
+def conv_s2(x, weight):
+    """F.conv2d(x, weight, None, stride=2, padding=k // 2) for k = 3 or 7."""
+    return _ConvS2.apply(x, weight)
+
+
+# ----------------------------------------------------------------------------------------------
 # f1 ResidualAttentionUnit of the Fusion_v3 front-end (reference networks/fusion_v2.py:46-137)
 # ----------------------------------------------------------------------------------------------
 PLAIN, PIXEL_SHUFFLE2 = "plain", "ps2"

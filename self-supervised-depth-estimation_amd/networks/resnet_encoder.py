@@ -28,6 +28,7 @@ def _bn_act(x, bn, res=None, relu=True, groups=1):
     return F.relu(y) if relu else y
 
 
+CONV_S2 = True        # 7x7 / 2 stem and 3x3 / 2 convolutions on depthcore's implicit-GEMM kernels (GPU)
 GEMM_1X1 = True       # 1x1 stride-2 `downsample` convolutions on depthcore's NCHW MFMA GEMM (GPU)
 WINO_TRUNK = True     # stride-1 3x3 trunk convolutions on depthcore's fused Winograd kernel (GPU, even widths)
 
@@ -44,7 +45,13 @@ def _conv(conv, x):
             and (conv.stride == (1, 1) or (x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0))):
         # Bottleneck conv1 / conv3 and every `downsample` branch: NCHW fp32-MFMA GEMMs (dc_conv1x1_*), no layout transposes
         return _ops.conv1x1(x, conv.weight, conv.stride[0])
-    return conv(x)
+    if (CONV_S2 and x.is_cuda and conv.stride == (2, 2) and conv.kernel_size in ((3, 3), (7, 7)) and conv.groups == 1
+            and conv.padding == (conv.kernel_size[0] // 2,) * 2 and conv.dilation == (1, 1) and conv.bias is None
+            and x.dtype == torch.float32 and _ops.conv_s2_supported(x, conv.weight)
+            and (conv.kernel_size == (7, 7) or (conv.in_channels % 4 == 0 and conv.out_channels % 32 == 0))):
+        # 7x7 / 2 stem and the 3x3 / 2 convolutions: implicit GEMMs on the matrix cores (dc_convs2_*)
+        return _ops.conv_s2(x, conv.weight)
+    return conv(x)      # shapes outside the kernels' 16-byte staging (odd or tiny maps in tests): the framework's convolution
 
 
 class BasicBlock(nn.Module):
@@ -175,7 +182,7 @@ class ResnetEncoder(nn.Module):
         e._g[0] = int(bn_groups)
         self.features = []
         x = (input_image - 0.45) / 0.225
-        x = _bn_act(e.conv1(x), e.bn1, groups=e._g[0])
+        x = _bn_act(_conv(e.conv1, x), e.bn1, groups=e._g[0])
         self.features.append(x)
         self.features.append(e.layer1(_ops.maxpool3x3s2(x) if x.is_cuda else e.maxpool(x)))
         self.features.append(e.layer2(self.features[-1]))

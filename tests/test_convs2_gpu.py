@@ -1,0 +1,78 @@
+"""The strided trunk convolutions (dc_convs2_*: 7x7 / 2 stem, 3x3 / 2) against torch's fp64 convolution: forward, data
+gradient (3x3) and weight gradient; determinism; the encoder no longer calls a library convolution at the bench shapes."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, Ci, Co, H, W, k
+    (2, 3, 64, 64, 96, 7),         # depth stem (small)
+    (2, 6, 64, 64, 96, 7),         # pose stem: 6 input channels (K = 294 -> padded rows of 320)
+    (12, 3, 64, 192, 640, 7),      # depth stem at BASELINE configs[1]
+    (4, 64, 128, 48, 160, 3),      # resnet18 layer2.0.conv1 at 192x640
+    (2, 128, 256, 24, 80, 3),      # layer3.0.conv1
+    (3, 256, 512, 12, 40, 3),      # layer4.0.conv1: 120 output pixels per image (partial last reduction chunk at B = 3)
+    (1, 256, 512, 12, 40, 3),      # BASELINE configs[0] batch
+    (2, 128, 128, 80, 256, 3),     # resnet50 layer2.0.conv2 at 320x1024
+    (2, 512, 512, 20, 64, 3),      # resnet50 layer4.0.conv2
+    (2, 64, 96, 16, 24, 3),        # small map, 96 output channels (three 32-channel reduction chunks in the data gradient)
+]
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,k", CASES)
+def test_convs2_vs_torch(B, Ci, Co, H, W, k):
+    from depthcore import ops
+    g = torch.Generator().manual_seed(B * 100 + Ci + k)
+    need_dx = k == 3
+    x = torch.randn(B, Ci, H, W, generator=g).cuda().requires_grad_(need_dx)
+    w = (torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (Ci * k * k)) ** 0.5).cuda().requires_grad_(True)
+    assert ops.conv_s2_supported(x, w)
+    y = ops.conv_s2(x, w)
+    gy = torch.randn(y.shape, generator=g).cuda()
+    y.backward(gy)
+    xr, wr = x.detach().double().requires_grad_(need_dx), w.detach().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 2, k // 2)
+    yr.backward(gy.double())
+    checks = [("y", y, yr), ("dw", w.grad, wr.grad)] + ([("dx", x.grad, xr.grad)] if need_dx else [])
+    for name, got, ref in checks:
+        err = (got.double() - ref).abs().max().item()
+        assert err <= 1e-5 * max(ref.abs().max().item(), 1e-6), "%s: %.3e (scale %.3e)" % (name, err, ref.abs().max().item())
+
+
+def test_convs2_deterministic_and_stem_has_no_data_gradient():
+    from depthcore import ops, _lib
+    x = torch.randn(4, 64, 48, 160).cuda().requires_grad_(True)
+    w = torch.randn(128, 64, 3, 3).cuda().requires_grad_(True)
+    gy = torch.randn(4, 128, 24, 80).cuda()
+    outs = []
+    for _ in range(2):
+        x.grad = w.grad = None
+        y = ops.conv_s2(x, w)
+        y.backward(gy)
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    xs = torch.randn(1, 3, 32, 64).cuda().requires_grad_(True)
+    ws = torch.randn(64, 3, 7, 7).cuda().requires_grad_(True)
+    with pytest.raises(_lib.DepthcoreError):
+        ops.conv_s2(xs, ws).sum().backward()
+
+
+def test_encoder_runs_without_library_convolutions(monkeypatch):
+    """At the bench shapes every convolution of the trunk is a depthcore launch: torch's convolution is never entered."""
+    import networks
+    calls = []
+    orig = F.conv2d
+    monkeypatch.setattr(torch.nn.functional, "conv2d", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    real = torch.nn.Conv2d.forward
+    monkeypatch.setattr(torch.nn.Conv2d, "forward", lambda self, x: (calls.append(self), real(self, x))[1])
+    for layers, shape in ((18, (2, 3, 192, 640)), (50, (1, 3, 320, 1024))):
+        torch.manual_seed(0)
+        enc = networks.ResnetEncoder(layers, False).cuda()
+        enc.train()
+        x = torch.rand(shape, device="cuda")
+        feats = enc(x)
+        sum(f.mean() for f in feats).backward()
+        assert calls == [], "library convolution entered for %r" % calls[:3]
