@@ -326,6 +326,23 @@ int dc_attnconv_bwd(const dc_attn_map* x, const dc_attn_params* p, const dc_attn
                     const float* dx_add, const dc_attn_map* dres, float* dparams, void* ws, int B, int C, int H, int W, int relu_in,
                     int relu_res, void* stream);
 
+/* ------------------------------------------------------------------ f2 ConvGRU temporal fusion (gru_version v5) */
+/* networks/rnn.py:101-143 `ConvGRUCell`: the two 3x3 convolutions are dc_conv3x3_fwd calls with (x, h) / (x, r*h) as the two
+ * concatenated sources, zero padding, bias, sigmoid / tanh epilogue; these entry points are the gate arithmetic between
+ * them.  gates (B,2C,P) = [reset r | update u]; h, cnm, rh, h_next (B,C,P).
+ *   dc_gru_rh_*:     rh = r * h                        backward: d_gates = [g * h | 0], d_h = g * r
+ *   dc_gru_blend_*:  h_next = (1 - u) * h + u * cnm    backward: d_gates = [0 | g * (cnm - h)], d_h = g * (1 - u), d_cnm = g * u
+ * (each backward writes all of its d_gates; autograd sums the two.)
+ *   dc_gru_residual_*: out[i] = f[i] + (H[i+1] + H[i]) / 2 over a sequence of n frames, H = its n+1 hidden states stacked
+ *   (trainer_gru.py:637-639); f, out (n, M), H (n+1, M); backward: d_f = g, d_H[j] = (g[j] + g[j-1]) / 2. */
+int dc_gru_rh_fwd(const float* gates, const float* h, float* rh, int B, int C, int P, void* stream);
+int dc_gru_rh_bwd(const float* gates, const float* h, const float* g, float* d_gates, float* d_h, int B, int C, int P, void* stream);
+int dc_gru_blend_fwd(const float* gates, const float* h, const float* cnm, float* h_next, int B, int C, int P, void* stream);
+int dc_gru_blend_bwd(const float* gates, const float* h, const float* cnm, const float* g, float* d_gates, float* d_h, float* d_cnm,
+                     int B, int C, int P, void* stream);
+int dc_gru_residual_fwd(const float* f, const float* H, float* out, int n, size_t M, void* stream);
+int dc_gru_residual_bwd(const float* g, float* d_H, int n, size_t M, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@ over plain state dicts.  Used as the checker of the full-step parity test and as
 import torch
 
 from . import fusion_ref as FR
+from . import gru_ref as GR
 from . import ref_cpu as R
 from .resnet_ref import resnet_encoder_forward
 
@@ -31,7 +32,11 @@ class CpuTrainer:
 
     def process_batch(self, inputs, noise):
         o = self.opt
-        if "fusion" in self.state:
+        if "gru" in self.state:                      # trainer_gru.py:595-644: `inputs` = the sequence stacked along the batch
+            feats = resnet_encoder_forward(self.state["encoder"], inputs[("color", 0, 0)], self.num_layers)
+            feats = GR.run_gru_v5(feats, self.state["gru"])
+            outputs = R.depth_decoder_forward(self.state["depth"], feats, self.num_ch_enc, tuple(o.scales))
+        elif "fusion" in self.state:
             enc_input = torch.cat([inputs[("color_aug", i, 0)] for i in (-2, -1, 0)], 0)
             feats = resnet_encoder_forward(self.state["encoder"], enc_input, self.num_layers)
             dec = R.depth_decoder_forward(self.state["depth"], feats, self.num_ch_enc, tuple(o.scales))

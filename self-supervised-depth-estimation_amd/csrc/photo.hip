@@ -12,12 +12,11 @@
 //   * backward recomputes the warp (halo 2) instead of saving it, routes the min() gradient by the
 //     1-byte argmin map the forward wrote, and reduces the pose gradient per wave -> per block ->
 //     fixed-order final sum (no float atomics, bitwise reproducible);
-//   * the target image's 3x3 window statistics (mu_y, sigma_y + C2, mu_y^2 + C1 per channel) do not depend on the
-//     scale, the source frame or the direction: identity_kernel, which streams the target anyway, computes them once
-//     per step and stores them next to the target pixel (12 floats per pixel); the four scale-waves of the forward and
-//     of the backward load them instead of redoing the two 3x3 sums per channel (8x per step before);
 //   * the SSIM derivative of the backward is evaluated for ONE source frame per pixel, the one the argmin map routes the
-//     gradient to (the other frame's coefficient is exactly zero), except under avg_reprojection where both get half.
+//     gradient to (the other frame's coefficients are exactly zero), except under avg_reprojection where both get half.
+//     (Tried and dropped: target window statistics precomputed once per step by identity_kernel and loaded by the eight
+//     scale-wave passes -- 20 % fewer VALU instructions in the backward, but the 48 B/pixel side stream made the forward
+//     chain 40 us slower than the backward gained.)
 #include <mutex>
 #include <vector>
 
@@ -52,8 +51,7 @@ struct PhotoArgs {
     const float* noise[DC_MAX_SCALES];
     unsigned long long seed;
     float* idl;                        // identity losses, pixel-interleaved (B, H, W, 2|1)
-    float* pk[3];                      // [0]: target + window statistics (B,H,W,3 channels x {t, mu, sig+C2, mu^2+C1});
-                                       // [1], [2]: pixel-interleaved RGBx copies (B,H,W,4) of source -1 / source +1
+    float* pk[3];                      // pixel-interleaved RGBx copies (B,H,W,4) of target / source -1 / source +1
     int rows_f, rows_b;                // image rows a wave produces in the forward / backward march (even)
     uint8_t* argmin[DC_MAX_SCALES];
     float* depth[DC_MAX_SCALES];
@@ -101,9 +99,6 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 typedef int i2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f3 bload3(rsrc_t r, unsigned voff) {      // one RGB pixel of a packed image
     return __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, 0, 0));
-}
-__device__ __forceinline__ f4v bload4(rsrc_t r, unsigned voff, unsigned imm) {
-    return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)imm, 0));
 }
 __device__ __forceinline__ f2 bload2(rsrc_t r, unsigned voff) {
     return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0));
@@ -154,8 +149,7 @@ struct Ctx {   // per-wave constants (scalar registers)
     int H, W;
     unsigned plane4;        // bytes of one channel plane
     rsrc_t tg, s0, s1;      // target / source -1 / source +1 of this batch element (3 planes each)
-    rsrc_t ptg;             // target pixel + its 3x3 window statistics (48 B per pixel, written by identity_kernel)
-    rsrc_t ps0, ps1;        // pixel-interleaved RGBx copies of the sources (16 B per pixel)
+    rsrc_t ptg, ps0, ps1;   // their pixel-interleaved RGBx copies (16 B per pixel)
     rsrc_t dp;              // disparity of this (scale, batch element)
     int hs, ws;
     float ry, rx;
@@ -175,7 +169,7 @@ __device__ __forceinline__ void make_ctx(Ctx& c, const PhotoArgs& p, int b, int 
     c.tg = make_rsrc(p.target + img, 3u * c.plane4);
     c.s0 = make_rsrc(p.src[0] + img, 3u * c.plane4);
     c.s1 = make_rsrc(p.src[1] + img, 3u * c.plane4);
-    c.ptg = make_rsrc(p.pk[0] + (size_t)b * plane * 12, 12u * c.plane4);
+    c.ptg = make_rsrc(p.pk[0] + (size_t)b * plane * 4, 4u * c.plane4);
     c.ps0 = make_rsrc(p.pk[1] + (size_t)b * plane * 4, 4u * c.plane4);
     c.ps1 = make_rsrc(p.pk[2] + (size_t)b * plane * 4, 4u * c.plane4);
     c.hs = p.hs[s]; c.ws = p.ws[s];
@@ -214,7 +208,7 @@ __device__ __forceinline__ float disp_value(const DispTaps& t, const Ctx& c) {
 // ---- one pixel, both source frames: disp -> depth -> BackprojectDepth -> Project3D -> grid_sample
 // coordinates (layers.py:21-24,163-192; trainer.py:508-511), with the 3 + 12 + 12 loads left in flight.
 struct Taps {
-    f4v ts[3];           // per channel: target pixel, mu_y, sig_y + C2, mu_y^2 + C1   (pk[0])
+    f3 t;                // target pixel (RGB)
     f3 tap[2][4];        // [frame][nw, ne, sw, se] RGB pixels
     float wx1[2], wy1[2];
     float sx[2], sy[2];  // backward only: d(ix)/du, d(iy)/dv incl. the border-clamp zero
@@ -247,12 +241,7 @@ __device__ __forceinline__ TapOff tap_offsets(float x, float y, int H, int W) {
 template <int MODE, bool LOGS>
 __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, float disp, int x, int y, RowLog& lg,
                                           float* park) {
-    {
-        const unsigned o = (unsigned)(y * c.W + x) * 48u;
-        r.ts[0] = bload4(c.ptg, o, 0);
-        r.ts[1] = bload4(c.ptg, o, 16);
-        r.ts[2] = bload4(c.ptg, o, 32);
-    }
+    r.t = bload3(c.ptg, (unsigned)(y * c.W + x) * 16u);
     const float scaled = c.min_disp + c.disp_range * disp;
     const float depth = frcp(scaled);
     const float xf = (float)x, yf = (float)y;
@@ -299,13 +288,9 @@ __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, f
     r.tap[0][3] = bload3(c.ps0, to[0].o11); r.tap[1][3] = bload3(c.ps1, to[1].o11);
 }
 
-struct TStat {
-    float mu_y, sig_y_c2, mu_yy_c1;   // mu_y, sig_y + C2, mu_y^2 + C1
-};
 struct Row {   // raw values of one image row at the lane's own pixel: target + both warped frames
     float t[3];
     float w[2][3];
-    TStat st[3];   // window statistics of the target centred on this row (gather kernels: loaded, not recomputed)
 };
 
 __device__ __forceinline__ void blend_row(const Taps& r, Row& o) {
@@ -318,10 +303,7 @@ __device__ __forceinline__ void blend_row(const Taps& r, Row& o) {
             o.w[f][ch] = r.tap[f][0][ch] * wnw + r.tap[f][1][ch] * wne + r.tap[f][2][ch] * wsw + r.tap[f][3][ch] * wse;
     }
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        o.t[ch] = r.ts[ch].x;
-        o.st[ch].mu_y = r.ts[ch].y; o.st[ch].sig_y_c2 = r.ts[ch].z; o.st[ch].mu_yy_c1 = r.ts[ch].w;
-    }
+    for (int ch = 0; ch < 3; ++ch) o.t[ch] = r.t[ch];
 }
 
 // 3-tap horizontal sum across lanes: two DPP-fused adds
@@ -329,6 +311,9 @@ __device__ __forceinline__ float hsum3(float v) { return from_left(v) + v + from
 
 // Window statistics of one channel: vertical sums in-lane over the three rows held in registers, then
 // the horizontal 3-sum on the five column sums (instead of ringing five h-sums per channel and frame).
+struct TStat {
+    float mu_y, sig_y_c2, mu_yy_c1;   // mu_y, sig_y + C2, mu_y^2 + C1
+};
 __device__ __forceinline__ TStat target_stat(float a, float b, float c) {
     const float sy = hsum3(a + b + c);
     const float syy = hsum3(fmaf(a, a, fmaf(b, b, c * c)));
@@ -368,15 +353,12 @@ __device__ __forceinline__ WStat warp_stat(const TStat& ts, float xa, float xb, 
 }
 
 // 0.85 * mean_c SSIM + 0.15 * mean_c |t - w|  (trainer.py:517-529) for both frames; rows a,b,c = p-1,p,p+1
-// STORED: the centre row carries the precomputed target statistics (gather kernels); otherwise they are computed here
-// (identity_kernel, which is also where they are produced -- bit-identical by construction).
-template <bool STORED>
 __device__ __forceinline__ void reproj_values(const Row& a, const Row& b, const Row& c, bool no_ssim, float out[2]) {
     float ss[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         TStat ts;
-        if (!no_ssim) ts = STORED ? b.st[ch] : target_stat(a.t[ch], b.t[ch], c.t[ch]);
+        if (!no_ssim) ts = target_stat(a.t[ch], b.t[ch], c.t[ch]);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             l1[f] += fabsf(b.t[ch] - b.w[f][ch]);
@@ -441,31 +423,18 @@ __global__ __launch_bounds__(64) void identity_kernel(PhotoArgs p) {
         const int yy = y0 - 1 + i;
         const Row cur = nxt;
         load_row(yy + 1);   // next row flies during this row's math
-        // pixel-interleaved copies of the two source images for the gather kernels (rows this wave owns)
+        // pixel-interleaved copies of the three images for the gather kernels (rows this wave owns)
         if (i >= 1 && i <= ID_ROWS && yy < H && lane_ok) {
             const unsigned o = (unsigned)(yy * W + x) * 16u;
+            bstore4(c.ptg, o, cur.t[0], cur.t[1], cur.t[2], 0.f);
             bstore4(c.ps0, o, cur.w[0][0], cur.w[0][1], cur.w[0][2], 0.f);
             bstore4(c.ps1, o, cur.w[1][0], cur.w[1][1], cur.w[1][2], 0.f);
         }
-        // target pixel + its window statistics of row py = yy-1 (window rows yy-2, yy-1, yy), once for all scales,
-        // both source frames, forward and backward
-        Row mid = r_new;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) mid.st[ch] = target_stat(r_old.t[ch], r_new.t[ch], cur.t[ch]);
-        const int py = yy - 1;
-        const bool out_ok = i >= 2 && py < H && lane_ok;
-        if (out_ok) {
-            const unsigned o = (unsigned)(py * W + x) * 48u;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch)
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    __builtin_bit_cast(i4, (f4v){mid.t[ch], mid.st[ch].mu_y, mid.st[ch].sig_y_c2, mid.st[ch].mu_yy_c1}), c.ptg,
-                    (int)o, ch * 16, 0);
-        }
         if (IDENT) {
             float r[2];
-            reproj_values<true>(r_old, mid, cur, no_ssim, r);
-            if (out_ok) {
+            reproj_values(r_old, r_new, cur, no_ssim, r);
+            const int py = yy - 1;
+            if (i >= 2 && py < H && lane_ok) {
                 const unsigned o = (unsigned)(py * W + x);
                 if (avg) bstore(idl, o * 4u, 0, (r[0] + r[1]) * 0.5f);
                 else bstore2(idl, o * 8u, r[0], r[1]);
@@ -552,7 +521,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
             if (float* dep = p.depth[s]) dep[(size_t)b * plane + o] = lg_cur.depth;
         }
         float r[2];
-        reproj_values<true>(r_old, r_new, cur, no_ssim, r);
+        reproj_values(r_old, r_new, cur, no_ssim, r);
         const int py = yy - 1;
         if (i >= 2 && py < H && lane_ok) {
             // ---- min over [identity(-1), identity(+1), reproj(-1), reproj(+1)]  (trainer.py:592-610)
@@ -789,10 +758,7 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
             }
         }
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            cur.t[ch] = tp.ts[ch].x;
-            cur.st[ch].mu_y = tp.ts[ch].y; cur.st[ch].sig_y_c2 = tp.ts[ch].z; cur.st[ch].mu_yy_c1 = tp.ts[ch].w;
-        }
+        for (int ch = 0; ch < 3; ++ch) cur.t[ch] = tp.t[ch];
         const int m_cur = m_in;
         // ---------------- all loads of the step: row yy+1 (taps, target, argmin) and disparity of row yy+2
         issue_row<1, false>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), nolog,
@@ -842,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
                 for (int f = 0; f < 2; ++f) gs[f] = (p_ok && (sel_all || m_new == selv[f])) ? sel_val * g_ssim : 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    const TStat ts = r_new.st[ch];
+                    const TStat ts = target_stat(r_old.t[ch], r_new.t[ch], cur.t[ch]);
 #pragma unroll
                     for (int f = 0; f < 2; ++f) {
                         const WStat t = warp_stat(ts, r_old.w[f][ch], r_new.w[f][ch], cur.w[f][ch], r_old.t[ch], r_new.t[ch],
@@ -860,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
                 const float gsel = (p_ok && (s1 || m_new == selv[0])) ? sel_val * g_ssim : 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    const TStat ts = r_new.st[ch];
+                    const TStat ts = target_stat(r_old.t[ch], r_new.t[ch], cur.t[ch]);
                     const WSums w0 = warp_sums(r_old.w[0][ch], r_new.w[0][ch], cur.w[0][ch], r_old.t[ch], r_new.t[ch], cur.t[ch]);
                     const WSums w1 = warp_sums(r_old.w[1][ch], r_new.w[1][ch], cur.w[1][ch], r_old.t[ch], r_new.t[ch], cur.t[ch]);
                     const WStat t = warp_from_sums(ts, s1 ? w1.sx : w0.sx, s1 ? w1.sxx : w0.sxx, s1 ? w1.sxy : w0.sxy);
@@ -1124,8 +1090,7 @@ static Carve carve(const dc_photo_desc* d) {
     c.nchunk = ceil_div(d->H * d->W, SM_CHUNK);
     size_t off = 0;
     c.idl = off; off += align256(N * 2 * 4);
-    c.pk[0] = off; off += align256(N * 48);           // target + window statistics: 3 channels x 4 floats
-    for (int k = 1; k < 3; ++k) { c.pk[k] = off; off += align256(N * 16); }
+    for (int k = 0; k < 3; ++k) { c.pk[k] = off; off += align256(N * 16); }
     c.part_photo = off; off += align256((size_t)d->num_scales * c.nblk_f * 4);
     c.part_smooth = off; off += align256((size_t)d->num_scales * d->B * c.nchunk * 3 * 4);
     c.stats = off; off += align256((size_t)d->num_scales * d->B * 3 * 4);

@@ -120,6 +120,12 @@ def _sig(lib):
         "dc_convs2_dgrad": (i, [p, p, p, p, i, i, i, i, i, i, p]),
         "dc_convs2_wgrad_workspace": (z, [i, i, i, i, i, i]),
         "dc_convs2_wgrad": (i, [p, p, p, p, i, i, i, i, i, i, p]),
+        "dc_gru_rh_fwd": (i, [p, p, p, i, i, i, p]),
+        "dc_gru_rh_bwd": (i, [p, p, p, p, p, i, i, i, p]),
+        "dc_gru_blend_fwd": (i, [p, p, p, p, i, i, i, p]),
+        "dc_gru_blend_bwd": (i, [p, p, p, p, p, p, p, i, i, i, p]),
+        "dc_gru_residual_fwd": (i, [p, p, p, i, z, p]),
+        "dc_gru_residual_bwd": (i, [p, p, i, z, p]),
         "dc_attnconv_fwd": (i, [POINTER(AttnMap), POINTER(AttnParams), POINTER(AttnMap), p, i, i, i, i, i, i, p]),
         "dc_attnconv_param_count": (i, [i]),
         "dc_attnconv_bwd_workspace": (z, [i, i, i, i]),

@@ -861,3 +861,97 @@ def residual_attention_unit(srcs, kinds, params1, params2):
     """srcs / kinds: the unit's input channels as a list of tensors (`PLAIN` (B,c,H,W) or `PIXEL_SHUFFLE2` (B,4,H/2,W/2));
     params1 / params2: (rel_h, rel_w, key w, key b, query w, query b, value w, value b) of atten1 / atten2."""
     return _ResidualAttentionUnit.apply(tuple(kinds), len(srcs), *srcs, *params1, *params2)
+
+
+# ----------------------------------------------------------------------------------------------
+# f2 ConvGRU cell gate arithmetic + sequence residual        (reference networks/rnn.py:101-143, trainer_gru.py:637-639)
+# ----------------------------------------------------------------------------------------------
+class _GruRH(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gates, h):
+        L = _lib.lib()
+        gt, hh = _c(gates.detach()), _c(h.detach())
+        B, C = hh.shape[0], hh.shape[1]
+        P = hh.shape[2] * hh.shape[3]
+        if tuple(gt.shape) != (B, 2 * C) + tuple(hh.shape[2:]):
+            raise _lib.DepthcoreError("gates %s do not match state %s" % (tuple(gt.shape), tuple(hh.shape)))
+        rh = torch.empty_like(hh)
+        check(L.dc_gru_rh_fwd(ptr(gt), ptr(hh), ptr(rh), B, C, P, stream(hh)), "dc_gru_rh_fwd")
+        ctx.save_for_backward(gt, hh)
+        return rh
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        gt, hh = ctx.saved_tensors
+        B, C = hh.shape[0], hh.shape[1]
+        P = hh.shape[2] * hh.shape[3]
+        g_c = _c(g)
+        dg, dh = torch.empty_like(gt), torch.empty_like(hh)
+        check(L.dc_gru_rh_bwd(ptr(gt), ptr(hh), ptr(g_c), ptr(dg), ptr(dh), B, C, P, stream(hh)), "dc_gru_rh_bwd")
+        return dg, dh
+
+
+class _GruBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gates, h, cnm):
+        L = _lib.lib()
+        gt, hh, cc = _c(gates.detach()), _c(h.detach()), _c(cnm.detach())
+        B, C = hh.shape[0], hh.shape[1]
+        P = hh.shape[2] * hh.shape[3]
+        if tuple(gt.shape) != (B, 2 * C) + tuple(hh.shape[2:]) or cc.shape != hh.shape:
+            raise _lib.DepthcoreError("gates %s / candidate %s do not match state %s" % (tuple(gt.shape), tuple(cc.shape), tuple(hh.shape)))
+        out = torch.empty_like(hh)
+        check(L.dc_gru_blend_fwd(ptr(gt), ptr(hh), ptr(cc), ptr(out), B, C, P, stream(hh)), "dc_gru_blend_fwd")
+        ctx.save_for_backward(gt, hh, cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        gt, hh, cc = ctx.saved_tensors
+        B, C = hh.shape[0], hh.shape[1]
+        P = hh.shape[2] * hh.shape[3]
+        g_c = _c(g)
+        dg, dh, dc = torch.empty_like(gt), torch.empty_like(hh), torch.empty_like(cc)
+        check(L.dc_gru_blend_bwd(ptr(gt), ptr(hh), ptr(cc), ptr(g_c), ptr(dg), ptr(dh), ptr(dc), B, C, P, stream(hh)), "dc_gru_blend_bwd")
+        return dg, dh, dc
+
+
+class _GruResidual(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, H):
+        L = _lib.lib()
+        ff, HH = _c(f.detach()), _c(H.detach())
+        n = ff.shape[0]
+        M = ff[0].numel()
+        if tuple(HH.shape) != (n + 1,) + tuple(ff.shape[1:]):
+            raise _lib.DepthcoreError("hidden states %s must be (n+1, ...) for features %s" % (tuple(HH.shape), tuple(ff.shape)))
+        out = torch.empty_like(ff)
+        check(L.dc_gru_residual_fwd(ptr(ff), ptr(HH), ptr(out), n, M, stream(ff)), "dc_gru_residual_fwd")
+        ctx.dims = (n, M, HH.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        n, M, hshape = ctx.dims
+        g_c = _c(g)
+        dH = torch.empty(hshape, dtype=torch.float32, device=g.device)
+        check(L.dc_gru_residual_bwd(ptr(g_c), ptr(dH), n, M, stream(g_c)), "dc_gru_residual_bwd")
+        return g_c, dH
+
+
+def gru_reset_times_state(gates, h):
+    """r * h with r = gates[:, :C]."""
+    return _GruRH.apply(gates, h)
+
+
+def gru_blend(gates, h, cnm):
+    """(1 - u) * h + u * cnm with u = gates[:, C:]."""
+    return _GruBlend.apply(gates, h, cnm)
+
+
+def gru_sequence_residual(features, hidden_states):
+    """features (n,C,H,W) + (H[1:] + H[:-1]) / 2 with H (n+1,C,H,W)."""
+    return _GruResidual.apply(features, hidden_states)

@@ -28,3 +28,16 @@ def synthetic_batch(batch, height, width, device, num_scales=4, frame_ids=(0, -1
         inputs[("K", s)] = torch.from_numpy(K).to(device).unsqueeze(0).repeat(batch, 1, 1).contiguous()
         inputs[("inv_K", s)] = torch.from_numpy(inv_K).to(device).unsqueeze(0).repeat(batch, 1, 1).contiguous()
     return inputs
+
+
+def synthetic_sequence_batch(len_sequence, height, width, device, num_scales=4, frame_ids=(0, -1, 1), seed=0):
+    """One sequence of `len_sequence` frames in the schema of datasets/kitti_dataset_seq.py:110-140 (batch size 1):
+    ("color", f, s, j), ("K", s, j), ("inv_K", s, j)."""
+    flat = synthetic_batch(len_sequence, height, width, device, num_scales, frame_ids, seed)
+    out = {}
+    for k, v in flat.items():
+        if k[0] == "color_aug":
+            continue
+        for j in range(len_sequence):
+            out[k + (j,)] = v[j:j + 1].contiguous()
+    return out

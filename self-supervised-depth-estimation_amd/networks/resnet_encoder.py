@@ -48,7 +48,8 @@ def _conv(conv, x):
     if (CONV_S2 and x.is_cuda and conv.stride == (2, 2) and conv.kernel_size in ((3, 3), (7, 7)) and conv.groups == 1
             and conv.padding == (conv.kernel_size[0] // 2,) * 2 and conv.dilation == (1, 1) and conv.bias is None
             and x.dtype == torch.float32 and _ops.conv_s2_supported(x, conv.weight)
-            and (conv.kernel_size == (7, 7) or (conv.in_channels % 4 == 0 and conv.out_channels % 32 == 0))):
+            and ((conv.kernel_size == (7, 7) and not x.requires_grad)        # (the stem kernels have no data gradient)
+                 or (conv.kernel_size == (3, 3) and conv.in_channels % 4 == 0 and conv.out_channels % 32 == 0))):
         # 7x7 / 2 stem and the 3x3 / 2 convolutions: implicit GEMMs on the matrix cores (dc_convs2_*)
         return _ops.conv_s2(x, conv.weight)
     return conv(x)      # shapes outside the kernels' 16-byte staging (odd or tiny maps in tests): the framework's convolution

@@ -13,6 +13,9 @@ Two equivalent loss paths, both on hand-written gfx950 kernels:
 
 `opt.fusion = "v3"` switches the front-end to the reference's trainer_fusion_v3.py:277-330: frames [-2, -1, 0] are stacked
 through the depth encoder + decoder and fused by `networks.Fusion_v3` (BASELINE configs[4]).
+`opt.gru = "v5"` switches it to trainer_gru.py:595-644 (`run_gru_v5`, BASELINE configs[3]): a batch is ONE sequence of
+`opt.len_sequence` frames (dict keys carry the sequence index: ("color", f, s, j), ("K", s, j)), the encoder features of the
+sequence pass through `networks.ConvGRUBlocks_v5`, and the loss runs on the sequence stacked along the batch.
 """
 import json
 import os
@@ -60,6 +63,14 @@ class Trainer:
             raise NotImplementedError("fusion front-ends: None (trainer.py) or 'v3' (trainer_fusion_v3.py)")
         if self.opt.fusion and -2 not in self.opt.frame_ids:
             raise ValueError("the Fusion_v3 front-end stacks frames [-2, -1, 0]: frame_ids must be [0, -2, -1, 1]")
+        if getattr(self.opt, "gru", None) not in (None, "v5"):
+            raise NotImplementedError("ConvGRU front-ends: None or 'v5' (trainer_gru.py run_gru_v5)")
+        if self.opt.gru and self.opt.fusion:
+            raise ValueError("fusion and gru front-ends are separate trainers in the reference; pick one")
+        if self.opt.gru and self.opt.batch_size != 1:
+            raise ValueError("run_gru_v5 works for batch_size = 1 only (trainer_gru.py:596)")
+        # images per loss evaluation: the reference's GRU trainer stacks the sequence along the batch (trainer_gru.py:256-263)
+        self.loss_batch = self.opt.batch_size * (self.opt.len_sequence if self.opt.gru else 1)
         self.num_scales = len(self.opt.scales)
         self.num_pose_frames = 2
 
@@ -69,6 +80,10 @@ class Trainer:
         self.models["depth"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, self.opt.scales)
         if self.opt.fusion:                                      # trainer_fusion_v3.py:74
             self.models["fusion"] = networks.Fusion_v3(attention=not self.opt.disable_attention)
+        if self.opt.gru:                                         # trainer_gru.py:128
+            self.models["gru"] = networks.ConvGRUBlocks_v5(kernel_size=(3, 3), bias=True, device="cpu", height=self.opt.height,
+                                                           width=self.opt.width,
+                                                           num_ch_enc=tuple(int(c) for c in self.models["encoder"].num_ch_enc))
         self.models["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, self.opt.weights_init == "pretrained",
                                                              num_input_images=self.num_pose_frames)
         self.models["pose"] = networks.PoseDecoder(self.models["pose_encoder"].num_ch_enc, num_input_features=1,
@@ -84,7 +99,8 @@ class Trainer:
             broadcast_parameters(self.models.values(), 0, process_group)
         # in the order the forward runs the modules (GradBuckets exchanges in the reverse of it): with overlap_streams
         # the pose branch is issued first (process_batch), so its gradients are the last ones backward produces
-        main = ["encoder", "depth"] + [k for k in ("fusion", "predictive_mask") if k in self.models]
+        main = ["encoder"] + [k for k in ("gru",) if k in self.models] + ["depth"] + \
+            [k for k in ("fusion", "predictive_mask") if k in self.models]
         order = (["pose_encoder", "pose"] + main) if getattr(self.opt, "overlap_streams", False) else (main + ["pose_encoder", "pose"])
         order = order + [k for k in self.models if k not in order]
         named = [(k + "." + n, p) for k in order for n, p in self.models[k].named_parameters()]
@@ -97,8 +113,8 @@ class Trainer:
         self.backproject_depth, self.project_3d = {}, {}
         for s in self.opt.scales:
             h, w = self.opt.height // (2 ** s), self.opt.width // (2 ** s)
-            self.backproject_depth[s] = BackprojectDepth(self.opt.batch_size, h, w).to(self.device)
-            self.project_3d[s] = Project3D(self.opt.batch_size, h, w).to(self.device)
+            self.backproject_depth[s] = BackprojectDepth(self.loss_batch, h, w).to(self.device)
+            self.project_3d[s] = Project3D(self.loss_batch, h, w).to(self.device)
         self.step = 0
         self.epoch = 0
         self._side_stream = None
@@ -114,10 +130,28 @@ class Trainer:
             m.eval()
 
     # ------------------------------------------------------------------ trainer.py:256-376
+    def _stack_sequence(self, inputs):
+        """Sequence dict (datasets/kitti_dataset_seq.py:110-140: ("color", f, s, j), ("K", s, j), ("inv_K", s, j), j = frame
+        of the sequence) -> the ordinary dict with the sequence stacked along the batch, as trainer_gru.py:819-821,886-896,
+        943-944 concatenate it at every use.  The GRU trainer feeds the un-augmented images to both networks."""
+        n = self.opt.len_sequence
+        out = {}
+        for f in (0, -1, 1):
+            for s in self.opt.scales:
+                if ("color", f, s, 0) in inputs:
+                    out[("color", f, s)] = torch.cat([inputs[("color", f, s, j)] for j in range(n)], 0)
+                    out[("color_aug", f, s)] = out[("color", f, s)]
+        for s in self.opt.scales:
+            for k in ("K", "inv_K"):
+                out[(k, s)] = torch.cat([inputs[(k, s, j)] for j in range(n)], 0)
+        return out
+
     def process_batch(self, inputs):
         for key, ipt in inputs.items():
             if ipt.device != self.device:
                 inputs[key] = ipt.to(self.device)
+        if self.opt.gru:
+            inputs = self._stack_sequence(inputs)
         if getattr(self.opt, "overlap_streams", False) and self.device.type == "cuda":
             # The pose network (pose encoder + decoder) and the depth network are independent until the loss: run them
             # on two HIP streams so that one branch's kernels fill the other's tails and small launches.  Autograd
@@ -152,6 +186,9 @@ class Trainer:
             enc_input = torch.cat([inputs[("color_aug", i, 0)] for i in (-2, -1, 0)], 0)
             features = self.models["encoder"](enc_input)
             outputs = dict(self.models["fusion"](self.models["depth"](features)))
+        elif self.opt.gru:                                       # trainer_gru.py:595-644, batch size 1
+            features = self.models["encoder"](inputs[("color", 0, 0)])
+            outputs = dict(self.models["depth"](self.models["gru"].run_sequence(features)))
         else:
             features = self.models["encoder"](inputs[("color_aug", 0, 0)])
             outputs = dict(self.models["depth"](features))
