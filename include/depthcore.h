@@ -343,6 +343,35 @@ int dc_gru_blend_bwd(const float* gates, const float* h, const float* cnm, const
 int dc_gru_residual_fwd(const float* f, const float* H, float* out, int n, size_t M, void* stream);
 int dc_gru_residual_bwd(const float* g, float* d_H, int n, size_t M, void* stream);
 
+/* ------------------------------------------------------------------ f4 per-item data step (decoded frames -> `inputs`) */
+/* datasets/mono_dataset.py:92-118 `preprocess` and the image part of :139-211 `__getitem__`, for a whole batch of decoded
+ * frames resident in HBM as uint8 HWC (n_img images, contiguous).  Byte-exact with Pillow's `Image.resize(LANCZOS)`
+ * (= the reference's Image.ANTIALIAS, :57), torchvision's PIL ColorJitter (:73-76, :186-190) and ToTensor (:67).
+ *
+ * dc_resample_ksize / dc_resample_table (HOST functions, no GPU): Pillow's 8-bit Lanczos coefficient table for one axis
+ *   in_size -> out_size: bounds (out_size, 2) int32 [first source index, tap count], kk (out_size, ksize) int32, 22
+ *   fractional bits.  Upload both once per (in_size, out_size) and reuse.
+ * dc_data_resize_axis: one 8-bit pass along axis 1 (width; `flip` (n_img) uint8 or NULL mirrors the source row first, i.e.
+ *   transpose(FLIP_LEFT_RIGHT) of get_color) or axis 0 (height; flip must be NULL).  src (n, Hi, Wi, 3) -> dst with the
+ *   axis resized to out_size.  Pillow resizes width first, then height, and skips a pass whose size is unchanged.
+ * dc_data_flip: the mirror alone (for a native image that already has the target width).
+ * dc_data_jitter: ColorJitter IN PLACE on (n, npix, 3): per image four steps, steps (n, 4) int32 = DC_JITTER_* in execution
+ *   order (or DC_JITTER_NONE), params (n, 4) float32 = that step's factor (for DC_JITTER_HUE: the uint8 H shift,
+ *   `np.uint8(hue_factor * 255)`, as a float).  sums: (n) uint64 scratch.  steps / params / sums are DEVICE pointers.
+ * dc_data_to_tensor: (n, npix, 3) uint8 -> (n, 3, npix) float32, value / 255 (true division). */
+#define DC_JITTER_NONE (-1)
+#define DC_JITTER_BRIGHTNESS 0
+#define DC_JITTER_CONTRAST 1
+#define DC_JITTER_SATURATION 2
+#define DC_JITTER_HUE 3
+int dc_resample_ksize(int in_size, int out_size);
+int dc_resample_table(int in_size, int out_size, int* bounds, int* kk);
+int dc_data_resize_axis(const uint8_t* src, uint8_t* dst, int n_img, int Hi, int Wi, int out_size, int axis, const int* bounds,
+                        const int* kk, int ksize, const uint8_t* flip, void* stream);
+int dc_data_flip(const uint8_t* src, uint8_t* dst, int n_img, int H, int W, const uint8_t* flip, void* stream);
+int dc_data_jitter(uint8_t* img, int n_img, int npix, const int* steps, const float* params, unsigned long long* sums, void* stream);
+int dc_data_to_tensor(const uint8_t* img, float* out, int n_img, int npix, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

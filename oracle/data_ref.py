@@ -120,36 +120,39 @@ def adjust_saturation(img, f):
 
 
 def rgb_to_hsv(img):
-    """PIL convert("HSV") (libImaging/Convert.c rgb2hsv_row, after colorsys): single-precision arithmetic, H = 255 * hue
-    truncated, S = 255 * saturation truncated, V = max."""
+    """PIL convert("HSV") (libImaging/Convert.c rgb2hsv_row, after colorsys).  The C code keeps h, s, rc, gc, bc in `float`
+    but its literals are `double`: every expression is evaluated in double and ROUNDED TO FLOAT when stored, and the final
+    `(int)(h * 255.0)` / `(int)(s * 255.0)` are double products of those floats, truncated."""
     r, g, b = (img[..., i].astype(np.int32) for i in range(3))
     maxc, minc = np.maximum(np.maximum(r, g), b), np.minimum(np.minimum(r, g), b)
     cr = (maxc - minc).astype(np.float32)
     safe = np.where(cr == 0, np.float32(1), cr)
-    s = cr / np.where(maxc == 0, 1, maxc).astype(np.float32)
-    rc, gc, bc = ((maxc - c).astype(np.float32) / safe for c in (r, g, b))
-    h = np.where(r == maxc, bc - gc, np.where(g == maxc, np.float32(2.0) + rc - bc, np.float32(4.0) + gc - rc)).astype(np.float32)
-    h = np.fmod((h.astype(np.float64) / 6.0 + 1.0), 1.0)
-    uh = np.clip((h * 255.0).astype(np.int32), 0, 255)
+    s = (cr / np.where(maxc == 0, 1, maxc).astype(np.float32)).astype(np.float32)
+    rc, gc, bc = (((maxc - c).astype(np.float32) / safe).astype(np.float32) for c in (r, g, b))
+    rc64, gc64, bc64 = rc.astype(np.float64), gc.astype(np.float64), bc.astype(np.float64)
+    h = np.where(r == maxc, (bc - gc).astype(np.float64), np.where(g == maxc, 2.0 + rc64 - bc64, 4.0 + gc64 - rc64)).astype(np.float32)
+    h = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+    uh = np.clip((h.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
     us = np.clip((s.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
     grey = maxc == minc
     return np.stack([np.where(grey, 0, uh), np.where(grey, 0, us), maxc], -1).astype(np.uint8)
 
 
 def hsv_to_rgb(hsv):
-    """PIL HSV -> RGB (Convert.c hsv2rgb): sextant i = floor(h * 6 / 255), p / q / t rounded to nearest."""
+    """PIL HSV -> RGB (Convert.c hsv2rgb): sextant i = floor(h * 6 / 255) in double, f and fs stored as float, p / q / t
+    = round() (half away from zero) of double products."""
     h, s, v = (hsv[..., i].astype(np.int32) for i in range(3))
-    fs = s.astype(np.float32) / np.float32(255.0)
-    fh = h.astype(np.float32) * np.float32(6.0) / np.float32(255.0)
+    fh = h.astype(np.float64) * 6.0 / 255.0
     i = np.floor(fh).astype(np.int32)
-    f = fh - i.astype(np.float32)
-    vf = v.astype(np.float32)
+    f = (fh - i).astype(np.float32).astype(np.float64)
+    fs = (s.astype(np.float64) / 255.0).astype(np.float32).astype(np.float64)
+    vf = v.astype(np.float64)
 
     def rnd(x):
-        return np.clip(np.round(x.astype(np.float64)).astype(np.int32), 0, 255)      # C round(): half away from zero, x >= 0 here
-    p = rnd(vf * (np.float32(1.0) - fs))
-    q = rnd(vf * (np.float32(1.0) - fs * f))
-    t = rnd(vf * (np.float32(1.0) - fs * (np.float32(1.0) - f)))
+        return np.clip(np.floor(x + 0.5).astype(np.int32), 0, 255)     # round(): half away from zero, x >= 0 here
+    p = rnd(vf * (1.0 - fs))
+    q = rnd(vf * (1.0 - fs * f))
+    t = rnd(vf * (1.0 - fs * (1.0 - f)))
     i6 = i % 6
     r = np.choose(i6, [v, q, p, p, t, v])
     g = np.choose(i6, [t, v, v, q, p, p])

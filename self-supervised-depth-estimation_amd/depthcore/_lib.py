@@ -126,6 +126,12 @@ def _sig(lib):
         "dc_gru_blend_bwd": (i, [p, p, p, p, p, p, p, i, i, i, p]),
         "dc_gru_residual_fwd": (i, [p, p, p, i, z, p]),
         "dc_gru_residual_bwd": (i, [p, p, i, z, p]),
+        "dc_resample_ksize": (i, [i, i]),
+        "dc_resample_table": (i, [i, i, p, p]),
+        "dc_data_resize_axis": (i, [p, p, i, i, i, i, i, p, p, i, p, p]),
+        "dc_data_flip": (i, [p, p, i, i, i, p, p]),
+        "dc_data_jitter": (i, [p, i, i, p, p, p, p]),
+        "dc_data_to_tensor": (i, [p, p, i, i, p]),
         "dc_attnconv_fwd": (i, [POINTER(AttnMap), POINTER(AttnParams), POINTER(AttnMap), p, i, i, i, i, i, i, p]),
         "dc_attnconv_param_count": (i, [i]),
         "dc_attnconv_bwd_workspace": (z, [i, i, i, i]),

@@ -56,3 +56,30 @@ def random_poses(B, seed, scale=0.01):
         tr = scale * torch.randn(B, 1, 3, generator=g)
         out.append(R.transformation_from_parameters(aa, tr, invert=(f < 0)))
     return out
+
+
+# ---- data step (row f4): cases shared by tests/golden/make_golden_data.py and the tests -------------------------------
+# name: (native H, native W, height, width, num_scales, flip, jitter order or None, factors (b, c, s, hue), seed)
+DATA_CASES = {
+    "kitti_small": (94, 311, 48, 160, 4, True, (2, 0, 3, 1), (1.13, 0.86, 1.19, -0.07), 1),
+    "down_noflip": (75, 250, 32, 96, 3, False, (3, 1, 0, 2), (0.81, 1.2, 0.8, 0.1), 2),
+    "upscale": (20, 30, 32, 64, 2, True, None, None, 3),
+    "same_width": (60, 64, 32, 64, 2, True, (1, 2, 3, 0), (1.0, 0.95, 1.05, 0.0), 4),
+    "interp_only": (40, 100, 16, 48, 2, False, (0, 1, 2, 3), (0.9, 0.85, 0.8, -0.1), 5),
+}
+
+
+def data_case_image(h, w, seed):
+    """uint8 (h, w, 3): smooth ramps + blocks of saturated colours + noise, so clips, grey pixels and every hue sextant occur."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([255.0 * xx / max(w - 1, 1), 255.0 * yy / max(h - 1, 1), 127.5 + 127.5 * np.sin(xx / 7.0 + yy / 5.0)], -1)
+    img = base + rng.normal(0, 25, (h, w, 3))
+    blocks = rng.randint(0, 2, (h // 8 + 1, w // 8 + 1, 3)) * 255
+    mask = rng.rand(h // 8 + 1, w // 8 + 1) < 0.25
+    big = np.repeat(np.repeat(blocks, 8, 0), 8, 1)[:h, :w]
+    bigm = np.repeat(np.repeat(mask, 8, 0), 8, 1)[:h, :w]
+    img = np.where(bigm[..., None], big, img)
+    grey = rng.rand(h, w) < 0.05
+    img = np.where(grey[..., None], img[..., :1], img)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
