@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Workload for the HBM-traffic PMC passes: a calibration kernel with a KNOWN dword-access byte count
 (dc_disp_to_depth_fwd on 64 Mi floats: reads 256 MiB, writes 512 MiB) followed by the fused photometric
-forward + backward at BASELINE config 2 and two full training steps (Winograd convolution kernels).  Run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+forward + backward at the BASELINE config given by DC_B / DC_H / DC_W / DC_LAYERS (default C2) and two full training steps (Winograd convolution kernels).  Run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
 (separate passes); tools/pmc_traffic.sh prints calibrated bytes per launch."""
 import os
 import sys
@@ -21,12 +21,12 @@ def main():
     for _ in range(3):
         ops.disp_to_depth(big, 0.1, 100.0)
     torch.cuda.synchronize()
-    B, H, W = 12, 192, 640
+    B, H, W, NL = (int(os.environ.get(k, d)) for k, d in (("DC_B", 12), ("DC_H", 192), ("DC_W", 640), ("DC_LAYERS", 18)))
     inp = synthetic_batch(B, H, W, dev, seed=0)
     g = torch.Generator(device=dev).manual_seed(0)
     disps = []
     for s in range(4):
-        lo = torch.rand(B, 1, 6, 20, device=dev, generator=g)
+        lo = torch.rand(B, 1, H // 32, W // 32, device=dev, generator=g)
         disps.append(torch.nn.functional.interpolate(lo, size=(H >> s, W >> s), mode="bicubic").clamp(0.01, 0.99)
                      .contiguous().requires_grad_())
     T = []
@@ -44,7 +44,7 @@ def main():
     torch.cuda.synchronize()
     # two full training steps: the Winograd convolution kernels (mean HBM bytes per launch over all layers)
     import trainer as T
-    tr = T.Trainer(T.default_options(batch_size=B, overlap_streams=False), device=dev)
+    tr = T.Trainer(T.default_options(batch_size=B, height=H, width=W, num_layers=NL, overlap_streams=False), device=dev)
     tr.set_train()
     for _ in range(2):
         tr.train_step(inp)
