@@ -132,7 +132,10 @@ typedef struct dc_photo_desc {
     const float* disp[DC_MAX_SCALES];    /* outputs[("disp",s)]  (B,1,H>>s,W>>s) */
     const float* noise[DC_MAX_SCALES];   /* tie-break randn (B,2,H,W) per scale ((B,1,H,W) with
                                             AVG_REPROJ), trainer.py:594-595; NULL = on-device RNG */
-    uint64_t rng_seed;            /* used when noise[s] == NULL */
+    uint64_t rng_seed;            /* used when noise[s] == NULL: counter-based on-device noise keyed non-linearly by
+                                     (all 64 seed bits, scale, frame) and indexed by pixel.  Distribution: Irwin-Hall(4)
+                                     of the hash bytes, zero mean / unit variance, 1021 values within +-3.45 sigma -- a
+                                     tie-breaker, not torch.randn; pass noise[] for bit-parity with a randn stream */
     /* outputs of forward */
     float* losses;                /* (num_scales+1): loss/0.., loss */
     uint8_t* argmin[DC_MAX_SCALES];      /* (B,H,W) winning channel of torch.min(combined,1) */

@@ -827,13 +827,20 @@ static bool wino_enabled() {
     static const bool v = [] { const char* e = getenv("DC_CONV_WINO"); return !e || atoi(e) != 0; }();
     return v;
 }
-static inline bool wino_fwd(int C0, int C1, int Co, int H, int W) { return wino_enabled() && wino_conv_eligible(C0, C1, H, W); }
+// the Winograd kernels address their operands with 32-bit buffer offsets: a tensor of 2 GiB or more takes the direct kernels
+static inline bool wino_fits(int B, int C0, int C1, int Co, int H, int W) {
+    return (size_t)B * std::max(std::max(C0, C1), Co) * H * W * 4 < 0x7fffffffull;
+}
+static inline bool wino_fwd(int C0, int C1, int B, int Co, int H, int W) {
+    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && wino_fits(B, C0, C1, Co, H, W);
+}
 static inline bool wino_gp_ok(int B, int Co, int H, int W, int act) { return act == ACT_NONE || ((size_t)B * Co * H * W) % 4 == 0; }
 static inline bool wino_dx(int C0, int C1, int B, int Co, int H, int W, int act) {
-    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && wino_gp_ok(B, Co, H, W, act);
+    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && wino_gp_ok(B, Co, H, W, act) && wino_fits(B, C0, C1, Co, H, W);
 }
 static inline bool wino_dw(int C0, int C1, int B, int Co, int H, int W, int act) {
-    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && Co >= 64 && wino_gp_ok(B, Co, H, W, act);
+    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && Co >= 64 && wino_gp_ok(B, Co, H, W, act) &&
+           wino_fits(B, C0, C1, Co, H, W);
 }
 
 }  // namespace dc
@@ -844,7 +851,7 @@ using namespace dc;
 extern "C" size_t dc_conv3x3_fwd_workspace(int C0, int C1, int B, int Co, int H, int W) {
     if (C0 < 0 || C1 < 0 || C0 + C1 <= 0 || Co <= 0 || B <= 0 || H <= 0 || W <= 0) return 0;
     const size_t direct = al256((size_t)9 * (C0 + C1) * Co * sizeof(float));
-    return wino_fwd(C0, C1, Co, H, W) ? std::max(direct, wino_conv_ws_bytes(B, C0 + C1, Co, H, W)) : direct;
+    return wino_fwd(C0, C1, B, Co, H, W) ? std::max(direct, wino_conv_ws_bytes(B, C0 + C1, Co, H, W)) : direct;
 }
 
 extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
@@ -859,7 +866,7 @@ extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1,
     if (wino_enabled() && dispconv_eligible(C0, C1, up0 ? 1 : 0, Co, H, W))
         return dispconv_fwd(x0, weight, bias, y, B, C0, H, W, act, pad_mode, ST);
     // even widths: fused Winograd F(2x2,3x3) (wino.hip); otherwise the direct implicit GEMM below
-    if (wino_fwd(C0, C1, Co, H, W))
+    if (wino_fwd(C0, C1, B, Co, H, W))
         return wino_conv_fused_fwd(x0, C0, up0 ? 1 : 0, x1, C1, weight, bias, y, ws, B, Co, H, W, act, pad_mode, ST);
     float* wf = (float*)ws;
     hipLaunchKernelGGL(conv_wprep_kernel, dim3(ceil_div(Co * Cin * 9, 256)), dim3(256), 0, ST, weight, wf,

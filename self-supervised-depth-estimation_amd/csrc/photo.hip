@@ -375,13 +375,21 @@ __device__ __forceinline__ void reproj_values(const Row& a, const Row& b, const 
 }
 
 // On-device tie-break noise (used only when no noise tensor is given; trainer.py:594-595 adds randn*1e-5 to the
-// identity losses purely to break ties).  Counter-based: a 32-bit integer hash of (seed, pixel, stream); the
-// four bytes of the hash are summed (v_sad_u8) into an Irwin-Hall(4) variate, scaled to zero mean / unit variance.
-__device__ __forceinline__ float rng_normal(unsigned long long seed, unsigned idx, unsigned stream) {
-    unsigned h = idx * 0x9E3779B1u + (unsigned)seed + stream * 0x85EBCA77u;
+// identity losses purely to break ties).  Counter-based: key = mix(mix(seed_lo ^ seed_hi * K1) ^ stream * K2) is
+// wave-uniform (scalar ALU) and depends non-linearly on the 64-bit seed and on the stream (scale, frame), so different
+// steps / ranks / scales draw unrelated fields instead of one sequence shifted in pixel index; the per-pixel part is
+// two more mix rounds of key + idx * A.  The four bytes of the hash are summed (v_sad_u8) into an Irwin-Hall(4)
+// variate scaled to zero mean / unit variance: 1021 discrete values bounded at +-3.45 sigma -- NOT torch.randn; it only
+// has to break ties at the 1e-5 level (the cpu_tiebreak_noise option feeds real randn for bit-parity runs).
+__device__ __forceinline__ unsigned rng_mix(unsigned h) {
     h ^= h >> 15; h *= 0x2C1B3C6Du;
     h ^= h >> 12; h *= 0x297A2D39u;
     h ^= h >> 15;
+    return h;
+}
+__device__ __forceinline__ float rng_normal(unsigned long long seed, unsigned idx, unsigned stream) {
+    const unsigned key = rng_mix(rng_mix((unsigned)seed ^ ((unsigned)(seed >> 32) * 0xC2B2AE3Du)) ^ (stream * 0x85EBCA77u));
+    const unsigned h = rng_mix(key + idx * 0x9E3779B1u);
     const unsigned sum4 = __builtin_amdgcn_sad_u8(h, 0u, 0u);       // sum of the four bytes, mean 510, sigma 147.8
     return fmaf((float)sum4, 1.f / 147.8f, -510.f / 147.8f);
 }

@@ -637,7 +637,11 @@ class _WinoConv(torch.autograd.Function):
 
 
 def wino_conv3x3(x, weight):
-    """F.conv2d(x, weight, None, 1, 1) for 3x3 kernels on even-width maps (fused Winograd on the matrix cores)."""
+    """F.conv2d(x, weight, None, 1, 1) for 3x3 kernels on even-width maps (fused Winograd on the matrix cores).
+    The Winograd kernels use 32-bit buffer offsets: a tensor of 2 GiB or more takes the direct implicit-GEMM kernels of
+    the fused conv block (same arithmetic contract, size_t indexing) instead."""
+    if max(x.numel(), x.numel() // x.shape[1] * weight.shape[0]) * 4 >= 0x7fffffff:
+        return conv3x3_block(x, None, weight, None, False, ACT_NONE, PAD_ZERO)
     return _WinoConv.apply(x, weight)
 
 

@@ -87,3 +87,31 @@ def test_wino_full_size_adjoint_and_linearity(B, C, H, W):
         y2 = ops.wino_conv3x3(x2, w.detach())
         err = (y12 - (y.detach() + 0.5 * y2)).abs().max().item()
     assert err <= 2e-5 * y.detach().abs().max().item()
+
+
+def test_two_gib_tensor_takes_the_direct_kernels():
+    """A 2 GiB activation is beyond the Winograd kernels' 32-bit buffer offsets: wino_conv3x3 must route it to the direct
+    implicit-GEMM kernels (size_t indexing) instead of failing, forward and backward.  Checked on crops against the CPU
+    convolution (the operator is local) and, for the weight gradient, by the adjoint identity <gy, conv(x, w)> = <gw, w>."""
+    from depthcore import ops
+    dev = "cuda:0"
+    B, Ci, Co, H, W = 8, 64, 32, 1024, 1024
+    assert B * Ci * H * W * 4 >= 0x7fffffff
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = (torch.rand(B, Ci, H, W, device=dev, generator=g) - 0.5).requires_grad_()
+    w = (torch.randn(Co, Ci, 3, 3, device=dev, generator=g) * 0.05).requires_grad_()
+    y = ops.wino_conv3x3(x, w)
+    gy = torch.rand(y.shape, device=dev, generator=g) - 0.5
+    gx, gw = torch.autograd.grad(y, [x, w], gy)
+    for b, r0 in ((0, 0), (B - 1, H - 40), (3, 500)):
+        xc = x.detach()[b:b + 1, :, r0:r0 + 40].cpu().requires_grad_()
+        wc = w.detach().cpu()
+        yc = F.conv2d(xc, wc, None, 1, 1)
+        lo, hi = (0 if r0 == 0 else 1), (40 if r0 + 40 == H else 39)          # rows whose 3x3 support lies inside the crop
+        assert torch.allclose(y[b, :, r0 + lo:r0 + hi].cpu(), yc[0, :, lo:hi].detach(), rtol=1e-4, atol=1e-5)
+        gyc = gy[b:b + 1, :, r0:r0 + 40].cpu()
+        (gxc,) = torch.autograd.grad(yc, [xc], gyc)
+        assert torch.allclose(gx[b, :, r0 + lo:r0 + hi].cpu(), gxc[0, :, lo:hi], rtol=1e-4, atol=1e-5)
+    lhs = float((gy.double() * y.detach().double()).sum())
+    rhs = float((gw.double() * w.detach().double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
