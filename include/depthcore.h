@@ -346,6 +346,25 @@ int dc_gru_blend_bwd(const float* gates, const float* h, const float* cnm, const
 int dc_gru_residual_fwd(const float* f, const float* H, float* out, int n, size_t M, void* stream);
 int dc_gru_residual_bwd(const float* g, float* d_H, int n, size_t M, void* stream);
 
+/* ------------------------------------------------------------------ transformed-weight cache of the Winograd kernels */
+/* Every stride-1 3x3 convolution on the Winograd kernels (dc_wino3x3_fwd / _dgrad and the Winograd branch of
+ * dc_conv3x3_fwd / _bwd) starts by transforming its filter (U = G g G^T; the data gradient uses the rotated, transposed
+ * filter): one small launch in front of every convolution, although the weights only change in the optimiser step.
+ *   dc_wino_cache_register(weight, Ci, Co): `weight` (Co,Ci,3,3) stays at this address for the life of the model.
+ *   dc_wino_cache_refresh(stream): ONE launch that transforms every (weight, pass, tile layout) variant the kernels have
+ *     asked for so far; from then on those launches read the cached U.  Call it at the start of a training step, after
+ *     the weights were last written, on a stream every consumer stream waits for.
+ *   dc_wino_cache_invalidate(): the cached transforms are stale (call after the step's backward, before the optimiser).
+ *   dc_wino_cache_clear(): drop registrations and free the buffers (device-synchronising).
+ *   dc_wino_cache_variants(): number of cached variants (diagnostics / tests).
+ * A convolution whose weight is not registered, or met before the first refresh, transforms in place exactly as before:
+ * the cache changes launch counts, never results (the transform is the same device function). */
+int dc_wino_cache_register(const float* weight, int Ci, int Co);
+int dc_wino_cache_refresh(void* stream);
+void dc_wino_cache_invalidate(void);
+int dc_wino_cache_clear(void);
+int dc_wino_cache_variants(void);
+
 /* ------------------------------------------------------------------ f4 per-item data step (decoded frames -> `inputs`) */
 /* datasets/mono_dataset.py:92-118 `preprocess` and the image part of :139-211 `__getitem__`, for a whole batch of decoded
  * frames resident in HBM as uint8 HWC (n_img images, contiguous).  Byte-exact with Pillow's `Image.resize(LANCZOS)`

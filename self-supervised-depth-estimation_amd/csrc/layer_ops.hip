@@ -288,6 +288,11 @@ struct SStat {
 };
 template <int LW>
 __device__ __forceinline__ SStat ssim_stat(const float* sx, const float* sy, int cy, int cx) {
+    // Unfused throughout, as torch evaluates layers.py:219-231.  Contraction is the compiler's choice per operation: it
+    // packed sum(x^2), sum(y^2) into v_pk_fma_f32 but paired sum(xy) with sum(x) in a v_pk_add_f32 of a separately rounded
+    // product, so E[x^2] and E[xy] differed by an ulp (6e-8) for x == y -- amplified by 1 / C2 to 6e-5 in SSIM(x, x).
+    // With every product rounded, numerator and denominator are bitwise equal for x == y (the reference's KAT: == 0).
+#pragma clang fp contract(off)
     float ax = 0.f, ay = 0.f, axx = 0.f, ayy = 0.f, axy = 0.f;
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
@@ -297,18 +302,12 @@ __device__ __forceinline__ SStat ssim_stat(const float* sx, const float* sy, int
             ax += xv; ay += yv; axx += xv * xv; ayy += yv * yv; axy += xv * yv;
         }
     SStat s;
-    {
-        // Unfused, as torch evaluates layers.py:219-231: with a fused multiply-add the compiler rounds E[x^2] - mu^2 and
-        // E[xy] - mu_x mu_y at different points, and the one-ulp difference of E[x^2] (6e-8) is amplified by 1 / C2 to 6e-5 in
-        // SSIM(x, x).  Rounded products make numerator and denominator bitwise equal for x == y (the reference's KAT: == 0).
-#pragma clang fp contract(off)
-        s.mu_x = ax * s9; s.mu_y = ay * s9;
-        const float mxx = s.mu_x * s.mu_x, myy = s.mu_y * s.mu_y, mxy = s.mu_x * s.mu_y;
-        const float sig_x = axx * s9 - mxx, sig_y = ayy * s9 - myy;
-        const float sig_xy = axy * s9 - mxy;
-        s.n1 = 2.f * mxy + sC1; s.n2 = 2.f * sig_xy + sC2;
-        s.d1 = mxx + myy + sC1; s.d2 = sig_x + sig_y + sC2;
-    }
+    s.mu_x = ax * s9; s.mu_y = ay * s9;
+    const float mxx = s.mu_x * s.mu_x, myy = s.mu_y * s.mu_y, mxy = s.mu_x * s.mu_y;
+    const float sig_x = axx * s9 - mxx, sig_y = ayy * s9 - myy;
+    const float sig_xy = axy * s9 - mxy;
+    s.n1 = 2.f * mxy + sC1; s.n2 = 2.f * sig_xy + sC2;
+    s.d1 = mxx + myy + sC1; s.d2 = sig_x + sig_y + sC2;
     return s;
 }
 

@@ -34,6 +34,7 @@
 #include "wino.h"
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 namespace dc {
@@ -44,9 +45,8 @@ using wrsrc_t = __amdgpu_buffer_rsrc_t;
 
 // U = G g G^T for every (m, k), written in staging order.  grid over padded (Mp x Kp); one thread per (m, k).
 template <bool DGRAD>
-__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ uhat,
-                                                           int Co, int Ci, int MT, int Mp, int Kp, int WK) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wino_weight_one(const float* __restrict__ w, float* __restrict__ uhat, int idx, int Co, int Ci, int MT,
+                                                int Mp, int Kp, int WK) {
     if (idx >= Mp * Kp) return;
     const int m = idx / Kp, k = idx - m * Kp;
     const int M = DGRAD ? Ci : Co, K = DGRAD ? Co : Ci;
@@ -82,6 +82,29 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 #pragma unroll
     for (int pq = 0; pq < 4; ++pq)
         *reinterpret_cast<float4*>(dst + (size_t)pq * MT * 4) = make_float4(u[pq][0], u[pq][1], u[pq][2], u[pq][3]);
+}
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ uhat,
+                                                           int Co, int Ci, int MT, int Mp, int Kp, int WK) {
+    wino_weight_one<DGRAD>(w, uhat, blockIdx.x * 256 + threadIdx.x, Co, Ci, MT, Mp, Kp, WK);
+}
+
+// Every registered weight of a model in ONE launch (dc_wino_cache_refresh): `table` holds one descriptor per (weight,
+// dgrad, MT) variant with the first block of its range; a block finds its descriptor by binary search.
+struct WinoWDesc {
+    const float* w; float* uhat;
+    int Co, Ci, MT, Mp, Kp, dgrad, block0, pad_;
+};
+__global__ __launch_bounds__(256) void wino_weights_batched_kernel(const WinoWDesc* __restrict__ table, int n, int WK) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WinoWDesc d = table[lo];
+    const int idx = ((int)blockIdx.x - d.block0) * 256 + threadIdx.x;
+    if (d.dgrad) wino_weight_one<true>(d.w, d.uhat, idx, d.Co, d.Ci, d.MT, d.Mp, d.Kp, WK);
+    else wino_weight_one<false>(d.w, d.uhat, idx, d.Co, d.Ci, d.MT, d.Mp, d.Kp, WK);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -407,6 +430,38 @@ static inline size_t wino_uhat_bytes(int Ci, int Co) {
     return wino_al256(a * b * 16 * sizeof(float));
 }
 
+// ---- transformed-weight cache ---------------------------------------------------------------------------------------
+// A training step uses every convolution weight twice (forward: G g G^T, data gradient: the same of the rotated,
+// transposed filter) and, in the sequence models, once per frame; the weights only change in the optimiser step.  The
+// host registers the weights of a model once (dc_wino_cache_register), calls dc_wino_cache_refresh at the start of a
+// step -- ONE launch that transforms every variant seen so far instead of one 8 us launch in front of every convolution
+// -- and dc_wino_cache_invalidate when the step's backward is done.  Between the two, wino_launch takes U from the
+// cache; a variant (dgrad, MT) it has not met yet is transformed in place as before and joins the next refresh.
+struct WcVariant { int dgrad, MT, Mp, Kp; float* buf; bool fresh; };
+struct WcEntry { const float* w; int Ci, Co; std::vector<WcVariant> v; };
+static std::mutex g_wc_mu;
+static std::vector<WcEntry> g_wc;
+static bool g_wc_valid = false, g_wc_dirty = true;
+static WinoWDesc* g_wc_table = nullptr;
+static int g_wc_table_cap = 0, g_wc_table_n = 0, g_wc_blocks = 0;
+
+// -> cached U for this launch, or nullptr (then the caller transforms into its workspace)
+static const float* wc_lookup(const float* w, int Ci, int Co, bool dgrad, int MT, int Mp, int Kp) {
+    std::lock_guard<std::mutex> lk(g_wc_mu);
+    for (auto& e : g_wc) {
+        if (e.w != w) continue;
+        if (e.Ci != Ci || e.Co != Co) return nullptr;
+        for (auto& v : e.v)
+            if (v.dgrad == (int)dgrad && v.MT == MT) return (g_wc_valid && v.fresh) ? v.buf : nullptr;
+        WcVariant v{(int)dgrad, MT, Mp, Kp, nullptr, false};
+        if (hipMalloc((void**)&v.buf, (size_t)Mp * Kp * 16 * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        e.v.push_back(v);
+        g_wc_dirty = true;
+        return nullptr;
+    }
+    return nullptr;
+}
+
 #ifdef WINO_DIAG
 static unsigned long long* g_wino_diag = nullptr;
 extern "C" void dc_wino_set_diag(void* p) { g_wino_diag = (unsigned long long*)p; }
@@ -472,11 +527,15 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     float* slabs = (float*)((char*)d.ws + wino_uhat_bytes(d.Ci, d.Co));
     a.y = ksplit > 1 ? slabs : d.out;
     a.slab_stride = ksplit > 1 ? nout : 0;
-    if (d.dgrad)
-        hipLaunchKernelGGL((wino_weights_kernel<true>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, d.weight, (float*)d.ws, d.Co, d.Ci, MT, Mp, Kp, PSK);
-    else
-        hipLaunchKernelGGL((wino_weights_kernel<false>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, d.weight, (float*)d.ws, d.Co, d.Ci, MT, Mp, Kp, PSK);
-    DC_CHECK_LAUNCH();
+    if (const float* cached = wc_lookup(d.weight, d.Ci, d.Co, d.dgrad, MT, Mp, Kp)) {
+        a.uhat = cached;
+    } else {
+        if (d.dgrad)
+            hipLaunchKernelGGL((wino_weights_kernel<true>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, d.weight, (float*)d.ws, d.Co, d.Ci, MT, Mp, Kp, PSK);
+        else
+            hipLaunchKernelGGL((wino_weights_kernel<false>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, d.weight, (float*)d.ws, d.Co, d.Ci, MT, Mp, Kp, PSK);
+        DC_CHECK_LAUNCH();
+    }
 #ifdef WINO_DIAG
     a.diag = g_wino_diag;
 #endif
@@ -583,6 +642,72 @@ extern "C" int dc_conv_profile_collect(int kind, double* ms, double* algorithmic
     if (launches) *launches = d.used;
     d.used = 0; d.flops = d.exec = d.bytes = 0.0;
     return DC_OK;
+}
+
+extern "C" int dc_wino_cache_register(const float* weight, int Ci, int Co) {
+    if (!weight || Ci <= 0 || Co <= 0) return DC_EINVAL;
+    std::lock_guard<std::mutex> lk(g_wc_mu);
+    for (auto& e : g_wc)
+        if (e.w == weight) return (e.Ci == Ci && e.Co == Co) ? DC_OK : DC_EINVAL;
+    g_wc.push_back(WcEntry{weight, Ci, Co, {}});
+    return DC_OK;
+}
+
+extern "C" int dc_wino_cache_refresh(void* stream) {
+    std::lock_guard<std::mutex> lk(g_wc_mu);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_wc_dirty) {
+        std::vector<WinoWDesc> host;
+        int blocks = 0;
+        for (auto& e : g_wc)
+            for (auto& v : e.v) {
+                host.push_back(WinoWDesc{e.w, v.buf, e.Co, e.Ci, v.MT, v.Mp, v.Kp, v.dgrad, blocks, 0});
+                blocks += ceil_div(v.Mp * v.Kp, 256);
+            }
+        if ((int)host.size() > g_wc_table_cap) {
+            if (g_wc_table && hipFree(g_wc_table) != hipSuccess) return DC_ELAUNCH;
+            g_wc_table_cap = (int)host.size() + 64;
+            if (hipMalloc((void**)&g_wc_table, sizeof(WinoWDesc) * g_wc_table_cap) != hipSuccess) { g_wc_table = nullptr; g_wc_table_cap = 0; return DC_ELAUNCH; }
+        }
+        // synchronous upload (the descriptor list only changes while the variants of a model are still being met)
+        if (!host.empty() && hipStreamSynchronize(st) != hipSuccess) return DC_ELAUNCH;
+        if (!host.empty() && hipMemcpy(g_wc_table, host.data(), sizeof(WinoWDesc) * host.size(), hipMemcpyHostToDevice) != hipSuccess) return DC_ELAUNCH;
+        g_wc_table_n = (int)host.size(); g_wc_blocks = blocks; g_wc_dirty = false;
+    }
+    if (g_wc_table_n > 0) {
+        hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(g_wc_blocks), dim3(256), 0, st, (const WinoWDesc*)g_wc_table, g_wc_table_n, PSK);
+        DC_CHECK_LAUNCH();
+    }
+    for (auto& e : g_wc)
+        for (auto& v : e.v) v.fresh = true;
+    g_wc_valid = true;
+    return DC_OK;
+}
+
+extern "C" void dc_wino_cache_invalidate(void) {
+    std::lock_guard<std::mutex> lk(g_wc_mu);
+    g_wc_valid = false;
+}
+
+extern "C" int dc_wino_cache_clear(void) {
+    std::lock_guard<std::mutex> lk(g_wc_mu);
+    int rc = DC_OK;
+    if (hipDeviceSynchronize() != hipSuccess) rc = DC_ELAUNCH;
+    for (auto& e : g_wc)
+        for (auto& v : e.v)
+            if (v.buf && hipFree(v.buf) != hipSuccess) rc = DC_ELAUNCH;
+    g_wc.clear();
+    if (g_wc_table && hipFree(g_wc_table) != hipSuccess) rc = DC_ELAUNCH;
+    g_wc_table = nullptr; g_wc_table_cap = g_wc_table_n = g_wc_blocks = 0;
+    g_wc_valid = false; g_wc_dirty = true;
+    return rc;
+}
+
+extern "C" int dc_wino_cache_variants(void) {
+    std::lock_guard<std::mutex> lk(g_wc_mu);
+    int n = 0;
+    for (auto& e : g_wc) n += (int)e.v.size();
+    return n;
 }
 
 extern "C" size_t dc_wino3x3_workspace(int B, int Ci, int Co, int H, int W) {

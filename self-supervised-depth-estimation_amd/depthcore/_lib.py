@@ -126,6 +126,11 @@ def _sig(lib):
         "dc_gru_blend_bwd": (i, [p, p, p, p, p, p, p, i, i, i, p]),
         "dc_gru_residual_fwd": (i, [p, p, p, i, z, p]),
         "dc_gru_residual_bwd": (i, [p, p, i, z, p]),
+        "dc_wino_cache_register": (i, [p, i, i]),
+        "dc_wino_cache_refresh": (i, [p]),
+        "dc_wino_cache_invalidate": (None, []),
+        "dc_wino_cache_clear": (i, []),
+        "dc_wino_cache_variants": (i, []),
         "dc_resample_ksize": (i, [i, i]),
         "dc_resample_table": (i, [i, i, p, p]),
         "dc_data_resize_axis": (i, [p, p, i, i, i, i, i, p, p, i, p, p]),

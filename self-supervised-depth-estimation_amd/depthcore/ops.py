@@ -4,6 +4,7 @@ Every op enqueues hand-written gfx950 kernels on the current HIP stream; tensors
 are allocated by PyTorch's caching allocator and passed down as raw pointers.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -643,6 +644,54 @@ def wino_conv3x3(x, weight):
     if max(x.numel(), x.numel() // x.shape[1] * weight.shape[0]) * 4 >= 0x7fffffff:
         return conv3x3_block(x, None, weight, None, False, ACT_NONE, PAD_ZERO)
     return _WinoConv.apply(x, weight)
+
+
+# ---- transformed-weight cache of the Winograd kernels (include/depthcore.h: dc_wino_cache_*) ----------------------
+class WinoWeightCache:
+    """Owner of libdepthcore's process-wide Winograd weight cache for ONE set of parameters (a Trainer's models).
+
+    `refresh()` at the start of a training step transforms every registered 3x3 weight in one launch; the step's
+    convolutions (forward, data gradient, and every frame of the sequence models) then skip their per-launch transform;
+    `invalidate()` once the backward is done, before the optimiser rewrites the weights.  Only one owner at a time: a new
+    cache takes the registry over (the previous owner's convolutions transform per launch again -- same results)."""
+    _owner = None
+
+    def __init__(self, params):
+        L = _lib.lib()
+        check(L.dc_wino_cache_clear(), "dc_wino_cache_clear")
+        self._keep = []
+        for p_ in params:
+            if p_.dim() == 4 and tuple(p_.shape[2:]) == (3, 3) and p_.is_cuda and p_.dtype == torch.float32 and p_.is_contiguous():
+                check(L.dc_wino_cache_register(p_.data_ptr(), int(p_.shape[1]), int(p_.shape[0])), "dc_wino_cache_register")
+                self._keep.append(p_)           # the registry holds raw addresses: keep the tensors alive with it
+        WinoWeightCache._owner = weakref.ref(self)
+
+    def _mine(self):
+        o = WinoWeightCache._owner
+        return o is not None and o() is self
+
+    def refresh(self):
+        if self._mine() and self._keep:
+            check(_lib.lib().dc_wino_cache_refresh(stream(self._keep[0])), "dc_wino_cache_refresh")
+
+    def invalidate(self):
+        if self._mine():
+            _lib.lib().dc_wino_cache_invalidate()
+
+    def variants(self):
+        return int(_lib.lib().dc_wino_cache_variants()) if self._mine() else 0
+
+    def close(self):
+        if self._mine():
+            WinoWeightCache._owner = None
+            check(_lib.lib().dc_wino_cache_clear(), "dc_wino_cache_clear")
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ----------------------------------------------------------------------------------------------

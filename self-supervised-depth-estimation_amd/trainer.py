@@ -29,6 +29,7 @@ import networks
 from layers import (BackprojectDepth, Project3D, SSIM, disp_to_depth, get_smooth_loss, grid_sample,
                     interpolate_bilinear, transformation_from_parameters)
 from depthcore import ops
+from depthcore.ops import WinoWeightCache
 from depthcore.ddp import GradBuckets, broadcast_parameters
 
 
@@ -42,6 +43,18 @@ def default_options(**kw):
     for k, v in kw.items():
         setattr(o, k, v)
     return o
+
+
+class _NoWinoCache:
+    """wino_weight_cache = 0 (or a CPU trainer used for bookkeeping): every convolution transforms its own weights."""
+
+    def refresh(self):
+        pass
+
+    invalidate = close = refresh
+
+    def variants(self):
+        return 0
 
 
 class Trainer:
@@ -118,6 +131,8 @@ class Trainer:
         self.step = 0
         self.epoch = 0
         self._side_stream = None
+        use_cache = self.device.type == "cuda" and getattr(self.opt, "wino_weight_cache", True)
+        self.wino_cache = WinoWeightCache(self.parameters_to_train) if use_cache else _NoWinoCache()
         if getattr(self.opt, "load_weights_folder", None):       # trainer.py:137-138
             self.load_model()
 
@@ -377,9 +392,13 @@ class Trainer:
 
     # ------------------------------------------------------------------ trainer.py:233-237
     def train_step(self, inputs):
-        outputs, losses = self.process_batch(inputs)
-        self.buckets.zero()                     # model_optimizer.zero_grad(set_to_none=True)
-        losses["loss"].backward()
+        self.wino_cache.refresh()               # every 3x3 weight -> Winograd domain, one launch per step
+        try:
+            outputs, losses = self.process_batch(inputs)
+            self.buckets.zero()                     # model_optimizer.zero_grad(set_to_none=True)
+            losses["loss"].backward()
+        finally:
+            self.wino_cache.invalidate()        # the optimiser step below rewrites the weights
         self.buckets.finish()                   # RCCL all-reduce (mean) launched from the backward hooks
         self.model_optimizer.step()
         self.step += 1

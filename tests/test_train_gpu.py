@@ -292,3 +292,35 @@ def test_fusion_v3_training_steps():
     assert all(np.isfinite(ls)) and min(ls[-4:]) < ls[0], ls
     for n, p in tr.models["fusion"].named_parameters():
         assert (p.grad is None) == n.startswith("fusion_block_4.upscale"), n
+
+
+@pytest.mark.parametrize("gru", [None, "v5"])
+def test_wino_weight_cache_changes_nothing(gru):
+    """dc_wino_cache_*: one batched weight transform per step instead of one launch per convolution.  Same device function,
+    so the first step's loss agrees to the last bits with and without the cache and the following steps to the rounding of
+    the few order-dependent reductions; the set of cached variants is complete after the first step."""
+    import trainer as T
+    from depthcore.synthetic import synthetic_batch, synthetic_sequence_batch
+
+    def run(cache):
+        kw = dict(gru="v5", len_sequence=3, batch_size=1) if gru else dict(batch_size=2)
+        opt = T.default_options(height=64, width=96, wino_weight_cache=cache, **kw)
+        tr = T.Trainer(opt, device=DEV, seed=5)
+        tr.set_train()
+        inputs = synthetic_sequence_batch(3, 64, 96, torch.device(DEV), seed=2) if gru else synthetic_batch(2, 64, 96, torch.device(DEV), seed=2)
+        losses, variants = [], []
+        for _ in range(3):
+            _, l = tr.train_step(dict(inputs))
+            losses.append(float(l["loss"].detach()))
+            variants.append(tr.wino_cache.variants())
+        w = tr.models["encoder"].encoder.layer1[0].conv1.weight.detach().clone()
+        tr.wino_cache.close()
+        return losses, variants, w
+
+    la, va, wa = run(True)
+    lb, vb, wb = run(False)
+    assert va[0] > 20 and va[0] == va[1] == va[2], va          # every variant is met in the first step
+    assert vb == [0, 0, 0]
+    assert abs(la[0] - lb[0]) <= 1e-6 * abs(lb[0]), (la, lb)      # same forward arithmetic (the loss sums use float atomics)
+    assert np.allclose(la, lb, rtol=2e-4, atol=0), (la, lb)      # (Adam turns last-bit gradient differences into +-lr updates)
+    assert float((wa - wb).abs().max()) <= 3.5e-4                 # 3 steps x lr 1e-4
