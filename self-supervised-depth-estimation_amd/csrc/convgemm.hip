@@ -28,18 +28,23 @@ struct CgArgs {
     float* out;
     int B, Co, Ci, Hi, Wi, Ho, Wo;
     int K, Kp;            // Ci * KS * KS and its padded row length in `w`
+    unsigned xbytes;      // size of x (buffer descriptor of the gathers)
     int mtiles, ntiles;
     int splits, chunks;   // weight gradient
 };
 
-// four stride-2 taps of one input row: x[ix0], x[ix0+2], x[ix0+4], x[ix0+6] with zero padding outside [0, Wi)
-__device__ __forceinline__ gf4 gather4_s2(const float* row, int ix0, int Wi, bool row_ok) {
-    gf4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row_ok) {
-        if (ix0 >= 0 && ix0 < Wi) v.x = row[ix0];
-        if (ix0 + 2 >= 0 && ix0 + 2 < Wi) v.y = row[ix0 + 2];
-        if (ix0 + 4 >= 0 && ix0 + 4 < Wi) v.z = row[ix0 + 4];
-        if (ix0 + 6 >= 0 && ix0 + 6 < Wi) v.w = row[ix0 + 6];
+// four stride-2 taps of one input row: x[ix0], x[ix0+2], x[ix0+4], x[ix0+6] with zero padding outside [0, Wi) and for a row
+// outside the image.  Buffer loads with a 32-bit byte offset: an invalid tap gets an offset past num_records and the
+// hardware returns 0 -- no branches, no 64-bit address arithmetic, no selects (the predicated dword loads this replaces
+// cost ~75 vector instructions per four taps, 5 per MFMA at the stem, and left the matrix pipe 51 % busy).
+using cgrsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ gf4 gather4_s2(cgrsrc_t xr, unsigned rowoff, bool row_ok, int ix0, int Wi) {
+    gf4 v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ix = ix0 + 2 * t;
+        const unsigned off = (row_ok && (unsigned)ix < (unsigned)Wi) ? rowoff + 4u * (unsigned)ix : 0x80000000u;
+        v[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)off, 0, 0));
     }
     return v;
 }
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void cg_fwd_kernel(CgArgs a) {
     const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
     const int m0 = (lb % a.mtiles) * BM, n0 = (lb / a.mtiles) * BN;
     const int P = a.Ho * a.Wo, N = a.B * P;
-    const size_t plane = (size_t)a.Hi * a.Wi;
+    const unsigned plane = (unsigned)(a.Hi * a.Wi);
 
     const float* asrc[NA];
     int adst[NA];
@@ -72,8 +77,12 @@ __global__ __launch_bounds__(256) void cg_fwd_kernel(CgArgs a) {
     const int c4 = tid % (BN / 4), krow0 = tid / (BN / 4);
     const int ng = min(n0 + c4 * 4, N - 4);
     const int b = ng / P, pp = ng - b * P, py = pp / a.Wo, px0 = pp - py * a.Wo;
-    const float* xb = a.x + (size_t)b * a.Ci * plane;
+    const cgrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
+    const unsigned xboff = (unsigned)b * (unsigned)a.Ci * plane;           // elements; the whole tensor is < 2^29 elements (cg_ok)
     const int iy0 = 2 * py - PAD, ix0 = 2 * px0 - PAD;
+    // (a second register stage -- loads of chunk c+2 in flight during the MFMAs of chunk c -- was measured: 200 VGPRs, two
+    // blocks per CU instead of three, 8-28 % slower.  The gathers are bound by L1 line throughput, not by latency: a
+    // stride-2 dword gather touches 16 cache lines per wave instruction and uses an eighth of each.)
     gf4 ra[NA], rb[NB];
     auto gload = [&](int k0) {
 #pragma unroll
@@ -83,8 +92,8 @@ __global__ __launch_bounds__(256) void cg_fwd_kernel(CgArgs a) {
             const int k = k0 + krow0 + j * (1024 / BN);
             const int ci = k / T, tap = k - ci * T, ky = tap / KS, kx = tap - ky * KS;
             const int iy = iy0 + ky;
-            const bool ok = k < a.K && iy >= 0 && iy < a.Hi;
-            rb[j] = gather4_s2(xb + (size_t)min(ci, a.Ci - 1) * plane + (size_t)max(min(iy, a.Hi - 1), 0) * a.Wi, ix0 + kx, a.Wi, ok);
+            const bool ok = k < a.K && (unsigned)iy < (unsigned)a.Hi;
+            rb[j] = gather4_s2(xr, (xboff + (unsigned)ci * plane + (unsigned)(iy * a.Wi)) * 4u, ok, ix0 + kx, a.Wi);
         }
     };
     auto commit = [&](int buf) {
@@ -105,13 +114,8 @@ __global__ __launch_bounds__(256) void cg_fwd_kernel(CgArgs a) {
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) gload((c + 1) * KC);
-#pragma unroll
-        for (int q = 0; q < KC / 8; ++q) {
-            float av[4][2], bv[4][2];
-            read_red<MT, KC>(As + buf * ASZ, wm * 16 * MT, q, lane, av);
-            read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, bv);
-            mma_octet<MT, NT>(av, bv, acc);
-        }
+        mma_chunk32<MT, NT>([&](int q, float (&v)[4][2]) { read_red<MT, KC>(As + buf * ASZ, wm * 16 * MT, q, lane, v); },
+                            [&](int q, float (&v)[4][2]) { read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, v); }, acc);
         if (c + 1 < nchunk) commit(buf ^ 1);
         __syncthreads();
     }
@@ -144,13 +148,14 @@ __global__ __launch_bounds__(256) void cg_wgrad_kernel(CgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = (blockIdx.x % a.mtiles) * BM, c0 = (blockIdx.x / a.mtiles) * BN;
     const int P = a.Ho * a.Wo;
-    const size_t plane = (size_t)a.Hi * a.Wi;
+    const unsigned plane = (unsigned)(a.Hi * a.Wi);
+    const cgrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
     const int kq = tid % (KC / 4), row0 = tid / (KC / 4);
     size_t arow[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) arow[j] = (size_t)min(m0 + row0 + j * (1024 / KC), a.Co - 1) * P;
     // this thread's B rows: column r of dw <-> (ci, ky, kx), fixed for the whole loop
-    size_t bch[NB];
+    unsigned bch[NB];
     int bky[NB], bkx[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) void cg_wgrad_kernel(CgArgs a) {
         const int ci = r / T, tap = r - ci * T;
         bky[j] = tap / KS - PAD;
         bkx[j] = tap - (tap / KS) * KS - PAD;
-        bch[j] = (size_t)ci * plane;
+        bch[j] = (unsigned)ci * plane;
     }
     gf4 ra[NA], rb[NB];
     const int Ntot = a.B * P;
@@ -168,14 +173,13 @@ __global__ __launch_bounds__(256) void cg_wgrad_kernel(CgArgs a) {
         const int n = min(n_, Ntot - 4);
         const int b = n / P, p = n - b * P, py = p / a.Wo, px0 = p - py * a.Wo;
         const float* ga = a.gy + (size_t)b * a.Co * P + p;
-        const float* xb = a.x + (size_t)b * a.Ci * plane;
+        const unsigned xboff = (unsigned)b * (unsigned)a.Ci * plane;
 #pragma unroll
         for (int j = 0; j < NA; ++j) ra[j] = okn ? *reinterpret_cast<const gf4*>(ga + arow[j]) : gf4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int iy = 2 * py + bky[j];
-            const bool ok = iy >= 0 && iy < a.Hi;
-            rb[j] = gather4_s2(xb + bch[j] + (size_t)max(min(iy, a.Hi - 1), 0) * a.Wi, 2 * px0 + bkx[j], a.Wi, ok);
+            rb[j] = gather4_s2(xr, (xboff + bch[j] + (unsigned)(iy * a.Wi)) * 4u, (unsigned)iy < (unsigned)a.Hi, 2 * px0 + bkx[j], a.Wi);
         }
     };
     auto commit = [&](int buf) {
@@ -201,13 +205,8 @@ __global__ __launch_bounds__(256) void cg_wgrad_kernel(CgArgs a) {
         const int buf = (ch - ch0) & 1;
         const bool more = ch + 1 < ch1;
         if (more) gload(ch + 1);
-#pragma unroll
-        for (int q = 0; q < KC / 8; ++q) {
-            float av[4][2], bv[4][2];
-            read_red<MT, KC>(g1_smem + buf * ASZ, wm * 16 * MT, q, lane, av);
-            read_red<NT, KC>(g1_smem + 2 * ASZ + buf * BSZ, wn * 16 * NT, q, lane, bv);
-            mma_octet<MT, NT>(av, bv, acc);
-        }
+        mma_chunk32<MT, NT>([&](int q, float (&v)[4][2]) { read_red<MT, KC>(g1_smem + buf * ASZ, wm * 16 * MT, q, lane, v); },
+                            [&](int q, float (&v)[4][2]) { read_red<NT, KC>(g1_smem + 2 * ASZ + buf * BSZ, wn * 16 * NT, q, lane, v); }, acc);
         if (more) commit(buf ^ 1);
         __syncthreads();
     }
@@ -222,14 +221,6 @@ __global__ __launch_bounds__(256) void cg_wgrad_kernel(CgArgs a) {
                 const int col = c0 + wn * 16 * NT + nt * 16 + (lane & 15);
                 if (m < a.Co && col < a.K) slab[(size_t)m * a.K + col] = acc[mt][nt][r];
             }
-}
-
-__global__ __launch_bounds__(256) void cg_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float t = slab[i];
-    for (int s = 1; s < splits; ++s) t += slab[(size_t)s * n + i];
-    dw[i] = t;
 }
 
 // =====================================================================================================================
@@ -319,21 +310,11 @@ __global__ __launch_bounds__(256) void cg_dgrad3_kernel(CgArgs a) {
         int ky, kx, co0;
         tap_of(c, ky, kx, co0);
         if (kx == 1) {
-#pragma unroll
-            for (int q = 0; q < KC / 8; ++q) {
-                float av[4][2], bv[4][2];
-                read_idx<MT, SA>(As + buf * ASZ, wm * 16 * MT, q, lane, av);
-                read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, bv);
-                mma_octet<MT, NT>(av, bv, acc[0]);
-            }
+            mma_chunk32<MT, NT>([&](int q, float (&v)[4][2]) { read_idx<MT, SA>(As + buf * ASZ, wm * 16 * MT, q, lane, v); },
+                                [&](int q, float (&v)[4][2]) { read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, v); }, acc[0]);
         } else {
-#pragma unroll
-            for (int q = 0; q < KC / 8; ++q) {
-                float av[4][2], bv[4][2];
-                read_idx<MT, SA>(As + buf * ASZ, wm * 16 * MT, q, lane, av);
-                read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, bv);
-                mma_octet<MT, NT>(av, bv, acc[1]);
-            }
+            mma_chunk32<MT, NT>([&](int q, float (&v)[4][2]) { read_idx<MT, SA>(As + buf * ASZ, wm * 16 * MT, q, lane, v); },
+                                [&](int q, float (&v)[4][2]) { read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, v); }, acc[1]);
         }
         if (c + 1 < nchunk) commit(buf ^ 1);
         __syncthreads();
@@ -399,7 +380,7 @@ static bool cg_ok(int B, int Ci, int Co, int Hi, int Wi, int ks) {
     if ((Hi & 1) || (Wi & 1)) return false;
     const int Ho = Hi / 2, Wo = Wi / 2;
     if (Wo & 3) return false;                           // 16-byte pixel groups inside one output row
-    if ((size_t)B * std::max(Ci, Co) * Hi * Wi >= (1ull << 31)) return false;
+    if ((size_t)B * std::max(Ci, Co) * Hi * Wi >= (1ull << 29)) return false;      // 32-bit byte offsets of the buffer gathers
     return true;
 }
 static int cg_kp(int Ci, int ks) { return ceil_div(Ci * ks * ks, GKC) * GKC; }
@@ -419,6 +400,7 @@ extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void
     CgArgs a{};
     a.x = x; a.out = y; a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
     a.K = Ci * ksize * ksize; a.Kp = cg_kp(Ci, ksize);
+    a.xbytes = (unsigned)((size_t)B * Ci * Hi * Wi * sizeof(float));
     if (a.Kp != a.K) {       // stem: rows of 147 / 294 floats are neither 16-byte aligned nor a multiple of the chunk
         hipLaunchKernelGGL(cg_wpad_kernel, dim3(ceil_div(Co * a.Kp, 256)), dim3(256), 0, st, weight, (float*)ws, Co, a.K, a.Kp);
         DC_CHECK_LAUNCH();
@@ -460,6 +442,7 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
     CgArgs a{};
     a.x = x; a.gy = gy; a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
     a.K = Ci * ksize * ksize; a.Kp = a.K;
+    a.xbytes = (unsigned)((size_t)B * Ci * Hi * Wi * sizeof(float));
     a.chunks = ceil_div(B * a.Ho * a.Wo, GKC);
     a.mtiles = ceil_div(Co, 64); a.ntiles = ceil_div(a.K, 64);
     a.splits = cg_wsplits(a.mtiles * a.ntiles, a.chunks);
@@ -471,7 +454,7 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
     DC_CHECK_LAUNCH();
     if (a.splits > 1) {
         const int n = Co * a.K;
-        hipLaunchKernelGGL(cg_slab_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, (const float*)ws, dweight, a.splits, n);
+        hipLaunchKernelGGL(slab_reduce16_kernel<float>, dim3(ceil_div(n, 16)), dim3(256), 0, st, (const float*)ws, dweight, a.splits, n);
         DC_CHECK_LAUNCH();
     }
     return DC_OK;

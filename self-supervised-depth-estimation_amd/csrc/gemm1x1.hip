@@ -126,13 +126,8 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) gload((c + 1) * KC);
-#pragma unroll
-        for (int q = 0; q < KC / 8; ++q) {
-            float av[4][2], bv[4][2];
-            read_red<MT, KC>(As + buf * ASZ, wm * 16 * MT, q, lane, av);
-            read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, bv);
-            mma_octet<MT, NT>(av, bv, acc);
-        }
+        mma_chunk32<MT, NT>([&](int q, float (&v)[4][2]) { read_red<MT, KC>(As + buf * ASZ, wm * 16 * MT, q, lane, v); },
+                            [&](int q, float (&v)[4][2]) { read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, v); }, acc);
         if (c + 1 < nchunk) commit(buf ^ 1);
         __syncthreads();
     }
@@ -218,13 +213,8 @@ __global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) gload((c + 1) * KC);
-#pragma unroll
-        for (int q = 0; q < KC / 8; ++q) {
-            float av[4][2], bv[4][2];
-            read_idx<MT, SA>(As + buf * ASZ, wm * 16 * MT, q, lane, av);
-            read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, bv);
-            mma_octet<MT, NT>(av, bv, acc);
-        }
+        mma_chunk32<MT, NT>([&](int q, float (&v)[4][2]) { read_idx<MT, SA>(As + buf * ASZ, wm * 16 * MT, q, lane, v); },
+                            [&](int q, float (&v)[4][2]) { read_idx<NT, SB>(Bs + buf * BSZ, wn * 16 * NT, q, lane, v); }, acc);
         if (c + 1 < nchunk) commit(buf ^ 1);
         __syncthreads();
     }
@@ -330,13 +320,8 @@ __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
         const int buf = (ch - ch0) & 1;
         const bool more = ch + 1 < ch1;
         if (more) gload(ch + 1);
-#pragma unroll
-        for (int q = 0; q < KC / 8; ++q) {
-            float av[4][2], bv[4][2];
-            read_red<MT, KC>(g1_smem + buf * ASZ, wm * 16 * MT, q, lane, av);
-            read_red<NT, KC>(g1_smem + 2 * ASZ + buf * BSZ, wn * 16 * NT, q, lane, bv);
-            mma_octet<MT, NT>(av, bv, acc);
-        }
+        mma_chunk32<MT, NT>([&](int q, float (&v)[4][2]) { read_red<MT, KC>(g1_smem + buf * ASZ, wm * 16 * MT, q, lane, v); },
+                            [&](int q, float (&v)[4][2]) { read_red<NT, KC>(g1_smem + 2 * ASZ + buf * BSZ, wn * 16 * NT, q, lane, v); }, acc);
         if (more) commit(buf ^ 1);
         __syncthreads();
     }
@@ -351,15 +336,6 @@ __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
                 const int ci = c0 + wn * 16 * NT + nt * 16 + (lane & 15);
                 if (m < a.Co && ci < a.Ci) slab[(size_t)m * a.Ci + ci] = acc[mt][nt][r];
             }
-}
-
-// dw = sum of the slabs in fixed order (float4 per thread; slabs are L2-hot)
-__global__ __launch_bounds__(256) void g1_wreduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int n4) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    gf4 t = reinterpret_cast<const gf4*>(slab)[i];
-    for (int s = 1; s < splits; ++s) t += reinterpret_cast<const gf4*>(slab + (size_t)s * n4 * 4)[i];
-    reinterpret_cast<gf4*>(dw)[i] = t;
 }
 
 // ---- bias + activation backward of the 1x1 convolutions that have them (pose decoder): g' = gy * act'(y), dbias = sum g'
@@ -535,7 +511,7 @@ extern "C" int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight,
     DC_CHECK_LAUNCH();
     if (a.splits > 1) {
         const int n4 = Co * Ci / 4;
-        hipLaunchKernelGGL(g1_wreduce_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, st, (const float*)ws, dweight, a.splits, n4);
+        hipLaunchKernelGGL(slab_reduce16_kernel<gf4>, dim3(ceil_div(n4, 16)), dim3(256), 0, st, (const gf4*)ws, (gf4*)dweight, a.splits, n4);
         DC_CHECK_LAUNCH();
     }
     return DC_OK;

@@ -323,4 +323,4 @@ def test_wino_weight_cache_changes_nothing(gru):
     assert vb == [0, 0, 0]
     assert abs(la[0] - lb[0]) <= 1e-6 * abs(lb[0]), (la, lb)      # same forward arithmetic (the loss sums use float atomics)
     assert np.allclose(la, lb, rtol=2e-4, atol=0), (la, lb)      # (Adam turns last-bit gradient differences into +-lr updates)
-    assert float((wa - wb).abs().max()) <= 3.5e-4                 # 3 steps x lr 1e-4
+    assert float((wa - wb).abs().max()) <= 7e-4                   # two trajectories, 3 steps, each update within +-lr = 1e-4
