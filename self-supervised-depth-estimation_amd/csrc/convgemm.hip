@@ -17,6 +17,8 @@
 #include "dc_common.h"
 #include "gemm_tiles.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 namespace dc {
@@ -338,6 +340,270 @@ __global__ __launch_bounds__(256) void cg_dgrad3_kernel(CgArgs a) {
         }
 }
 
+// =====================================================================================================================
+// The 7x7 / 2 stem (Ci = 3 or 6, Co = 64) with the input PATCH staged in LDS.
+// In the gather formulation above every (tap, pixel) pair is its own dword load: each input element is fetched 49/4 = 12
+// times, by stride-2 wave instructions that touch 16 cache lines and use an eighth of each -- the L1 path is as busy as
+// the matrix pipe (SQ counters: MFMA 51 % busy, waits on vector memory, none on LDS).  Here a block owns a tile of 2 x 64
+// output pixels of one image and loads the (2*2+5) x (2*64+8) x Ci input patch ONCE with aligned 16-byte loads,
+// de-interleaved by column parity on the way into LDS (E[j] = x[2j], O[j] = x[2j+1]): tap kx of output column c is then
+//   kx odd : E[c + (kx+1)/2]      kx even : O[c + kx/2]        (j counted from input column 2*ox0 - 4)
+// i.e. CONTIGUOUS in c, so the B operand of the implicit GEMM (k = (ci,ky,kx), n = pixel) is read straight from the
+// patch with ds_read_b32 at  koff[k] + r * 2 * ROW + c  -- no im2col tile, no per-tap global traffic.
+// =====================================================================================================================
+constexpr int ST_TH = 2, ST_TW = 64, ST_PW = 68, ST_ROWS = 2 * ST_TH + 5, ST_ROW = 2 * ST_PW;   // one patch row = [E | O]
+struct StemArgs {
+    const float* x; const float* w; const float* gy; float* out;
+    int B, Ci, Co, Hi, Wi, Ho, Wo, K, Kp;
+    int tiles_x, tiles_y, ntiles;     // tiles per row, per image column, total (B * tiles_y * tiles_x)
+    int nblocks;                      // weight gradient: blocks that share the tiles
+    unsigned xbytes;
+};
+
+// koff of reduction index k = (ci, ky, kx): float offset of tap k for tile pixel (r = 0, c = 0)
+__device__ __forceinline__ int stem_koff(int k, int K) {
+    if (k >= K) return 0;                                 // padded columns: weight 0 / never stored; any valid address
+    const int ci = k / 49, tap = k - ci * 49, ky = tap / 7, kx = tap - ky * 7;
+    return (ci * ST_ROWS + ky) * ST_ROW + ((kx & 1) ? (kx + 1) / 2 : ST_PW + kx / 2);
+}
+
+// the patch of tile (b, ty, tx): 16-byte loads of rows 2*oy0-3 .. +8, columns 2*ox0-4 .. +135; rows / columns outside
+// the image come back as zeros from the buffer descriptor
+template <int NV>
+__device__ __forceinline__ void stem_patch_load(const StemArgs& a, cgrsrc_t xr, int b, int oy0, int ox0, int tid, gf4 (&v)[NV]) {
+    const int nitems = a.Ci * ST_ROWS * (ST_ROW / 4);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = tid + j * 256;
+        const int row = idx / (ST_ROW / 4), m = idx - row * (ST_ROW / 4);
+        const int ci = row / ST_ROWS, pr = row - ci * ST_ROWS;
+        const int Y = 2 * oy0 - 3 + pr, X = 2 * ox0 - 4 + 4 * m;
+        const bool ok = idx < nitems && (unsigned)Y < (unsigned)a.Hi && (unsigned)X < (unsigned)a.Wi;
+        const unsigned off = ok ? (((unsigned)(b * a.Ci + ci) * a.Hi + Y) * a.Wi + X) * 4u : 0x80000000u;
+        v[j] = __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+    }
+}
+template <int NV>
+__device__ __forceinline__ void stem_patch_store(const StemArgs& a, float* P, int tid, const gf4 (&v)[NV]) {
+    const int nitems = a.Ci * ST_ROWS * (ST_ROW / 4);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = tid + j * 256;
+        if (idx >= nitems) continue;
+        const int row = idx / (ST_ROW / 4), m = idx - row * (ST_ROW / 4);
+        float* e = P + row * ST_ROW + 2 * m;
+        *reinterpret_cast<gf2*>(e) = gf2{v[j].x, v[j].z};
+        *reinterpret_cast<gf2*>(e + ST_PW) = gf2{v[j].y, v[j].w};
+    }
+}
+
+// ---- forward: block = tile x 64 output channels; 4 waves = (channel half wm) x (tile row wn); MT = 2, NT = 4 ------------
+constexpr int ST_NVP = 8;        // ceil(6 * 9 * 34 / 256) patch vectors per thread
+__global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
+    constexpr int KC = GKC, MT = 2, NT = 4, ASZ = 64 * (KC + RP);
+    float* const As = g1_smem;                       // [2][64][KC + RP]
+    float* const P = g1_smem + 2 * ASZ;              // [Ci][ST_ROWS][E | O]
+    int* const ktab = reinterpret_cast<int*>(P + a.Ci * ST_ROWS * ST_ROW);      // [Kp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int b = lb / per_img, tr = lb - b * per_img, ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    const int m0 = blockIdx.y * 64;
+    const cgrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
+
+    gf4 pv[ST_NVP];
+    stem_patch_load<ST_NVP>(a, xr, b, oy0, ox0, tid, pv);
+    const float* asrc[2];
+    int adst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = tid + j * 256, row = idx / (KC / 4), kq = idx % (KC / 4);
+        asrc[j] = a.w + (size_t)(m0 + row) * a.Kp + kq * 4;
+        adst[j] = row * (KC + RP) + kq * 4;
+    }
+    gf4 ra[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j]);
+    for (int k = tid; k < a.Kp; k += 256) ktab[k] = stem_koff(k, a.K);
+    stem_patch_store<ST_NVP>(a, P, tid, pv);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) store_red4(As + adst[j], ra[j]);
+    __syncthreads();
+
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
+    const int i = lane & 15, kp = lane >> 4;
+    const float* Pl = P + wn * 2 * ST_ROW + i;            // this lane's pixel (r = wn, c = 16 t + i), tap offset added per k
+    const int nchunk = a.Kp / KC;
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j] + (c + 1) * KC);
+        }
+        mma_chunk32<MT, NT>([&](int q, float (&v)[4][2]) { read_red<MT, KC>(As + buf * ASZ, wm * 16 * MT, q, lane, v); },
+                            [&](int q, float (&v)[4][2]) {
+                                const int2 ko = *reinterpret_cast<const int2*>(ktab + c * KC + q * 8 + 2 * kp);
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) { v[t][0] = Pl[ko.x + 16 * t]; v[t][1] = Pl[ko.y + 16 * t]; }
+                            }, acc);
+        if (c + 1 < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) store_red4(As + (buf ^ 1) * ASZ + adst[j], ra[j]);
+        }
+        __syncthreads();
+    }
+    const int oy = oy0 + wn;
+    if (oy < a.Ho) {
+        const int P2 = a.Ho * a.Wo;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + mt * 16 + kp * 4 + r;
+                float* dst = a.out + ((size_t)b * a.Co + m) * P2 + (size_t)oy * a.Wo + ox0 + i;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (ox0 + 16 * t + i < a.Wo) dst[16 * t] = acc[mt][t][r];
+            }
+    }
+}
+
+// ---- weight gradient: a block walks a contiguous range of tiles and keeps dw[64][Kp] in registers ------------------------
+// 4 waves = (channel half wm) x (column half wn); a wave owns 32 channels x Kp/2 columns = MT 2 x NT (5 or 10) tiles.
+// Reduction = the tile's 128 pixels in octets of 8 along a row: A = gy[co][pixel] (reduction-contiguous image, as the
+// GEMM kernels), B[k][pixel] = patch[koff[k] + r * 2 * ROW + c] with koff fixed per lane for the whole kernel.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemArgs a) {
+    constexpr int MT = 2, GS = 128 + RP, NVG = 8;
+    float* const G = g1_smem;                        // [64][128 + RP]   gy of the tile, pixel = r * 64 + c
+    float* const P = g1_smem + 64 * GS;              // patch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 15, kp = lane >> 4;
+    const cgrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
+    const int per = (a.ntiles + a.nblocks - 1) / a.nblocks;
+    const int t0 = blockIdx.x * per, t1 = min(t0 + per, a.ntiles);
+    const int per_img = a.tiles_y * a.tiles_x, P2 = a.Ho * a.Wo;
+    int koff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) koff[t] = stem_koff(wn * 16 * NT + 16 * t + i, a.K);
+
+    // the next tile's patch is prefetched into registers during the MFMAs; its gy rows too when the accumulators leave
+    // room (NT = 5) -- with NT = 10 (80 accumulator registers) they are fetched in the commit phase instead (no spills at
+    // two blocks per CU; the other block multiplies meanwhile)
+    constexpr bool PREFETCH_G = NT <= 5;
+    gf4 pv[ST_NVP], gv[PREFETCH_G ? NVG : 1];
+    auto tile_org = [&](int tile, int& b, int& oy0, int& ox0) {
+        b = tile / per_img;
+        const int tr = tile - b * per_img, ty = tr / a.tiles_x;
+        oy0 = ty * ST_TH; ox0 = (tr - ty * a.tiles_x) * ST_TW;
+    };
+    auto gy_vec = [&](int b, int oy0, int ox0, int j) {          // gy: 64 channels x 2 rows x 16 float4
+        const int idx = tid + j * 256, co = idx >> 5, rr = (idx >> 4) & 1, c4 = idx & 15;
+        const int oy = oy0 + rr, ox = ox0 + c4 * 4;
+        return (oy < a.Ho && ox < a.Wo) ? *reinterpret_cast<const gf4*>(a.gy + ((size_t)b * a.Co + co) * P2 + (size_t)oy * a.Wo + ox)
+                                        : gf4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto gy_store = [&](int j, gf4 v) {
+        const int idx = tid + j * 256, co = idx >> 5, rr = (idx >> 4) & 1, c4 = idx & 15;
+        store_red4(G + co * GS + rr * 64 + c4 * 4, v);
+    };
+    auto gload = [&](int tile) {
+        int b, oy0, ox0;
+        tile_org(tile, b, oy0, ox0);
+        stem_patch_load<ST_NVP>(a, xr, b, oy0, ox0, tid, pv);
+        if constexpr (PREFETCH_G) {
+#pragma unroll
+            for (int j = 0; j < NVG; ++j) gv[j] = gy_vec(b, oy0, ox0, j);
+        }
+    };
+    auto commit = [&](int tile) {
+        stem_patch_store<ST_NVP>(a, P, tid, pv);
+        if constexpr (PREFETCH_G) {
+#pragma unroll
+            for (int j = 0; j < NVG; ++j) gy_store(j, gv[j]);
+        } else {
+            int b, oy0, ox0;
+            tile_org(tile, b, oy0, ox0);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                gf4 t4[NVG / 2];
+#pragma unroll
+                for (int j = 0; j < NVG / 2; ++j) t4[j] = gy_vec(b, oy0, ox0, h2 * (NVG / 2) + j);
+#pragma unroll
+                for (int j = 0; j < NVG / 2; ++j) gy_store(h2 * (NVG / 2) + j, t4[j]);
+            }
+        }
+    };
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
+    if (t0 < t1) gload(t0);
+    for (int tile = t0; tile < t1; ++tile) {
+        commit(tile);
+        __syncthreads();
+        if (tile + 1 < t1) gload(tile + 1);
+#pragma unroll 1
+        for (int h = 0; h < 4; ++h) {                   // half rows of 32 pixels: r = h >> 1, c from (h & 1) * 32
+            const float* Gh = G + h * 32;
+            const float* Ph = P + (h >> 1) * 2 * ST_ROW + (h & 1) * 32 + 2 * kp;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float av[MT][2], bv[NT][2];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const gf2 v = *reinterpret_cast<const gf2*>(Gh + (wm * 32 + mt * 16 + i) * GS + q * 8 + 2 * kp);
+                    av[mt][0] = v.x; av[mt][1] = v.y;
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { bv[t][0] = Ph[koff[t] + q * 8]; bv[t][1] = Ph[koff[t] + q * 8 + 1]; }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s2], bv[t][s2], acc[mt][t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* slab = a.out + (size_t)blockIdx.x * 64 * a.Kp;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[(size_t)(wm * 32 + mt * 16 + kp * 4 + r) * a.Kp + wn * 16 * NT + 16 * t + i] = acc[mt][t][r];
+}
+
+// dw[co][k] (k < K) = sum over blocks of slab[block][co][Kp], 16 block groups x 16 lanes (fixed order)
+__global__ __launch_bounds__(256) void stem_wreduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nblocks, int K, int Kp) {
+    __shared__ float sm[256];
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int o = blockIdx.x * 16 + l;                  // over 64 * K outputs
+    const int n = 64 * K;
+    const int co = min(o, n - 1) / K, k = min(o, n - 1) - co * K;
+    const int per = (nblocks + 15) / 16, s0 = g * per, s1 = min(s0 + per, nblocks);
+    float t = 0.f;
+    for (int s = s0; s < s1; ++s) t += slab[((size_t)s * 64 + co) * Kp + k];
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    if (g == 0 && o < n) {
+        float r = sm[l];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) r += sm[j * 16 + l];
+        dw[o] = r;
+    }
+}
+
 // ---- weight re-layouts (once per call; a few hundred KB) ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void cg_wpad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int K, int Kp) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -370,6 +636,24 @@ template <typename K>
 static bool cg_set_lds(K kernel, size_t bytes) {
     return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
+
+// the patch-staged stem kernels: 7x7 / 2, 64 output channels, 3 or 6 input channels (DC_STEM_PATCH=0: gather kernels, A/B)
+static bool stem_enabled() {
+    static const bool v = [] { const char* e = getenv("DC_STEM_PATCH"); return !e || atoi(e) != 0; }();
+    return v;
+}
+static bool stem_ok(int Ci, int Co, int ks) { return stem_enabled() && ks == 7 && Co == 64 && (Ci == 3 || Ci == 6); }
+static StemArgs stem_args(int B, int Ci, int Co, int Hi, int Wi) {
+    StemArgs a{};
+    a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
+    a.K = Ci * 49; a.Kp = ceil_div(a.K, GKC) * GKC;
+    a.tiles_x = ceil_div(a.Wo, ST_TW); a.tiles_y = ceil_div(a.Ho, ST_TH); a.ntiles = B * a.tiles_y * a.tiles_x;
+    a.nblocks = std::min(a.ntiles, 512);
+    a.xbytes = (unsigned)((size_t)B * Ci * Hi * Wi * sizeof(float));
+    return a;
+}
+static size_t stem_lds_fwd(int Ci, int Kp) { return ((size_t)2 * 64 * (GKC + RP) + (size_t)Ci * ST_ROWS * ST_ROW + Kp) * sizeof(float); }
+static size_t stem_lds_wgrad(int Ci) { return ((size_t)64 * (128 + RP) + (size_t)Ci * ST_ROWS * ST_ROW) * sizeof(float); }
 
 }  // namespace dc
 
@@ -408,6 +692,13 @@ extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void
     } else {
         a.w = weight;
     }
+    if (stem_ok(Ci, Co, ksize)) {
+        StemArgs sa = stem_args(B, Ci, Co, Hi, Wi);
+        sa.x = x; sa.w = a.w; sa.out = y;
+        hipLaunchKernelGGL(stem_fwd_kernel, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(Ci, sa.Kp), st, sa);
+        DC_CHECK_LAUNCH();
+        return DC_OK;
+    }
     const int N = B * a.Ho * a.Wo;
     const CgTile t = cg_pick(Co, N);
     a.mtiles = ceil_div(Co, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
@@ -430,6 +721,10 @@ extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void
 extern "C" size_t dc_convs2_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize) {
     if (!cg_ok(B, Ci, Co, Hi, Wi, ksize)) return 0;
     const int K = Ci * ksize * ksize;
+    if (stem_ok(Ci, Co, ksize)) {
+        const StemArgs sa = stem_args(B, Ci, Co, Hi, Wi);
+        return (size_t)sa.nblocks * 64 * sa.Kp * sizeof(float);
+    }
     const int tiles = ceil_div(Co, 64) * ceil_div(K, 64);
     const int splits = cg_wsplits(tiles, ceil_div(B * (Hi / 2) * (Wi / 2), GKC));
     return splits > 1 ? (size_t)splits * Co * K * sizeof(float) : 16;
@@ -439,6 +734,17 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
                                int ksize, void* stream) {
     if (!x || !gy || !dweight || !ws || !cg_ok(B, Ci, Co, Hi, Wi, ksize)) return DC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (stem_ok(Ci, Co, ksize)) {
+        StemArgs sa = stem_args(B, Ci, Co, Hi, Wi);
+        sa.x = x; sa.gy = gy; sa.out = (float*)ws;
+        const size_t lds = stem_lds_wgrad(Ci);
+        if (Ci == 3) hipLaunchKernelGGL(stem_wgrad_kernel<5>, dim3(sa.nblocks), dim3(256), lds, st, sa);
+        else hipLaunchKernelGGL(stem_wgrad_kernel<10>, dim3(sa.nblocks), dim3(256), lds, st, sa);
+        DC_CHECK_LAUNCH();
+        hipLaunchKernelGGL(stem_wreduce_kernel, dim3(ceil_div(64 * sa.K, 16)), dim3(256), 0, st, (const float*)ws, dweight, sa.nblocks, sa.K, sa.Kp);
+        DC_CHECK_LAUNCH();
+        return DC_OK;
+    }
     CgArgs a{};
     a.x = x; a.gy = gy; a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
     a.K = Ci * ksize * ksize; a.Kp = a.K;

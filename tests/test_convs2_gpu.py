@@ -11,6 +11,10 @@ CASES = [
     (2, 3, 64, 64, 96, 7),         # depth stem (small)
     (2, 6, 64, 64, 96, 7),         # pose stem: 6 input channels (K = 294 -> padded rows of 320)
     (12, 3, 64, 192, 640, 7),      # depth stem at BASELINE configs[1]
+    (3, 6, 64, 66, 200, 7),        # patch-staged stem: odd number of output rows (33), ragged last column tile (100 = 64 + 36)
+    (2, 3, 64, 34, 40, 7),         # a single, mostly empty tile column (Wo = 20), odd Ho
+    (2, 6, 64, 320, 1024, 7),      # pose stem at BASELINE configs[2]
+    (2, 6, 32, 64, 96, 7),         # 32 output channels: the gather kernels
     (4, 64, 128, 48, 160, 3),      # resnet18 layer2.0.conv1 at 192x640
     (2, 128, 256, 24, 80, 3),      # layer3.0.conv1
     (3, 256, 512, 12, 40, 3),      # layer4.0.conv1: 120 output pixels per image (partial last reduction chunk at B = 3)
