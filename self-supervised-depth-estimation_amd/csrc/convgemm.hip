@@ -341,6 +341,179 @@ __global__ __launch_bounds__(256) void cg_dgrad3_kernel(CgArgs a) {
 }
 
 // =====================================================================================================================
+// 3x3 / 2 with TRIPLE gathers.  The three kx taps of one (ci, ky) and four consecutive output pixels read input columns
+// 2*ox0-1 .. 2*ox0+7 of one row: two aligned 16-byte loads and one dword give all twelve values, where the per-tap gather
+// issues twelve stride-2 dword loads (each touching 16 cache lines per wave and using an eighth of them).  Reduction index
+// k = ci*9 + ky*3 + kx, so a (ci, ky) pair is three consecutive rows (forward: B rows; weight gradient: dw columns).
+//   forward: super-chunks of 96 reduction rows = 32 triples, one LDS buffer, global loads of the next super-chunk in
+//   registers during the 12 MFMA octets; the weight matrix (Co, Ci*9) as it lies in memory is the A operand.
+// =====================================================================================================================
+struct Trip { gf4 f0, f1; float e; };
+__device__ __forceinline__ Trip trip_load(cgrsrc_t xr, unsigned rowoff, bool row_ok, int X0) {
+    Trip t;
+    const unsigned o = row_ok ? rowoff + 4u * (unsigned)X0 : 0x80000000u;
+    t.f0 = __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)o, 0, 0));
+    t.f1 = __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)o, 16, 0));
+    t.e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)((row_ok && X0 > 0) ? o - 4u : 0x80000000u), 0, 0));
+    return t;
+}
+__device__ __forceinline__ gf4 trip_tap(const Trip& t, int kx) {
+    return kx == 0 ? gf4{t.e, t.f0.y, t.f0.w, t.f1.y} : (kx == 1 ? gf4{t.f0.x, t.f0.z, t.f1.x, t.f1.z} : gf4{t.f0.y, t.f0.w, t.f1.y, t.f1.w});
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void cg_fwd3_kernel(CgArgs a) {
+    constexpr int BM = 32 * MT, BN = 32 * NT, KC3 = 96, SB = IdxStride<NT, BN>::v;
+    constexpr int NA = BM * KC3 / 1024, NG = 32 * (BN / 4) / 256;
+    constexpr int ASZ = BM * (KC3 + RP);
+    float* const As = g1_smem;
+    float* const Bs = g1_smem + ASZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int m0 = (lb % a.mtiles) * BM, n0 = (lb / a.mtiles) * BN;
+    const int P = a.Ho * a.Wo, N = a.B * P;
+    const unsigned plane = (unsigned)(a.Hi * a.Wi);
+
+    const float* asrc[NA];
+    int adst[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int idx = tid + j * 256, row = idx / (KC3 / 4), kq = idx % (KC3 / 4);
+        asrc[j] = a.w + (size_t)min(m0 + row, a.Co - 1) * a.K + kq * 4;
+        adst[j] = row * (KC3 + RP) + kq * 4;
+    }
+    const int c4 = tid % (BN / 4), trow0 = tid / (BN / 4);
+    const int ng = min(n0 + c4 * 4, N - 4);
+    const int b = ng / P, pp = ng - b * P, py = pp / a.Wo, px0 = pp - py * a.Wo;
+    const cgrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
+    const unsigned xboff = (unsigned)b * (unsigned)a.Ci * plane;
+    gf4 ra[NA];
+    Trip rt[NG];
+    auto gload = [&](int sc) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j] + sc * KC3);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int t3 = sc * 32 + trow0 + j * (1024 / BN);          // = k / 3 = ci * 3 + ky
+            const int ci = t3 / 3, ky = t3 - ci * 3;
+            const int iy = 2 * py + ky - 1;
+            rt[j] = trip_load(xr, (xboff + (unsigned)ci * plane + (unsigned)(iy * a.Wi)) * 4u, (unsigned)iy < (unsigned)a.Hi, 2 * px0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) store_red4(As + adst[j], ra[j]);
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                *reinterpret_cast<gf4*>(Bs + ((trow0 + j * (1024 / BN)) * 3 + kx) * SB + c4 * 4) = trip_tap(rt[j], kx);
+    };
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
+    const int nsc = a.K / KC3;
+    gload(0);
+    for (int sc = 0; sc < nsc; ++sc) {
+        commit();
+        __syncthreads();
+        if (sc + 1 < nsc) gload(sc + 1);
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            mma_chunk32<MT, NT>([&](int q, float (&v)[4][2]) { read_red<MT, KC3>(As, wm * 16 * MT, u * 4 + q, lane, v); },
+                                [&](int q, float (&v)[4][2]) { read_idx<NT, SB>(Bs, wn * 16 * NT, u * 4 + q, lane, v); }, acc);
+        __syncthreads();
+    }
+    const int j = lane & 15;
+    const int n = n0 + wn * 16 * NT + j * NT;
+    if (n < N) {
+        const int bo = n / P, p = n - bo * P;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
+                if (m >= a.Co) continue;
+                float* dst = a.out + ((size_t)bo * a.Co + m) * P + p;
+                if constexpr (NT == 4) *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                else *reinterpret_cast<gf2*>(dst) = gf2{acc[mt][0][r], acc[mt][1][r]};
+            }
+    }
+}
+
+// weight gradient of the 3x3 / 2 convolution: 64 output channels x 96 columns (= 32 (ci, ky) pairs x 3 kx) per block;
+// one triple gather per thread and reduction chunk of 32 pixels.  Same split / slab scheme as cg_wgrad_kernel.
+__global__ __launch_bounds__(256) void cg_wgrad3_kernel(CgArgs a) {
+    constexpr int MT = 2, NT = 3, BM = 64, BN = 96, KC = GKC;
+    constexpr int NA = BM * KC / 1024;
+    constexpr int ASZ = BM * (KC + RP), BSZ = BN * (KC + RP);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = (blockIdx.x % a.mtiles) * BM, c0 = (blockIdx.x / a.mtiles) * BN;
+    const int P = a.Ho * a.Wo;
+    const unsigned plane = (unsigned)(a.Hi * a.Wi);
+    const cgrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
+    const int kq = tid % (KC / 4), row0 = tid / (KC / 4);           // row0 = 0..31: A rows row0, row0 + 32; B triple row0
+    size_t arow[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) arow[j] = (size_t)min(m0 + row0 + j * 32, a.Co - 1) * P;
+    const int t3 = c0 / 3 + row0, tci = t3 / 3, tky = t3 - tci * 3;
+    gf4 ra[NA];
+    Trip rt;
+    const int Ntot = a.B * P;
+    auto gload = [&](int ch) {
+        const int n_ = ch * KC + kq * 4;
+        const bool okn = n_ < Ntot;
+        const int n = min(n_, Ntot - 4);
+        const int b = n / P, p = n - b * P, py = p / a.Wo, px0 = p - py * a.Wo;
+        const float* ga = a.gy + (size_t)b * a.Co * P + p;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) ra[j] = okn ? *reinterpret_cast<const gf4*>(ga + arow[j]) : gf4{0.f, 0.f, 0.f, 0.f};
+        const int iy = 2 * py + tky - 1;
+        rt = trip_load(xr, ((unsigned)(b * a.Ci + tci) * plane + (unsigned)(iy * a.Wi)) * 4u, (unsigned)iy < (unsigned)a.Hi, 2 * px0);
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) store_red4(g1_smem + buf * ASZ + (row0 + j * 32) * (KC + RP) + kq * 4, ra[j]);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) store_red4(g1_smem + 2 * ASZ + buf * BSZ + (row0 * 3 + kx) * (KC + RP) + kq * 4, trip_tap(rt, kx));
+    };
+    gf4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
+    const int per = (a.chunks + a.splits - 1) / a.splits;
+    const int ch0 = blockIdx.y * per, ch1 = min(ch0 + per, a.chunks);
+    if (ch0 < ch1) {
+        gload(ch0);
+        commit(0);
+    }
+    __syncthreads();
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int buf = (ch - ch0) & 1;
+        const bool more = ch + 1 < ch1;
+        if (more) gload(ch + 1);
+        mma_chunk32<MT, NT>([&](int q, float (&v)[4][2]) { read_red<MT, KC>(g1_smem + buf * ASZ, wm * 16 * MT, q, lane, v); },
+                            [&](int q, float (&v)[4][2]) { read_red<NT, KC>(g1_smem + 2 * ASZ + buf * BSZ, wn * 16 * NT, q, lane, v); }, acc);
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+    }
+    float* slab = a.out + (size_t)blockIdx.y * a.Co * a.K;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
+                const int col = c0 + wn * 16 * NT + nt * 16 + (lane & 15);
+                if (m < a.Co) slab[(size_t)m * a.K + col] = acc[mt][nt][r];
+            }
+}
+
+// =====================================================================================================================
 // The 7x7 / 2 stem (Ci = 3 or 6, Co = 64) with the input PATCH staged in LDS.
 // In the gather formulation above every (tap, pixel) pair is its own dword load: each input element is fetched 49/4 = 12
 // times, by stride-2 wave instructions that touch 16 cache lines and use an eighth of each -- the L1 path is as busy as
@@ -642,6 +815,11 @@ static bool stem_enabled() {
     static const bool v = [] { const char* e = getenv("DC_STEM_PATCH"); return !e || atoi(e) != 0; }();
     return v;
 }
+// triple-gather kernels of the 3x3 / 2 convolutions: whole (ci, ky) triples per 96-row super-chunk (DC_CONV_TRIP=0: A/B)
+static bool trip_ok(int Ci, int ks) {
+    static const bool v = [] { const char* e = getenv("DC_CONV_TRIP"); return !e || atoi(e) != 0; }();
+    return v && ks == 3 && Ci % 32 == 0;
+}
 static bool stem_ok(int Ci, int Co, int ks) { return stem_enabled() && ks == 7 && Co == 64 && (Ci == 3 || Ci == 6); }
 static StemArgs stem_args(int B, int Ci, int Co, int Hi, int Wi) {
     StemArgs a{};
@@ -700,6 +878,17 @@ extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void
         return DC_OK;
     }
     const int N = B * a.Ho * a.Wo;
+    if (trip_ok(Ci, ksize)) {
+        const CgTile t = ((long)ceil_div(Co, 64) * ceil_div(N, 128) >= 300 || N >= 8 * Co) ? CgTile{2, 4} : CgTile{2, 2};
+        a.mtiles = ceil_div(Co, 64); a.ntiles = ceil_div(N, 32 * t.nt);
+        const size_t lds3 = ((size_t)64 * (96 + RP) + (size_t)96 * (t.nt == 4 ? 128 : 80)) * sizeof(float);
+        static const bool attr3 = cg_set_lds(cg_fwd3_kernel<2, 4>, ((size_t)64 * (96 + RP) + (size_t)96 * 128) * sizeof(float));
+        if (!attr3) return DC_ELAUNCH;
+        if (t.nt == 4) hipLaunchKernelGGL((cg_fwd3_kernel<2, 4>), dim3(a.mtiles * a.ntiles), dim3(256), lds3, st, a);
+        else hipLaunchKernelGGL((cg_fwd3_kernel<2, 2>), dim3(a.mtiles * a.ntiles), dim3(256), lds3, st, a);
+        DC_CHECK_LAUNCH();
+        return DC_OK;
+    }
     const CgTile t = cg_pick(Co, N);
     a.mtiles = ceil_div(Co, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
     const dim3 grid(a.mtiles * a.ntiles);
@@ -725,7 +914,7 @@ extern "C" size_t dc_convs2_wgrad_workspace(int B, int Ci, int Co, int Hi, int W
         const StemArgs sa = stem_args(B, Ci, Co, Hi, Wi);
         return (size_t)sa.nblocks * 64 * sa.Kp * sizeof(float);
     }
-    const int tiles = ceil_div(Co, 64) * ceil_div(K, 64);
+    const int tiles = ceil_div(Co, 64) * ceil_div(K, trip_ok(Ci, ksize) ? 96 : 64);
     const int splits = cg_wsplits(tiles, ceil_div(B * (Hi / 2) * (Wi / 2), GKC));
     return splits > 1 ? (size_t)splits * Co * K * sizeof(float) : 16;
 }
@@ -750,12 +939,14 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
     a.K = Ci * ksize * ksize; a.Kp = a.K;
     a.xbytes = (unsigned)((size_t)B * Ci * Hi * Wi * sizeof(float));
     a.chunks = ceil_div(B * a.Ho * a.Wo, GKC);
-    a.mtiles = ceil_div(Co, 64); a.ntiles = ceil_div(a.K, 64);
+    const bool trip = trip_ok(Ci, ksize);
+    a.mtiles = ceil_div(Co, 64); a.ntiles = ceil_div(a.K, trip ? 96 : 64);
     a.splits = cg_wsplits(a.mtiles * a.ntiles, a.chunks);
     a.out = a.splits > 1 ? (float*)ws : dweight;
     const dim3 grid(a.mtiles * a.ntiles, a.splits);
-    const size_t lds = cg_lds_wgrad({2, 2});
-    if (ksize == 3) hipLaunchKernelGGL((cg_wgrad_kernel<2, 2, 3>), grid, dim3(256), lds, st, a);
+    const size_t lds = trip ? (size_t)2 * (64 + 96) * (GKC + RP) * sizeof(float) : cg_lds_wgrad({2, 2});
+    if (trip) hipLaunchKernelGGL(cg_wgrad3_kernel, grid, dim3(256), lds, st, a);
+    else if (ksize == 3) hipLaunchKernelGGL((cg_wgrad_kernel<2, 2, 3>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((cg_wgrad_kernel<2, 2, 7>), grid, dim3(256), lds, st, a);
     DC_CHECK_LAUNCH();
     if (a.splits > 1) {
