@@ -13,7 +13,11 @@ SRC = os.path.join(REPO, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r2
 DST = os.path.join(REPO, "profiles")
 FAMILIES = [("wino_ps_kernel", "Winograd 3x3 forward / data gradient"), ("wino_wgrad_kernel", "Winograd 3x3 weight gradient"),
             ("wino_", "Winograd transforms (weights, filter reduce)"), ("g1_", "tiled 1x1 GEMMs (fwd / dgrad / wgrad / reduce)"),
-            ("cg_", "strided implicit-GEMM convolutions (7x7/2 stem, 3x3/2)"), ("pw_", "general 1x1 kernels"),
+            ("stem_", "7x7/2 stem, patch-staged (forward, weight gradient, reduce)"),
+            ("cg_", "3x3/2 implicit-GEMM convolutions (forward, data / weight gradient, helpers)"),
+            ("slab_reduce16", "fixed-order slab reduce of the split weight gradients"),
+            ("conv_", "direct 3x3 kernels of the thin decoder levels (forward, gradients, fold, reduce)"),
+            ("maxpool", "max-pool forward / backward"), ("pw_", "general 1x1 kernels"),
             ("bn_", "BatchNorm (+ReLU / residual) forward and backward"), ("photo_", "photometric forward / backward"),
             ("identity_kernel", "identity reprojection + target statistics"), ("disp_grad", "disparity gradient"),
             ("conv3x3", "direct 3x3 (decoder heads, reflection pad)"), ("dispconv", "dispconv + sigmoid"),
@@ -24,6 +28,7 @@ for cfg in ("c2", "c3"):
     stats = glob.glob(os.path.join(SRC, "rocprof_%s" % cfg, "*", "*kernel_stats.csv"))
     if not stats:
         continue
+    stats = [max(stats, key=os.path.getmtime)]          # (gpurun merges runs into one directory: take the latest)
     shutil.copy(stats[0], os.path.join(DST, "round2_%s_kernel_stats.csv" % cfg))
     for a, b in (("bench_%s.json" % cfg, "round2_%s_bench_n1.json" % cfg),
                  ("bench_%s_under_rocprof.json" % cfg, "round2_%s_bench_n1_under_rocprof.json" % cfg),
