@@ -393,6 +393,12 @@ int dc_data_resize_axis(const uint8_t* src, uint8_t* dst, int n_img, int Hi, int
 int dc_data_flip(const uint8_t* src, uint8_t* dst, int n_img, int H, int W, const uint8_t* flip, void* stream);
 int dc_data_jitter(uint8_t* img, int n_img, int npix, const int* steps, const float* params, unsigned long long* sums, void* stream);
 int dc_data_to_tensor(const uint8_t* img, float* out, int n_img, int npix, void* stream);
+/* The fused form the host uses: both ToTensor outputs of one pyramid level from ONE uint8 image, the jitter chain evaluated
+ * per pixel in registers -- color (n,3,npix) from the untouched pixels, color_aug (n,3,npix) through the item's chain
+ * (color_aug NULL: only `color`; then steps / params / sums may be NULL).  Two passes (L sum in front of the contrast step,
+ * then everything), nothing written in between; results identical to dc_data_jitter + dc_data_to_tensor. */
+int dc_data_jitter_to_tensor(const uint8_t* img, float* color, float* color_aug, int n_img, int npix, const int* steps,
+                             const float* params, unsigned long long* sums, void* stream);
 
 #ifdef __cplusplus
 }

@@ -153,6 +153,25 @@ __global__ __launch_bounds__(256) void data_luma_sum_kernel(const uint8_t* __res
     if ((threadIdx.x & 63) == 0) atomicAdd(&sums[im], a);
 }
 
+// one ColorJitter operation on one pixel (the arithmetic of the in-place kernel below and of the fused chain kernels)
+__device__ __forceinline__ void jitter_op(int& r, int& g, int& b, int op, float a, int mean) {
+    if (op == DC_JITTER_HUE) {
+        int h, s, v;
+        rgb2hsv(r, g, b, h, s, v);
+        h = (h + (int)a) & 0xFF;
+        hsv2rgb(h, s, v, r, g, b);
+    } else if (op >= 0) {
+        const bool interp = a >= 0.f && a <= 1.f;
+        int d0 = 0;
+        if (op == DC_JITTER_CONTRAST) d0 = mean;
+        else if (op == DC_JITTER_SATURATION) d0 = luma(r, g, b);
+        r = blend(d0, r, a, interp);
+        g = blend(d0, g, a, interp);
+        b = blend(d0, b, a, interp);
+    }
+}
+__device__ __forceinline__ int luma_mean(unsigned long long sum, int npix) { return (int)((double)sum / (double)npix + 0.5); }   // int(ImageStat mean + 0.5)
+
 __global__ __launch_bounds__(256) void data_jitter_kernel(uint8_t* __restrict__ img, int npix, const int* __restrict__ steps,
                                                          const float* __restrict__ params, int step,
                                                          const unsigned long long* __restrict__ sums) {
@@ -160,29 +179,72 @@ __global__ __launch_bounds__(256) void data_jitter_kernel(uint8_t* __restrict__ 
     const int op = steps[im * 4 + step];
     if (op < 0) return;
     const float a = params[im * 4 + step];
-    const bool interp = a >= 0.f && a <= 1.f;
-    int mean = 0;
-    if (op == DC_JITTER_CONTRAST) mean = (int)((double)sums[im] / (double)npix + 0.5);   // int(ImageStat mean + 0.5)
-    const int shift = op == DC_JITTER_HUE ? (int)a : 0;
+    const int mean = op == DC_JITTER_CONTRAST ? luma_mean(sums[im], npix) : 0;
     uint8_t* base = img + (size_t)im * npix * 3;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
         uint8_t* p = base + (size_t)3 * i;
         int r = p[0], g = p[1], b = p[2];
-        if (op == DC_JITTER_HUE) {
-            int h, s, v;
-            rgb2hsv(r, g, b, h, s, v);
-            h = (h + shift) & 0xFF;
-            hsv2rgb(h, s, v, r, g, b);
-            p[0] = (uint8_t)r, p[1] = (uint8_t)g, p[2] = (uint8_t)b;
-        } else {
-            int d0 = 0, d1 = 0, d2 = 0;
-            if (op == DC_JITTER_CONTRAST)
-                d0 = d1 = d2 = mean;
-            else if (op == DC_JITTER_SATURATION)
-                d0 = d1 = d2 = luma(r, g, b);
-            p[0] = blend(d0, r, a, interp);
-            p[1] = blend(d1, g, a, interp);
-            p[2] = blend(d2, b, a, interp);
+        jitter_op(r, g, b, op, a, mean);
+        p[0] = (uint8_t)r, p[1] = (uint8_t)g, p[2] = (uint8_t)b;
+    }
+}
+
+// ---- the whole chain of an item in two passes over the uint8 image, nothing written in between ----------------------------
+// ColorJitter is four per-pixel operations; only contrast needs something global (the mean of the L image AT THAT POINT of
+// the chain).  Pass 1 re-applies the operations in front of the contrast step and sums L (exact integers; skipped for an
+// image without a contrast step); pass 2 recomputes the whole chain per pixel and writes BOTH float tensors of ToTensor --
+// ("color", s) from the untouched pixel and ("color_aug", s) from the jittered one.  Per scale: 2 launches instead of 14.
+struct JChain { int op[4]; float a[4]; int c; };
+__device__ __forceinline__ JChain jchain_load(const int* steps, const float* params, int im) {
+    JChain ch;
+    ch.c = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ch.op[k] = steps ? steps[im * 4 + k] : DC_JITTER_NONE;
+        ch.a[k] = steps ? params[im * 4 + k] : 0.f;
+        if (ch.op[k] == DC_JITTER_CONTRAST && ch.c < 0) ch.c = k;
+    }
+    return ch;
+}
+__global__ __launch_bounds__(256) void data_chain_sum_kernel(const uint8_t* __restrict__ img, int npix, const int* __restrict__ steps,
+                                                            const float* __restrict__ params, unsigned long long* __restrict__ sums) {
+    const int im = blockIdx.y;
+    const JChain ch = jchain_load(steps, params, im);
+    if (ch.c < 0) return;
+    const uint8_t* p = img + (size_t)im * npix * 3;
+    unsigned int acc = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        int r = p[3 * i], g = p[3 * i + 1], b = p[3 * i + 2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < ch.c) jitter_op(r, g, b, ch.op[k], ch.a[k], 0);
+        acc += luma(r, g, b);
+    }
+    unsigned long long a = acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[im], a);
+}
+__global__ __launch_bounds__(256) void data_chain_tensor_kernel(const uint8_t* __restrict__ img, float* __restrict__ color,
+                                                               float* __restrict__ color_aug, int npix, const int* __restrict__ steps,
+                                                               const float* __restrict__ params, const unsigned long long* __restrict__ sums) {
+    const int im = blockIdx.y;
+    const JChain ch = jchain_load(steps, params, im);
+    const int mean = ch.c >= 0 ? luma_mean(sums[im], npix) : 0;
+    const uint8_t* p = img + (size_t)im * npix * 3;
+    float* o = color + (size_t)im * npix * 3;
+    float* oa = color_aug ? color_aug + (size_t)im * npix * 3 : nullptr;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        int r = p[3 * i], g = p[3 * i + 1], b = p[3 * i + 2];
+        o[i] = (float)r / 255.0f;
+        o[(size_t)npix + i] = (float)g / 255.0f;
+        o[(size_t)2 * npix + i] = (float)b / 255.0f;
+        if (oa) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) jitter_op(r, g, b, ch.op[k], ch.a[k], mean);
+            oa[i] = (float)r / 255.0f;
+            oa[(size_t)npix + i] = (float)g / 255.0f;
+            oa[(size_t)2 * npix + i] = (float)b / 255.0f;
         }
     }
 }
@@ -290,6 +352,21 @@ extern "C" int dc_data_jitter(uint8_t* img, int n_img, int npix, const int* step
         hipLaunchKernelGGL(data_luma_sum_kernel, dim3(bx, n_img), dim3(256), 0, (hipStream_t)stream, img, npix, steps, step, sums);
         hipLaunchKernelGGL(data_jitter_kernel, dim3(bx, n_img), dim3(256), 0, (hipStream_t)stream, img, npix, steps, params, step, sums);
     }
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_data_jitter_to_tensor(const uint8_t* img, float* color, float* color_aug, int n_img, int npix, const int* steps,
+                                        const float* params, unsigned long long* sums, void* stream) {
+    if (!img || !color || n_img <= 0 || n_img > 65535 || npix <= 0 || npix > (1 << 28)) return DC_EINVAL;
+    if (color_aug && (!steps || !params || !sums)) return DC_EINVAL;
+    const int bx = std::min((npix + 255) / 256, 1024);
+    if (color_aug) {
+        if (hipMemsetAsync(sums, 0, sizeof(unsigned long long) * n_img, (hipStream_t)stream) != hipSuccess) return DC_ELAUNCH;
+        hipLaunchKernelGGL(data_chain_sum_kernel, dim3(bx, n_img), dim3(256), 0, (hipStream_t)stream, img, npix, steps, params, sums);
+    }
+    hipLaunchKernelGGL(data_chain_tensor_kernel, dim3(bx, n_img), dim3(256), 0, (hipStream_t)stream, img, color, color_aug, npix,
+                       color_aug ? steps : (const int*)nullptr, params, (const unsigned long long*)sums);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }

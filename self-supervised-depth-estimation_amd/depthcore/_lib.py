@@ -137,6 +137,7 @@ def _sig(lib):
         "dc_data_flip": (i, [p, p, i, i, i, p, p]),
         "dc_data_jitter": (i, [p, i, i, p, p, p, p]),
         "dc_data_to_tensor": (i, [p, p, i, i, p]),
+        "dc_data_jitter_to_tensor": (i, [p, p, p, i, i, p, p, p, p]),
         "dc_attnconv_fwd": (i, [POINTER(AttnMap), POINTER(AttnParams), POINTER(AttnMap), p, i, i, i, i, i, i, p]),
         "dc_attnconv_param_count": (i, [i]),
         "dc_attnconv_bwd_workspace": (z, [i, i, i, i]),

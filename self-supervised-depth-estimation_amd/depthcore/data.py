@@ -135,14 +135,13 @@ class GpuPreprocessor:
         for s in range(self.num_scales):
             h, w = self.height // (2 ** s), self.width // (2 ** s)
             img = self._resize(img, h, w, flip if s == 0 else None)
-            color = self._to_tensor(img).view(Fn, B, 3, h, w)
-            if steps is not None:
-                aug = img.clone()
-                check(L.dc_data_jitter(aug.data_ptr(), n, h * w, steps.data_ptr(), params.data_ptr(), sums.data_ptr(), stream(aug)),
-                      "dc_data_jitter")
-                color_aug = self._to_tensor(aug).view(Fn, B, 3, h, w)
-            else:
-                color_aug = color
+            color = torch.empty((n, 3, h, w), dtype=torch.float32, device=img.device)
+            aug = torch.empty_like(color) if steps is not None else None
+            check(L.dc_data_jitter_to_tensor(img.data_ptr(), color.data_ptr(), aug.data_ptr() if aug is not None else None, n, h * w,
+                                             steps.data_ptr() if aug is not None else None, params.data_ptr() if aug is not None else None,
+                                             sums.data_ptr() if aug is not None else None, stream(img)), "dc_data_jitter_to_tensor")
+            color = color.view(Fn, B, 3, h, w)
+            color_aug = aug.view(Fn, B, 3, h, w) if aug is not None else color
             for i, f in enumerate(self.frame_idxs):
                 out[("color", f, s)] = color[i]
                 out[("color_aug", f, s)] = color_aug[i]
