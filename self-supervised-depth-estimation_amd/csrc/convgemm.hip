@@ -840,7 +840,7 @@ using namespace dc;
 static bool cg_ok(int B, int Ci, int Co, int Hi, int Wi, int ks) {
     if (B <= 0 || Ci <= 0 || Co <= 0 || Hi <= 0 || Wi <= 0 || (ks != 3 && ks != 7)) return false;
     if ((Hi & 1) || (Wi & 1)) return false;
-    const int Ho = Hi / 2, Wo = Wi / 2;
+    const int Wo = Wi / 2;
     if (Wo & 3) return false;                           // 16-byte pixel groups inside one output row
     if ((size_t)B * std::max(Ci, Co) * Hi * Wi >= (1ull << 29)) return false;      // 32-bit byte offsets of the buffer gathers
     return true;

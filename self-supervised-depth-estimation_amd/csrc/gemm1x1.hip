@@ -20,7 +20,8 @@
 //     elements with one ds_read_b64 and uses them in two successive MFMA steps.
 // Both patterns are bank-conflict free (strides chosen per MI355X_MICROARCH.md's LDS table: b128 rows = 0 mod 64 dwords;
 // index-major rows = 2 mod 32 dwords, which serves both ds_read_b64 and the ds_read2_b64 pairs the compiler forms from
-// them -- 16 lanes x 2 dwords tile the 32 banks; rows of 4 * odd dwords measured 60 % conflict cycles under read2).  The reduction order inside a chunk of 8 is permuted identically for A and B
+// them -- 16 lanes x 2 dwords tile the 32 banks; rows of 4 * odd dwords measured 60 % conflict cycles under read2).
+// The reduction order inside a chunk of 8 is permuted identically for A and B
 // (element 2 k' + s of the chunk goes to MFMA step s, k-lane k'), which changes nothing in the sum.
 //
 // Main loop: reduction chunks of 32 (128 MFMAs per wave between barriers at 128 x 128), LDS double-buffered with ONE

@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
         float* rs = ring + (size_t)slot3 * RING_VALS * 64;
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            const float wx1 = tp.wx1[f], wy1 = tp.wy1[f], wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+            const float wx1 = tp.wx1[f], wy1 = tp.wy1[f];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 const float nw = tp.tap[f][0][ch], ne = tp.tap[f][1][ch], sw = tp.tap[f][2][ch], se = tp.tap[f][3][ch];
