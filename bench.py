@@ -262,7 +262,7 @@ def run_rank(args):
 
     opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
                             cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap,
-                            wino_weight_cache=not args.no_wino_cache)
+                            wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph) and world == 1)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     tr = T.Trainer(opt, device=device, rank=rank, world_size=world)
     tr.set_train()
@@ -277,10 +277,11 @@ def run_rank(args):
     for _ in range(args.warmup):
         _, losses = tr.train_step(inputs)
         loss0 = losses["loss"].detach().clone() if loss0 is None else loss0
-    ops.profile_enable(args.steps + 8)
-    # every 7th conv launch carries an event pair (7 is coprime with the launches per step, so all layers are
-    # sampled over the timed region); bracketing every launch costs ~4 % of the step
-    ops.conv_profile_enable((args.steps + 2) * 40, 7)
+    if not tr.graph_enabled:                    # (event pairs cannot be part of a captured step)
+        ops.profile_enable(args.steps + 8)
+        # every 7th conv launch carries an event pair (7 is coprime with the launches per step, so all layers are
+        # sampled over the timed region); bracketing every launch costs ~4 % of the step
+        ops.conv_profile_enable((args.steps + 2) * 40, 7)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -289,6 +290,8 @@ def run_rank(args):
     dt = time.perf_counter() - t0
     loss_last = float(losses["loss"].detach())
     del losses, _                       # drop the autograd graph before the stream layout changes below
+    graphed = tr.graph_enabled and tr._graph is not None
+    tr.graph_enabled = False            # the diagnostic steps below are eager
     prof = ops.profile_collect()
     ops.profile_enable(0)
     cprof_c, wprof_c = ops.conv_profile_collect(0), ops.conv_profile_collect(1)
@@ -388,7 +391,8 @@ def run_rank(args):
                                    "frames {0,-1,+1}, automasking, Adam lr 1e-4; random-init weights"
                                    % (label, args.num_layers, args.height, args.width, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                       "tiebreak_noise": "cpu-randn+h2d" if args.cpu_noise else "on-device counter RNG"},
+                       "tiebreak_noise": "cpu-randn+h2d" if args.cpu_noise else "on-device counter RNG",
+                       "step_launch": "one hipGraph replay per step" if graphed else "eager (one launch per kernel)"},
             "roofline": {"kernel": "dc::wino_ps_kernel (Winograd F(2x2,3x3) fp32-MFMA convolution: forward + data gradient of "
                                    "the trunk and decoder 3x3 convolutions)",
                          "bound": "mfma", "achieved": round(c_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -463,6 +467,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-noise", action="store_true", help="reference-style CPU randn tie-break noise + H2D copy")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
+    ap.add_argument("--graph", action="store_true", help="single GPU: capture the training step in one hipGraph and replay it (opt.hip_graph)")
     ap.add_argument("--no-wino-cache", action="store_true", help="per-launch Winograd weight transforms (A/B of wino_weight_cache)")
     ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: let ranks share GPUs (use with DC_DIST_BACKEND=gloo)")

@@ -136,6 +136,9 @@ typedef struct dc_photo_desc {
                                      (all 64 seed bits, scale, frame) and indexed by pixel.  Distribution: Irwin-Hall(4)
                                      of the hash bytes, zero mean / unit variance, 1021 values within +-3.45 sigma -- a
                                      tie-breaker, not torch.randn; pass noise[] for bit-parity with a randn stream */
+    const uint64_t* rng_seed_dev; /* optional: when not NULL the seed is READ FROM DEVICE MEMORY when the kernel runs
+                                     (rng_seed is ignored) -- a step captured in a hipGraph advances the value with a
+                                     device-side add and every replay draws a new noise field */
     /* outputs of forward */
     float* losses;                /* (num_scales+1): loss/0.., loss */
     uint8_t* argmin[DC_MAX_SCALES];      /* (B,H,W) winning channel of torch.min(combined,1) */

@@ -50,6 +50,7 @@ struct PhotoArgs {
     float ry[DC_MAX_SCALES], rx[DC_MAX_SCALES];
     const float* noise[DC_MAX_SCALES];
     unsigned long long seed;
+    const unsigned long long* seed_ptr;   // when set: the seed is read from device memory at run time (hipGraph replays)
     float* idl;                        // identity losses, pixel-interleaved (B, H, W, 2|1)
     float* pk[3];                      // pixel-interleaved RGBx copies (B,H,W,4) of target / source -1 / source +1
     int rows_f, rows_b;                // image rows a wave produces in the forward / backward march (even)
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
     Ctx c;
     make_ctx(c, p, b, s);
     const unsigned plane = c.plane4 / 4;
+    const unsigned long long seedv = p.seed_ptr ? *p.seed_ptr : p.seed;       // (uniform: one scalar load)
     const bool no_ssim = p.flags & DC_OPT_NO_SSIM;
     const bool automask = !(p.flags & DC_OPT_NO_AUTOMASK);
     const bool avg = p.flags & DC_OPT_AVG_REPROJ;
@@ -540,14 +542,14 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
                 const float rr = (r[0] + r[1]) * 0.5f;
                 best = rr;
                 if (automask) {
-                    const float n0 = ext_noise ? idn_cur[2] : rng_normal(p.seed, b * plane + o, s * 2);
+                    const float n0 = ext_noise ? idn_cur[2] : rng_normal(seedv, b * plane + o, s * 2);
                     const float id = __fadd_rn(idn_cur[0], __fmul_rn(n0, 0.00001f));
                     best = id;
                     if (rr < best) { best = rr; idx = 1; }
                 }
             } else if (automask) {
-                const float n0 = ext_noise ? idn_cur[2] : rng_normal(p.seed, b * plane + o, s * 2);
-                const float n1 = ext_noise ? idn_cur[3] : rng_normal(p.seed, b * plane + o, s * 2 + 1);
+                const float n0 = ext_noise ? idn_cur[2] : rng_normal(seedv, b * plane + o, s * 2);
+                const float n1 = ext_noise ? idn_cur[3] : rng_normal(seedv, b * plane + o, s * 2 + 1);
                 const float i0 = __fadd_rn(idn_cur[0], __fmul_rn(n0, 0.00001f));
                 const float i1 = __fadd_rn(idn_cur[1], __fmul_rn(n1, 0.00001f));
                 best = i0;
@@ -1130,6 +1132,7 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
     a.target = d->target; a.src[0] = d->source[0]; a.src[1] = d->source[1];
     a.K = d->K; a.invK = d->inv_K; a.T[0] = d->T[0]; a.T[1] = d->T[1];
     a.seed = d->rng_seed;
+    a.seed_ptr = (const unsigned long long*)d->rng_seed_dev;
     char* ws = (char*)d->workspace;
     for (int s = 0; s < d->num_scales; ++s) {
         if (!d->disp[s] || !d->color_s[s] || !d->argmin[s]) return DC_EINVAL;

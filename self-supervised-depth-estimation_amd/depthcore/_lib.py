@@ -38,7 +38,7 @@ class PhotoDesc(Structure):
         ("flags", c_uint32), ("min_depth", c_float), ("max_depth", c_float), ("smoothness", c_float),
         ("target", _F), ("source", _F * 2), ("color_s", _F * MAX_SCALES),
         ("K", _F), ("inv_K", _F), ("T", _F * 2),
-        ("disp", _F * MAX_SCALES), ("noise", _F * MAX_SCALES), ("rng_seed", c_uint64),
+        ("disp", _F * MAX_SCALES), ("noise", _F * MAX_SCALES), ("rng_seed", c_uint64), ("rng_seed_dev", _F),
         ("losses", _F), ("argmin", _F * MAX_SCALES),
         ("depth", _F * MAX_SCALES), ("sample", (_F * 2) * MAX_SCALES), ("color", (_F * 2) * MAX_SCALES),
         ("identity_selection", _F * MAX_SCALES),

@@ -54,7 +54,9 @@ class PhotoConfig:
                       | (_lib.OPT_NO_SSIM if no_ssim else 0)
                       | (_lib.OPT_ALIGN_CORNERS if align_corners else 0))
         self.materialize = materialize
-        self.rng_seed = int(rng_seed)
+        # an int, or a one-element int64 device tensor read by the kernel at run time (hipGraph replays)
+        self.rng_seed_dev = rng_seed if torch.is_tensor(rng_seed) else None
+        self.rng_seed = 0 if torch.is_tensor(rng_seed) else int(rng_seed)
         self.extras = {}          # filled by forward: argmin maps + optional log tensors
 
 
@@ -93,6 +95,8 @@ def _fill_desc(cfg, T0, T1, disps):
                 raise _lib.DepthcoreError("noise[%d] must be %s" % (s, (B, nch, H, W)))
             d.noise[s] = ptr(cfg.noise[s])
     d.rng_seed = cfg.rng_seed
+    if cfg.rng_seed_dev is not None:
+        d.rng_seed_dev = ptr(cfg.rng_seed_dev, torch.int64)
     return d
 
 

@@ -93,6 +93,7 @@ _BUILD = [
     ("cpu_tiebreak_noise", int, 0, [0, 1]),      # 1: the reference's CPU randn + H2D copy (trainer.py:594-595)
     ("materialize_logs", int, 0, [0, 1]),        # 1: fused path also writes depth / sample / color tensors
     ("fusion", str, None, [None, "v3"]),         # front-end of trainer_fusion_v3.py
+    ("hip_graph", int, 0, [0, 1]),               # single-GPU: capture the whole step (fwd + bwd + Adam) in one hipGraph and replay it
     ("wino_weight_cache", int, 1, [0, 1]),       # all 3x3 weights -> Winograd domain once per step (one launch)
     ("gru", str, None, [None, "v5"]),            # front-end of trainer_gru.py (run_gru_v5; sequences of len_sequence frames)
 ]

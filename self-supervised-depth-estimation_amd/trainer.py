@@ -118,8 +118,15 @@ class Trainer:
         order = order + [k for k in self.models if k not in order]
         named = [(k + "." + n, p) for k in order for n, p in self.models[k].named_parameters()]
         self.buckets = GradBuckets(named, self.opt.bucket_mb, world_size, process_group)
+        # hipGraph mode (opt.hip_graph, one GPU): the step is captured once and replayed, so everything that changes from
+        # step to step must live in device memory -- Adam's step count (capturable) and the tie-break noise seed
+        self.graph_enabled = bool(getattr(self.opt, "hip_graph", False)) and self.device.type == "cuda" and world_size == 1
+        if self.graph_enabled and self.opt.cpu_tiebreak_noise:
+            raise ValueError("hip_graph replays cannot include the reference's CPU randn + host-to-device copy (cpu_tiebreak_noise)")
         self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate,
-                                          fused=self.device.type == "cuda")
+                                          fused=self.device.type == "cuda", capturable=self.graph_enabled)
+        self._seed_dev = torch.full((1,), rank, dtype=torch.int64, device=self.device) if self.graph_enabled else None
+        self._graph, self._graph_key, self._graph_warm, self._graph_stream = None, None, 0, None
         self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
 
         self.ssim = SSIM()
@@ -248,7 +255,7 @@ class Trainer:
             noise=self._noise(B, 1 if o.avg_reprojection else 2), min_depth=o.min_depth, max_depth=o.max_depth,
             smoothness=o.disparity_smoothness, disable_automasking=o.disable_automasking,
             avg_reprojection=o.avg_reprojection, no_ssim=o.no_ssim, materialize=materialize,
-            rng_seed=self.step * 1000003 + self.rank)
+            rng_seed=self._seed_dev if self._seed_dev is not None else self.step * 1000003 + self.rank)
         lv = ops.photometric_loss(cfg, outputs[("cam_T_cam", 0, -1)], outputs[("cam_T_cam", 0, 1)],
                                   [outputs[("disp", s)] for s in o.scales])
         losses = {"loss/{}".format(s): lv[i] for i, s in enumerate(o.scales)}
@@ -391,7 +398,44 @@ class Trainer:
             self.model_optimizer.load_state_dict(torch.load(adam, map_location=self.device))
 
     # ------------------------------------------------------------------ trainer.py:233-237
+    GRAPH_WARMUP = 3      # eager steps before a capture: lazy allocations, LDS attributes, the weight cache's variants
+
     def train_step(self, inputs):
+        if not self.graph_enabled:
+            return self._train_step_eager(inputs)
+        key = (tuple((k, tuple(v.shape)) for k, v in inputs.items()), tuple(g["lr"] for g in self.model_optimizer.param_groups))
+        if self._graph is None or self._graph_key != key:
+            # Everything a capture will see must already have happened on a NON-default stream: autograd binds each
+            # parameter's AccumulateGrad node to the stream of its first use, and a node bound to the legacy default stream
+            # makes the backward touch that stream inside the capture (fatal).  So the eager warm-up steps of graph mode
+            # run on the stream the capture will use.
+            if self._graph_stream is None:
+                self._graph_stream = torch.cuda.Stream(self.device)
+            gs, cur = self._graph_stream, torch.cuda.current_stream(self.device)
+            if self._graph_warm < self.GRAPH_WARMUP:
+                self._graph_warm += 1
+                gs.wait_stream(cur)
+                with torch.cuda.stream(gs):
+                    out = self._train_step_eager(inputs)
+                cur.wait_stream(gs)
+                return out
+            # capture: records the launches of one step (both streams, backward, Adam) without running them
+            self._static_in = {k: v.clone() for k, v in inputs.items()}
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=gs):
+                self._static_out = self._train_step_eager(self._static_in)
+            self._graph, self._graph_key = g, key
+            self.step -= 1                      # (the recorded step has not run yet: the replay below is that step)
+        else:
+            for k, v in inputs.items():
+                if v is not self._static_in[k]:
+                    self._static_in[k].copy_(v, non_blocking=True)
+        self._graph.replay()
+        self.step += 1
+        return self._static_out               # static tensors: rewritten by every replay
+
+    def _train_step_eager(self, inputs):
         self.wino_cache.refresh()               # every 3x3 weight -> Winograd domain, one launch per step
         try:
             outputs, losses = self.process_batch(inputs)
@@ -401,5 +445,7 @@ class Trainer:
             self.wino_cache.invalidate()        # the optimiser step below rewrites the weights
         self.buckets.finish()                   # RCCL all-reduce (mean) launched from the backward hooks
         self.model_optimizer.step()
+        if self._seed_dev is not None:
+            self._seed_dev.add_(1000003)        # next step's noise seed (device side: part of a captured step)
         self.step += 1
         return outputs, losses

@@ -324,3 +324,36 @@ def test_wino_weight_cache_changes_nothing(gru):
     assert abs(la[0] - lb[0]) <= 1e-6 * abs(lb[0]), (la, lb)      # same forward arithmetic (the loss sums use float atomics)
     assert np.allclose(la, lb, rtol=2e-4, atol=0), (la, lb)      # (Adam turns last-bit gradient differences into +-lr updates)
     assert float((wa - wb).abs().max()) <= 7e-4                   # two trajectories, 3 steps, each update within +-lr = 1e-4
+
+
+@pytest.mark.parametrize("gru", [None, "v5"])
+def test_hip_graph_replays_train_like_eager_steps(gru):
+    """opt.hip_graph: after three eager steps the whole step (two streams, backward, capturable fused Adam, the device-side
+    noise-seed increment) is captured in one hipGraph and replayed.  Same kernels, same seeds: the loss sequence follows the
+    eager trainer's; replays really train (losses move) and the static output tensors are rewritten in place.
+    (64 x 128: every convolution is a depthcore launch -- the library convolution that tiny or odd maps fall back to is not
+    capturable.)"""
+    import trainer as T
+    from depthcore.synthetic import synthetic_batch, synthetic_sequence_batch
+
+    def run(graph, n=7):
+        kw = dict(gru="v5", len_sequence=3, batch_size=1) if gru else dict(batch_size=2)
+        tr = T.Trainer(T.default_options(height=64, width=128, hip_graph=graph, **kw), device=DEV, seed=5)
+        tr.set_train()
+        batches = [synthetic_sequence_batch(3, 64, 128, torch.device(DEV), seed=s) if gru else synthetic_batch(2, 64, 128, torch.device(DEV), seed=s)
+                   for s in (2, 3)]
+        losses = []
+        for i in range(n):
+            _, l = tr.train_step(dict(batches[i % 2]))
+            losses.append(float(l["loss"].detach()))
+        assert tr.step == n
+        captured = tr._graph is not None
+        tr.wino_cache.close()
+        return losses, captured
+
+    le, ce = run(False)
+    lg, cg = run(True)
+    assert cg and not ce
+    assert np.allclose(le[:3], lg[:3], rtol=1e-5), (le, lg)          # eager warm-up steps of both trainers
+    assert np.allclose(le, lg, rtol=5e-4), (le, lg)                  # captured step + replays (capturable Adam: bias correction in fp32 on the device)
+    assert len(set(round(v, 7) for v in lg[3:])) == len(lg[3:])      # every replay is a new step
