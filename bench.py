@@ -260,13 +260,26 @@ def run_rank(args):
     from depthcore.synthetic import synthetic_batch
     import trainer as T
 
+    front = {}
+    if args.front == "gru":          # BASELINE configs[3]: one sequence of --len-sequence frames per rank (batch size 1)
+        front = dict(gru="v5", len_sequence=args.len_sequence)
+        args.batch = 1
+    elif args.front == "fusion":     # BASELINE configs[4]: frames [-2, -1, 0] stacked through encoder + decoder, then Fusion_v3
+        front = dict(fusion="v3", frame_ids=[0, -2, -1, 1])
     opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
                             cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap,
-                            wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph) and world == 1)
+                            wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph) and world == 1, **front)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     tr = T.Trainer(opt, device=device, rank=rank, world_size=world)
     tr.set_train()
-    inputs = synthetic_batch(args.batch, args.height, args.width, device, seed=100 + rank)
+    if args.front == "gru":
+        from depthcore.synthetic import synthetic_sequence_batch
+        inputs = synthetic_sequence_batch(args.len_sequence, args.height, args.width, device, seed=100 + rank)
+    elif args.front == "fusion":
+        inputs = synthetic_batch(args.batch, args.height, args.width, device, seed=100 + rank, frame_ids=(0, -2, -1, 1))
+    else:
+        inputs = synthetic_batch(args.batch, args.height, args.width, device, seed=100 + rank)
+    imgs_per_step = args.len_sequence if args.front == "gru" else args.batch        # target frames that get a loss per rank and step
 
     def sync():
         if world > 1:
@@ -355,8 +368,12 @@ def run_rank(args):
 
     if rank == 0:
         cfg = (args.num_layers, args.height, args.width, args.batch)
-        cfg_key = {(18, 192, 640, 12): "c2", (50, 320, 1024, 8): "c3"}.get(cfg, "other")
+        cfg_key = {(18, 192, 640, 12): "c2", (50, 320, 1024, 8): "c3"}.get(cfg, "other") if args.front == "none" else "other"
         label = {"c2": "BASELINE configs[1]: ", "c3": "BASELINE configs[2] (per rank): "}.get(cfg_key, "")
+        if args.front == "gru":
+            label = "BASELINE configs[3] (per rank): ConvGRU v5 temporal fusion, one sequence of %d frames, " % args.len_sequence
+        elif args.front == "fusion":
+            label = "BASELINE configs[4] (per rank, fp32): Fusion_v3 attention fusion on frames {-2,-1,0}, "
         N = args.batch * args.height * args.width
         bytes_fwd = sum(36.0 * N + 16.0 * (N >> (2 * s)) for s in range(4))
         bytes_bwd = sum(36.0 * N + 20.0 * (N >> (2 * s)) for s in range(4))
@@ -381,7 +398,7 @@ def run_rank(args):
         out = {
             "metric": "training images/sec at %dx%d bs%d (resnet%d depth+pose, 4-scale photometric+smoothness)"
                       % (args.height, args.width, args.batch, args.num_layers),
-            "value": round(world * args.batch * args.steps / dt, 3),
+            "value": round(world * imgs_per_step * args.steps / dt, 3),
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -446,7 +463,7 @@ def run_rank(args):
         }
         if world > 1 and (backend != "nccl" or args.oversubscribe):
             out["rehearsal"] = "backend %s%s: not an RCCL/xGMI measurement" % (backend, ", ranks share GPUs" if args.oversubscribe else "")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.front == "none":
             out["cpu_baseline"] = cpu_baseline(opt, tr)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -467,6 +484,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-noise", action="store_true", help="reference-style CPU randn tie-break noise + H2D copy")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
+    ap.add_argument("--front", choices=["none", "gru", "fusion"], default="none",
+                    help="sequence front-end: gru = ConvGRU v5 (configs[3], batch 1 x --len-sequence frames), fusion = Fusion_v3 (configs[4])")
+    ap.add_argument("--len-sequence", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="single GPU: capture the training step in one hipGraph and replay it (opt.hip_graph)")
     ap.add_argument("--no-wino-cache", action="store_true", help="per-launch Winograd weight transforms (A/B of wino_weight_cache)")
     ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")
