@@ -1,19 +1,26 @@
 // The strided convolutions of the ResNet trunks -- the 7x7 / 2 stem (3 or 6 input channels) and the 3x3 / 2 first
 // convolution of layer2-4 (reference networks/resnet_encoder.py:87-98 via torchvision) -- as implicit GEMMs on the tiled
-// fp32-MFMA kernels of gemm_tiles.h, straight on the NCHW tensors: no im2col tensor, no NHWC transposes, exact fp32
+// fp32-MFMA pieces of gemm_tiles.h, straight on the NCHW tensors: no im2col tensor, no NHWC transposes, exact fp32
 // products with fp32 accumulation (the library's weight gradient of the stem was measured 1 % off an fp64 reference).
 //
 //   forward   y[b,co,oy,ox]  = sum_{ci,ky,kx} w[co,ci,ky,kx] * x[b,ci,2oy+ky-p,2ox+kx-p]        p = KS/2, zero padding
-//     GEMM: M = co, N = flattened (b,oy,ox), reduction k = (ci,ky,kx) -- the (Co, Ci*KS*KS) weight matrix as it lies in
-//     memory is the A operand (rows padded to a multiple of the 32-wide chunk for the stem: K = 147 / 294); the B tile is
-//     gathered by the loader: row k of the chunk -> (ci,ky,kx), four consecutive output pixels -> four stride-2 taps.
+//     GEMM: M = co, N = flattened (b,oy,ox), reduction k = (ci,ky,kx)
 //   weight gradient   dw[co,(ci,ky,kx)] = sum_n gy[co,n] * x[..]: M = co, N = (ci,ky,kx), reduction = pixels, split over
-//     blocks with a fixed-order slab reduce; the B rows are gathered the same way (row -> tap fixed, pixel group per chunk).
+//     blocks with a fixed-order slab reduce
 //   data gradient (3x3 only; the stem's input is the image)   dx[b,ci,2oy+dy,2ox+dx] = sum over the taps whose parity
 //     matches: (dy,dx) = (0,0): 1 tap, (0,1) / (1,0): 2 taps, (1,1): 4 taps -- 9 taps per 4 input pixels, nothing multiplied
 //     by a structural zero.  One block owns an output-grid pixel tile and one row parity dy and keeps BOTH column parities
 //     in registers, so it stores whole 32-byte runs of dx.  Weights are re-laid out once per call to [tap][co][ci].
-// All three are deterministic (no atomics).
+//
+// Three families of kernels, in the order they were written (DESIGN.md 4b has the counters that drove each step):
+//   cg_fwd_kernel / cg_wgrad_kernel<KS>  general gather formulation: B-operand row k -> (ci,ky,kx), four consecutive output
+//       pixels -> four stride-2 dword buffer loads.  Bound by L1 line throughput (a wave-level gather touches 16 cache lines
+//       and uses an eighth of each); kept for shapes the others decline (Co != 64 stems, Ci % 32 != 0).
+//   stem_fwd_kernel / stem_wgrad_kernel  the 7x7 / 2 stem with the input patch of a 2 x 64 pixel tile staged ONCE in LDS,
+//       de-interleaved by column parity so that every tap is a contiguous run; operands read straight from the patch.
+//   cg_fwd3_kernel / cg_wgrad3_kernel    3x3 / 2 with triple gathers: two aligned 16-byte loads + one dword give the three kx
+//       taps of four pixels; 96-row super-chunks (forward), 64 x 96 tiles (weight gradient).
+// All deterministic (no atomics).
 #include "dc_common.h"
 #include "gemm_tiles.h"
 
