@@ -47,8 +47,14 @@ using wrsrc_t = __amdgpu_buffer_rsrc_t;
 template <bool DGRAD>
 __device__ __forceinline__ void wino_weight_one(const float* __restrict__ w, float* __restrict__ uhat, int idx, int Co, int Ci, int MT,
                                                 int Mp, int Kp, int WK) {
-    if (idx >= Mp * Kp) return;
-    const int m = idx / Kp, k = idx - m * Kp;
+    // 256 consecutive threads = a 16 (m) x 16 (k) tile with m fastest: the 16-byte stores of 16 consecutive m are one
+    // 256-byte run (the staging order has m innermost), and the filter reads stay efficient -- 16 consecutive k of a row are
+    // 576 contiguous bytes (forward), 16 consecutive m are (data gradient).  With k fastest the batched launch spent 310 us
+    // on 440 MB: every store instruction scattered 16-byte pieces 256 bytes apart.
+    const int tiles_k = (Kp + 15) >> 4;
+    const int tile = idx >> 8, within = idx & 255;
+    const int m = (tile / tiles_k) * 16 + (within & 15), k = (tile % tiles_k) * 16 + (within >> 4);
+    if (m >= Mp || k >= Kp) return;
     const int M = DGRAD ? Ci : Co, K = DGRAD ? Co : Ci;
     float g[3][3];
 #pragma unroll
@@ -95,13 +101,10 @@ struct WinoWDesc {
     const float* w; float* uhat;
     int Co, Ci, MT, Mp, Kp, dgrad, block0, pad_;
 };
-__global__ __launch_bounds__(256) void wino_weights_batched_kernel(const WinoWDesc* __restrict__ table, int n, int WK) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (table[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const WinoWDesc d = table[lo];
+__global__ __launch_bounds__(256) void wino_weights_batched_kernel(const WinoWDesc* __restrict__ table, const int* __restrict__ blk2desc, int WK) {
+    // (a per-block binary search over the table -- eight dependent global loads in front of every block -- made this launch
+    // 310 us for 0.5 GB; the host uploads the block -> descriptor map next to the table instead)
+    const WinoWDesc d = table[blk2desc[blockIdx.x]];
     const int idx = ((int)blockIdx.x - d.block0) * 256 + threadIdx.x;
     if (d.dgrad) wino_weight_one<true>(d.w, d.uhat, idx, d.Co, d.Ci, d.MT, d.Mp, d.Kp, WK);
     else wino_weight_one<false>(d.w, d.uhat, idx, d.Co, d.Ci, d.MT, d.Mp, d.Kp, WK);
@@ -425,6 +428,7 @@ static void wino_ps_pick_region(int TH, int TW, int& RH, int& RW, int& RS) {
     }
 }
 
+static inline int wino_wblocks(int Mp, int Kp) { return (Mp / 16) * ((Kp + 15) / 16); }   // 16 x 16 tiles of wino_weight_one
 static inline size_t wino_uhat_bytes(int Ci, int Co) {
     const size_t a = (size_t)ceil_div(Ci, 32) * 32, b = (size_t)ceil_div(Co, 32) * 32;
     return wino_al256(a * b * 16 * sizeof(float));
@@ -443,7 +447,8 @@ static std::mutex g_wc_mu;
 static std::vector<WcEntry> g_wc;
 static bool g_wc_valid = false, g_wc_dirty = true;
 static WinoWDesc* g_wc_table = nullptr;
-static int g_wc_table_cap = 0, g_wc_table_n = 0, g_wc_blocks = 0;
+static int* g_wc_b2d = nullptr;
+static int g_wc_table_cap = 0, g_wc_table_n = 0, g_wc_blocks = 0, g_wc_b2d_cap = 0;
 
 // -> cached U for this launch, or nullptr (then the caller transforms into its workspace)
 static const float* wc_lookup(const float* w, int Ci, int Co, bool dgrad, int MT, int Mp, int Kp) {
@@ -531,9 +536,9 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
         a.uhat = cached;
     } else {
         if (d.dgrad)
-            hipLaunchKernelGGL((wino_weights_kernel<true>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, d.weight, (float*)d.ws, d.Co, d.Ci, MT, Mp, Kp, PSK);
+            hipLaunchKernelGGL((wino_weights_kernel<true>), dim3(wino_wblocks(Mp, Kp)), dim3(256), 0, st, d.weight, (float*)d.ws, d.Co, d.Ci, MT, Mp, Kp, PSK);
         else
-            hipLaunchKernelGGL((wino_weights_kernel<false>), dim3(ceil_div(Mp * Kp, 256)), dim3(256), 0, st, d.weight, (float*)d.ws, d.Co, d.Ci, MT, Mp, Kp, PSK);
+            hipLaunchKernelGGL((wino_weights_kernel<false>), dim3(wino_wblocks(Mp, Kp)), dim3(256), 0, st, d.weight, (float*)d.ws, d.Co, d.Ci, MT, Mp, Kp, PSK);
         DC_CHECK_LAUNCH();
     }
 #ifdef WINO_DIAG
@@ -658,12 +663,20 @@ extern "C" int dc_wino_cache_refresh(void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (g_wc_dirty) {
         std::vector<WinoWDesc> host;
+        std::vector<int> b2d;
         int blocks = 0;
         for (auto& e : g_wc)
             for (auto& v : e.v) {
+                const int nb = wino_wblocks(v.Mp, v.Kp);
+                b2d.insert(b2d.end(), nb, (int)host.size());
                 host.push_back(WinoWDesc{e.w, v.buf, e.Co, e.Ci, v.MT, v.Mp, v.Kp, v.dgrad, blocks, 0});
-                blocks += ceil_div(v.Mp * v.Kp, 256);
+                blocks += nb;
             }
+        if (blocks > g_wc_b2d_cap) {
+            if (g_wc_b2d && hipFree(g_wc_b2d) != hipSuccess) return DC_ELAUNCH;
+            g_wc_b2d_cap = blocks + 4096;
+            if (hipMalloc((void**)&g_wc_b2d, sizeof(int) * g_wc_b2d_cap) != hipSuccess) { g_wc_b2d = nullptr; g_wc_b2d_cap = 0; return DC_ELAUNCH; }
+        }
         if ((int)host.size() > g_wc_table_cap) {
             if (g_wc_table && hipFree(g_wc_table) != hipSuccess) return DC_ELAUNCH;
             g_wc_table_cap = (int)host.size() + 64;
@@ -672,10 +685,11 @@ extern "C" int dc_wino_cache_refresh(void* stream) {
         // synchronous upload (the descriptor list only changes while the variants of a model are still being met)
         if (!host.empty() && hipStreamSynchronize(st) != hipSuccess) return DC_ELAUNCH;
         if (!host.empty() && hipMemcpy(g_wc_table, host.data(), sizeof(WinoWDesc) * host.size(), hipMemcpyHostToDevice) != hipSuccess) return DC_ELAUNCH;
+        if (!b2d.empty() && hipMemcpy(g_wc_b2d, b2d.data(), sizeof(int) * b2d.size(), hipMemcpyHostToDevice) != hipSuccess) return DC_ELAUNCH;
         g_wc_table_n = (int)host.size(); g_wc_blocks = blocks; g_wc_dirty = false;
     }
     if (g_wc_table_n > 0) {
-        hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(g_wc_blocks), dim3(256), 0, st, (const WinoWDesc*)g_wc_table, g_wc_table_n, PSK);
+        hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(g_wc_blocks), dim3(256), 0, st, (const WinoWDesc*)g_wc_table, (const int*)g_wc_b2d, PSK);
         DC_CHECK_LAUNCH();
     }
     for (auto& e : g_wc)
@@ -698,7 +712,8 @@ extern "C" int dc_wino_cache_clear(void) {
             if (v.buf && hipFree(v.buf) != hipSuccess) rc = DC_ELAUNCH;
     g_wc.clear();
     if (g_wc_table && hipFree(g_wc_table) != hipSuccess) rc = DC_ELAUNCH;
-    g_wc_table = nullptr; g_wc_table_cap = g_wc_table_n = g_wc_blocks = 0;
+    if (g_wc_b2d && hipFree(g_wc_b2d) != hipSuccess) rc = DC_ELAUNCH;
+    g_wc_table = nullptr; g_wc_b2d = nullptr; g_wc_table_cap = g_wc_table_n = g_wc_blocks = g_wc_b2d_cap = 0;
     g_wc_valid = false; g_wc_dirty = true;
     return rc;
 }
