@@ -22,25 +22,38 @@ __device__ __forceinline__ float block_sum256(float v, float* sm) {
 }
 
 // grid (chunks_per_plane, C, N), block 256: partial[(c*N + n)*chunks + chunk] = {sum, sumsq}
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, float* part, int C, int HW) {
+// Small planes (layer3 / layer4: 480 / 120 elements): a block per (channel, sample) spends its life on the prologue -- 12 K
+// blocks of 120 elements ran 9-16 us for 6-18 MB.  `ns` > 1 gives a block `ns` consecutive samples of its channel (same
+// BatchNorm group; one plane per wave and pass, so the ReLU mask's per-wave ballot layout is unchanged) and one partial.
+struct BnSpan { int n_first, n_step, i_first, i_step; };
+__device__ __forceinline__ BnSpan bn_span(int ns) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    return ns > 1 ? BnSpan{wave, 4, lane * 4, 256} : BnSpan{0, 1, (int)threadIdx.x * 4, 1024};
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, float* part, int C, int HW, int ns) {
     __shared__ float sm[4];
-    const int c = blockIdx.y, n = blockIdx.z;
-    const float* p = x + ((size_t)n * C + c) * HW;
+    const int c = blockIdx.y, n0 = blockIdx.z * ns;
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     float s = 0.f, q = 0.f;
     if ((HW & 3) == 0) {
-        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
-            const float4 v = *reinterpret_cast<const float4*>(p + i);
-            s += (v.x + v.y) + (v.z + v.w);
-            q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        const BnSpan sp = bn_span(ns);
+        for (int nn = sp.n_first; nn < ns; nn += sp.n_step) {
+            const float* p = x + ((size_t)(n0 + nn) * C + c) * HW;
+            for (int i = lo + sp.i_first; i < hi; i += sp.i_step) {
+                const float4 v = *reinterpret_cast<const float4*>(p + i);
+                s += (v.x + v.y) + (v.z + v.w);
+                q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
         }
     } else {
+        const float* p = x + ((size_t)n0 * C + c) * HW;
         for (int i = lo + threadIdx.x; i < hi; i += 256) { const float v = p[i]; s += v; q += v * v; }
     }
     s = block_sum256(s, sm);
     q = block_sum256(q, sm);
     if (threadIdx.x == 0) {
-        float* o = part + (((size_t)c * gridDim.z + n) * gridDim.x + blockIdx.x) * 2;
+        float* o = part + (((size_t)c * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * 2;
         o[0] = s; o[1] = q;
     }
 }
@@ -65,10 +78,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
                                                        float* mean, float* invstd, float* run_mean, float* run_var,
                                                        const float* gamma, const float* beta, float* y, int C, int HW,
                                                        int relu, int n_per_group, int groups, float eps, float momentum,
-                                                       unsigned long long* mask) {
+                                                       unsigned long long* mask, int ns) {
     __shared__ float sm[4];
-    const int c = blockIdx.y, n = blockIdx.z, N = gridDim.z;
-    const int nparts = N * gridDim.x, per = nparts / groups;
+    const int c = blockIdx.y, n0 = blockIdx.z * ns, n = n0;
+    const int nparts = gridDim.z * gridDim.x, per = nparts / groups;
     const int gidx = n / n_per_group;
     const float count = (float)n_per_group * (float)HW;
     float s, q;
@@ -89,11 +102,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
         }
         if (threadIdx.x == 0) { run_mean[c] = rm; run_var[c] = rv; }
     }
-    const size_t base = ((size_t)n * C + c) * HW;
     const float a = is * gamma[c], b = beta[c] - m * a;
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     if ((HW & 3) == 0) {
-        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      const BnSpan sp = bn_span(ns);
+      for (int nn = sp.n_first; nn < ns; nn += sp.n_step) {
+        const int n = n0 + nn;
+        const size_t base = ((size_t)n * C + c) * HW;
+        for (int i = lo + sp.i_first; i < hi; i += sp.i_step) {
             float4 v = *reinterpret_cast<const float4*>(x + base + i);
             v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
             if (res) {
@@ -115,7 +131,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
             }
             *reinterpret_cast<float4*>(y + base + i) = v;
         }
+      }
     } else {
+        const size_t base = ((size_t)n * C + c) * HW;
         for (int i = lo + threadIdx.x; i < hi; i += 256) {
             float v = fmaf(x[base + i], a, b);
             if (res) v += res[base + i];
@@ -142,23 +160,28 @@ __device__ __forceinline__ float4 bn_mask_grad(float4 g, const unsigned long lon
 // backward stats: partial {sum g, sum g*x_hat}, g = gy*[y>0] when relu
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const float* y, const float* gy,
                                                            const float* mean, const float* invstd, float* part, int C,
-                                                           int HW, int relu, int n_per_group, const unsigned long long* mask) {
+                                                           int HW, int relu, int n_per_group, const unsigned long long* mask, int ns) {
     __shared__ float sm[4];
-    const int c = blockIdx.y, n = blockIdx.z;
-    const size_t base = ((size_t)n * C + c) * HW;
-    const int gc = (n / n_per_group) * C + c;
+    const int c = blockIdx.y, n0 = blockIdx.z * ns;
+    const int gc = (n0 / n_per_group) * C + c;
     const float m = mean[gc], is = invstd[gc];
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     float s = 0.f, q = 0.f;
     if ((HW & 3) == 0) {
-        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      const BnSpan sp = bn_span(ns);
+      for (int nn = sp.n_first; nn < ns; nn += sp.n_step) {
+        const int n = n0 + nn;
+        const size_t base = ((size_t)n * C + c) * HW;
+        for (int i = lo + sp.i_first; i < hi; i += sp.i_step) {
             const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
             float4 g = *reinterpret_cast<const float4*>(gy + base + i);
             if (relu) g = bn_mask_grad(g, mask, y, (size_t)n * C + c, C, HW, base, i);
             s += (g.x + g.y) + (g.z + g.w);
             q += (g.x * (xv.x - m) + g.y * (xv.y - m)) + (g.z * (xv.z - m) + g.w * (xv.w - m));
         }
+      }
     } else {
+        const size_t base = ((size_t)n0 * C + c) * HW;
         for (int i = lo + threadIdx.x; i < hi; i += 256) {
             float g = gy[base + i];
             if (relu && !(y[base + i] > 0.f)) g = 0.f;
@@ -168,7 +191,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const
     s = block_sum256(s, sm);
     q = block_sum256(q, sm) * is;
     if (threadIdx.x == 0) {
-        float* o = part + (((size_t)c * gridDim.z + n) * gridDim.x + blockIdx.x) * 2;
+        float* o = part + (((size_t)c * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * 2;
         o[0] = s; o[1] = q;
     }
 }
@@ -179,10 +202,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
                                                            const float* mean, const float* invstd, const float* gamma,
                                                            const float* part, float* dgamma, float* dbeta, float* dx,
                                                            float* dres, int C, int HW, int relu, int n_per_group,
-                                                           int groups, const unsigned long long* mask) {
+                                                           int groups, const unsigned long long* mask, int ns) {
     __shared__ float sm[4];
-    const int c = blockIdx.y, n = blockIdx.z, N = gridDim.z;
-    const int nparts = N * gridDim.x, per = nparts / groups;
+    const int c = blockIdx.y, n0 = blockIdx.z * ns, n = n0;
+    const int nparts = gridDim.z * gridDim.x, per = nparts / groups;
     const int gidx = n / n_per_group;
     const float count = (float)n_per_group * (float)HW;
     float s, q;
@@ -199,12 +222,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
             if (dgamma) dgamma[c] = tq;
         }
     }
-    const size_t base = ((size_t)n * C + c) * HW;
     const int gc = gidx * C + c;
     const float m = mean[gc], is = invstd[gc], k = gamma[c] * is, a = s / count, bq = (q / count) * is;
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     if ((HW & 3) == 0) {
-        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      const BnSpan sp = bn_span(ns);
+      for (int nn = sp.n_first; nn < ns; nn += sp.n_step) {
+        const int n = n0 + nn;
+        const size_t base = ((size_t)n * C + c) * HW;
+        for (int i = lo + sp.i_first; i < hi; i += sp.i_step) {
             const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
             float4 g = *reinterpret_cast<const float4*>(gy + base + i);
             if (relu) g = bn_mask_grad(g, mask, y, (size_t)n * C + c, C, HW, base, i);
@@ -214,7 +240,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
             d.z = k * (g.z - a - (xv.z - m) * bq); d.w = k * (g.w - a - (xv.w - m) * bq);
             *reinterpret_cast<float4*>(dx + base + i) = d;
         }
+      }
     } else {
+        const size_t base = ((size_t)n * C + c) * HW;
         for (int i = lo + threadIdx.x; i < hi; i += 256) {
             float g = gy[base + i];
             if (relu && !(y[base + i] > 0.f)) g = 0.f;
@@ -228,6 +256,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
 
 using namespace dc;
 #define ST ((hipStream_t)stream)
+
+// samples per block: the largest divisor of the group size whose planes still fit one chunk (1 for planes of half a chunk
+// or more, and on the scalar path)
+static int bn_ns(int n_per_group, int HW) {
+    if ((HW & 3) || HW * 2 > BN_CHUNK) return 1;
+    int best = 1;
+    for (int d = 2; d <= n_per_group; ++d)
+        if (n_per_group % d == 0 && d * HW <= BN_CHUNK) best = d;
+    return best;
+}
 
 extern "C" size_t dc_bn_workspace(int N, int C, int HW) {
     if (N <= 0 || C <= 0 || HW <= 0) return 0;
@@ -245,13 +283,13 @@ extern "C" int dc_bn_relu_fwd(const float* x, const float* res, const float* gam
                               void* stream) {
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !ws || N <= 0 || C <= 0 || HW <= 0) return DC_EINVAL;
     if (groups < 1 || N % groups) return DC_EINVAL;
-    const int chunks = ceil_div(HW, BN_CHUNK);
+    const int chunks = ceil_div(HW, BN_CHUNK), ns = bn_ns(N / groups, HW);
     float* part = (float*)ws;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, part, C, HW);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(chunks, C, N / ns), dim3(256), 0, ST, x, part, C, HW, ns);
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, res, (const float*)part, save_mean,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(chunks, C, N / ns), dim3(256), 0, ST, x, res, (const float*)part, save_mean,
                        save_invstd, running_mean, running_var, gamma, beta, y, C, HW, relu, N / groups, groups, eps, momentum,
-                       (HW & 3) ? (unsigned long long*)nullptr : (unsigned long long*)relu_mask);
+                       (HW & 3) ? (unsigned long long*)nullptr : (unsigned long long*)relu_mask, ns);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -264,13 +302,13 @@ extern "C" int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, c
     const unsigned long long* mk = (HW & 3) ? nullptr : (const unsigned long long*)relu_mask;
     if (relu && !y && !mk) return DC_EINVAL;
     if (groups < 1 || N % groups) return DC_EINVAL;
-    const int chunks = ceil_div(HW, BN_CHUNK);
+    const int chunks = ceil_div(HW, BN_CHUNK), ns = bn_ns(N / groups, HW);
     float* part = (float*)ws;
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, part, C,
-                       HW, relu, N / groups, mk);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(chunks, C, N / ns), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, part, C,
+                       HW, relu, N / groups, mk, ns);
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chunks, C, N), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, gamma,
-                       (const float*)part, dgamma, dbeta, dx, dres, C, HW, relu, N / groups, groups, mk);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chunks, C, N / ns), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, gamma,
+                       (const float*)part, dgamma, dbeta, dx, dres, C, HW, relu, N / groups, groups, mk, ns);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
