@@ -346,6 +346,36 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, float*
     code[plane * Ho * Wo + i] = (uint8_t)bc;
 }
 
+// two adjacent outputs per thread (ox0 even, W % 4 == 0): a window row is one aligned 16-byte load + one dword instead of
+// six stride-2 dword loads; same scan order and tie-break as the scalar kernel
+__global__ __launch_bounds__(256) void maxpool_fwd2_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ code,
+                                                           int H, int W, int Ho, int Wo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t plane = blockIdx.y;
+    const int Wo2 = Wo >> 1;
+    if (i >= Ho * Wo2) return;
+    const int oy = i / Wo2, ox0 = (i - oy * Wo2) * 2;
+    const float* p = x + plane * H * W;
+    float ba = -INFINITY, bb = -INFINITY;
+    int ca = 0, cb = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = oy * 2 - 1 + ky;
+        if (yy < 0 || yy >= H) continue;
+        const float* row = p + (size_t)yy * W + 2 * ox0;
+        const float4 f = *reinterpret_cast<const float4*>(row);
+        if (ox0 > 0) { const float e = row[-1]; if (e > ba || e != e) { ba = e; ca = ky * 3; } }
+        if (f.x > ba || f.x != f.x) { ba = f.x; ca = ky * 3 + 1; }
+        if (f.y > ba || f.y != f.y) { ba = f.y; ca = ky * 3 + 2; }
+        if (f.y > bb || f.y != f.y) { bb = f.y; cb = ky * 3; }
+        if (f.z > bb || f.z != f.z) { bb = f.z; cb = ky * 3 + 1; }
+        if (f.w > bb || f.w != f.w) { bb = f.w; cb = ky * 3 + 2; }
+    }
+    const size_t o = plane * Ho * Wo + (size_t)oy * Wo + ox0;
+    *reinterpret_cast<float2*>(y + o) = make_float2(ba, bb);
+    *reinterpret_cast<uchar2*>(code + o) = make_uchar2((uint8_t)ca, (uint8_t)cb);
+}
+
 __device__ __forceinline__ float maxpool_gather(const float* g, const uint8_t* cd, int yy, int xx, int Ho, int Wo) {
     float acc = 0.f;
     // windows oy with oy*2-1 <= yy <= oy*2+1
@@ -408,8 +438,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* gy, const
 extern "C" int dc_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* code, int NC, int H, int W, void* stream) {
     if (!x || !y || !code || NC <= 0 || H < 2 || W < 2 || NC > 65535) return DC_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(dc::maxpool_fwd_kernel, dim3(dc::ceil_div(Ho * Wo, 256), NC), dim3(256), 0, (hipStream_t)stream, x, y,
-                       code, H, W, Ho, Wo);
+    if ((W & 3) == 0 && (Wo & 1) == 0)
+        hipLaunchKernelGGL(dc::maxpool_fwd2_kernel, dim3(dc::ceil_div(Ho * (Wo >> 1), 256), NC), dim3(256), 0, (hipStream_t)stream, x, y,
+                           code, H, W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(dc::maxpool_fwd_kernel, dim3(dc::ceil_div(Ho * Wo, 256), NC), dim3(256), 0, (hipStream_t)stream, x, y,
+                           code, H, W, Ho, Wo);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
