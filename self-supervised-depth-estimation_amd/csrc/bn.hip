@@ -433,6 +433,44 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* gy, const
     *reinterpret_cast<float4*>(dx + plane * H * W + (size_t)yy * W + x0) = out;
 }
 
+// eight consecutive input pixels per thread (x0 % 8 == 0, W % 8 == 0): the five windows ox = x0/2 .. x0/2+4 of a window row
+// are one aligned 32-bit code load + one byte and one 16-byte gy load + one dword, routed to two float4 stores
+__global__ __launch_bounds__(256) void maxpool_bwd8_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ code,
+                                                           float* __restrict__ dx, int H, int W, int Ho, int Wo) {
+    const size_t plane = blockIdx.y;
+    const float* g = gy + plane * Ho * Wo;
+    const uint8_t* cd = code + plane * Ho * Wo;
+    const int W8 = W >> 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W8) return;
+    const int yy = i / W8, x0 = (i - yy * W8) * 8;
+    float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int oy0 = yy >> 1, oy1 = min((yy + 1) >> 1, Ho - 1);
+    const int oxb = x0 >> 1;                                  // multiple of 4
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        const int ky = yy - (oy * 2 - 1);
+        const unsigned c4 = *reinterpret_cast<const unsigned*>(cd + (size_t)oy * Wo + oxb);
+        const float4 g4 = *reinterpret_cast<const float4*>(g + (size_t)oy * Wo + oxb);
+        const bool has5 = oxb + 4 < Wo;
+        const int c5 = has5 ? cd[(size_t)oy * Wo + oxb + 4] : 255;
+        const float g5 = has5 ? g[(size_t)oy * Wo + oxb + 4] : 0.f;
+        const int cds[5] = {(int)(c4 & 255u), (int)((c4 >> 8) & 255u), (int)((c4 >> 16) & 255u), (int)(c4 >> 24), c5};
+        const float gs[5] = {g4.x, g4.y, g4.z, g4.w, g5};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (cds[j] / 3 == ky) {
+                const int px = (oxb + j) * 2 - 1 + (cds[j] - ky * 3) - x0;    // pixel of the group hit by this window (-1 .. 9)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (px == q) out[q] += gs[j];
+            }
+        }
+    }
+    float* o = dx + plane * H * W + (size_t)yy * W + x0;
+    *reinterpret_cast<float4*>(o) = make_float4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(out[4], out[5], out[6], out[7]);
+}
+
 }  // namespace dc
 
 extern "C" int dc_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* code, int NC, int H, int W, void* stream) {
@@ -451,7 +489,10 @@ extern "C" int dc_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* code, int 
 extern "C" int dc_maxpool3x3s2_bwd(const float* gy, const uint8_t* code, float* dx, int NC, int H, int W, void* stream) {
     if (!gy || !code || !dx || NC <= 0 || H < 2 || W < 2 || NC > 65535) return DC_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    if ((W & 3) == 0)
+    if ((W & 7) == 0)
+        hipLaunchKernelGGL(dc::maxpool_bwd8_kernel, dim3(dc::ceil_div(H * (W >> 3), 256), NC), dim3(256), 0, (hipStream_t)stream, gy, code,
+                           dx, H, W, Ho, Wo);
+    else if ((W & 3) == 0)
         hipLaunchKernelGGL(dc::maxpool_bwd_kernel<true>, dim3(dc::ceil_div(H * (W >> 2), 256), NC), dim3(256), 0,
                            (hipStream_t)stream, gy, code, dx, H, W, Ho, Wo);
     else
