@@ -358,11 +358,17 @@ int dc_gru_residual_bwd(const float* g, float* d_H, int n, size_t M, void* strea
  *     asked for so far; from then on those launches read the cached U.  Call it at the start of a training step, after
  *     the weights were last written, on a stream every consumer stream waits for.
  *   dc_wino_cache_invalidate(): the cached transforms are stale (call after the step's backward, before the optimiser).
- *   dc_wino_cache_clear(): drop registrations and free the buffers (device-synchronising).
+ *   dc_wino_cache_unregister(weight): forget one weight.  Its buffers are parked, not freed -- a captured hipGraph of the
+ *     former owner may still name them -- until dc_wino_cache_clear().
+ *   dc_wino_cache_clear(): drop ALL registrations and free every buffer (device-synchronising; only when no captured
+ *     graph that used the cache will be replayed again).
  *   dc_wino_cache_variants(): number of cached variants (diagnostics / tests).
  * A convolution whose weight is not registered, or met before the first refresh, transforms in place exactly as before:
- * the cache changes launch counts, never results (the transform is the same device function). */
+ * the cache changes launch counts, never results (the transform is the same device function).  Nothing here allocates,
+ * synchronises or copies while `stream` is being captured into a hipGraph: a variant first met inside a capture keeps its
+ * per-launch transform, and a refresh inside a capture launches the descriptor table as it stood before the capture. */
 int dc_wino_cache_register(const float* weight, int Ci, int Co);
+int dc_wino_cache_unregister(const float* weight);
 int dc_wino_cache_refresh(void* stream);
 void dc_wino_cache_invalidate(void);
 int dc_wino_cache_clear(void);

@@ -49,6 +49,14 @@ def residual_attention_unit(x, st, p):
     return out + r
 
 
+def residual_conv_unit(x, st, p):
+    """networks/fusion_v2.py:11-43 (`attention=False`): conv2(relu(conv1(relu(x)))) + relu(x) (in-place ReLU, as above)."""
+    r = F.relu(x)
+    out = F.conv2d(r, st[p + "conv1.weight"], st[p + "conv1.bias"], padding=1)
+    out = F.conv2d(F.relu(out), st[p + "conv2.weight"], st[p + "conv2.bias"], padding=1)
+    return out + r
+
+
 def conv3x3_reflect(x, w, b):
     """layers.py:121-136 (ReflectionPad2d(1) + Conv2d(3))."""
     return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b)
@@ -70,8 +78,9 @@ def upscale_ps_shuffle_only(y, scale=2):
     return y.view(B, c, scale, scale, H, W).permute(0, 1, 4, 2, 5, 3).reshape(B, c, H * scale, W * scale)
 
 
-def fusion_block_v3(dt, upt, dt_1, dt_2, st, p, init_scale):
-    """networks/fusion_v2.py:304-320."""
+def fusion_block_v3(dt, upt, dt_1, dt_2, st, p, init_scale, attention=True):
+    """networks/fusion_v2.py:304-320 (units per :294-302)."""
+    residual_attention_unit = globals()["residual_attention_unit"] if attention else residual_conv_unit
     if init_scale:
         dt_upt = F.conv2d(dt, st[p + "conv_1.weight"], st[p + "conv_1.bias"], padding=1)
     else:
@@ -85,7 +94,7 @@ def fusion_block_v3(dt, upt, dt_1, dt_2, st, p, init_scale):
     return depth, up
 
 
-def fusion_v3_forward(st, depth_dec_outputs):
+def fusion_v3_forward(st, depth_dec_outputs, attention=True):
     """networks/fusion_v2.py:335-363.  Every decoder output (3B, 1, h, w) is split into three chunks along the batch;
     chunk 0 plays `dt`, chunks 1 and 2 the context (the caller stacks frames [-2, -1, 0], trainer_fusion_v3.py:319,
     so chunk 0 is frame -2: kept as is).  No sigmoid on the outputs."""
@@ -96,7 +105,7 @@ def fusion_v3_forward(st, depth_dec_outputs):
     outputs, up = {}, None
     for i, s in enumerate((3, 2, 1, 0)):
         outputs[("disp", s)], up = fusion_block_v3(cur[("disp", s)], up, t1[("disp", s)], t2[("disp", s)], st,
-                                                   "fusion_block_%d." % (i + 1), init_scale=(i == 0))
+                                                   "fusion_block_%d." % (i + 1), init_scale=(i == 0), attention=attention)
     return outputs
 
 

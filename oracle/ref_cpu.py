@@ -398,11 +398,13 @@ def depth_decoder_forward(state, features, num_ch_enc, scales=(0, 1, 2, 3), use_
 # --------------------------------------------------------------------------
 # a4  PoseDecoder                        reference networks/pose_decoder.py:14-54
 # --------------------------------------------------------------------------
-def pose_decoder_forward(state, input_features, num_frames_to_predict_for):
+def pose_decoder_forward(state, input_features, num_frames_to_predict_for, kinks=None):
+    """`kinks`: oracle.kinks.ForcedKinks to impose recorded ReLU decisions (default: plain F.relu)."""
+    relu = kinks.relu if kinks is not None else F.relu
     last = [f[-1] for f in input_features]
-    cat = torch.cat([F.relu(F.conv2d(f, state["net.0.weight"], state["net.0.bias"])) for f in last], 1)
-    out = F.relu(F.conv2d(cat, state["net.1.weight"], state["net.1.bias"], padding=1))
-    out = F.relu(F.conv2d(out, state["net.2.weight"], state["net.2.bias"], padding=1))
+    cat = torch.cat([relu(F.conv2d(f, state["net.0.weight"], state["net.0.bias"])) for f in last], 1)
+    out = relu(F.conv2d(cat, state["net.1.weight"], state["net.1.bias"], padding=1))
+    out = relu(F.conv2d(out, state["net.2.weight"], state["net.2.bias"], padding=1))
     out = F.conv2d(out, state["net.3.weight"], state["net.3.bias"])
     out = out.mean(3).mean(2)
     out = 0.01 * out.view(-1, num_frames_to_predict_for, 1, 6)

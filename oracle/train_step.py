@@ -11,6 +11,7 @@ import torch
 from . import fusion_ref as FR
 from . import gru_ref as GR
 from . import ref_cpu as R
+from .kinks import ForcedKinks
 from .resnet_ref import resnet_encoder_forward
 
 
@@ -30,26 +31,50 @@ class CpuTrainer:
         self.optim = torch.optim.Adam(self.params, lr)
         self.num_ch_enc = [64, 64, 128, 256, 512] if num_layers <= 34 else [64, 256, 512, 1024, 2048]
 
-    def process_batch(self, inputs, noise):
+    def process_batch(self, inputs, noise, kinks=None):
+        """`kinks`: {"encoder" | "pose_encoder" | "pose": tape entries recorded by the HIP path (depthcore.ops.KinkTape)} --
+        the ReLU / max-pool decisions of those networks are then imposed (oracle/kinks.py); the imposed-vs-own disagreements
+        are left in `self.kink_report`.  The HIP path stacks both pose pairs along the batch: pair i = rows [i*B, (i+1)*B)."""
         o = self.opt
+        used = []
+
+        def forced(name, part=None, parts=1):
+            if not kinks or name not in kinks:
+                return None
+            n = kinks[name][0][1].shape[0] // parts
+            k = ForcedKinks(kinks[name], None if part is None else slice(part * n, (part + 1) * n))
+            used.append((name, k))
+            return k
+        enc_k = forced("encoder")
         if "gru" in self.state:                      # trainer_gru.py:595-644: `inputs` = the sequence stacked along the batch
-            feats = resnet_encoder_forward(self.state["encoder"], inputs[("color", 0, 0)], self.num_layers)
+            feats = resnet_encoder_forward(self.state["encoder"], inputs[("color", 0, 0)], self.num_layers, kinks=enc_k)
             feats = GR.run_gru_v5(feats, self.state["gru"])
             outputs = R.depth_decoder_forward(self.state["depth"], feats, self.num_ch_enc, tuple(o.scales))
         elif "fusion" in self.state:
             enc_input = torch.cat([inputs[("color_aug", i, 0)] for i in (-2, -1, 0)], 0)
-            feats = resnet_encoder_forward(self.state["encoder"], enc_input, self.num_layers)
+            feats = resnet_encoder_forward(self.state["encoder"], enc_input, self.num_layers, kinks=enc_k)
             dec = R.depth_decoder_forward(self.state["depth"], feats, self.num_ch_enc, tuple(o.scales))
             outputs = FR.fusion_v3_forward(self.state["fusion"], dec)
         else:
-            feats = resnet_encoder_forward(self.state["encoder"], inputs[("color_aug", 0, 0)], self.num_layers)
+            feats = resnet_encoder_forward(self.state["encoder"], inputs[("color_aug", 0, 0)], self.num_layers, kinks=enc_k)
             outputs = R.depth_decoder_forward(self.state["depth"], feats, self.num_ch_enc, tuple(o.scales))
-        outputs.update(R.predict_poses(
-            inputs,
-            lambda x: resnet_encoder_forward(self.state["pose_encoder"], x, self.num_layers),
-            lambda f: R.pose_decoder_forward(self.state["pose"], f, 2)))
+        pair = [0, 0]           # R.predict_poses runs the encoder and the decoder once per pair, (-1, 0) first
+
+        def pose_enc(x):
+            k = forced("pose_encoder", pair[0], 2)
+            pair[0] += 1
+            return resnet_encoder_forward(self.state["pose_encoder"], x, self.num_layers, kinks=k)
+
+        def pose_dec(f):
+            k = forced("pose", pair[1], 2)
+            pair[1] += 1
+            return R.pose_decoder_forward(self.state["pose"], f, 2, kinks=k)
+        outputs.update(R.predict_poses(inputs, pose_enc, pose_dec))
         R.generate_images_pred(inputs, outputs, o)
         losses = R.compute_losses(inputs, outputs, o, noise)
+        for _, k in used:
+            k.done()
+        self.kink_report = [(name,) + d for name, k in used for d in k.disagree]
         return outputs, losses
 
     def train_step(self, inputs, noise):

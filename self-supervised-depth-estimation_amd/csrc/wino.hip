@@ -441,7 +441,7 @@ static inline size_t wino_uhat_bytes(int Ci, int Co) {
 // step -- ONE launch that transforms every variant seen so far instead of one 8 us launch in front of every convolution
 // -- and dc_wino_cache_invalidate when the step's backward is done.  Between the two, wino_launch takes U from the
 // cache; a variant (dgrad, MT) it has not met yet is transformed in place as before and joins the next refresh.
-struct WcVariant { int dgrad, MT, Mp, Kp; float* buf; bool fresh; };
+struct WcVariant { int dgrad, MT, Mp, Kp; float* buf; bool fresh, in_table; };
 struct WcEntry { const float* w; int Ci, Co; std::vector<WcVariant> v; };
 static std::mutex g_wc_mu;
 static std::vector<WcEntry> g_wc;
@@ -449,16 +449,27 @@ static bool g_wc_valid = false, g_wc_dirty = true;
 static WinoWDesc* g_wc_table = nullptr;
 static int* g_wc_b2d = nullptr;
 static int g_wc_table_cap = 0, g_wc_table_n = 0, g_wc_blocks = 0, g_wc_b2d_cap = 0;
+// Device buffers a captured hipGraph may still name in its kernel arguments (descriptor tables that were outgrown, the
+// variant buffers of unregistered weights): parked here, released only by dc_wino_cache_clear().
+static std::vector<void*> g_wc_retired;
 
-// -> cached U for this launch, or nullptr (then the caller transforms into its workspace)
-static const float* wc_lookup(const float* w, int Ci, int Co, bool dgrad, int MT, int Mp, int Kp) {
+static bool wc_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+// -> cached U for this launch, or nullptr (then the caller transforms into its workspace).  Nothing is allocated while
+// `st` is being captured (hipMalloc is illegal there): an unseen variant is then transformed per launch, as before.
+static const float* wc_lookup(const float* w, int Ci, int Co, bool dgrad, int MT, int Mp, int Kp, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_wc_mu);
     for (auto& e : g_wc) {
         if (e.w != w) continue;
         if (e.Ci != Ci || e.Co != Co) return nullptr;
         for (auto& v : e.v)
             if (v.dgrad == (int)dgrad && v.MT == MT) return (g_wc_valid && v.fresh) ? v.buf : nullptr;
-        WcVariant v{(int)dgrad, MT, Mp, Kp, nullptr, false};
+        if (wc_capturing(st)) return nullptr;
+        WcVariant v{(int)dgrad, MT, Mp, Kp, nullptr, false, false};
         if (hipMalloc((void**)&v.buf, (size_t)Mp * Kp * 16 * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         e.v.push_back(v);
         g_wc_dirty = true;
@@ -532,7 +543,7 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     float* slabs = (float*)((char*)d.ws + wino_uhat_bytes(d.Ci, d.Co));
     a.y = ksplit > 1 ? slabs : d.out;
     a.slab_stride = ksplit > 1 ? nout : 0;
-    if (const float* cached = wc_lookup(d.weight, d.Ci, d.Co, d.dgrad, MT, Mp, Kp)) {
+    if (const float* cached = wc_lookup(d.weight, d.Ci, d.Co, d.dgrad, MT, Mp, Kp, st)) {
         a.uhat = cached;
     } else {
         if (d.dgrad)
@@ -658,10 +669,25 @@ extern "C" int dc_wino_cache_register(const float* weight, int Ci, int Co) {
     return DC_OK;
 }
 
+extern "C" int dc_wino_cache_unregister(const float* weight) {
+    std::lock_guard<std::mutex> lk(g_wc_mu);
+    for (size_t i = 0; i < g_wc.size(); ++i)
+        if (g_wc[i].w == weight) {
+            for (auto& v : g_wc[i].v)
+                if (v.buf) g_wc_retired.push_back(v.buf);      // a captured graph of the former owner may still write it
+            g_wc.erase(g_wc.begin() + i);
+            g_wc_dirty = true;
+            return DC_OK;
+        }
+    return DC_OK;
+}
+
 extern "C" int dc_wino_cache_refresh(void* stream) {
     std::lock_guard<std::mutex> lk(g_wc_mu);
     hipStream_t st = (hipStream_t)stream;
-    if (g_wc_dirty) {
+    // The descriptor upload allocates, synchronises and copies: none of it is legal on a capturing stream.  A capture that
+    // meets a dirty registry replays the table as it stands (variants outside it keep transforming per launch).
+    if (g_wc_dirty && !wc_capturing(st)) {
         std::vector<WinoWDesc> host;
         std::vector<int> b2d;
         int blocks = 0;
@@ -672,28 +698,28 @@ extern "C" int dc_wino_cache_refresh(void* stream) {
                 host.push_back(WinoWDesc{e.w, v.buf, e.Co, e.Ci, v.MT, v.Mp, v.Kp, v.dgrad, blocks, 0});
                 blocks += nb;
             }
-        if (blocks > g_wc_b2d_cap) {
-            if (g_wc_b2d && hipFree(g_wc_b2d) != hipSuccess) return DC_ELAUNCH;
-            g_wc_b2d_cap = blocks + 4096;
-            if (hipMalloc((void**)&g_wc_b2d, sizeof(int) * g_wc_b2d_cap) != hipSuccess) { g_wc_b2d = nullptr; g_wc_b2d_cap = 0; return DC_ELAUNCH; }
-        }
-        if ((int)host.size() > g_wc_table_cap) {
-            if (g_wc_table && hipFree(g_wc_table) != hipSuccess) return DC_ELAUNCH;
-            g_wc_table_cap = (int)host.size() + 64;
-            if (hipMalloc((void**)&g_wc_table, sizeof(WinoWDesc) * g_wc_table_cap) != hipSuccess) { g_wc_table = nullptr; g_wc_table_cap = 0; return DC_ELAUNCH; }
-        }
+        // A rebuilt table goes to fresh memory and the old one is retired, not freed or rewritten: a captured graph holds
+        // the old address and block count and must keep seeing the old contents.
+        if (g_wc_b2d) g_wc_retired.push_back(g_wc_b2d);
+        if (g_wc_table) g_wc_retired.push_back(g_wc_table);
+        g_wc_b2d = nullptr; g_wc_table = nullptr; g_wc_table_n = g_wc_blocks = 0;
+        g_wc_b2d_cap = blocks; g_wc_table_cap = (int)host.size();
+        if (blocks > 0 && hipMalloc((void**)&g_wc_b2d, sizeof(int) * blocks) != hipSuccess) { g_wc_b2d = nullptr; return DC_ELAUNCH; }
+        if (!host.empty() && hipMalloc((void**)&g_wc_table, sizeof(WinoWDesc) * host.size()) != hipSuccess) { g_wc_table = nullptr; return DC_ELAUNCH; }
         // synchronous upload (the descriptor list only changes while the variants of a model are still being met)
         if (!host.empty() && hipStreamSynchronize(st) != hipSuccess) return DC_ELAUNCH;
         if (!host.empty() && hipMemcpy(g_wc_table, host.data(), sizeof(WinoWDesc) * host.size(), hipMemcpyHostToDevice) != hipSuccess) return DC_ELAUNCH;
         if (!b2d.empty() && hipMemcpy(g_wc_b2d, b2d.data(), sizeof(int) * b2d.size(), hipMemcpyHostToDevice) != hipSuccess) return DC_ELAUNCH;
         g_wc_table_n = (int)host.size(); g_wc_blocks = blocks; g_wc_dirty = false;
+        for (auto& e : g_wc)
+            for (auto& v : e.v) v.in_table = true;
     }
-    if (g_wc_table_n > 0) {
+    if (g_wc_table_n > 0 && g_wc_blocks > 0) {
         hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(g_wc_blocks), dim3(256), 0, st, (const WinoWDesc*)g_wc_table, (const int*)g_wc_b2d, PSK);
         DC_CHECK_LAUNCH();
     }
     for (auto& e : g_wc)
-        for (auto& v : e.v) v.fresh = true;
+        for (auto& v : e.v) v.fresh = v.in_table;
     g_wc_valid = true;
     return DC_OK;
 }
@@ -711,6 +737,9 @@ extern "C" int dc_wino_cache_clear(void) {
         for (auto& v : e.v)
             if (v.buf && hipFree(v.buf) != hipSuccess) rc = DC_ELAUNCH;
     g_wc.clear();
+    for (void* q : g_wc_retired)
+        if (hipFree(q) != hipSuccess) rc = DC_ELAUNCH;
+    g_wc_retired.clear();
     if (g_wc_table && hipFree(g_wc_table) != hipSuccess) rc = DC_ELAUNCH;
     if (g_wc_b2d && hipFree(g_wc_b2d) != hipSuccess) rc = DC_ELAUNCH;
     g_wc_table = nullptr; g_wc_b2d = nullptr; g_wc_table_cap = g_wc_table_n = g_wc_blocks = g_wc_b2d_cap = 0;

@@ -127,6 +127,7 @@ def _sig(lib):
         "dc_gru_residual_fwd": (i, [p, p, p, i, z, p]),
         "dc_gru_residual_bwd": (i, [p, p, i, z, p]),
         "dc_wino_cache_register": (i, [p, i, i]),
+        "dc_wino_cache_unregister": (i, [p]),
         "dc_wino_cache_refresh": (i, [p]),
         "dc_wino_cache_invalidate": (None, []),
         "dc_wino_cache_clear": (i, []),

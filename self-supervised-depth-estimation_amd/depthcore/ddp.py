@@ -74,20 +74,25 @@ class GradBuckets:
         self.packed = 0         # gradients that had to be copied into their slice this step (0 on the all-depthcore path)
         self.streams = []       # streams on which gradients are produced besides the current one (Trainer.overlap_streams)
         self.comm = None        # communication stream (created on first use)
-        self.nbytes = sum(p.numel() * 4 for plist in self.buckets for p in plist)
+        self.nbytes = sum((p.numel() + 3) // 4 * 16 for plist in self.buckets for p in plist)    # bytes exchanged per step
         if self.world == 1:
             return
         backend = dist.get_backend(process_group)
         self.avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
         for bi, plist in enumerate(self.buckets):
-            n = sum(p.numel() for p in plist)
-            flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
-            off, views = 0, []
+            # every slice starts on a 16-byte boundary (the kernels write gradients into it with 16-byte vector stores;
+            # 1-element dispconv biases and 3-element rel_h / rel_w would otherwise leave their successors misaligned);
+            # the padding stays zero and is exchanged along with the rest
+            offs, n = [], 0
             for p in plist:
+                offs.append(n)
+                n += (p.numel() + 3) // 4 * 4
+            flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
+            views = []
+            for p, off in zip(plist, offs):
                 v = flat[off:off + p.numel()].view_as(p)
                 views.append(v)
                 p._dc_grad_slot = GradSlot(v)
-                off += p.numel()
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
             self.flat.append(flat)
             self.views.append(views)

@@ -16,6 +16,29 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class KinkTape:
+    """Test hook: while active, every fused ReLU records its output (`("relu", y)`: the decision taken is y > 0) and the
+    max-pool its argmax codes (`("maxpool", code)`), in call order.  The parity tests replay these decisions inside the fp64
+    oracle (oracle/kinks.py) so that both sides evaluate the same smooth function.  Records references, copies nothing."""
+    _active = []
+
+    def __init__(self):
+        self.entries = []
+
+    def __enter__(self):
+        KinkTape._active.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        KinkTape._active.remove(self)
+        return False
+
+
+def _record_kink(kind, t):
+    if KinkTape._active:
+        KinkTape._active[-1].entries.append((kind, t))
+
+
 def _slot(param):
     """forward(): the parameter's slice of its flat DDP gradient bucket, if depthcore.ddp.GradBuckets gave it one."""
     return getattr(param, "_dc_grad_slot", None)
@@ -488,6 +511,8 @@ class _Conv3x3(torch.autograd.Function):
         check(L.dc_conv3x3_fwd(ptr(a0), C0, int(up0), ptr(a1), C1, ptr(w), ptr(bs), ptr(y), ws.data_ptr(), B, Co, H, W,
                                int(act), int(pad), stream(a0)), "dc_conv3x3_fwd")
         ctx.save_for_backward(a0, a1, w, y)
+        if act == ACT_RELU:
+            _record_kink("relu", y)
         ctx.cfg = (int(up0), int(act), int(pad), bias is not None)
         ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
         return y
@@ -541,6 +566,8 @@ class _BNReLU(torch.autograd.Function):
                                ptr(running_mean), ptr(running_var), ws.data_ptr(), mask.data_ptr() if nmask else None,
                                N, C, H * W, float(eps), float(momentum), int(relu), int(groups), stream(xx)), "dc_bn_relu_fwd")
         ctx.save_for_backward(xx, y, g, mean, invstd, mask)
+        if relu:
+            _record_kink("relu", y)
         ctx.cfg = (int(relu), res is not None, int(groups))
         ctx.slots = (_slot(gamma), _slot(beta))
         return y
@@ -585,6 +612,7 @@ class _MaxPool(torch.autograd.Function):
         code = torch.empty(N, C, Ho, Wo, dtype=torch.uint8, device=xx.device)
         check(L.dc_maxpool3x3s2_fwd(ptr(xx), ptr(y), code.data_ptr(), N * C, H, W, stream(xx)), "dc_maxpool3x3s2_fwd")
         ctx.save_for_backward(code)
+        _record_kink("maxpool", code)
         ctx.dims = (N, C, H, W)
         return y
 
@@ -651,51 +679,57 @@ def wino_conv3x3(x, weight):
 
 
 # ---- transformed-weight cache of the Winograd kernels (include/depthcore.h: dc_wino_cache_*) ----------------------
+def _wino_unregister(addresses):
+    """weakref.finalize target: runs when a WinoWeightCache is closed or collected (never touches the dead object)."""
+    try:
+        L = _lib.lib()
+        for a in addresses:
+            L.dc_wino_cache_unregister(a)
+    except Exception:
+        pass
+
+
 class WinoWeightCache:
-    """Owner of libdepthcore's process-wide Winograd weight cache for ONE set of parameters (a Trainer's models).
+    """A model's registrations in libdepthcore's Winograd weight cache (one per Trainer).
 
     `refresh()` at the start of a training step transforms every registered 3x3 weight in one launch; the step's
     convolutions (forward, data gradient, and every frame of the sequence models) then skip their per-launch transform;
-    `invalidate()` once the backward is done, before the optimiser rewrites the weights.  Only one owner at a time: a new
-    cache takes the registry over (the previous owner's convolutions transform per launch again -- same results)."""
-    _owner = None
+    `invalidate()` once the backward is done, before the optimiser rewrites the weights.
+
+    The registry is shared by all caches of the process: constructing a second one never frees what the first registered,
+    so a hipGraph captured by the first owner keeps replaying on valid buffers; `close()` (also run when the object is
+    collected) unregisters this owner's weights only, and their device buffers are parked until `clear_all()`."""
 
     def __init__(self, params):
         L = _lib.lib()
-        check(L.dc_wino_cache_clear(), "dc_wino_cache_clear")
         self._keep = []
         for p_ in params:
             if p_.dim() == 4 and tuple(p_.shape[2:]) == (3, 3) and p_.is_cuda and p_.dtype == torch.float32 and p_.is_contiguous():
                 check(L.dc_wino_cache_register(p_.data_ptr(), int(p_.shape[1]), int(p_.shape[0])), "dc_wino_cache_register")
                 self._keep.append(p_)           # the registry holds raw addresses: keep the tensors alive with it
-        WinoWeightCache._owner = weakref.ref(self)
-
-    def _mine(self):
-        o = WinoWeightCache._owner
-        return o is not None and o() is self
+        self._fin = weakref.finalize(self, _wino_unregister, [p_.data_ptr() for p_ in self._keep])
 
     def refresh(self):
-        if self._mine() and self._keep:
+        if self._fin.alive and self._keep:
             check(_lib.lib().dc_wino_cache_refresh(stream(self._keep[0])), "dc_wino_cache_refresh")
 
     def invalidate(self):
-        if self._mine():
+        if self._fin.alive:
             _lib.lib().dc_wino_cache_invalidate()
 
     def variants(self):
-        return int(_lib.lib().dc_wino_cache_variants()) if self._mine() else 0
+        """cached (weight, pass, tile layout) variants in the whole registry (0 once every owner is closed)."""
+        return int(_lib.lib().dc_wino_cache_variants()) if self._fin.alive else 0
 
     def close(self):
-        if self._mine():
-            WinoWeightCache._owner = None
-            check(_lib.lib().dc_wino_cache_clear(), "dc_wino_cache_clear")
+        self._fin()                             # unregister once (idempotent)
         self._keep = []
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+    @staticmethod
+    def clear_all():
+        """Drop every registration and free every parked buffer (device-synchronising).  Only when no captured graph that
+        used the cache will be replayed again."""
+        check(_lib.lib().dc_wino_cache_clear(), "dc_wino_cache_clear")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -715,6 +749,8 @@ class _Conv1x1(torch.autograd.Function):
         check(L.dc_conv1x1_bias_act_fwd(ptr(xx), ptr(ww), ptr(bs), ptr(y), B, Ci, Co, Hi, Wi, int(stride), int(act), stream(xx)),
               "dc_conv1x1_bias_act_fwd")
         plain = bias is None and act == ACT_NONE
+        if act == ACT_RELU:
+            _record_kink("relu", y)
         ctx.save_for_backward(xx, ww, None if plain else y)
         ctx.cfg = (int(stride), int(act), bias is not None)
         ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)

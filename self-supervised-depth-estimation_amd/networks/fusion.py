@@ -9,6 +9,7 @@ memory), the three tiny 3x3 convolutions of a block run on the fused conv block 
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 import torch.nn.init as init
 
 from depthcore import ops as _ops
@@ -57,6 +58,31 @@ class ResidualAttentionUnit(nn.Module):
         return _ops.residual_attention_unit(srcs, kinds, self.atten1.params(), self.atten2.params())
 
 
+class ResidualConvUnit(nn.Module):
+    """networks/fusion_v2.py:11-43 (`Fusion_v3(attention=False)`, reference option --disable_attention): conv2(relu(conv1(
+    relu(x)))) + relu(x) -- the in-place ReLU rewrites the unit's input here as well.  Both 3x3 convolutions (zero padding,
+    bias, ReLU of the first in its epilogue) run on the fused conv block; the unit's input is assembled with stock tensor
+    ops (this variant is not on a BASELINE configuration: its 2-4 channel concatenations are not worth a gather kernel)."""
+
+    def __init__(self, features):
+        super().__init__()
+        self.conv1 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
+        self.conv2 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, srcs, kinds=None):
+        if isinstance(srcs, torch.Tensor):
+            srcs = [srcs]
+        if not srcs[0].is_cuda:
+            raise DepthcoreError("Fusion_v3 runs on depthcore kernels only; there is no CPU path")
+        kinds = kinds or [_ops.PLAIN] * len(srcs)
+        parts = [t if k == _ops.PLAIN else F.pixel_shuffle(t, 2) for t, k in zip(srcs, kinds)]
+        r = torch.relu(parts[0] if len(parts) == 1 else torch.cat(parts, 1))
+        c1, c2 = self.conv1, self.conv2
+        h = _ops.conv3x3_block(r, None, c1.weight, c1.bias, False, _ops.ACT_RELU, _ops.PAD_ZERO)
+        return _ops.conv3x3_block(h, None, c2.weight, c2.bias, False, _ops.ACT_NONE, _ops.PAD_ZERO) + r
+
+
 class UpscalePS(nn.Module):
     """networks/fusion_v2.py:226-236.  `forward` returns the PRE-shuffle tensor tanh(conv(x)) (B, out*scale^2, h, w); its
     consumer reads it through the PixelShuffle index map (depthcore.ops.PIXEL_SHUFFLE2)."""
@@ -77,14 +103,13 @@ class FeatureFusionBlock_v3(nn.Module):
 
     def __init__(self, features, attention=True, init_scale=False):
         super().__init__()
-        if not attention:
-            raise NotImplementedError("Fusion_v3(attention=False) (ResidualConvUnit) is not on the BASELINE configs")
         self.init_scale = init_scale
         if self.init_scale:
             self.conv_1 = nn.Conv2d(1, 2, kernel_size=3, stride=1, padding=1, bias=True)
-        self.resConfUnit1 = ResidualAttentionUnit(features)
-        self.resConfUnit2 = ResidualAttentionUnit(features)
-        self.resConfUnit3 = ResidualAttentionUnit(features * 2)
+        unit = ResidualAttentionUnit if attention else ResidualConvUnit           # fusion_v2.py:294-302
+        self.resConfUnit1 = unit(features)
+        self.resConfUnit2 = unit(features)
+        self.resConfUnit3 = unit(features * 2)
         self.conv3x3 = Conv3x3(features * 2, 1)
         self.upscale = UpscalePS(features * 2, 1, 2)
 

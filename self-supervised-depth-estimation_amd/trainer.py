@@ -89,7 +89,14 @@ class Trainer:
 
         torch.manual_seed(seed)                                  # same initial weights on every rank
         self.models = {}
-        self.models["encoder"] = networks.ResnetEncoder(self.opt.num_layers, self.opt.weights_init == "pretrained")
+        # weights_init = "pretrained" (the reference's CLI default, also found in every opt.json it writes) means the
+        # torchvision ImageNet download there (networks/resnet_encoder.py:53).  No network here: `opt.imagenet_weights`
+        # (path of a torchvision resnet{N}-*.pth) supplies them; with `load_weights_folder` set the initial values are
+        # overwritten by load_model() anyway and a scratch init stands in; otherwise ResnetEncoder refuses.
+        pretrained = self.opt.weights_init == "pretrained"
+        if pretrained:
+            pretrained = getattr(self.opt, "imagenet_weights", None) or (not getattr(self.opt, "load_weights_folder", None))
+        self.models["encoder"] = networks.ResnetEncoder(self.opt.num_layers, pretrained)
         self.models["depth"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, self.opt.scales)
         if self.opt.fusion:                                      # trainer_fusion_v3.py:74
             self.models["fusion"] = networks.Fusion_v3(attention=not self.opt.disable_attention)
@@ -97,7 +104,7 @@ class Trainer:
             self.models["gru"] = networks.ConvGRUBlocks_v5(kernel_size=(3, 3), bias=True, device="cpu", height=self.opt.height,
                                                            width=self.opt.width,
                                                            num_ch_enc=tuple(int(c) for c in self.models["encoder"].num_ch_enc))
-        self.models["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, self.opt.weights_init == "pretrained",
+        self.models["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, pretrained,
                                                              num_input_images=self.num_pose_frames)
         self.models["pose"] = networks.PoseDecoder(self.models["pose_encoder"].num_ch_enc, num_input_features=1,
                                                    num_frames_to_predict_for=2)
@@ -126,7 +133,7 @@ class Trainer:
         self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate,
                                           fused=self.device.type == "cuda", capturable=self.graph_enabled)
         self._seed_dev = torch.full((1,), rank, dtype=torch.int64, device=self.device) if self.graph_enabled else None
-        self._graph, self._graph_key, self._graph_warm, self._graph_stream = None, None, 0, None
+        self._graphs, self._graph, self._graph_warm, self._graph_stream = {}, None, {}, None
         self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
 
         self.ssim = SSIM()
@@ -146,6 +153,24 @@ class Trainer:
     def set_train(self):
         for m in self.models.values():
             m.train()
+
+    def freeze_hidden_states(self):
+        """trainer_gru.py:295-307: from epoch `opt.h_s_epoch` on the learned initial hidden states of the ConvGRU cells stop
+        training (`h0_layer1.requires_grad = False`; they stay in Adam's parameter list and simply receive no gradient any
+        more, as in the reference).  Captured hipGraphs recorded the old autograd graph and are dropped (re-captured after
+        the usual warm-up)."""
+        if "gru" not in self.models:
+            return
+        for cell in self.models["gru"].cells():
+            cell.h0_layer1.requires_grad = False
+            cell.h0_layer1.grad = None
+        self._graphs, self._graph, self._graph_warm = {}, None, {}
+
+    def start_epoch(self, epoch):
+        """Per-epoch hooks of the reference's train loops: trainer_gru.py:295 (`(epoch + 1) == h_s_epoch`)."""
+        self.epoch = epoch
+        if self.opt.gru and (epoch + 1) == self.opt.h_s_epoch:
+            self.freeze_hidden_states()
 
     def set_eval(self):
         for m in self.models.values():
@@ -403,8 +428,10 @@ class Trainer:
     def train_step(self, inputs):
         if not self.graph_enabled:
             return self._train_step_eager(inputs)
-        key = (tuple((k, tuple(v.shape)) for k, v in inputs.items()), tuple(g["lr"] for g in self.model_optimizer.param_groups))
-        if self._graph is None or self._graph_key != key:
+        shapes = tuple((k, tuple(v.shape)) for k, v in inputs.items())
+        key = (shapes, tuple(g["lr"] for g in self.model_optimizer.param_groups))
+        entry = self._graphs.get(key)
+        if entry is None:
             # Everything a capture will see must already have happened on a NON-default stream: autograd binds each
             # parameter's AccumulateGrad node to the stream of its first use, and a node bound to the legacy default stream
             # makes the backward touch that stream inside the capture (fatal).  So the eager warm-up steps of graph mode
@@ -412,28 +439,38 @@ class Trainer:
             if self._graph_stream is None:
                 self._graph_stream = torch.cuda.Stream(self.device)
             gs, cur = self._graph_stream, torch.cuda.current_stream(self.device)
-            if self._graph_warm < self.GRAPH_WARMUP:
-                self._graph_warm += 1
+            # Warm-up is counted PER INPUT SHAPE: a new shape meets new kernel variants, lazy workspace sizes and weight-cache
+            # variants, and all of that (allocations, attribute calls, a synchronous table upload) must happen in eager
+            # steps, not inside a capture.  A learning-rate change on a known shape captures at once.
+            warm = self._graph_warm.get(shapes, 0)
+            if warm < self.GRAPH_WARMUP:
+                self._graph_warm[shapes] = warm + 1
                 gs.wait_stream(cur)
                 with torch.cuda.stream(gs):
                     out = self._train_step_eager(inputs)
                 cur.wait_stream(gs)
                 return out
             # capture: records the launches of one step (both streams, backward, Adam) without running them
-            self._static_in = {k: v.clone() for k, v in inputs.items()}
+            static_in = {k: v.clone() for k, v in inputs.items()}
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=gs):
-                self._static_out = self._train_step_eager(self._static_in)
-            self._graph, self._graph_key = g, key
+                static_out = self._train_step_eager(static_in)
+            entry = self._graphs[key] = (g, static_in, static_out)
             self.step -= 1                      # (the recorded step has not run yet: the replay below is that step)
         else:
             for k, v in inputs.items():
-                if v is not self._static_in[k]:
-                    self._static_in[k].copy_(v, non_blocking=True)
-        self._graph.replay()
+                if v is not entry[1][k]:
+                    entry[1][k].copy_(v, non_blocking=True)
+        self._graph = entry[0]
+        entry[0].replay()
         self.step += 1
-        return self._static_out               # static tensors: rewritten by every replay
+        return entry[2]                       # static tensors: rewritten by every replay of this graph
+
+    def close(self):
+        """Drop the captured graphs (they name the weight cache's buffers) and this trainer's cache registrations."""
+        self._graphs, self._graph = {}, None
+        self.wino_cache.close()
 
     def _train_step_eager(self, inputs):
         self.wino_cache.refresh()               # every 3x3 weight -> Winograd domain, one launch per step

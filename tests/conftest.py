@@ -23,4 +23,4 @@ def golden():
     d = os.path.join(REPO, "tests", "golden")
     return {name: np.load(os.path.join(d, name + ".npz"), allow_pickle=False)
             for name in ("layers_ops", "trainer_losses", "decoders", "pose_even", "fusion_v3", "trainer_ablations", "convgru",
-                         "data_pillow")}
+                         "data_pillow", "fusion_v3_noattn")}

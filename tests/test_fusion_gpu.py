@@ -121,6 +121,35 @@ def test_fusion_v3_module_vs_reference_fixture(golden):
             close(gr[4 + j], want, rtol=2e-3, atol=3e-4, msg=k)
 
 
+def test_fusion_v3_without_attention_vs_reference_fixture(golden):
+    """`Fusion_v3(attention=False)` (reference --disable_attention; ResidualConvUnit, networks/fusion_v2.py:11-43,294-302):
+    both convolutions of every unit on the fused conv block, against the reference's own outputs and gradients."""
+    import networks
+    from test_fusion_oracle import noattn_state
+    g = golden["fusion_v3_noattn"]
+    fu = networks.Fusion_v3(attention=False).to(DEV)
+    assert list(fu.state_dict().keys()) == list(g["keys"])
+    fu.load_state_dict(noattn_state(g["keys"], g["shapes"]))
+    inp, _ = MG2.fusion_inputs()
+    inp = {k: v.to(DEV).requires_grad_() for k, v in inp.items()}
+    o = fu(inp)
+    tot = 0
+    for s in range(4):
+        close(o[("disp", s)], g["disp%d" % s], rtol=1e-3, atol=1e-4, msg="disp%d" % s)
+        tot = tot + (o[("disp", s)] * T(g["cot%d" % s]).to(DEV)).sum()
+    params = dict(fu.named_parameters())
+    names = list(params)
+    gr = torch.autograd.grad(tot, [inp[("disp", s)] for s in range(4)] + [params[k] for k in names], allow_unused=True)
+    for s in range(4):
+        assert rel_l2(gr[s], g["gin%d" % s]) < 1e-3, ("gin%d" % s, rel_l2(gr[s], g["gin%d" % s]))
+    for j, k in enumerate(names):
+        want = g["g_" + k]
+        if want.size == 0:
+            assert gr[4 + j] is None
+        else:
+            assert rel_l2(gr[4 + j], want) < 1e-3, (k, rel_l2(gr[4 + j], want))
+
+
 def test_fusion_v3_full_size_properties():
     """BASELINE configs[4] size (B=12, 192x640, 3 stacked frames): deterministic (bitwise) forward and gradients, finite."""
     import networks

@@ -51,7 +51,8 @@ def test_all_parameter_gradients_vs_oracle(fusion):
     """Every parameter gradient of one full step (both encoders, decoders, [Fusion_v3]) against the CPU oracle's autograd,
     per network by relative L2 norm.  The photometric gradient is ill-conditioned in fp32 (see test_photo_gpu), so the
     bound is calibrated: the oracle is also run in fp64, and the HIP path may be at most 5x as far from fp64 as the
-    oracle's own fp32 run (floor 2e-4; the ratio between two fp32 evaluations of such a sum is itself noisy)."""
+    oracle's own fp32 run (floor 2e-4; the ratio between two fp32 evaluations of such a sum is itself noisy) -- for EVERY
+    network."""
     import trainer as T
     B, H, W = 2, 64, 96
     gru = fusion == "gru"                    # one sequence of B frames at batch size 1 (trainer_gru.py run_gru_v5)
@@ -75,16 +76,24 @@ def test_all_parameter_gradients_vs_oracle(fusion):
     inputs = R.synthetic_inputs(B, H, W, seed=0, frame_ids=(0, -2, -1, 1) if fusion == "v3" else (0, -1, 1))
     noise = R.tiebreak_noise(B, H, W)
 
-    def oracle(dtype):
-        st = {k: {n: (t.to(dtype) if t.is_floating_point() else t) for n, t in sd.items()} for k, sd in state.items()}
-        ct = CpuTrainer(st, R.Opt(height=H, width=W))
-        inp = {k: v.to(dtype) for k, v in inputs.items()}
-        _, ol = ct.process_batch(inp, [n.to(dtype) for n in noise])
-        ol["loss"].backward()
-        return float(ol["loss"].detach()), _grads_by_model({(k, n): t.grad for k, sd in ct.state.items() for n, t in sd.items()
-                                                            if t.requires_grad and t.grad is not None})
-    l64, g64 = oracle(torch.float64)
-    l32, g32 = oracle(torch.float32)
+    # The HIP step runs first and records every ReLU / max-pool decision of the two encoders and the pose decoder
+    # (depthcore.ops.KinkTape); the oracle is then evaluated with those decisions imposed (oracle/kinks.py), so both sides
+    # differentiate the same smooth function and a pre-activation within rounding of zero cannot re-route a gradient
+    # (tests/test_encoder_gpu.py).  No network is exempted from the bound below.
+    from depthcore import ops
+    tapes = {}
+
+    def taped(name):
+        mod, orig = tr.models[name], tr.models[name].forward
+
+        def fwd(*a, **k):
+            with ops.KinkTape() as t:
+                out = orig(*a, **k)
+            tapes[name] = t.entries
+            return out
+        mod.forward = fwd
+    for name in ("encoder", "pose_encoder", "pose"):
+        taped(name)
     torch.manual_seed(1234)
     tr.buckets.zero()
     dev_in = {k: v.to(DEV) for k, v in inputs.items()}
@@ -93,20 +102,31 @@ def test_all_parameter_gradients_vs_oracle(fusion):
     _, gl = tr.process_batch(dev_in)
     gl["loss"].backward()
     gh = _grads_by_model({(k, n): p.grad for k, m in tr.models.items() for n, p in m.named_parameters() if p.grad is not None})
+    assert set(tapes) == {"encoder", "pose_encoder", "pose"}
+
+    def oracle(dtype):
+        st = {k: {n: (t.to(dtype) if t.is_floating_point() else t) for n, t in sd.items()} for k, sd in state.items()}
+        ct = CpuTrainer(st, R.Opt(height=H, width=W))
+        inp = {k: v.to(dtype) for k, v in inputs.items()}
+        _, ol = ct.process_batch(inp, [n.to(dtype) for n in noise], kinks=tapes)
+        ol["loss"].backward()
+        return float(ol["loss"].detach()), _grads_by_model({(k, n): t.grad for k, sd in ct.state.items() for n, t in sd.items()
+                                                            if t.requires_grad and t.grad is not None}), ct.kink_report
+    l64, g64, rep64 = oracle(torch.float64)
+    l32, g32, _ = oracle(torch.float32)
+    # the imposed decisions differ from the fp64 oracle's own only on near-ties (|pre-activation| at rounding level)
+    assert max([d[4] for d in rep64] or [0.0]) < 2e-5, rep64
     assert abs(float(gl["loss"].detach()) - l64) <= (1e-3 if fusion == "v3" else 1e-4) * abs(l64)
     assert set(gh) == set(g64)
-    report, loose = {}, []
+    report = {}
     for k in g64:
         assert gh[k].shape == g64[k].shape, k          # the same parameters received a gradient
         e_hip, e_32 = rel_l2(gh[k], g64[k]), rel_l2(g32[k], g64[k])
         report[k] = (e_hip, e_32)
-        if e_hip > 5.0 * e_32 + 2e-4:
-            loose.append(k)
-        assert e_hip <= 2e-2, report
-    # one pre-activation within fp32 rounding of a ReLU kink re-routes that element's gradient and shifts every upstream
-    # gradient by ~0.5 % on these small tensors (see tests/test_encoder_gpu.py): tolerated in at most one network
-    assert len(loose) <= 1, (loose, report)
-    print("per-network gradient error (hip vs f64, f32 oracle vs f64):", report)
+    print("per-network gradient error (hip vs f64, f32 oracle vs f64):", report,
+          "; decisions differing from fp64:", sum(d[3] for d in rep64))
+    for k, (e_hip, e_32) in report.items():
+        assert e_hip <= 5.0 * e_32 + 2e-4, (k, report)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (12, 192, 640)])
@@ -263,10 +283,39 @@ def test_trainer_ablations_golden(golden, tag):
     losses = tr.compute_losses(inputs, outputs)
     close(losses["loss"], g[tag + "_loss"], rtol=1e-3, atol=0)
     grads = torch.autograd.grad(losses["loss"], leaves + pose + masks)
+
+    # Gradient bound calibrated like the default path's (test_photo_gpu): the oracle, pinned to the reference's outputs for
+    # these ablations by tests/test_oracle_golden.py, is evaluated on the same leaves in fp64 and in fp32; the HIP gradients
+    # may be at most 3x as far from fp64 as the oracle's own fp32 evaluation is (floor 2e-4).
+    def oracle(dtype):
+        inp = {k: v.to(dtype) for k, v in R.synthetic_inputs(B, H, W, seed=0).items()}
+        d_, aa_, tr__, m_ = MG2.ablation_inputs(tag)
+        lv = [d_[s].to(dtype).requires_grad_() for s in range(4)]
+        ps = [aa_[-1].to(dtype).requires_grad_(), aa_[1].to(dtype).requires_grad_(), tr__[-1].to(dtype).requires_grad_(),
+              tr__[1].to(dtype).requires_grad_()]
+        out = {("disp", s): lv[s] for s in range(4)}
+        ms = []
+        if m_ is not None:
+            ms = [m_[s].to(dtype).requires_grad_() for s in range(4)]
+            out["predictive_mask"] = {("disp", s): ms[s] for s in range(4)}
+        for j, f in enumerate((-1, 1)):
+            out[("cam_T_cam", 0, f)] = R.transformation_from_parameters(ps[j], ps[2 + j], invert=(f < 0))
+        opt = R.Opt(height=H, width=W, **kw)
+        R.generate_images_pred(inp, out, opt)
+        torch.manual_seed(1234)
+        nz = None if tag == "pmask" else [torch.randn(B, 2, H >> s, W >> s).to(dtype) for s in range(4)]
+        return torch.autograd.grad(R.compute_losses(inp, out, opt, nz)["loss"], lv + ps + ms)
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+    report = []
+    for i in range(len(grads)):
+        e_hip, e_32 = rel_l2(grads[i], g64[i]), rel_l2(g32[i], g64[i])
+        report.append((i, e_hip, e_32))
+        assert e_hip <= 3.0 * e_32 + 2e-4, report
+    print("ablation %s gradients (leaf, |hip-f64|/|f64|, |f32-f64|/|f64|):" % tag, report)
+    # ... and against the reference's own fp32 numbers (they carry the same conditioning error, hence the looser figures)
     for s in range(4):
         close(losses["loss/%d" % s], g[tag + "_loss%d" % s], rtol=1e-3, atol=0)
-        # (same conditioning as the default path, see test_photo_gpu; the mask product adds a factor)
-        assert rel_l2(grads[s], g[tag + "_gdisp%d" % s]) < 6e-2, (s, rel_l2(grads[s], g[tag + "_gdisp%d" % s]))
+        assert rel_l2(grads[s], g[tag + "_gdisp%d" % s]) < 3e-2, (s, rel_l2(grads[s], g[tag + "_gdisp%d" % s]))
         if masks:    # the mask gradient follows the per-pixel argmin over the two frames: near-ties flip between implementations
             assert rel_l2(grads[8 + s], g[tag + "_gmask%d" % s]) < 2e-2
     for j, f in enumerate((-1, 1)):
@@ -321,7 +370,7 @@ def test_wino_weight_cache_changes_nothing(gru):
     lb, vb, wb = run(False)
     assert va[0] > 20 and va[0] == va[1] == va[2], va          # every variant is met in the first step
     assert vb == [0, 0, 0]
-    assert abs(la[0] - lb[0]) <= 1e-6 * abs(lb[0]), (la, lb)      # same forward arithmetic (the loss sums use float atomics)
+    assert abs(la[0] - lb[0]) <= 1e-6 * abs(lb[0]), (la, lb)      # same forward arithmetic, same fixed-order reductions
     assert np.allclose(la, lb, rtol=2e-4, atol=0), (la, lb)      # (Adam turns last-bit gradient differences into +-lr updates)
     assert float((wa - wb).abs().max()) <= 7e-4                   # two trajectories, 3 steps, each update within +-lr = 1e-4
 
@@ -357,3 +406,122 @@ def test_hip_graph_replays_train_like_eager_steps(gru):
     assert np.allclose(le[:3], lg[:3], rtol=1e-5), (le, lg)          # eager warm-up steps of both trainers
     assert np.allclose(le, lg, rtol=5e-4), (le, lg)                  # captured step + replays (capturable Adam: bias correction in fp32 on the device)
     assert len(set(round(v, 7) for v in lg[3:])) == len(lg[3:])      # every replay is a new step
+
+
+def test_second_trainer_does_not_break_a_captured_graph():
+    """The Winograd weight cache is process-wide and a captured hipGraph bakes its buffers into kernel arguments: building
+    (and closing) another Trainer must neither free nor rewrite anything the first trainer's graph reads or writes.  Trainer
+    A captures; trainer B is built, trains eagerly with its own weights and is closed; A's replays must still follow an
+    eager trainer that never saw a B."""
+    import trainer as T
+    from depthcore.synthetic import synthetic_batch
+    dev = torch.device(DEV)
+    batches = [synthetic_batch(2, 64, 128, dev, seed=s) for s in (2, 3)]
+
+    def opts(graph):
+        return T.default_options(height=64, width=128, batch_size=2, hip_graph=graph)
+
+    ref = T.Trainer(opts(False), device=DEV, seed=5)
+    ref.set_train()
+    want = [float(ref.train_step(dict(batches[i % 2]))[1]["loss"].detach()) for i in range(9)]
+    ref.close()
+
+    a = T.Trainer(opts(True), device=DEV, seed=5)
+    a.set_train()
+    got = [float(a.train_step(dict(batches[i % 2]))[1]["loss"].detach()) for i in range(5)]
+    assert a._graph is not None
+    b = T.Trainer(opts(False), device=DEV, seed=77)          # registers ITS weights in the shared registry
+    b.set_train()
+    for i in range(2):
+        b.train_step(dict(batches[i % 2]))                   # new variants -> the descriptor table is rebuilt
+        got.append(float(a.train_step(dict(batches[(5 + i) % 2]))[1]["loss"].detach()))
+    b.close()
+    del b
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(64)]      # whatever was freed gets reused
+    got += [float(a.train_step(dict(batches[(7 + i) % 2]))[1]["loss"].detach()) for i in range(2)]
+    del junk
+    a.close()
+    assert np.allclose(want, got, rtol=5e-4), (want, got)
+
+
+def test_hip_graph_with_two_batch_shapes():
+    """A new input shape inside graph mode: its first steps run eagerly (new kernel variants, workspace sizes and weight-cache
+    variants may allocate and synchronise -- illegal inside a capture), then it gets its own graph; going back to the first
+    shape replays that shape's graph.  Losses follow an eager trainer fed the same sequence of batches."""
+    import trainer as T
+    from depthcore.synthetic import synthetic_batch
+    dev = torch.device(DEV)
+    small = [synthetic_batch(2, 64, 128, dev, seed=s) for s in (2, 3)]
+    wide = [synthetic_batch(1, 64, 256, dev, seed=s) for s in (4, 5)]
+    seq = [small[0], small[1], small[0], small[1], small[0], wide[0], wide[1], wide[0], wide[1], wide[0], small[1], wide[1],
+           small[0]]
+
+    def run(graph):
+        tr = T.Trainer(T.default_options(height=64, width=128, batch_size=2, hip_graph=graph), device=DEV, seed=9)
+        tr.set_train()
+        # the geometry modules are built per (batch, height, width): give the second shape its own
+        out = []
+        for b in seq:
+            B, _, H, W = b[("color", 0, 0)].shape
+            tr.opt.batch_size, tr.opt.height, tr.opt.width = B, H, W
+            tr.loss_batch = B
+            out.append(float(tr.train_step(dict(b))[1]["loss"].detach()))
+        n = len(tr._graphs)
+        tr.close()
+        return out, n
+
+    le, ne = run(False)
+    lg, ng = run(True)
+    assert ne == 0 and ng == 2
+    assert np.allclose(le, lg, rtol=1e-3), (le, lg)
+
+
+def test_gru_hidden_state_freeze_schedule():
+    """trainer_gru.py:295-307: when epoch + 1 == h_s_epoch the learned initial states stop receiving gradients (and stop
+    moving: Adam skips parameters without a gradient); the rest of the model keeps training."""
+    import trainer as T
+    from depthcore.synthetic import synthetic_sequence_batch
+    tr = T.Trainer(T.default_options(height=64, width=128, batch_size=1, gru="v5", len_sequence=3, h_s_epoch=2), device=DEV, seed=4)
+    tr.set_train()
+    batch = synthetic_sequence_batch(3, 64, 128, torch.device(DEV), seed=1)
+    h0 = [c.h0_layer1 for c in tr.models["gru"].cells()]
+    tr.start_epoch(0)
+    tr.train_step(dict(batch))
+    assert all(p.requires_grad and p.grad is not None and float(p.grad.abs().sum()) > 0 for p in h0)
+    before = [p.detach().clone() for p in h0]
+    w_before = tr.models["gru"].cgru_0.cgru_1.conv_gates.weight.detach().clone()
+    tr.start_epoch(1)                                     # (1 + 1) == h_s_epoch
+    assert not any(p.requires_grad for p in h0)
+    tr.train_step(dict(batch))
+    assert all(p.grad is None for p in h0)
+    assert all(torch.equal(a, b) for a, b in zip(before, h0))
+    assert not torch.equal(w_before, tr.models["gru"].cgru_0.cgru_1.conv_gates.weight)
+    tr.close()
+
+
+def test_c3_full_train_step_properties(monkeypatch):
+    """BASELINE configs[2] per rank (resnet50, 320x1024, B=8): one whole training step -- finite, no framework convolution
+    entered, and bitwise reproducible from the same state (all reductions are fixed-order)."""
+    import torch.nn.functional as F
+    import trainer as T
+    from depthcore.synthetic import synthetic_batch
+    calls = []
+    orig = F.conv2d
+    monkeypatch.setattr(torch.nn.functional, "conv2d", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    real = torch.nn.Conv2d.forward
+    monkeypatch.setattr(torch.nn.Conv2d, "forward", lambda self, x: (calls.append(self), real(self, x))[1])
+    batch = synthetic_batch(8, 320, 1024, torch.device(DEV), seed=3)
+    res = []
+    for _ in range(2):
+        tr = T.Trainer(T.default_options(height=320, width=1024, batch_size=8, num_layers=50), device=DEV, seed=6)
+        tr.set_train()
+        _, losses = tr.train_step(dict(batch))
+        g = torch.cat([p.grad.flatten() for p in tr.parameters_to_train if p.grad is not None])
+        res.append((float(losses["loss"].detach()), g.clone(), tr.models["encoder"].encoder.layer3[5].conv3.weight.detach().clone()))
+        tr.close()
+        del tr
+        torch.cuda.empty_cache()
+    assert calls == [], "library convolution entered for %r" % calls[:3]
+    assert np.isfinite(res[0][0]) and bool(torch.isfinite(res[0][1]).all())
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
