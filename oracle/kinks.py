@@ -31,11 +31,12 @@ class ForcedKinks(Kinks):
     ("maxpool", code) with code[n,c,oy,ox] = ky * 3 + kx of the selected window entry (dc_maxpool3x3s2_fwd).
     `batch`: slice of the recorded batch this evaluation covers (the HIP path stacks independent sub-batches)."""
 
-    def __init__(self, entries, batch=None):
+    def __init__(self, entries, batch=None, keep_pre=False):
         self.entries = list(entries)
         self.batch = batch if batch is not None else slice(None)
         self.cursor = 0
         self.disagree = []       # (kind, index, number of differing decisions, max |margin| / rms of the tensor)
+        self.pre = {} if keep_pre else None      # entry index -> the tensor the decision was taken on (detached)
 
     def _next(self, kind):
         assert self.cursor < len(self.entries), "kink tape exhausted: the oracle makes more %s decisions than were recorded" % kind
@@ -52,6 +53,8 @@ class ForcedKinks(Kinks):
         assert y.shape == x.shape, (tuple(y.shape), tuple(x.shape))
         mask = y > 0
         xd = x.detach()
+        if self.pre is not None:
+            self.pre[self.cursor - 1] = xd
         diff = (xd > 0) != mask
         n = int(diff.sum())
         if n:
@@ -63,6 +66,8 @@ class ForcedKinks(Kinks):
         code = self._next("maxpool").long()
         N, C, H, W = x.shape
         Ho, Wo = code.shape[2], code.shape[3]
+        if self.pre is not None:
+            self.pre[self.cursor - 1] = x.detach()
         oy = torch.arange(Ho).view(1, 1, Ho, 1)
         ox = torch.arange(Wo).view(1, 1, 1, Wo)
         iy, ix = oy * 2 - 1 + code // 3, ox * 2 - 1 + code % 3
@@ -77,3 +82,19 @@ class ForcedKinks(Kinks):
             gap = (ref.reshape(N, C, Ho * Wo) - out.detach().reshape(N, C, Ho * Wo))[diff].abs().max()
             self.disagree.append(("maxpool", self.cursor - 1, n, float(gap) / max(rms, 1e-30)))
         return out
+
+
+def uncalibrated_disagreements(kn64, kn32, factor=4.0, floor=1e-6):
+    """The disagreements of `kn64` (ForcedKinks of an fp64 evaluation, keep_pre=True) that are NOT explained by fp32
+    rounding: a recorded fp32 decision may differ from the fp64 one at an element only if the fp64 value there is within the
+    recorded path's own rounding error of zero.  That error is calibrated per tensor by the oracle itself: `kn32` is the same
+    evaluation in fp32, and the margin allowed is `factor` x its largest deviation from fp64 on that tensor (+ `floor`),
+    both relative to the tensor's rms."""
+    bad = []
+    for kind, idx, n, margin in kn64.disagree:
+        a, b = kn64.pre[idx].double(), kn32.pre[idx].double()
+        rms = float(a.pow(2).mean().sqrt())
+        e32 = float((a - b).abs().max()) / max(rms, 1e-30)
+        if margin > factor * e32 + floor:
+            bad.append((kind, idx, n, margin, e32))
+    return bad

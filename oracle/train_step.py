@@ -42,7 +42,7 @@ class CpuTrainer:
             if not kinks or name not in kinks:
                 return None
             n = kinks[name][0][1].shape[0] // parts
-            k = ForcedKinks(kinks[name], None if part is None else slice(part * n, (part + 1) * n))
+            k = ForcedKinks(kinks[name], None if part is None else slice(part * n, (part + 1) * n), keep_pre=True)
             used.append((name, k))
             return k
         enc_k = forced("encoder")
@@ -75,6 +75,7 @@ class CpuTrainer:
         for _, k in used:
             k.done()
         self.kink_report = [(name,) + d for name, k in used for d in k.disagree]
+        self.kink_objs = used
         return outputs, losses
 
     def train_step(self, inputs, noise):

@@ -63,7 +63,10 @@ def test_bucketed_exchange_over_rccl_with_stream_overlap(front):
                               ((k + "." + n_, p_) for n_, p_ in m.named_parameters()) if p.grad is not None})
                 grads[-1]["__loss__"] = float(losses["loss"].detach())
             assert grads[0]["__loss__"] == grads[1]["__loss__"]
-            assert set(grads[0]) == set(grads[1])
+            # a parameter without a gradient (Fusion_v3's unused last `upscale`) stays None on one GPU and contributes zeros to
+            # the exchange (depthcore/ddp.py, same as torch's DistributedDataParallel)
+            extra = set(grads[1]) - set(grads[0])
+            assert set(grads[0]) <= set(grads[1]) and all("fusion_block_4.upscale" in n and not grads[1][n].any() for n in extra), extra
             for n in grads[0]:
                 if n == "__loss__":
                     continue

@@ -13,8 +13,11 @@ the recorded window position).  Both sides then evaluate the same smooth functio
     other layers) must meet the calibrated bound on EVERY input: at most 4x as far from fp64 as torch's own fp32 evaluation
     of the same function (training-mode BatchNorm on small maps amplifies rounding -- a fixed number would be loose for the
     stem or flaky for layer4), floor 5e-5;
-  * wherever the imposed decision differs from the oracle's own, the pre-activation (or the gap between the two window
-    entries) must be at rounding level -- i.e. the HIP path only ever "disagrees" on genuine near-ties.  The count is printed.
+  * wherever the imposed decision differs from the fp64 oracle's own, the fp64 pre-activation (or the gap between the two
+    window entries) must be at rounding level -- i.e. the HIP path only ever "disagrees" on genuine near-ties.  "Rounding
+    level" is calibrated per tensor the same way: at most 4x the largest deviation of the oracle's own fp32 evaluation from
+    fp64 on that tensor (BatchNorm over the 32 elements of a 2x4 layer4 map at batch 4 amplifies rounding to ~1e-4 of the
+    tensor's rms in resnet50; the stem sits at 1e-7).  The count is printed.
 
 The input image itself never needs a gradient on this path (the stem's kernels have none, see dc_convs2_dgrad)."""
 import pytest
@@ -24,7 +27,6 @@ from helpers import rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-NEAR_TIE = 2e-5        # |pre-activation| / rms of its tensor where an imposed decision may differ from the fp64 one
 
 
 def _oracle(state, x, cots, num_layers, groups, dtype, tape):
@@ -34,7 +36,7 @@ def _oracle(state, x, cots, num_layers, groups, dtype, tape):
               (v.to(dtype) if v.is_floating_point() else v)) for k, v in state.items()}
     xr = x.to(dtype)
     n = x.shape[0] // groups
-    kn = [ForcedKinks(tape, slice(g * n, (g + 1) * n)) for g in range(groups)]
+    kn = [ForcedKinks(tape, slice(g * n, (g + 1) * n), keep_pre=True) for g in range(groups)]
     parts = [resnet_encoder_forward(st, xr[g * n:(g + 1) * n], num_layers, training=True, kinks=kn[g]) for g in range(groups)]
     for k in kn:
         k.done()
@@ -42,7 +44,7 @@ def _oracle(state, x, cots, num_layers, groups, dtype, tape):
     loss = sum((f * c.to(dtype)).sum() for f, c in zip(feats, cots))
     names = [k for k, v in st.items() if v.requires_grad and ".fc." not in k]
     grads = torch.autograd.grad(loss, [st[k] for k in names])
-    return feats, dict(zip(names, grads)), [d for k in kn for d in k.disagree]
+    return feats, dict(zip(names, grads)), kn
 
 
 @pytest.mark.parametrize("num_layers,groups,nimg,B,H,W", [
@@ -77,15 +79,18 @@ def _one_input(num_layers, groups, nimg, B, H, W, seed):
     params = {"encoder." + n: p for n, p in enc.encoder.named_parameters() if not n.startswith("fc.")}
     gh_p = dict(zip(params.keys(), torch.autograd.grad(loss, list(params.values()))))
 
-    f64, g64, dis64 = _oracle(state, x, cots, num_layers, groups, torch.float64, tape.entries)
-    f32, g32, _ = _oracle(state, x, cots, num_layers, groups, torch.float32, tape.entries)
+    from oracle.kinks import uncalibrated_disagreements
+    f64, g64, kn64 = _oracle(state, x, cots, num_layers, groups, torch.float64, tape.entries)
+    f32, g32, kn32 = _oracle(state, x, cots, num_layers, groups, torch.float32, tape.entries)
+    dis64 = [d for k in kn64 for d in k.disagree]
 
     # (1) the recorded decisions are legitimate: they differ from the fp64 decisions only on near-ties
     nrelu = sum(1 for k, _ in tape.entries if k == "relu")
     assert nrelu == {18: 17, 34: 33, 50: 49, 101: 100}[num_layers] and sum(1 for k, _ in tape.entries if k == "maxpool") == 1
     flips = sum(d[2] for d in dis64)
     worst_margin = max([d[3] for d in dis64] or [0.0])
-    assert worst_margin < NEAR_TIE, ("a HIP ReLU / max-pool decision differs from fp64 away from a tie", dis64)
+    far = [d for a, b in zip(kn64, kn32) for d in uncalibrated_disagreements(a, b)]
+    assert not far, ("a HIP ReLU / max-pool decision differs from fp64 away from a tie (kind, entry, count, margin, fp32 error)", far)
 
     # (2) with the decisions imposed, everything meets the calibrated bound -- no exceptions
     def bound(e32):

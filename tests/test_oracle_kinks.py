@@ -87,7 +87,21 @@ def test_fp32_decisions_differ_from_fp64_only_on_near_ties():
     rec = Recorder()
     resnet_encoder_forward(st, x, 18, kinks=rec)
     st64 = {k: (v.double() if v.is_floating_point() else v) for k, v in st.items()}
-    fk = ForcedKinks(rec.entries)
+    from oracle.kinks import uncalibrated_disagreements
+    fk = ForcedKinks(rec.entries, keep_pre=True)
     resnet_encoder_forward(st64, x.double(), 18, kinks=fk)
     fk.done()
-    assert max([d[3] for d in fk.disagree] or [0.0]) < 2e-5, fk.disagree
+    fk32 = ForcedKinks(rec.entries, keep_pre=True)
+    resnet_encoder_forward(st, x, 18, kinks=fk32)
+    assert not uncalibrated_disagreements(fk, fk32), fk.disagree
+    # a decision flipped away from a tie is caught
+    big = rec.entries[5][1].clone()
+    pos = (big > big.mean() + big.std()).nonzero()[0]
+    big[tuple(pos)] = 0.0
+    tampered = list(rec.entries)
+    tampered[5] = ("relu", big)
+    fk = ForcedKinks(tampered, keep_pre=True)
+    resnet_encoder_forward(st64, x.double(), 18, kinks=fk)
+    fk32 = ForcedKinks(tampered, keep_pre=True)
+    resnet_encoder_forward(st, x, 18, kinks=fk32)
+    assert uncalibrated_disagreements(fk, fk32)

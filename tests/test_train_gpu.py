@@ -111,11 +111,15 @@ def test_all_parameter_gradients_vs_oracle(fusion):
         _, ol = ct.process_batch(inp, [n.to(dtype) for n in noise], kinks=tapes)
         ol["loss"].backward()
         return float(ol["loss"].detach()), _grads_by_model({(k, n): t.grad for k, sd in ct.state.items() for n, t in sd.items()
-                                                            if t.requires_grad and t.grad is not None}), ct.kink_report
-    l64, g64, rep64 = oracle(torch.float64)
-    l32, g32, _ = oracle(torch.float32)
-    # the imposed decisions differ from the fp64 oracle's own only on near-ties (|pre-activation| at rounding level)
-    assert max([d[4] for d in rep64] or [0.0]) < 2e-5, rep64
+                                                            if t.requires_grad and t.grad is not None}), ct
+    l64, g64, ct64 = oracle(torch.float64)
+    l32, g32, ct32 = oracle(torch.float32)
+    rep64 = ct64.kink_report
+    # the imposed decisions differ from the fp64 oracle's own only on near-ties: |pre-activation| within 4x the fp32 oracle's
+    # own rounding error on that tensor (tests/test_encoder_gpu.py)
+    from oracle.kinks import uncalibrated_disagreements
+    far = [(na,) + d for (na, a), (nb, b) in zip(ct64.kink_objs, ct32.kink_objs) for d in uncalibrated_disagreements(a, b)]
+    assert not far, far
     assert abs(float(gl["loss"].detach()) - l64) <= (1e-3 if fusion == "v3" else 1e-4) * abs(l64)
     assert set(gh) == set(g64)
     report = {}
@@ -312,15 +316,21 @@ def test_trainer_ablations_golden(golden, tag):
         report.append((i, e_hip, e_32))
         assert e_hip <= 3.0 * e_32 + 2e-4, report
     print("ablation %s gradients (leaf, |hip-f64|/|f64|, |f32-f64|/|f64|):" % tag, report)
-    # ... and against the reference's own fp32 numbers (they carry the same conditioning error, hence the looser figures)
+    # ... and against the reference's own fp32 numbers.  Those carry the same conditioning error (the reference's fp32
+    # disparity gradient at scale 1 of `pmask` is itself 4 % away from fp64), so each bound is twice the fixture's own
+    # distance from the fp64 oracle (+ 1e-3): a check that fixture, oracle and kernels solve the same problem.
+    def vs_fixture(i, name):
+        want = g[tag + name]
+        allowed = 2.0 * rel_l2(want, g64[i]) + 1e-3
+        assert rel_l2(grads[i], want) <= allowed, (name, rel_l2(grads[i], want), allowed)
     for s in range(4):
         close(losses["loss/%d" % s], g[tag + "_loss%d" % s], rtol=1e-3, atol=0)
-        assert rel_l2(grads[s], g[tag + "_gdisp%d" % s]) < 3e-2, (s, rel_l2(grads[s], g[tag + "_gdisp%d" % s]))
-        if masks:    # the mask gradient follows the per-pixel argmin over the two frames: near-ties flip between implementations
-            assert rel_l2(grads[8 + s], g[tag + "_gmask%d" % s]) < 2e-2
+        vs_fixture(s, "_gdisp%d" % s)
+        if masks:
+            vs_fixture(8 + s, "_gmask%d" % s)
     for j, f in enumerate((-1, 1)):
-        assert rel_l2(grads[4 + j], g[tag + "_gaa_%d" % f]) < 3e-2
-        assert rel_l2(grads[6 + j], g[tag + "_gtr_%d" % f]) < 3e-2
+        vs_fixture(4 + j, "_gaa_%d" % f)
+        vs_fixture(6 + j, "_gtr_%d" % f)
 
 
 def test_fusion_v3_training_steps():
