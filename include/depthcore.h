@@ -350,6 +350,19 @@ int dc_gru_residual_fwd(const float* f, const float* H, float* out, int n, size_
 int dc_gru_residual_bwd(const float* g, float* d_H, int n, size_t M, void* stream);
 
 /* ------------------------------------------------------------------ transformed-weight cache of the Winograd kernels */
+/* ------------------------------------------------------------------ reduced-precision networks (BASELINE configs[4]) */
+/* "Networks in reduced precision, loss in fp32" (trainer_fusion_v3.py:311-330 under mixed precision; the reference itself
+ * has no autocast -- this is the build's statement of that configuration).  Tensors stay fp32 in HBM (activations, master
+ * weights, gradients, BatchNorm statistics, the whole photometric chain); with DC_PREC_BF16 in effect a convolution entry
+ * point (dc_conv3x3_*, dc_wino3x3_*, dc_convs2_* 3x3, dc_conv1x1_*) rounds its two matrix operands to bf16 (round to nearest
+ * even) on the way into LDS and accumulates in fp32 on v_mfma_f32_16x16x32_bf16.  bf16 keeps fp32's exponent range: no loss
+ * scaling.  Shapes outside the bf16 kernels' 16-byte staging (W % 16 != 0, single-channel heads, the 7x7 stem) keep their
+ * fp32 kernels.  The setting is PER CALLING THREAD (autograd's backward thread sets its own); returns the previous value,
+ * or DC_EINVAL. */
+enum { DC_PREC_F32 = 0, DC_PREC_BF16 = 1 };
+int dc_set_matrix_precision(int precision);
+int dc_get_matrix_precision(void);
+
 /* Every stride-1 3x3 convolution on the Winograd kernels (dc_wino3x3_fwd / _dgrad and the Winograd branch of
  * dc_conv3x3_fwd / _bwd) starts by transforming its filter (U = G g G^T; the data gradient uses the rotated, transposed
  * filter): one small launch in front of every convolution, although the weights only change in the optimiser step.

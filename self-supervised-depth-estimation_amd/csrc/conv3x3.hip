@@ -14,6 +14,7 @@
 // Exact fp32: v_mfma_f32_16x16x4_f32 (k-ordered fmaf chain), so parity with the fp32 reference holds to
 // summation order.
 #include "dc_common.h"
+#include "conv_bf16.h"
 #include "dispconv.h"
 #include "wino.h"
 
@@ -843,6 +844,17 @@ static inline bool wino_dw(int C0, int C1, int B, int Co, int H, int W, int act)
            wino_fits(B, C0, C1, Co, H, W);
 }
 
+int conv_wreduce(const float* part, const float* pbias, float* dw, float* db, int split, int nW, int Co, hipStream_t st) {
+    hipLaunchKernelGGL(conv_wreduce_kernel, dim3(ceil_div(nW + Co, 16)), dim3(256), 0, st, part, pbias, dw, db, split, nW, Co);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+// bf16 matrix-core kernels (conv_bf16.hip) instead of the fp32 ones: thread precision + shapes of their 16-byte staging
+static inline bool bf16_path(int C0, int C1, int up0, int H, int W) {
+    return matrix_precision() == DC_PREC_BF16 && c3b_eligible(C0, C1, up0, H, W, 1);
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -850,7 +862,7 @@ using namespace dc;
 
 extern "C" size_t dc_conv3x3_fwd_workspace(int C0, int C1, int B, int Co, int H, int W) {
     if (C0 < 0 || C1 < 0 || C0 + C1 <= 0 || Co <= 0 || B <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t direct = al256((size_t)9 * (C0 + C1) * Co * sizeof(float));
+    const size_t direct = std::max(al256((size_t)9 * (C0 + C1) * Co * sizeof(float)), c3b_weights_bytes(C0 + C1, Co));
     return wino_fwd(C0, C1, B, Co, H, W) ? std::max(direct, wino_conv_ws_bytes(B, C0 + C1, Co, H, W)) : direct;
 }
 
@@ -865,6 +877,9 @@ extern "C" int dc_conv3x3_fwd(const float* x0, int C0, int up0, const float* x1,
     // single-channel heads: plain-FMA kernels (dispconv.hip)
     if (wino_enabled() && dispconv_eligible(C0, C1, up0 ? 1 : 0, Co, H, W))
         return dispconv_fwd(x0, weight, bias, y, B, C0, H, W, act, pad_mode, ST);
+    // reduced-precision policy: direct implicit GEMM on the bf16 matrix cores (conv_bf16.hip)
+    if (bf16_path(C0, C1, up0 ? 1 : 0, H, W))
+        return c3b_conv(x0, C0, up0 ? 1 : 0, x1, C1, weight, Co, Cin, 0, 0, bias, y, ws, B, H, W, act, pad_mode, 1, ST);
     // even widths: fused Winograd F(2x2,3x3) (wino.hip); otherwise the direct implicit GEMM below
     if (wino_fwd(C0, C1, B, Co, H, W))
         return wino_conv_fused_fwd(x0, C0, up0 ? 1 : 0, x1, C1, weight, bias, y, ws, B, Co, H, W, act, pad_mode, ST);
@@ -896,9 +911,9 @@ extern "C" size_t dc_conv3x3_bwd_workspace(int C0, int C1, int B, int Co, int H,
     if (C0 <= 0 || C1 < 0 || B <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;
     const int Cin = C0 + C1;
     const size_t nW = (size_t)Co * Cin * 9;
-    const int split = pick_split(B, H, W, Co, Cin);
-    const size_t direct = al256(nW * 4) + al256((size_t)B * Cin * (H + 2) * (W + 2) * 4) + al256((size_t)split * nW * 4) +
-                          al256((size_t)split * Co * 4) + al256((size_t)B * Co * H * W * 4);
+    const int split = std::max(pick_split(B, H, W, Co, Cin), c3b_wgrad_split(B, H, W, Co, Cin, 1));
+    const size_t direct = std::max(al256(nW * 4), c3b_weights_bytes(Cin, Co)) + al256((size_t)B * Cin * (H + 2) * (W + 2) * 4) +
+                          al256((size_t)split * nW * 4) + al256((size_t)std::max(split, DB_SPLIT) * Co * 4) + al256((size_t)B * Co * H * W * 4);
     // the Winograd passes keep their scratch behind the direct layout (dxpad and g' are shared)
     size_t extra = 0;
     if (wino_dx(C0, C1, B, Co, H, W, ACT_NONE)) extra += al256(wino_conv_ws_bytes(B, Cin, Co, H, W));
@@ -916,14 +931,16 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     const int Cin = C0 + C1;
     const size_t nW = (size_t)Co * Cin * 9;
     const int split = pick_split(B, H, W, Co, Cin);
+    const int split_ws = std::max(split, c3b_wgrad_split(B, H, W, Co, Cin, 1));      // (the layout of dc_conv3x3_bwd_workspace)
     char* p = (char*)ws;
-    float* wd = (float*)p; p += al256(nW * 4);
+    float* wd = (float*)p; p += std::max(al256(nW * 4), c3b_weights_bytes(Cin, Co));
     float* dxpad = (float*)p; p += al256((size_t)B * Cin * (H + 2) * (W + 2) * 4);
-    float* part = (float*)p; p += al256((size_t)split * nW * 4);
-    float* pbias = (float*)p; p += al256((size_t)split * Co * 4);
+    float* part = (float*)p; p += al256((size_t)split_ws * nW * 4);
+    float* pbias = (float*)p; p += al256((size_t)std::max(split_ws, DB_SPLIT) * Co * 4);
     float* gpbuf = (float*)p; p += al256((size_t)B * Co * H * W * 4);
-    const bool w_dx = (dx0 || dx1) && wino_dx(C0, C1, B, Co, H, W, act);
-    const bool w_dw = dweight && wino_dw(C0, C1, B, Co, H, W, act);
+    const bool b16 = bf16_path(C0, C1, up0 ? 1 : 0, H, W) && wino_gp_ok(B, Co, H, W, act);
+    const bool w_dx = !b16 && (dx0 || dx1) && wino_dx(C0, C1, B, Co, H, W, act);
+    const bool w_dw = !b16 && dweight && wino_dw(C0, C1, B, Co, H, W, act);
     void* wws = p; if (wino_dx(C0, C1, B, Co, H, W, ACT_NONE)) p += al256(wino_conv_ws_bytes(B, Cin, Co, H, W));
     void* gws = p; if (wino_dw(C0, C1, B, Co, H, W, ACT_NONE)) p += al256(wino_wgrad_ws_bytes(B, Cin, Co, H, W));
     float* pb2 = (float*)p;
@@ -931,7 +948,7 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     // fast path (v2 kernels): full 16-wide tiles, 16-byte aligned rows, chunks that do not straddle the concat
     const bool fast = (W % 16 == 0) && (C1 == 0 || C0 % CK == 0) && (C1 == 0 || C0 % CW == 0);
     const float* gp = gy;
-    if ((fast || w_dx || w_dw) && act != ACT_NONE && ((size_t)B * Co * H * W) % 4 == 0) {
+    if ((fast || w_dx || w_dw || b16) && act != ACT_NONE && ((size_t)B * Co * H * W) % 4 == 0) {
         const size_t n4 = (size_t)B * Co * H * W / 4;
         hipLaunchKernelGGL(conv_gprime_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, ST, gy, y,
                            gpbuf, n4, act);
@@ -942,6 +959,20 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
         // thin single-channel head: folded-window data gradient, no padded scratch / fold pass (dispconv.hip)
         const int rc = dispconv_dx(weight, y, gy, dx0, B, C0, H, W, act, pad_mode, ST);
         if (rc != DC_OK) return rc;
+    } else if (b16 && (dx0 || dx1)) {
+        // bf16 matrix cores: a zero-padded single-source block gets its data gradient directly (convolution of g' with the
+        // rotated, transposed filter); reflection / upsample / concat go through the padded domain and the fold below
+        if (pad_mode == PAD_ZERO && !up0 && C1 == 0) {
+            const int rc = c3b_conv(gp, Co, 0, nullptr, 0, weight, Co, Cin, 1, 0, nullptr, dx0, wd, B, H, W, ACT_NONE, PAD_ZERO, 1, ST);
+            if (rc != DC_OK) return rc;
+        } else {
+            const int rc = c3b_conv(gp, Co, 0, nullptr, 0, weight, Co, Cin, 1, 1, nullptr, dxpad, wd, B, H, W, ACT_NONE, PAD_ZERO, 1, ST);
+            if (rc != DC_OK) return rc;
+            const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
+            hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0, C1,
+                               up0 ? 1 : 0, H, W, pad_mode);
+            DC_CHECK_LAUNCH();
+        }
     } else if (w_dx) {
         // full correlation of g' with the rotated weights in the Winograd domain, then the same fold as below
         const int rc = wino_conv_full_dgrad(gp, weight, dxpad, wws, B, Cin, Co, H, W, ST);
@@ -975,7 +1006,21 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
                            C1, up0 ? 1 : 0, H, W, pad_mode);
         DC_CHECK_LAUNCH();
     }
-    if (w_dw) {
+    if (b16 && (dweight || dbias)) {
+        if (dweight) {
+            const int sp = c3b_wgrad_split(B, H, W, Co, Cin, 1);
+            int rc = c3b_wgrad(x0, C0, up0 ? 1 : 0, x1, C1, gp, part, sp, B, Co, H, W, pad_mode, 1, ST);
+            if (rc != DC_OK) return rc;
+            rc = conv_wreduce(part, nullptr, dweight, nullptr, sp, (int)nW, 0, ST);
+            if (rc != DC_OK) return rc;
+        }
+        if (dbias) {
+            hipLaunchKernelGGL(conv_dbias_kernel, dim3(Co, DB_SPLIT), dim3(256), 0, ST, gp, pbias, B, Co, H * W);
+            DC_CHECK_LAUNCH();
+            const int rc = conv_wreduce(nullptr, pbias, nullptr, dbias, DB_SPLIT, 0, Co, ST);
+            if (rc != DC_OK) return rc;
+        }
+    } else if (w_dw) {
         const int rc = wino_wgrad_fused(x0, C0, up0 ? 1 : 0, x1, C1, pad_mode, gp, dweight, gws, B, Co, H, W, ST);
         if (rc != DC_OK) return rc;
         if (dbias) {

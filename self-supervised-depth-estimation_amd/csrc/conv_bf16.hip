@@ -1,0 +1,495 @@
+// 3x3 convolutions on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulate) for gfx950 -- the
+// "reduced-precision networks, fp32 loss" policy of BASELINE configs[4] (trainer_fusion_v3.py:311-330 run under mixed
+// precision; networks/resnet_encoder.py:87-98, networks/depth_decoder.py:50-67, layers.py:106-136).
+//
+// Policy: tensors stay fp32 in HBM (activations, master weights, gradients, BatchNorm statistics); a convolution rounds its
+// two matrix operands to bf16 on the way into LDS and accumulates in fp32.  bf16 keeps fp32's exponent, so the backward
+// needs no loss scaling (an fp16 policy would).
+//
+// At 16x the fp32 matrix rate the multiplies are no longer what a 3x3 convolution costs, so these are DIRECT implicit GEMMs
+// (no Winograd transform, no row-combine epilogue): what bounds them is reading fp32 operands from HBM.
+//
+//   forward / data gradient (c3b_conv_kernel): M = output channels, N = pixels, K = 9 taps x input channels.
+//     A block owns a 16 x 16 (stride 2: 8 x 16) pixel tile x 16*MR output channels; per chunk of 32 input channels the
+//     input patch is staged ONCE as a channel-contiguous bf16 image [pixel][32 ch (+8 pad)] -- the fp32 -> bf16 rounding,
+//     the nearest-x2 upsample, the channel concat and the reflection / zero padding are all index arithmetic of the staging
+//     (16-byte global loads, channel pairs packed by v_cvt_pk_bf16_f32).  One MFMA consumes one tap of all 32 channels: the B
+//     operand of lane (pixel n, k-group kk) is ONE ds_read_b128 at pixel (y + ky, S*n + kx), channels 8kk..8kk+7; stride 2
+//     is the same read at a different pixel.  Weights are pre-packed once per call as [m-block][chunk][tap][k-group][m][8]
+//     bf16 (A operand = one ds_read_b128).  The next chunk's global loads are in flight during the MFMA phase.
+//     The decoder's data gradient runs over the padded output domain and is folded back by conv_fold_kernel (conv3x3.hip);
+//     zero-padded convolutions (the ResNet trunks) get it directly as a convolution with the rotated, transposed filter.
+//   weight gradient (c3b_wgrad_kernel): M = 64 output channels (one 16-row tile per wave), N = 32 input channels,
+//     K = pixels (32 per MFMA = two tile rows).  g' is staged pixel-contiguous (A operand: 8 consecutive pixels), the input
+//     patch in the same channel-contiguous image as above and read TRANSPOSED by ds_read_b64_tr_b16 (8 consecutive pixels of
+//     16 channels -> B operand); 9 accumulators per (wave, channel tile) = the 9 taps.  Split over pixel tiles into fp32
+//     slabs, summed in fixed order by conv_wreduce_kernel (deterministic, no atomics).
+#include "dc_common.h"
+#include "conv_bf16.h"
+
+#include <algorithm>
+
+namespace dc {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+typedef __attribute__((ext_vector_type(4))) short s4;
+typedef __attribute__((ext_vector_type(8))) short s8;
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+thread_local int g_matrix_prec = DC_PREC_F32;
+int matrix_precision() { return g_matrix_prec; }
+
+constexpr int BC = 32;        // reduction channels per chunk = the K of one v_mfma_f32_16x16x32_bf16
+constexpr int BPX = 40;       // bf16 per pixel of the LDS image: 32 channels + 8 (80-byte pixels spread the b128 reads over the banks)
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const bf2 p = {(__bf16)lo, (__bf16)hi};          // v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN)
+    return __builtin_bit_cast(unsigned, p);
+}
+
+__device__ __forceinline__ int pad_index_b(int i, int n, int pad, bool& ok) {
+    ok = true;
+    if (i >= 0 && i < n) return i;
+    if (pad == PAD_REFLECT) {
+        i = i < 0 ? -i : 2 * n - 2 - i;
+        return min(max(i, 0), n - 1);
+    }
+    ok = false;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights (Co,Cin,3,3) fp32 -> bf16 [m-block][chunk][tap][k-group 4][m MT][8]
+//   forward:        M = Co,  K = Cin, value = w[m][k][tap]
+//   data gradient:  M = Cin, K = Co,  value = w[k][m][8 - tap]      (rotated, transposed filter)
+// one thread per 16-byte item
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void c3b_wprep_kernel(const float* __restrict__ w, uint4* __restrict__ wb, int Co, int Cin, int dgrad,
+                                                        int MT, int nmblk, int nchunks) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nmblk * nchunks * 36 * MT) return;
+    const int m = idx % MT, cg = (idx / MT) & 3, tap = (idx / (4 * MT)) % 9;
+    const int chunk = (idx / (36 * MT)) % nchunks, mblk = idx / (36 * MT * nchunks);
+    const int M = dgrad ? Cin : Co, K = dgrad ? Co : Cin;
+    const int mm = mblk * MT + m;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = chunk * BC + cg * 8 + j;
+        float t = 0.f;
+        if (mm < M && k < K) t = dgrad ? w[((size_t)k * Cin + mm) * 9 + 8 - tap] : w[((size_t)mm * Cin + k) * 9 + tap];
+        v[j] = t;
+    }
+    wb[idx] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// staging of one 32-channel chunk of the input patch:  global fp32 (NCHW) -> registers -> LDS bf16 [pixel][BPX]
+//   S     convolution stride (1 | 2); the patch covers ((TH-1)*S + 3) x (15*S + 3) input pixels
+//   DPAD  the patch origin is the output tile origin - 2 and out-of-range pixels are zero (data gradient over the padded
+//         domain); otherwise origin - 1 with reflection / zero padding, fused upsample and concat
+// A thread item = (channel pair, patch row, aligned 4-column group) -> two 16-byte loads -> four packed dwords.
+// ------------------------------------------------------------------------------------------------
+struct PatchSrc {
+    const float* x0; int C0; int up0;
+    const float* x1; int C1;
+    int H, W, pad;          // full-resolution input maps
+};
+
+template <int S, int TH, bool DPAD, int NTHR = 256>
+struct PatchStager {
+    static constexpr int PH = (TH - 1) * S + 3, PW = 15 * S + 3;
+    static constexpr int OFF = DPAD ? 2 : 1;
+    static constexpr int NQ = 4 * S;                              // aligned quads per patch row
+    static constexpr int NE = (S == 1) ? 2 : 1;                   // edge columns per patch row
+    static constexpr int NIT = (16 * PH * NQ + NTHR - 1) / NTHR;
+    static constexpr int NEI = (16 * PH * NE + NTHR - 1) / NTHR;
+    static constexpr int LDS_ELEMS = PH * PW * BPX;               // bf16 elements of the image
+
+    float4 rv[NIT][2];
+    float re[NEI][2];
+
+    __device__ __forceinline__ static int edge_col(int e) { return S == 1 ? (DPAD ? e : e * (PW - 1)) : 0; }
+
+    __device__ __forceinline__ void prefetch(const PatchSrc& s, int k0, int b, int iy0, int ix0, int tid) {
+        // (iy0, ix0) = input coordinates of patch pixel (0, OFF): ix0 is a multiple of 16
+        const int K = s.C0 + s.C1;
+        const bool upmode = !DPAD && s.up0 && k0 < s.C0;          // this chunk lives in the half-resolution x0
+        const int quads = upmode ? NQ / 2 : NQ;
+        const int h0 = s.H >> s.up0, w0 = s.W >> s.up0;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int it = tid + i * NTHR;
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (it < 16 * PH * quads) {
+                const int q = it % quads, r = (it / quads) % PH, cp = it / (quads * PH);
+                const int ch = k0 + 2 * cp;
+                bool oky;
+                int yy = iy0 + r;
+                if (DPAD) oky = yy >= 0 && yy < s.H;
+                else yy = pad_index_b(yy, s.H, s.pad, oky);
+                const int xx = ix0 + 4 * q * (upmode ? 2 : 1);
+                if (oky && xx < s.W && ch < K) {
+                    const float* p;
+                    size_t plane;
+                    if (upmode) { p = s.x0 + (((size_t)b * s.C0 + ch) * h0 + (yy >> 1)) * w0 + (xx >> 1); plane = (size_t)h0 * w0; }
+                    else if (ch < s.C0) { p = s.x0 + (((size_t)b * s.C0 + ch) * h0 + yy) * w0 + xx; plane = (size_t)h0 * w0; }
+                    else { p = s.x1 + (((size_t)b * s.C1 + (ch - s.C0)) * s.H + yy) * s.W + xx; plane = (size_t)s.H * s.W; }
+                    v0 = *reinterpret_cast<const float4*>(p);
+                    if (ch + 1 < K) v1 = *reinterpret_cast<const float4*>(p + plane);
+                }
+            }
+            rv[i][0] = v0; rv[i][1] = v1;
+        }
+#pragma unroll
+        for (int i = 0; i < NEI; ++i) {
+            const int it = tid + i * NTHR;
+            float e0 = 0.f, e1 = 0.f;
+            if (it < 16 * PH * NE) {
+                const int e = it % NE, r = (it / NE) % PH, cp = it / (NE * PH);
+                const int ch = k0 + 2 * cp;
+                bool oky, okx;
+                int yy = iy0 + r;
+                int xx = ix0 - OFF + edge_col(e);
+                if (DPAD) { oky = yy >= 0 && yy < s.H; okx = xx >= 0 && xx < s.W; }
+                else { yy = pad_index_b(yy, s.H, s.pad, oky); xx = pad_index_b(xx, s.W, s.pad, okx); }
+                if (oky && okx && ch < K) {
+                    const float* p;
+                    size_t plane;
+                    if (ch < s.C0) { p = s.x0 + (((size_t)b * s.C0 + ch) * h0 + (yy >> s.up0)) * w0 + (xx >> s.up0); plane = (size_t)h0 * w0; }
+                    else { p = s.x1 + (((size_t)b * s.C1 + (ch - s.C0)) * s.H + yy) * s.W + xx; plane = (size_t)s.H * s.W; }
+                    e0 = p[0];
+                    if (ch + 1 < K) e1 = p[plane];
+                }
+            }
+            re[i][0] = e0; re[i][1] = e1;
+        }
+    }
+
+    __device__ __forceinline__ void commit(const PatchSrc& s, int k0, unsigned* img, int tid) const {
+        const bool upmode = !DPAD && s.up0 && k0 < s.C0;
+        const int quads = upmode ? NQ / 2 : NQ;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int it = tid + i * NTHR;
+            if (it < 16 * PH * quads) {
+                const int q = it % quads, r = (it / quads) % PH, cp = it / (quads * PH);
+                const float4 a = rv[i][0], c = rv[i][1];
+                const unsigned p0 = pack_bf16(a.x, c.x), p1 = pack_bf16(a.y, c.y), p2 = pack_bf16(a.z, c.z), p3 = pack_bf16(a.w, c.w);
+                unsigned* dst = img + (r * PW + OFF + (upmode ? 8 : 4) * q) * (BPX / 2) + cp;
+                if (upmode) {
+                    dst[0] = p0; dst[BPX / 2] = p0; dst[2 * (BPX / 2)] = p1; dst[3 * (BPX / 2)] = p1;
+                    dst[4 * (BPX / 2)] = p2; dst[5 * (BPX / 2)] = p2; dst[6 * (BPX / 2)] = p3; dst[7 * (BPX / 2)] = p3;
+                } else {
+                    dst[0] = p0; dst[BPX / 2] = p1; dst[2 * (BPX / 2)] = p2; dst[3 * (BPX / 2)] = p3;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NEI; ++i) {
+            const int it = tid + i * NTHR;
+            if (it < 16 * PH * NE) {
+                const int e = it % NE, r = (it / NE) % PH, cp = it / (NE * PH);
+                img[(r * PW + edge_col(e)) * (BPX / 2) + cp] = pack_bf16(re[i][0], re[i][1]);
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward / data gradient
+// ------------------------------------------------------------------------------------------------
+struct C3bArgs {
+    PatchSrc src;
+    const uint4* wb;        // prepared weights of this pass
+    const float* bias;
+    float* out;             // (B, M, OH, OW)
+    int B, M, K;            // M output channels, K = C0 + C1 reduction channels
+    int OH, OW;
+    int act;
+    int tiles_x, tiles_y, mblocks, nchunks;
+};
+
+template <int MR, int S, bool DPAD>
+__global__ __launch_bounds__(256, 2) void c3b_conv_kernel(C3bArgs a) {
+    constexpr int MT = 16 * MR;
+    constexpr int TH = S == 1 ? 16 : 8, RWV = TH / 4;
+    using Stager = PatchStager<S, TH, DPAD>;
+    constexpr int PW = Stager::PW;
+    constexpr int NWI = (36 * MT + 255) / 256;                    // 16-byte weight items per thread and chunk
+    __shared__ __attribute__((aligned(16))) unsigned img[Stager::LDS_ELEMS / 2];
+    __shared__ __attribute__((aligned(16))) uint4 wl[36 * MT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kk = lane >> 4;
+    // consecutive logical blocks (same tile, successive channel blocks) share an XCD: the patch is re-read from its L2
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int mblk = lb % a.mblocks;
+    const int rest = lb / a.mblocks;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int tile = rest % ntiles, b = rest / ntiles;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int m0 = mblk * MT;
+    const int iy0 = oy0 * S - Stager::OFF, ix0 = ox0 * S;
+
+    f4 acc[MR][RWV];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < RWV; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    Stager st;
+    uint4 rw[NWI];
+    const uint4* wsrc = a.wb + (size_t)mblk * a.nchunks * 36 * MT;
+    auto prefetch_w = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) {
+            const int it = tid + i * 256;
+            rw[i] = it < 36 * MT ? wsrc[(size_t)c * 36 * MT + it] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) {
+            const int it = tid + i * 256;
+            if (it < 36 * MT) wl[it] = rw[i];
+        }
+    };
+
+    st.prefetch(a.src, 0, b, iy0, ix0, tid);
+    prefetch_w(0);
+    const __bf16* pim = reinterpret_cast<const __bf16*>(img);
+    for (int c = 0; c < a.nchunks; ++c) {
+        __syncthreads();                       // the previous chunk's MFMAs are done with the LDS images
+        st.commit(a.src, c * BC, img, tid);
+        commit_w();
+        __syncthreads();
+        if (c + 1 < a.nchunks) {
+            st.prefetch(a.src, (c + 1) * BC, b, iy0, ix0, tid);
+            prefetch_w(c + 1);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+            bf8 af[MR], bfr[RWV];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) af[i] = __builtin_bit_cast(bf8, wl[(t * 4 + kk) * MT + i * 16 + n]);
+#pragma unroll
+            for (int j = 0; j < RWV; ++j)
+                bfr[j] = *reinterpret_cast<const bf8*>(pim + ((S * (wave * RWV + j) + ky) * PW + S * n + kx) * BPX + kk * 8);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < RWV; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: C/D layout col (pixel x) = lane & 15, row (m) = (lane >> 4) * 4 + reg
+    const int px = ox0 + n;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < RWV; ++j) {
+            const int py = oy0 + wave * RWV + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + kk * 4 + r;
+                if (m < a.M && py < a.OH && px < a.OW) {
+                    float v = acc[i][j][r];
+                    if (!DPAD) v = act_fwd(v + (a.bias ? a.bias[m] : 0.f), a.act);
+                    a.out[(((size_t)b * a.M + m) * a.OH + py) * a.OW + px] = v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dW[co][ci][t] = sum_{b,y,x} g'[b,co,y,x] * xpad[b,ci,S*y+ky-1,S*x+kx-1]
+// grid (split, ceil(Co/64), ceil(Cin/32)), 512 threads; a block walks its share of the pixel tiles; wave (cw, nt) owns output
+// channels 16cw..16cw+15 x input channels 16nt..16nt+15 of the block x 9 taps (9 accumulator tiles): no cross-wave sum.
+// ------------------------------------------------------------------------------------------------
+struct C3bWgArgs {
+    PatchSrc src;
+    const float* gp;        // g' = gy * act'(y): (B, Co, OH, OW)
+    float* part;            // [split][Co][Cin*9]
+    int B, Co, OH, OW;
+    int tiles_x, tiles_y, split;
+};
+
+template <int S>
+__global__ __launch_bounds__(512, 2) void c3b_wgrad_kernel(C3bWgArgs a) {
+    constexpr int TH = S == 1 ? 16 : 8;
+    using Stager = PatchStager<S, TH, false, 512>;
+    constexpr int PW = Stager::PW;
+    constexpr int GLS = TH * 16 + 8;                               // g' row stride in bf16 (528-byte rows: conflict-free b128 reads)
+    constexpr int NG = (64 * TH * 4) / 512;                        // float4 items of the g' tile per thread
+    __shared__ __attribute__((aligned(16))) unsigned img[Stager::LDS_ELEMS / 2];
+    __shared__ __attribute__((aligned(16))) unsigned gl[64 * GLS / 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cw = wave & 3, nt = wave >> 2;                       // wave = (16-row tile of output channels, 16-column tile of input channels)
+    const int n = lane & 15, kk = lane >> 4;
+    const int m0 = blockIdx.y * 64, c0 = blockIdx.z * BC;
+    const int Cin = a.src.C0 + a.src.C1;
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int ntiles = per_img * a.B;
+
+    f4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+
+    Stager st;
+    float4 rg[NG];
+    auto prefetch = [&](int tile) {
+        const int b = tile / per_img, tt = tile - b * per_img;
+        const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * 16;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int it = tid + i * 512;
+            const int q = it & 3, r = (it >> 2) % TH, m = it / (4 * TH);
+            const int co = m0 + m, yy = oy0 + r, xx = ox0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < a.Co && yy < a.OH && xx < a.OW) v = *reinterpret_cast<const float4*>(a.gp + (((size_t)b * a.Co + co) * a.OH + yy) * a.OW + xx);
+            rg[i] = v;
+        }
+        st.prefetch(a.src, c0, b, oy0 * S - 1, ox0 * S, tid);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int it = tid + i * 512;
+            const int q = it & 3, r = (it >> 2) % TH, m = it / (4 * TH);
+            const float4 v = rg[i];
+            *reinterpret_cast<uint2*>(gl + (m * GLS + r * 16 + 4 * q) / 2) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+        }
+        st.commit(a.src, c0, img, tid);
+    };
+
+    const __bf16* gim = reinterpret_cast<const __bf16*>(gl);
+    const short* xim = reinterpret_cast<const short*>(img);
+    // transposed read of the B operand: lane 4q+p of a 16-lane group supplies the address of pixel row q, channels 4p..4p+3
+    const int tq = n >> 2, tp = n & 3;
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += a.split) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (tile + a.split < ntiles) prefetch(tile + a.split);
+#pragma unroll 2
+        for (int s = 0; s < TH / 2; ++s) {
+            const int trow = 2 * s + (kk >> 1), tcol = 8 * (kk & 1);           // first of this lane's 8 output pixels
+            const bf8 af = *reinterpret_cast<const bf8*>(gim + (cw * 16 + n) * GLS + trow * 16 + tcol);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - ky * 3;
+                const int pix = (S * trow + ky) * PW + S * tcol + kx;          // patch pixel of output pixel 0 of the lane group
+                const short* base = xim + (pix + S * tq) * BPX + nt * 16 + 4 * tp;
+                const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base));
+                const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base + 4 * S * BPX));
+                const s8 bv = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf8, bv), acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- slab: part[split][co][ci*9 + t]; C/D layout col (ci) = lane & 15, row (co) = (lane >> 4) * 4 + reg
+    float* slab = a.part + (size_t)blockIdx.x * a.Co * Cin * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = m0 + cw * 16 + kk * 4 + r, ci = c0 + nt * 16 + n;
+            if (co < a.Co && ci < Cin) slab[((size_t)co * Cin + ci) * 9 + t] = acc[t][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static inline size_t al256b(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline int c3b_mr(int M) { return M > 32 ? 4 : (M > 16 ? 2 : 1); }
+
+bool c3b_eligible(int C0, int C1, int up0, int H, int W, int stride) {
+    // 16-byte staging: rows of 16 output pixels, chunks that do not straddle the concat, channel pairs inside one source
+    if (stride == 1) return W % 16 == 0 && H >= 2 && (C1 == 0 || C0 % BC == 0) && (!up0 || ((H | W) & 1) == 0);
+    return stride == 2 && W % 32 == 0 && H % 2 == 0 && C1 == 0 && !up0;
+}
+
+size_t c3b_weights_bytes(int Ci, int Co) {
+    // either pass: M padded to its 16*MR block, K to 32
+    const int a = ceil_div(Co, 16 * c3b_mr(Co)) * 16 * c3b_mr(Co), b = ceil_div(Ci, 16 * c3b_mr(Ci)) * 16 * c3b_mr(Ci);
+    const size_t fwd = (size_t)a * ceil_div(Ci, BC) * BC * 9 * 2, dg = (size_t)b * ceil_div(Co, BC) * BC * 9 * 2;
+    return al256b(std::max(fwd, dg));
+}
+
+int c3b_wgrad_split(int B, int OH, int OW, int Co, int Cin, int stride) {
+    const int TH = stride == 1 ? 16 : 8;
+    const int ntiles = ceil_div(OW, 16) * ceil_div(OH, TH) * B;
+    const int outer = ceil_div(Co, 64) * ceil_div(Cin, BC);
+    int split = std::max(1, std::min(ntiles, 1024 / std::max(outer, 1)));
+    split = std::min(split, std::max(1, ntiles / 2));
+    return std::min(split, 512);
+}
+
+// y / dxpad / dx = conv(cat(up2?(x0), x1), weight) on the bf16 matrix cores.
+//   dgrad = 0: forward (M = Co) with bias + activation;  dgrad = 1: rotated, transposed filter (M = Cin).
+//   dpad = 1: input = g' (B,K,H,W), output over the padded domain (H+2, W+2) (decoder data gradient; fold afterwards).
+int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight, int Co, int Cin, int dgrad, int dpad,
+             const float* bias, float* out, void* ws, int B, int H, int W, int act, int pad, int stride, hipStream_t st) {
+    const int M = dgrad ? Cin : Co, K = C0 + C1;
+    if (K != (dgrad ? Co : Cin)) return DC_EINVAL;
+    const int mr = c3b_mr(M), MT = 16 * mr;
+    const int mblocks = ceil_div(M, MT), nchunks = ceil_div(K, BC);
+    uint4* wb = (uint4*)ws;
+    const int nitems = mblocks * nchunks * 36 * MT;
+    hipLaunchKernelGGL(c3b_wprep_kernel, dim3(ceil_div(nitems, 256)), dim3(256), 0, st, weight, wb, Co, Cin, dgrad, MT, mblocks, nchunks);
+    DC_CHECK_LAUNCH();
+    C3bArgs a{};
+    a.src = PatchSrc{x0, C0, up0, x1, C1, H, W, pad};
+    a.wb = wb; a.bias = bias; a.out = out; a.B = B; a.M = M; a.K = K; a.act = act;
+    a.OH = dpad ? H + 2 : H / stride; a.OW = dpad ? W + 2 : W / stride;
+    const int TH = stride == 1 ? 16 : 8;
+    a.tiles_x = ceil_div(a.OW, 16); a.tiles_y = ceil_div(a.OH, TH); a.mblocks = mblocks; a.nchunks = nchunks;
+    const long nblk = (long)a.tiles_x * a.tiles_y * mblocks * B;
+    if (nblk > 0x7fffffffL) return DC_EINVAL;
+    const dim3 grid((unsigned)nblk);
+#define C3B_LAUNCH(MRV, SV, DP) hipLaunchKernelGGL((c3b_conv_kernel<MRV, SV, DP>), grid, dim3(256), 0, st, a)
+    if (stride == 2) {
+        if (dpad) return DC_EINVAL;
+        if (mr == 4) C3B_LAUNCH(4, 2, false); else if (mr == 2) C3B_LAUNCH(2, 2, false); else C3B_LAUNCH(1, 2, false);
+    } else if (dpad) {
+        if (mr == 4) C3B_LAUNCH(4, 1, true); else if (mr == 2) C3B_LAUNCH(2, 1, true); else C3B_LAUNCH(1, 1, true);
+    } else {
+        if (mr == 4) C3B_LAUNCH(4, 1, false); else if (mr == 2) C3B_LAUNCH(2, 1, false); else C3B_LAUNCH(1, 1, false);
+    }
+#undef C3B_LAUNCH
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+// part[split][Co][Cin*9] from x = cat(up2?(x0), x1) (B,Cin,H,W) and g' (B,Co,H/stride,W/stride); the caller reduces the slabs
+int c3b_wgrad(const float* x0, int C0, int up0, const float* x1, int C1, const float* gp, float* part, int split, int B, int Co, int H,
+              int W, int pad, int stride, hipStream_t st) {
+    C3bWgArgs a{};
+    a.src = PatchSrc{x0, C0, up0, x1, C1, H, W, pad};
+    a.gp = gp; a.part = part; a.B = B; a.Co = Co; a.OH = H / stride; a.OW = W / stride;
+    const int TH = stride == 1 ? 16 : 8;
+    a.tiles_x = ceil_div(a.OW, 16); a.tiles_y = ceil_div(a.OH, TH); a.split = split;
+    const dim3 grid(split, ceil_div(Co, 64), ceil_div(C0 + C1, BC));
+    if (stride == 1) hipLaunchKernelGGL((c3b_wgrad_kernel<1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((c3b_wgrad_kernel<2>), grid, dim3(512), 0, st, a);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+}  // namespace dc
+
+extern "C" int dc_set_matrix_precision(int precision) {
+    if (precision != DC_PREC_F32 && precision != DC_PREC_BF16) return DC_EINVAL;
+    const int prev = dc::g_matrix_prec;
+    dc::g_matrix_prec = precision;
+    return prev;
+}
+
+extern "C" int dc_get_matrix_precision(void) { return dc::g_matrix_prec; }

@@ -31,6 +31,7 @@
 // dgrad is the same kernel on the 180-degree-rotated, transposed weights (wino_weights_kernel<DGRAD>).
 // Requires even W (8-byte row alignment); H arbitrary.
 #include "dc_common.h"
+#include "conv_bf16.h"
 #include "wino.h"
 
 #include <algorithm>
@@ -612,6 +613,10 @@ int wino_conv_full_dgrad(const float* gp, const float* weight, float* dxpad, voi
 static int wino_run(const float* x, const float* w, float* y, void* ws, int B, int Ci, int Co, int H, int W, bool dgrad,
                     hipStream_t st) {
     if (!x || !w || !y || !ws || B <= 0 || Ci <= 0 || Co <= 0 || H < 1 || W < 2 || (W & 1)) return DC_EINVAL;
+    // reduced-precision policy: direct implicit GEMM on the bf16 matrix cores (conv_bf16.hip; the data gradient of a
+    // zero-padded convolution is the convolution with the rotated, transposed filter)
+    if (matrix_precision() == DC_PREC_BF16 && c3b_eligible(dgrad ? Co : Ci, 0, 0, H, W, 1))
+        return c3b_conv(x, dgrad ? Co : Ci, 0, nullptr, 0, w, Co, Ci, dgrad ? 1 : 0, 0, nullptr, y, ws, B, H, W, ACT_NONE, PAD_ZERO, 1, st);
     WinoLaunch d{};
     d.src0 = x; d.C0 = dgrad ? Co : Ci; d.weight = w; d.Co = Co; d.Ci = Ci; d.dgrad = dgrad; d.act = ACT_NONE; d.pad = PAD_ZERO;
     d.P = 1; d.out = y; d.ws = ws; d.B = B; d.H = H; d.W = W; d.M = dgrad ? Ci : Co; d.fused = false;
@@ -756,7 +761,7 @@ extern "C" int dc_wino_cache_variants(void) {
 
 extern "C" size_t dc_wino3x3_workspace(int B, int Ci, int Co, int H, int W) {
     if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;
-    return wino_uhat_bytes(Ci, Co) + wino_al256((size_t)2 * B * std::max(Ci, Co) * H * W * sizeof(float));
+    return std::max(wino_uhat_bytes(Ci, Co), c3b_weights_bytes(Ci, Co)) + wino_al256((size_t)2 * B * std::max(Ci, Co) * H * W * sizeof(float));
 }
 
 extern "C" int dc_wino3x3_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int H, int W,

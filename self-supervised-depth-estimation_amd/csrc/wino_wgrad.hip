@@ -23,6 +23,7 @@
 //     G^T.  Deterministic.
 // Requires even W; H arbitrary.
 #include "dc_common.h"
+#include "conv_bf16.h"
 #include "wino.h"
 
 #include <algorithm>
@@ -376,11 +377,17 @@ using namespace dc;
 
 extern "C" size_t dc_wino3x3_wgrad_workspace(int B, int Ci, int Co, int H, int W) {
     if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W < 2 || (W & 1)) return 0;
-    return wino_wgrad_ws_bytes(B, Ci, Co, H, W);
+    const size_t b16 = (size_t)c3b_wgrad_split(B, H, W, Co, Ci, 1) * Co * Ci * 9 * sizeof(float);
+    return std::max(wino_wgrad_ws_bytes(B, Ci, Co, H, W), b16);
 }
 
 extern "C" int dc_wino3x3_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int H, int W,
                                 void* stream) {
     if (!x || !gy || !dweight || !ws || B <= 0 || Ci <= 0 || Co <= 0 || H < 1 || W < 2 || (W & 1)) return DC_EINVAL;
+    if (matrix_precision() == DC_PREC_BF16 && c3b_eligible(Ci, 0, 0, H, W, 1)) {      // bf16 matrix cores (conv_bf16.hip)
+        const int sp = c3b_wgrad_split(B, H, W, Co, Ci, 1);
+        const int rc = c3b_wgrad(x, Ci, 0, nullptr, 0, gy, (float*)ws, sp, B, Co, H, W, PAD_ZERO, 1, (hipStream_t)stream);
+        return rc != DC_OK ? rc : conv_wreduce((const float*)ws, nullptr, dweight, nullptr, sp, Co * Ci * 9, 0, (hipStream_t)stream);
+    }
     return wg_launch(x, Ci, 0, nullptr, 0, PAD_ZERO, false, gy, dweight, ws, B, Co, H, W, (hipStream_t)stream);
 }

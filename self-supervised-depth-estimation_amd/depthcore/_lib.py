@@ -18,6 +18,7 @@ OPT_NO_AUTOMASK = 1
 OPT_AVG_REPROJ = 2
 OPT_NO_SSIM = 4
 OPT_ALIGN_CORNERS = 8
+PREC_F32, PREC_BF16 = 0, 1
 
 _ERR = {-1: "DC_EINVAL (bad shape / null pointer / unsupported option)",
         -2: "DC_ELAUNCH (hip launch failed)",
@@ -126,6 +127,8 @@ def _sig(lib):
         "dc_gru_blend_bwd": (i, [p, p, p, p, p, p, p, i, i, i, p]),
         "dc_gru_residual_fwd": (i, [p, p, p, i, z, p]),
         "dc_gru_residual_bwd": (i, [p, p, i, z, p]),
+        "dc_set_matrix_precision": (i, [i]),
+        "dc_get_matrix_precision": (i, []),
         "dc_wino_cache_register": (i, [p, i, i]),
         "dc_wino_cache_unregister": (i, [p]),
         "dc_wino_cache_refresh": (i, [p]),

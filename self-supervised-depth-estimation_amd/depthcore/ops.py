@@ -4,6 +4,7 @@ Every op enqueues hand-written gfx950 kernels on the current HIP stream; tensors
 are allocated by PyTorch's caching allocator and passed down as raw pointers.
 """
 import ctypes
+import threading
 import weakref
 
 import torch
@@ -32,6 +33,43 @@ class KinkTape:
     def __exit__(self, *exc):
         KinkTape._active.remove(self)
         return False
+
+
+# ---- matrix-core precision of the convolutions (include/depthcore.h: dc_set_matrix_precision) ----------------------------
+# "f32": exact fp32 MFMA (the reference's arithmetic, the default).  "bf16": the reduced-precision-networks policy of BASELINE
+# configs[4] -- convolution operands rounded to bf16 on their way into LDS, fp32 accumulation, everything else (tensors in HBM,
+# master weights, BatchNorm statistics, the photometric loss) fp32.  The C library keeps the setting per calling thread; a
+# convolution records the precision of its forward and its backward (run by autograd's thread) uses the same.
+PRECISIONS = {"f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
+_precision = [_lib.PREC_F32]
+_tls = threading.local()
+
+
+class matrix_precision:
+    """with ops.matrix_precision("bf16"): ...  -- convolutions issued inside use the bf16 matrix cores."""
+
+    def __init__(self, name):
+        if name not in PRECISIONS:
+            raise _lib.DepthcoreError("matrix precision must be one of %s, got %r" % (sorted(PRECISIONS), name))
+        self.prec = PRECISIONS[name]
+
+    def __enter__(self):
+        self.prev, _precision[0] = _precision[0], self.prec
+        return self
+
+    def __exit__(self, *exc):
+        _precision[0] = self.prev
+        return False
+
+
+def _use_precision(prec):
+    """Make `prec` the calling thread's library setting (one C call, only when it changes)."""
+    if getattr(_tls, "prec", _lib.PREC_F32) != prec:
+        rc = _lib.lib().dc_set_matrix_precision(prec)
+        if rc < 0:
+            check(rc, "dc_set_matrix_precision")
+        _tls.prec = prec
+    return prec
 
 
 def _record_kink(kind, t):
@@ -507,6 +545,7 @@ class _Conv3x3(torch.autograd.Function):
         if a1 is not None and tuple(a1.shape) != (B, C1, H, W):
             raise _lib.DepthcoreError("skip tensor %s must be %s" % (tuple(a1.shape), (B, C1, H, W)))
         y = torch.empty(B, Co, H, W, dtype=torch.float32, device=a0.device)
+        ctx.prec = _use_precision(_precision[0])
         ws = torch.empty(L.dc_conv3x3_fwd_workspace(C0, C1, B, Co, H, W), dtype=torch.uint8, device=a0.device)
         check(L.dc_conv3x3_fwd(ptr(a0), C0, int(up0), ptr(a1), C1, ptr(w), ptr(bs), ptr(y), ws.data_ptr(), B, Co, H, W,
                                int(act), int(pad), stream(a0)), "dc_conv3x3_fwd")
@@ -534,6 +573,7 @@ class _Conv3x3(torch.autograd.Function):
             db = _grad_dst(ctx.slots[1], None)
             if db is None:
                 db = torch.empty(Co, dtype=torch.float32, device=y.device)
+        _use_precision(ctx.prec)
         ws = torch.empty(L.dc_conv3x3_bwd_workspace(C0, C1, B, Co, H, W), dtype=torch.uint8, device=y.device)
         g_c = _c(gy)      # named: stays alive until the launch is enqueued
         check(L.dc_conv3x3_bwd(ptr(a0), C0, up0, ptr(a1), C1, ptr(w), ptr(y), ptr(g_c), ptr(dx0), ptr(dx1), ptr(dw),
@@ -642,6 +682,7 @@ class _WinoConv(torch.autograd.Function):
         B, Ci, H, W = xx.shape
         Co = ww.shape[0]
         y = torch.empty(B, Co, H, W, dtype=torch.float32, device=xx.device)
+        ctx.prec = _use_precision(_precision[0])
         ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
         check(L.dc_wino3x3_fwd(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, stream(xx)), "dc_wino3x3_fwd")
         ctx.save_for_backward(xx, ww)
@@ -656,6 +697,7 @@ class _WinoConv(torch.autograd.Function):
         Co = ww.shape[0]
         g_c = _c(gy)
         gx = gw = None
+        _use_precision(ctx.prec)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xx)
             ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
