@@ -43,6 +43,16 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD @2.4 GHz)
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (~2.5 PF)
+# kernel families that carry hipEvent pairs (include/depthcore.h: dc_conv_profile_*): id -> (name, what bounds it)
+FAMILIES = {
+    0: ("dc::wino_ps_kernel (Winograd F(2x2,3x3) fp32-MFMA convolution: forward + data gradient of the trunk and decoder 3x3 "
+        "convolutions)", "mfma"),
+    1: ("dc::wino_wgrad_kernel (Winograd-domain 3x3 weight gradient, fp32 MFMA)", "mfma"),
+    2: ("dc::c3b_conv_kernel (direct 3x3 convolution on the bf16 matrix cores, fp32 tensors in HBM: forward + data gradient)", "hbm"),
+    3: ("dc::c3b_wgrad_kernel (3x3 weight gradient on the bf16 matrix cores, transposed LDS reads, fp32 tensors in HBM)", "hbm"),
+    4: ("dc::g1_* (1x1 convolutions as NCHW fp32-MFMA GEMMs: forward, data gradient, weight gradient)", "mfma"),
+}
 VALU_LANE_OPS_PEAK = 78.6e12   # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: wave-level VALU instructions x 64 lanes per second
 
 
@@ -267,6 +277,7 @@ def run_rank(args):
     elif args.front == "fusion":     # BASELINE configs[4]: frames [-2, -1, 0] stacked through encoder + decoder, then Fusion_v3
         front = dict(fusion="v3", frame_ids=[0, -2, -1, 1])
     opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
+                            nets_dtype=args.nets_dtype,
                             cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap,
                             wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph) and world == 1, **front)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
@@ -294,7 +305,7 @@ def run_rank(args):
         ops.profile_enable(args.steps + 8)
         # every 7th conv launch carries an event pair (7 is coprime with the launches per step, so all layers are
         # sampled over the timed region); bracketing every launch costs ~4 % of the step
-        ops.conv_profile_enable((args.steps + 2) * 40, 7)
+        ops.conv_profile_enable((args.steps * args.windows + 2) * 60, 7)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -302,12 +313,21 @@ def run_rank(args):
     sync()
     dt = time.perf_counter() - t0
     loss_last = float(losses["loss"].detach())
+    # run-to-run spread: more windows of the same K steps right after the timed one (reported, not the headline)
+    windows = [dt / args.steps * 1e3]
+    for _w in range(args.windows - 1):
+        sync()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            _, losses = tr.train_step(inputs)
+        sync()
+        windows.append((time.perf_counter() - tw) / args.steps * 1e3)
     del losses, _                       # drop the autograd graph before the stream layout changes below
     graphed = tr.graph_enabled and tr._graph is not None
     tr.graph_enabled = False            # the diagnostic steps below are eager
     prof = ops.profile_collect()
     ops.profile_enable(0)
-    cprof_c, wprof_c = ops.conv_profile_collect(0), ops.conv_profile_collect(1)
+    fam_c = {k: ops.conv_profile_collect(k) for k in FAMILIES}
     ops.conv_profile_enable(0, 1)
 
     # ---- wall split of a step: forward / backward / exposed exchange / Adam (host-synchronised, after the timed region)
@@ -338,19 +358,19 @@ def run_rank(args):
     if tr.opt.overlap_streams:
         tr.opt.overlap_streams = False
         ops.profile_enable(SERIAL_STEPS + 2)
-        ops.conv_profile_enable((SERIAL_STEPS + 1) * 260, 1)
+        ops.conv_profile_enable((SERIAL_STEPS + 1) * 400, 1)
         for _ in range(SERIAL_STEPS):
             tr.train_step(inputs)
         torch.cuda.synchronize()
         prof = ops.profile_collect()
-        cprof, wprof = ops.conv_profile_collect(0), ops.conv_profile_collect(1)
+        fam = {k: ops.conv_profile_collect(k) for k in FAMILIES}
         ops.profile_enable(0)
         ops.conv_profile_enable(0, 1)
         tr.opt.overlap_streams = True
-        roof_src = "%d single-stream steps after the timed region, every launch" % SERIAL_STEPS
+        roof_src, fam_steps = "%d single-stream steps after the timed region, every launch" % SERIAL_STEPS, SERIAL_STEPS
     else:
-        cprof, wprof = cprof_c, wprof_c
-        roof_src = "timed region, every 7th launch"
+        fam = fam_c
+        roof_src, fam_steps = "timed region, every 7th launch", args.steps * args.windows / 7.0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -373,7 +393,8 @@ def run_rank(args):
         if args.front == "gru":
             label = "BASELINE configs[3] (per rank): ConvGRU v5 temporal fusion, one sequence of %d frames, " % args.len_sequence
         elif args.front == "fusion":
-            label = "BASELINE configs[4] (per rank, fp32): Fusion_v3 attention fusion on frames {-2,-1,0}, "
+            label = "BASELINE configs[4] (per rank, %s): Fusion_v3 attention fusion on frames {-2,-1,0}, " % (
+                "fp32" if args.nets_dtype == "f32" else "networks' convolutions on the bf16 matrix cores, everything else fp32")
         N = args.batch * args.height * args.width
         bytes_fwd = sum(36.0 * N + 16.0 * (N >> (2 * s)) for s in range(4))
         bytes_bwd = sum(36.0 * N + 20.0 * (N >> (2 * s)) for s in range(4))
@@ -390,10 +411,38 @@ def run_rank(args):
         def valu(k):
             v = traffic.get(k)
             return v.get("sq_insts_valu") if v else None
-        c_ms = cprof["ms"] / max(cprof["launches"], 1)
-        c_tf = cprof["flops"] / (cprof["ms"] * 1e-3) / 1e12 if cprof["ms"] > 0 else 0.0
-        c_ex = cprof["executed_flops"] / (cprof["ms"] * 1e-3) / 1e12 if cprof["ms"] > 0 else 0.0
-        w_tf = wprof["flops"] / (wprof["ms"] * 1e-3) / 1e12 if wprof["ms"] > 0 else 0.0
+        # every instrumented kernel family of the step; the roofline entry is the one that takes the most GPU time
+        def family_entry(k):
+            d, dc_ = fam[k], fam_c[k]
+            if d["launches"] == 0 or d["ms"] <= 0:
+                return None
+            name, bound = FAMILIES[k]
+            sec = d["ms"] * 1e-3
+            tf, ex = d["flops"] / sec / 1e12, d["executed_flops"] / sec / 1e12
+            e = {"kernel": name, "bound": bound, "family": k,
+                 "ms_per_step": round(d["ms"] / fam_steps, 3), "launches_per_step": round(d["launches"] / fam_steps, 1),
+                 "avg_kernel_ms": round(d["ms"] / d["launches"], 4), "launches_timed": d["launches"],
+                 "algorithmic_flops_per_launch": round(d["flops"] / d["launches"], 0),
+                 "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 0)}
+            if bound == "mfma":
+                e.update({"achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                          "flops_definition": "SURVEY 8d algorithmic: 2 MAC of the direct convolution, summed over the launches",
+                          "issued_to_matrix_cores_tflops": round(ex, 2),
+                          "issued_frac_of_peak": round(ex / MFMA_F32_PEAK_TFLOPS, 4)})
+            else:
+                gbs = d["bytes"] / sec / 1e9
+                e.update({"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                          "bytes_definition": "each fp32 operand tensor and the fp32 result once, per launch",
+                          "matrix_core_tflops_bf16": round(ex, 1), "matrix_core_frac_of_bf16_peak": round(ex / MFMA_BF16_PEAK_TFLOPS, 4)})
+            if dc_["launches"]:
+                e["avg_kernel_ms_in_timed_region"] = round(dc_["ms"] / dc_["launches"], 4)
+            return e
+        fams = [e for e in (family_entry(k) for k in FAMILIES) if e]
+        fams.sort(key=lambda e: -e["ms_per_step"])
+        dom = dict(fams[0]) if fams else {"kernel": None, "bound": "mfma", "achieved": 0.0, "peak": MFMA_F32_PEAK_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": 0.0}
+        dom_key = {0: "dc::wino_ps_kernel", 1: "dc::wino_wgrad_kernel", 2: "dc::c3b_conv_kernel", 3: "dc::c3b_wgrad_kernel"}.get(dom.get("family"))
         vb = valu("dc::photo_bwd_kernel")
         out = {
             "metric": "training images/sec at %dx%d bs%d (resnet%d depth+pose, 4-scale photometric+smoothness)"
@@ -403,34 +452,24 @@ def run_rank(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.nets_dtype == "f32" else "bf16-nets/f32-loss", "data": "synthetic",
+            "windows_ms_per_step": [round(w, 3) for w in windows],
             "config": {"workload": "%sresnet%d depth+pose, %dx%d, per-GPU batch %d, 4 scales, "
                                    "frames {0,-1,+1}, automasking, Adam lr 1e-4; random-init weights"
                                    % (label, args.num_layers, args.height, args.width, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "tiebreak_noise": "cpu-randn+h2d" if args.cpu_noise else "on-device counter RNG",
                        "step_launch": "one hipGraph replay per step" if graphed else "eager (one launch per kernel)"},
-            "roofline": {"kernel": "dc::wino_ps_kernel (Winograd F(2x2,3x3) fp32-MFMA convolution: forward + data gradient of "
-                                   "the trunk and decoder 3x3 convolutions)",
-                         "bound": "mfma", "achieved": round(c_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(c_tf / MFMA_F32_PEAK_TFLOPS, 4),
-                         "traffic": tr_bytes("dc::wino_ps_kernel"), "traffic_source": traffic_src,
-                         "flops_definition": "SURVEY 8d algorithmic: 2 MAC of the direct 3x3 convolution, summed over the launches",
-                         "algorithmic_flops_per_launch": round(cprof["flops"] / max(cprof["launches"], 1), 0),
-                         "algorithmic_bytes_per_launch": round(cprof["bytes"] / max(cprof["launches"], 1), 0),
-                         "avg_kernel_ms": round(c_ms, 4), "launches_timed": cprof["launches"], "measured_in": roof_src,
-                         "avg_kernel_ms_in_timed_region": round(cprof_c["ms"] / max(cprof_c["launches"], 1), 4),
+            "roofline": dict(dom, **{
+                         "traffic": tr_bytes(dom_key) if dom_key else None, "traffic_source": traffic_src if dom_key and tr_bytes(dom_key) else None,
+                         "measured_in": roof_src,
+                         "selection": "the instrumented kernel family with the largest GPU time per step; all of them under `families`",
                          "timed_region_note": "two-stream overlap: a launch shares the GPU with the other branch's kernels "
                                               "(sampled every 7th launch); rocprofv3 serialises dispatches and matches avg_kernel_ms",
-                         "note": "Winograd issues 16/36 of the algorithmic MACs to the matrix cores: `frac` follows the SURVEY 8d "
-                                 "definition, `issued_frac_of_peak` is the fraction of the fp32 MFMA peak actually used",
-                         "issued_to_matrix_cores_tflops": round(c_ex, 2),
-                         "issued_frac_of_peak": round(c_ex / MFMA_F32_PEAK_TFLOPS, 4),
-                         "wgrad_kernel": {"kernel": "dc::wino_wgrad_kernel", "achieved": round(w_tf, 2),
-                                          "frac": round(w_tf / MFMA_F32_PEAK_TFLOPS, 4), "launches_timed": wprof["launches"],
-                                          "issued_frac_of_peak": round(wprof["executed_flops"] / (wprof["ms"] * 1e-3) / 1e12 /
-                                                                       MFMA_F32_PEAK_TFLOPS, 4) if wprof["ms"] > 0 else 0.0,
-                                          "avg_kernel_ms": round(wprof["ms"] / max(wprof["launches"], 1), 4)},
+                         "note": "Winograd kernels issue 16/36 of the algorithmic MACs to the matrix cores: for them `frac` follows the "
+                                 "SURVEY 8d definition and can exceed what the pipe does; `issued_frac_of_peak` is the fraction of the "
+                                 "fp32 MFMA peak actually used",
+                         "families": fams[1:],
                          "photometric": {"kernel": "fused warp+SSIM+L1+automask+smoothness BACKWARD, whole chain of a step "
                                                    "(dc::photo_bwd_kernel + disp_grad_kernel + pose_grad_kernel; 4 scales x 2 frames)",
                                          "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -450,7 +489,7 @@ def run_rank(args):
                                                        "achieved": round(bytes_fwd / (fwd_chain_ms * 1e-3) / 1e9, 1)
                                                        if fwd_chain_ms > 0 else 0.0,
                                                        "frac": round(bytes_fwd / (fwd_chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                                       if fwd_chain_ms > 0 else 0.0}}},
+                                                       if fwd_chain_ms > 0 else 0.0}}}),
             "phases_ms": {"forward": round(ph[0], 3), "backward_incl_overlapped_exchange": round(ph[1], 3),
                           "exposed_exchange_wait": round(ph[2], 3), "adam": round(ph[3], 3),
                           "note": "host-synchronised between phases (slower than the pipelined step); %d steps after the "
@@ -487,6 +526,12 @@ def main():
     ap.add_argument("--front", choices=["none", "gru", "fusion"], default="none",
                     help="sequence front-end: gru = ConvGRU v5 (configs[3], batch 1 x --len-sequence frames), fusion = Fusion_v3 (configs[4])")
     ap.add_argument("--len-sequence", type=int, default=3)
+    ap.add_argument("--nets-dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: the reduced-precision-networks policy of BASELINE configs[4] (convolution operands rounded to bf16 "
+                         "for the matrix cores, fp32 accumulate; tensors, master weights, BatchNorm and the loss stay fp32); "
+                         "reported under its own dtype, never the headline")
+    ap.add_argument("--windows", type=int, default=4, help="timed windows of --steps steps: the first is the reported value, the "
+                                                            "others show the run-to-run spread (windows_ms_per_step)")
     ap.add_argument("--graph", action="store_true", help="single GPU: capture the training step in one hipGraph and replay it (opt.hip_graph)")
     ap.add_argument("--no-wino-cache", action="store_true", help="per-launch Winograd weight transforms (A/B of wino_weight_cache)")
     ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")

@@ -16,6 +16,8 @@ int c3b_wgrad_split(int B, int OH, int OW, int Co, int Cin, int stride);
 
 // out = act(conv3x3(pad1(cat(up2?(x0), x1))) + bias) (dgrad = 0), or the same convolution with the rotated, transposed
 // filter (dgrad = 1: `x0` holds g', C0 = Co, out has Cin channels); dpad = 1: output over the padded domain (H+2, W+2).
+// up0: 0 plain, 1 nearest-x2 upsampled x0, 3 DILATED x0 (full[2y][2x] = x0[y][x], zeros between: with dgrad = 1 and zero
+// padding that is the data gradient of the stride-2 convolution).
 int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight, int Co, int Cin, int dgrad, int dpad,
              const float* bias, float* out, void* ws, int B, int H, int W, int act, int pad, int stride, hipStream_t st);
 // part[split][Co][Cin*9] from x = cat(up2?(x0), x1) and g' (B,Co,H/stride,W/stride)

@@ -26,6 +26,7 @@
 //     slabs, summed in fixed order by conv_wreduce_kernel (deterministic, no atomics).
 #include "dc_common.h"
 #include "conv_bf16.h"
+#include "wino.h"
 
 #include <algorithm>
 
@@ -95,6 +96,8 @@ struct PatchSrc {
     const float* x0; int C0; int up0;
     const float* x1; int C1;
     int H, W, pad;          // full-resolution input maps
+    int dil;                // up0 = 1 only: x0 is DILATED instead of repeated -- full[2y][2x] = x0[y][x], zero elsewhere (the
+                            // data gradient of a stride-2 convolution is a stride-1 convolution over the dilated g')
 };
 
 template <int S, int TH, bool DPAD, int NTHR = 256>
@@ -130,6 +133,7 @@ struct PatchStager {
                 if (DPAD) oky = yy >= 0 && yy < s.H;
                 else yy = pad_index_b(yy, s.H, s.pad, oky);
                 const int xx = ix0 + 4 * q * (upmode ? 2 : 1);
+                if (upmode && s.dil && (yy & 1)) oky = false;          // odd rows of a dilated map are zero
                 if (oky && xx < s.W && ch < K) {
                     const float* p;
                     size_t plane;
@@ -154,6 +158,7 @@ struct PatchStager {
                 int xx = ix0 - OFF + edge_col(e);
                 if (DPAD) { oky = yy >= 0 && yy < s.H; okx = xx >= 0 && xx < s.W; }
                 else { yy = pad_index_b(yy, s.H, s.pad, oky); xx = pad_index_b(xx, s.W, s.pad, okx); }
+                if (s.dil && ch < s.C0 && ((yy | xx) & 1)) oky = false;
                 if (oky && okx && ch < K) {
                     const float* p;
                     size_t plane;
@@ -179,8 +184,9 @@ struct PatchStager {
                 const unsigned p0 = pack_bf16(a.x, c.x), p1 = pack_bf16(a.y, c.y), p2 = pack_bf16(a.z, c.z), p3 = pack_bf16(a.w, c.w);
                 unsigned* dst = img + (r * PW + OFF + (upmode ? 8 : 4) * q) * (BPX / 2) + cp;
                 if (upmode) {
-                    dst[0] = p0; dst[BPX / 2] = p0; dst[2 * (BPX / 2)] = p1; dst[3 * (BPX / 2)] = p1;
-                    dst[4 * (BPX / 2)] = p2; dst[5 * (BPX / 2)] = p2; dst[6 * (BPX / 2)] = p3; dst[7 * (BPX / 2)] = p3;
+                    const bool rep = !s.dil;                           // nearest x2: every value twice; dilation: value, zero
+                    dst[0] = p0; dst[BPX / 2] = rep ? p0 : 0u; dst[2 * (BPX / 2)] = p1; dst[3 * (BPX / 2)] = rep ? p1 : 0u;
+                    dst[4 * (BPX / 2)] = p2; dst[5 * (BPX / 2)] = rep ? p2 : 0u; dst[6 * (BPX / 2)] = p3; dst[7 * (BPX / 2)] = rep ? p3 : 0u;
                 } else {
                     dst[0] = p0; dst[BPX / 2] = p1; dst[2 * (BPX / 2)] = p2; dst[3 * (BPX / 2)] = p3;
                 }
@@ -446,7 +452,7 @@ int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const fl
     hipLaunchKernelGGL(c3b_wprep_kernel, dim3(ceil_div(nitems, 256)), dim3(256), 0, st, weight, wb, Co, Cin, dgrad, MT, mblocks, nchunks);
     DC_CHECK_LAUNCH();
     C3bArgs a{};
-    a.src = PatchSrc{x0, C0, up0, x1, C1, H, W, pad};
+    a.src = PatchSrc{x0, C0, up0 & 1, x1, C1, H, W, pad, (up0 >> 1) & 1};
     a.wb = wb; a.bias = bias; a.out = out; a.B = B; a.M = M; a.K = K; a.act = act;
     a.OH = dpad ? H + 2 : H / stride; a.OW = dpad ? W + 2 : W / stride;
     const int TH = stride == 1 ? 16 : 8;
@@ -454,6 +460,12 @@ int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const fl
     const long nblk = (long)a.tiles_x * a.tiles_y * mblocks * B;
     if (nblk > 0x7fffffffL) return DC_EINVAL;
     const dim3 grid((unsigned)nblk);
+    // algorithmic: 2 MAC per tap of the convolution as specified (the dilated data gradient counts the stride-2 convolution's
+    // MACs, i.e. a quarter of the positions); executed: what the matrix cores are issued; bytes: each operand and the result once
+    const double macs = (double)B * M * K * 9.0 * a.OH * a.OW * ((up0 & 2) ? 0.25 : 1.0);
+    const double in_elems = (double)B * ((double)C0 * (H >> (up0 & 1)) * (W >> (up0 & 1)) + (double)C1 * H * W);
+    hipEvent_t pe = conv_prof_begin(2, 2.0 * macs, 2.0 * (double)nblk * (stride == 1 ? 256 : 128) * MT * (double)(nchunks * BC) * 9.0,
+                                    4.0 * (in_elems + (double)B * M * a.OH * a.OW) + 36.0 * Co * Cin, st);
 #define C3B_LAUNCH(MRV, SV, DP) hipLaunchKernelGGL((c3b_conv_kernel<MRV, SV, DP>), grid, dim3(256), 0, st, a)
     if (stride == 2) {
         if (dpad) return DC_EINVAL;
@@ -464,6 +476,7 @@ int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const fl
         if (mr == 4) C3B_LAUNCH(4, 1, false); else if (mr == 2) C3B_LAUNCH(2, 1, false); else C3B_LAUNCH(1, 1, false);
     }
 #undef C3B_LAUNCH
+    conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -472,13 +485,19 @@ int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const fl
 int c3b_wgrad(const float* x0, int C0, int up0, const float* x1, int C1, const float* gp, float* part, int split, int B, int Co, int H,
               int W, int pad, int stride, hipStream_t st) {
     C3bWgArgs a{};
-    a.src = PatchSrc{x0, C0, up0, x1, C1, H, W, pad};
+    a.src = PatchSrc{x0, C0, up0, x1, C1, H, W, pad, 0};
     a.gp = gp; a.part = part; a.B = B; a.Co = Co; a.OH = H / stride; a.OW = W / stride;
     const int TH = stride == 1 ? 16 : 8;
     a.tiles_x = ceil_div(a.OW, 16); a.tiles_y = ceil_div(a.OH, TH); a.split = split;
     const dim3 grid(split, ceil_div(Co, 64), ceil_div(C0 + C1, BC));
+    const int Cin = C0 + C1;
+    const double in_elems = (double)B * ((double)C0 * (H >> up0) * (W >> up0) + (double)C1 * H * W);
+    hipEvent_t pe = conv_prof_begin(3, 2.0 * (double)B * Co * Cin * 9.0 * a.OH * a.OW,
+                                    2.0 * (double)a.tiles_x * a.tiles_y * B * TH * 16.0 * (grid.y * 64.0) * (grid.z * 32.0) * 9.0,
+                                    4.0 * (in_elems + (double)B * Co * a.OH * a.OW) + 36.0 * Co * Cin, st);
     if (stride == 1) hipLaunchKernelGGL((c3b_wgrad_kernel<1>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((c3b_wgrad_kernel<2>), grid, dim3(512), 0, st, a);
+    conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }

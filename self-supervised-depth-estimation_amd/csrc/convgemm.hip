@@ -22,6 +22,7 @@
 //       taps of four pixels; 96-row super-chunks (forward), 64 x 96 tiles (weight gradient).
 // All deterministic (no atomics).
 #include "dc_common.h"
+#include "conv_bf16.h"
 #include "gemm_tiles.h"
 
 #include <stdlib.h>
@@ -859,13 +860,16 @@ extern "C" int dc_convs2_supported(int B, int Ci, int Co, int Hi, int Wi, int ks
 extern "C" size_t dc_convs2_fwd_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize) {
     if (!cg_ok(B, Ci, Co, Hi, Wi, ksize)) return 0;
     const int K = Ci * ksize * ksize, Kp = cg_kp(Ci, ksize);
-    return Kp == K ? 16 : (size_t)Co * Kp * sizeof(float);
+    const size_t b16 = ksize == 3 ? c3b_weights_bytes(Ci, Co) : 0;
+    return std::max(Kp == K ? (size_t)16 : (size_t)Co * Kp * sizeof(float), b16);
 }
 
 extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int Hi, int Wi, int ksize,
                              void* stream) {
     if (!x || !weight || !y || !ws || !cg_ok(B, Ci, Co, Hi, Wi, ksize)) return DC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (ksize == 3 && matrix_precision() == DC_PREC_BF16 && c3b_eligible(Ci, 0, 0, Hi, Wi, 2))      // bf16 matrix cores (conv_bf16.hip)
+        return c3b_conv(x, Ci, 0, nullptr, 0, weight, Co, Ci, 0, 0, nullptr, y, ws, B, Hi, Wi, ACT_NONE, PAD_ZERO, 2, st);
     CgArgs a{};
     a.x = x; a.out = y; a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
     a.K = Ci * ksize * ksize; a.Kp = cg_kp(Ci, ksize);
@@ -923,13 +927,19 @@ extern "C" size_t dc_convs2_wgrad_workspace(int B, int Ci, int Co, int Hi, int W
     }
     const int tiles = ceil_div(Co, 64) * ceil_div(K, trip_ok(Ci, ksize) ? 96 : 64);
     const int splits = cg_wsplits(tiles, ceil_div(B * (Hi / 2) * (Wi / 2), GKC));
-    return splits > 1 ? (size_t)splits * Co * K * sizeof(float) : 16;
+    const size_t b16 = ksize == 3 ? (size_t)c3b_wgrad_split(B, Hi / 2, Wi / 2, Co, Ci, 2) * Co * K * sizeof(float) : 0;
+    return std::max(splits > 1 ? (size_t)splits * Co * K * sizeof(float) : (size_t)16, b16);
 }
 
 extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,
                                int ksize, void* stream) {
     if (!x || !gy || !dweight || !ws || !cg_ok(B, Ci, Co, Hi, Wi, ksize)) return DC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (ksize == 3 && matrix_precision() == DC_PREC_BF16 && c3b_eligible(Ci, 0, 0, Hi, Wi, 2)) {    // bf16 matrix cores
+        const int sp = c3b_wgrad_split(B, Hi / 2, Wi / 2, Co, Ci, 2);
+        const int rc = c3b_wgrad(x, Ci, 0, nullptr, 0, gy, (float*)ws, sp, B, Co, Hi, Wi, PAD_ZERO, 2, st);
+        return rc != DC_OK ? rc : conv_wreduce((const float*)ws, nullptr, dweight, nullptr, sp, Co * Ci * 9, 0, st);
+    }
     if (stem_ok(Ci, Co, ksize)) {
         StemArgs sa = stem_args(B, Ci, Co, Hi, Wi);
         sa.x = x; sa.gy = gy; sa.out = (float*)ws;
@@ -966,13 +976,17 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
 
 extern "C" size_t dc_convs2_dgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize) {
     if (!cg_ok(B, Ci, Co, Hi, Wi, ksize) || ksize != 3 || (Ci & 3) || Co % GKC) return 0;
-    return (size_t)9 * Co * Ci * sizeof(float);
+    return std::max((size_t)9 * Co * Ci * sizeof(float), c3b_weights_bytes(Ci, Co));
 }
 
 extern "C" int dc_convs2_dgrad(const float* gy, const float* weight, float* dx, void* ws, int B, int Ci, int Co, int Hi, int Wi,
                                int ksize, void* stream) {
     if (!gy || !weight || !dx || !ws || !dc_convs2_dgrad_workspace(B, Ci, Co, Hi, Wi, ksize)) return DC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    // bf16 matrix cores: stride-1 convolution of the DILATED g' with the rotated, transposed filter (conv_bf16.hip).  Three
+    // quarters of its multiplies meet a structural zero -- at 16x the fp32 matrix rate the kernel is bound by its HBM reads
+    if (matrix_precision() == DC_PREC_BF16 && c3b_eligible(Co, 0, 1, Hi, Wi, 1))
+        return c3b_conv(gy, Co, 3, nullptr, 0, weight, Co, Ci, 1, 0, nullptr, dx, ws, B, Hi, Wi, ACT_NONE, PAD_ZERO, 1, st);
     hipLaunchKernelGGL(cg_wt3_kernel, dim3(ceil_div(9 * Co * Ci, 256)), dim3(256), 0, st, weight, (float*)ws, Co, Ci);
     DC_CHECK_LAUNCH();
     CgArgs a{};

@@ -33,6 +33,7 @@
 // tile is fetched from HBM once per XCD pass and re-served by that XCD's L2; the weights are L2-resident.
 #include "dc_common.h"
 #include "gemm1x1.h"
+#include "wino.h"
 #include "gemm_tiles.h"
 
 #include <algorithm>
@@ -451,6 +452,7 @@ extern "C" int dc_gemm1x1_fwd(const float* x, const float* weight, const float* 
     static const bool attr = g1_set_lds(g1_fwd_kernel<4, 4, false>, g1_lds_fwd({4, 4})) &&
                              g1_set_lds(g1_fwd_kernel<4, 4, true>, g1_lds_fwd({4, 4}));
     if (!attr) return DC_ELAUNCH;
+    hipEvent_t pe = conv_prof_begin(4, 2.0 * (double)B * Co * Ci * a.Ho * a.Wo, 2.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * Ci, 4.0 * ((double)B * Ci * a.Ho * a.Wo + (double)B * Co * a.Ho * a.Wo + (double)Co * Ci), st);
 #define G1_FWD(MT, NT)                                                                            \
     do {                                                                                          \
         if (epi) hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, true>), grid, dim3(256), lds, st, a);  \
@@ -460,6 +462,7 @@ extern "C" int dc_gemm1x1_fwd(const float* x, const float* weight, const float* 
     else if (t.nt == 4) G1_FWD(2, 4);
     else G1_FWD(2, 2);
 #undef G1_FWD
+    conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -478,9 +481,11 @@ extern "C" int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx,
     const size_t lds = g1_lds_dgrad(t);
     static const bool attr = g1_set_lds(g1_dgrad_kernel<4, 4>, g1_lds_dgrad({4, 4}));
     if (!attr) return DC_ELAUNCH;
+    hipEvent_t pe = conv_prof_begin(4, 2.0 * (double)B * Co * Ci * a.Ho * a.Wo, 2.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * Co, 4.0 * ((double)B * Ci * a.Ho * a.Wo + (double)B * Co * a.Ho * a.Wo + (double)Co * Ci), st);
     if (t.mt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<4, 4>), grid, dim3(256), lds, st, a);
     else if (t.nt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<2, 4>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((g1_dgrad_kernel<2, 2>), grid, dim3(256), lds, st, a);
+    conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -509,8 +514,10 @@ extern "C" int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight,
     const size_t lds = g1_lds_wgrad(t);
     static const bool attr = g1_set_lds(g1_wgrad_kernel<4, 4>, g1_lds_wgrad({4, 4}));
     if (!attr) return DC_ELAUNCH;
+    hipEvent_t pe = conv_prof_begin(4, 2.0 * (double)B * Co * Ci * a.Ho * a.Wo, 2.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * (double)a.chunks * GKC, 4.0 * ((double)B * Ci * a.Ho * a.Wo + (double)B * Co * a.Ho * a.Wo + (double)Co * Ci), st);
     if (t.mt == 4) hipLaunchKernelGGL((g1_wgrad_kernel<4, 4>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((g1_wgrad_kernel<2, 2>), grid, dim3(256), lds, st, a);
+    conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     if (a.splits > 1) {
         const int n4 = Co * Ci / 4;

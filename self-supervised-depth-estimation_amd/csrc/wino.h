@@ -19,7 +19,8 @@ int wino_wgrad_fused(const float* x0, int C0, int up0, const float* x1, int C1, 
                      int B, int Co, int H, int W, hipStream_t st);
 
 // measurement hook (dc_conv_profile_*): hipEvent pair around the main kernel of a Winograd launch.
-// kind 0: wino_ps_kernel (forward / data gradient), 1: wino_wgrad_kernel.  Returns the end event or nullptr.
+// kind 0: wino_ps_kernel (forward / data gradient), 1: wino_wgrad_kernel, 2: c3b_conv_kernel (bf16 forward / data gradient),
+// 3: c3b_wgrad_kernel (bf16), 4: the 1x1 GEMM family (g1_*).  Returns the end event or nullptr.
 hipEvent_t conv_prof_begin(int kind, double algorithmic_flops, double executed_flops, double algorithmic_bytes, hipStream_t st);
 void conv_prof_end(hipEvent_t e, hipStream_t st);
 

@@ -491,9 +491,10 @@ struct ConvProf {
     int used = 0;
     double flops = 0.0, exec = 0.0, bytes = 0.0;
 };
-ConvProf g_cprof[2];
+constexpr int NPROF = 6;       // 0 wino_ps, 1 wino_wgrad, 2 c3b_conv (bf16), 3 c3b_wgrad (bf16), 4 1x1 GEMM family, 5 reserved
+ConvProf g_cprof[NPROF];
 int g_cprof_cap = 0, g_cprof_every = 1;
-unsigned g_cprof_seen[2] = {0, 0};
+unsigned g_cprof_seen[NPROF] = {0, 0, 0, 0, 0, 0};
 }  // namespace
 
 hipEvent_t conv_prof_begin(int kind, double algorithmic_flops, double executed_flops, double algorithmic_bytes, hipStream_t st) {
@@ -629,7 +630,7 @@ using namespace dc;
 
 extern "C" int dc_conv_profile_enable(int max_launches, int every) {
     g_cprof_every = every > 0 ? every : 1;
-    g_cprof_seen[0] = g_cprof_seen[1] = 0;
+    for (auto& v : g_cprof_seen) v = 0;
     for (auto& d : g_cprof) {
         for (auto e : d.e0) (void)hipEventDestroy(e);
         for (auto e : d.e1) (void)hipEventDestroy(e);
@@ -648,7 +649,7 @@ extern "C" int dc_conv_profile_enable(int max_launches, int every) {
 
 extern "C" int dc_conv_profile_collect(int kind, double* ms, double* algorithmic_flops, double* executed_flops,
                                        double* algorithmic_bytes, int* launches) {
-    if (kind < 0 || kind > 1) return DC_EINVAL;
+    if (kind < 0 || kind >= NPROF) return DC_EINVAL;
     ConvProf& d = g_cprof[kind];
     double tot = 0.0;
     for (int i = 0; i < d.used; ++i) {

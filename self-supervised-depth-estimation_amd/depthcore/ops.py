@@ -852,6 +852,7 @@ class _ConvS2(torch.autograd.Function):
             raise _lib.DepthcoreError("strided convolution %s on input %s is outside dc_convs2_* (3x3 / 7x7, stride 2, even "
                                       "sizes, output width %% 4 == 0)" % (tuple(ww.shape), tuple(xx.shape)))
         y = torch.empty(B, Co, Hi // 2, Wi // 2, dtype=torch.float32, device=xx.device)
+        ctx.prec = _use_precision(_precision[0])
         ws = torch.empty(L.dc_convs2_fwd_workspace(B, Ci, Co, Hi, Wi, ks), dtype=torch.uint8, device=xx.device)
         check(L.dc_convs2_fwd(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, Hi, Wi, ks, stream(xx)), "dc_convs2_fwd")
         ctx.save_for_backward(xx, ww)
@@ -866,6 +867,7 @@ class _ConvS2(torch.autograd.Function):
         Co, ks = ww.shape[0], ww.shape[-1]
         g_c = _c(gy)
         gx = gw = None
+        _use_precision(ctx.prec)
         if ctx.needs_input_grad[0]:
             n = L.dc_convs2_dgrad_workspace(B, Ci, Co, Hi, Wi, ks)
             if not n:

@@ -194,6 +194,13 @@ class Trainer:
         return out
 
     def process_batch(self, inputs):
+        """`opt.nets_dtype = "bf16"`: the reduced-precision-networks policy of BASELINE configs[4] -- every convolution of the
+        networks rounds its operands to bf16 for the matrix cores (fp32 accumulate); tensors, master weights, BatchNorm
+        statistics and the whole photometric loss stay fp32 (depthcore.ops.matrix_precision)."""
+        with ops.matrix_precision(getattr(self.opt, "nets_dtype", "f32")):
+            return self._process_batch(inputs)
+
+    def _process_batch(self, inputs):
         for key, ipt in inputs.items():
             if ipt.device != self.device:
                 inputs[key] = ipt.to(self.device)
