@@ -18,6 +18,7 @@
 #include "dispconv.h"
 #include "wino.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace dc {
@@ -186,6 +187,39 @@ __global__ void conv_gprime_kernel(const float* gy, const float* y, float* gp, s
         reinterpret_cast<float4*>(gp)[i] = g;
     }
 }
+
+// g' = gy * act'(y) AND the bias-gradient partials in the same pass (the separate per-channel sum read g' again at
+// 0.6 TB/s: 128 blocks cannot fill the chip).  grid (Co, split): block (co, sp) takes slice sp of channel co's B * HW / 4
+// float4 items, writes their g' (not when act == NONE: g' is gy itself) and one partial sum pbias[sp][co] (block tree,
+// fixed order); conv_wreduce_kernel adds the `split` partials in order.  HW % 4 == 0.
+__global__ __launch_bounds__(256) void conv_gprime_dbias_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                               float* __restrict__ gp, float* __restrict__ pbias, int B, int Co,
+                                                               int HW4, int act, int split) {
+    __shared__ float sm[256];
+    const int co = blockIdx.x, sp = blockIdx.y;
+    const int total = B * HW4, per = (total + split - 1) / split;
+    const int i1 = min(total, (sp + 1) * per);
+    float acc = 0.f;
+    for (int i = sp * per + threadIdx.x; i < i1; i += 256) {
+        const int b = i / HW4, q = i - b * HW4;
+        const size_t o = ((size_t)b * Co + co) * HW4 + q;
+        float4 g = reinterpret_cast<const float4*>(gy)[o];
+        if (act != ACT_NONE) {
+            const float4 v = reinterpret_cast<const float4*>(y)[o];
+            g.x *= act_bwd(v.x, act); g.y *= act_bwd(v.y, act); g.z *= act_bwd(v.z, act); g.w *= act_bwd(v.w, act);
+            reinterpret_cast<float4*>(gp)[o] = g;
+        }
+        acc += (g.x + g.y) + (g.z + g.w);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && pbias) pbias[(size_t)sp * Co + co] = sm[0];
+}
+static inline int gpd_split(int Co) { return std::max(8, std::min(256, 2048 / std::max(Co, 1))); }
 
 template <int MR, bool DGRAD>
 __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(ConvArgs a) {
@@ -387,29 +421,26 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(ConvArgs a) {
 // fold: dxpad (B,Cin,H+2,W+2) -> dx0 (B,C0,H>>up,W>>up) [2x2 sum when up], dx1 (B,C1,H,W)
 // reflect:  d x[r] = dxpad[r] + (r==1 ? dxpad[-1] : 0) + (r==H-2 ? dxpad[H] : 0), same along x.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fold_at(const float* p, int r, int c, int H, int W, int pad) {
-    const int PWd = W + 2;
-    // padded coordinates that map onto (r,c)
-    int rs[3], cs[3], nr = 1, nc = 1;
-    rs[0] = r; cs[0] = c; rs[1] = r; cs[1] = c;
-    if (pad == PAD_REFLECT) {
-        if (r == 1) rs[nr++] = -1;
-        if (r == H - 2) rs[nr++] = H;
-        if (c == 1) cs[nc++] = -1;
-        if (c == W - 2) cs[nc++] = W;
-    }
+__device__ __forceinline__ float fold_at(const float* p, int r, int c, int H, int W, int pad, int PWd) {
+    // padded coordinates that map onto (r, c): itself, and with ReflectionPad the mirror row (-1 onto 1, H onto H-2) and the
+    // mirror column.  Branch-free: the mirror terms are always loaded (from the pixel itself when there is none) and
+    // weighted 0 / 1 -- data-dependent branches around the loads made every load wait for the previous one.
     // (H == 3 would need three sources per axis; H, W >= 4 is enforced by the entry point)
-    float v = 0.f;
-    for (int i = 0; i < nr; ++i)
-        for (int j = 0; j < nc; ++j) v += p[(size_t)(rs[i] + 1) * PWd + cs[j] + 1];
-    return v;
+    const bool refl = pad == PAD_REFLECT;
+    const bool fr = refl && (r == 1 || r == H - 2), fc = refl && (c == 1 || c == W - 2);
+    const int mr = fr ? (r == 1 ? -1 : H) : r, mc = fc ? (c == 1 ? -1 : W) : c;
+    const float* row0 = p + (size_t)(r + 1) * PWd + 1;
+    const float* row1 = p + (size_t)(mr + 1) * PWd + 1;
+    const float v00 = row0[c], v01 = row0[mc], v10 = row1[c], v11 = row1[mc];
+    return v00 + (fc ? v01 : 0.f) + (fr ? v10 : 0.f) + ((fr && fc) ? v11 : 0.f);
 }
 
+// `pitch`: row pitch of dxpad in floats (W + 2, or c3b_dpad_pitch(W) behind the bf16 kernels)
 __global__ void conv_fold_kernel(const float* dxpad, float* dx0, float* dx1, int B, int C0, int C1, int up0, int H,
-                                 int W, int pad) {
+                                 int W, int pad, int pitch) {
     const int Cin = C0 + C1;
     const int b = blockIdx.z, ch = blockIdx.y;
-    const float* p = dxpad + ((size_t)b * Cin + ch) * (H + 2) * (W + 2);
+    const float* p = dxpad + ((size_t)b * Cin + ch) * (H + 2) * pitch;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch < C0) {
         if (!dx0) return;
@@ -418,17 +449,17 @@ __global__ void conv_fold_kernel(const float* dxpad, float* dx0, float* dx1, int
         const int y = i / w0, x = i - y * w0;
         float v;
         if (up0) {
-            v = (fold_at(p, 2 * y, 2 * x, H, W, pad) + fold_at(p, 2 * y, 2 * x + 1, H, W, pad)) +
-                (fold_at(p, 2 * y + 1, 2 * x, H, W, pad) + fold_at(p, 2 * y + 1, 2 * x + 1, H, W, pad));
+            v = (fold_at(p, 2 * y, 2 * x, H, W, pad, pitch) + fold_at(p, 2 * y, 2 * x + 1, H, W, pad, pitch)) +
+                (fold_at(p, 2 * y + 1, 2 * x, H, W, pad, pitch) + fold_at(p, 2 * y + 1, 2 * x + 1, H, W, pad, pitch));
         } else {
-            v = fold_at(p, y, x, H, W, pad);
+            v = fold_at(p, y, x, H, W, pad, pitch);
         }
         dx0[((size_t)b * C0 + ch) * h0 * w0 + i] = v;
     } else {
         if (!dx1) return;
         if (i >= H * W) return;
         const int y = i / W, x = i - y * W;
-        dx1[((size_t)b * C1 + (ch - C0)) * H * W + i] = fold_at(p, y, x, H, W, pad);
+        dx1[((size_t)b * C1 + (ch - C0)) * H * W + i] = fold_at(p, y, x, H, W, pad, pitch);
     }
 }
 
@@ -912,13 +943,13 @@ extern "C" size_t dc_conv3x3_bwd_workspace(int C0, int C1, int B, int Co, int H,
     const int Cin = C0 + C1;
     const size_t nW = (size_t)Co * Cin * 9;
     const int split = std::max(pick_split(B, H, W, Co, Cin), c3b_wgrad_split(B, H, W, Co, Cin, 1));
-    const size_t direct = std::max(al256(nW * 4), c3b_weights_bytes(Cin, Co)) + al256((size_t)B * Cin * (H + 2) * (W + 2) * 4) +
+    const size_t direct = std::max(al256(nW * 4), c3b_weights_bytes(Cin, Co)) + al256((size_t)B * Cin * (H + 2) * (W + 5) * 4) +
                           al256((size_t)split * nW * 4) + al256((size_t)std::max(split, DB_SPLIT) * Co * 4) + al256((size_t)B * Co * H * W * 4);
     // the Winograd passes keep their scratch behind the direct layout (dxpad and g' are shared)
     size_t extra = 0;
     if (wino_dx(C0, C1, B, Co, H, W, ACT_NONE)) extra += al256(wino_conv_ws_bytes(B, Cin, Co, H, W));
     if (wino_dw(C0, C1, B, Co, H, W, ACT_NONE)) extra += al256(wino_wgrad_ws_bytes(B, Cin, Co, H, W)) + al256((size_t)DB_SPLIT * Co * 4);
-    return direct + extra;
+    return direct + extra + al256((size_t)256 * Co * 4);        // + the bias-gradient partials of conv_gprime_dbias_kernel
 }
 
 extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
@@ -934,21 +965,31 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     const int split_ws = std::max(split, c3b_wgrad_split(B, H, W, Co, Cin, 1));      // (the layout of dc_conv3x3_bwd_workspace)
     char* p = (char*)ws;
     float* wd = (float*)p; p += std::max(al256(nW * 4), c3b_weights_bytes(Cin, Co));
-    float* dxpad = (float*)p; p += al256((size_t)B * Cin * (H + 2) * (W + 2) * 4);
+    float* dxpad = (float*)p; p += al256((size_t)B * Cin * (H + 2) * (W + 5) * 4);
     float* part = (float*)p; p += al256((size_t)split_ws * nW * 4);
     float* pbias = (float*)p; p += al256((size_t)std::max(split_ws, DB_SPLIT) * Co * 4);
     float* gpbuf = (float*)p; p += al256((size_t)B * Co * H * W * 4);
     const bool b16 = bf16_path(C0, C1, up0 ? 1 : 0, H, W) && wino_gp_ok(B, Co, H, W, act);
+    // (the bf16 weight-gradient kernel tiles 64 output channels: the thin 16 / 32-channel levels keep the fp32 direct kernel)
+    const bool b16_dw = b16 && Co >= 64;
     const bool w_dx = !b16 && (dx0 || dx1) && wino_dx(C0, C1, B, Co, H, W, act);
     const bool w_dw = !b16 && dweight && wino_dw(C0, C1, B, Co, H, W, act);
+    // bias gradient from the same pass that forms g' (whole float4s per channel plane)
+    const bool fused_db = dbias && (w_dw || b16_dw) && (H * W) % 4 == 0;
     void* wws = p; if (wino_dx(C0, C1, B, Co, H, W, ACT_NONE)) p += al256(wino_conv_ws_bytes(B, Cin, Co, H, W));
     void* gws = p; if (wino_dw(C0, C1, B, Co, H, W, ACT_NONE)) p += al256(wino_wgrad_ws_bytes(B, Cin, Co, H, W));
-    float* pb2 = (float*)p;
+    float* pb2 = (float*)p; if (wino_dw(C0, C1, B, Co, H, W, ACT_NONE)) p += al256((size_t)DB_SPLIT * Co * 4);
+    float* pbd = (float*)p;
     const int tiles_x = ceil_div(W, CT), tiles_y = ceil_div(H, CT);
     // fast path (v2 kernels): full 16-wide tiles, 16-byte aligned rows, chunks that do not straddle the concat
     const bool fast = (W % 16 == 0) && (C1 == 0 || C0 % CK == 0) && (C1 == 0 || C0 % CW == 0);
     const float* gp = gy;
-    if ((fast || w_dx || w_dw || b16) && act != ACT_NONE && ((size_t)B * Co * H * W) % 4 == 0) {
+    if (fused_db) {
+        hipLaunchKernelGGL(conv_gprime_dbias_kernel, dim3(Co, gpd_split(Co)), dim3(256), 0, ST, gy, y, gpbuf, pbd, B, Co, H * W / 4, act,
+                           gpd_split(Co));
+        DC_CHECK_LAUNCH();
+        if (act != ACT_NONE) gp = gpbuf;
+    } else if ((fast || w_dx || w_dw || b16) && act != ACT_NONE && ((size_t)B * Co * H * W) % 4 == 0) {
         const size_t n4 = (size_t)B * Co * H * W / 4;
         hipLaunchKernelGGL(conv_gprime_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, ST, gy, y,
                            gpbuf, n4, act);
@@ -970,7 +1011,7 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
             if (rc != DC_OK) return rc;
             const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
             hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0, C1,
-                               up0 ? 1 : 0, H, W, pad_mode);
+                               up0 ? 1 : 0, H, W, pad_mode, c3b_dpad_pitch(W));
             DC_CHECK_LAUNCH();
         }
     } else if (w_dx) {
@@ -979,7 +1020,7 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
         if (rc != DC_OK) return rc;
         const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
         hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0, C1,
-                           up0 ? 1 : 0, H, W, pad_mode);
+                           up0 ? 1 : 0, H, W, pad_mode, W + 2);
         DC_CHECK_LAUNCH();
     } else if (dx0 || dx1) {
         hipLaunchKernelGGL(conv_wprep_kernel, dim3(ceil_div((int)nW, 256)), dim3(256), 0, ST, weight, (float*)nullptr, wd,
@@ -1003,10 +1044,10 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
         DC_CHECK_LAUNCH();
         const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
         hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0,
-                           C1, up0 ? 1 : 0, H, W, pad_mode);
+                           C1, up0 ? 1 : 0, H, W, pad_mode, W + 2);
         DC_CHECK_LAUNCH();
     }
-    if (b16 && (dweight || dbias)) {
+    if (b16_dw && (dweight || dbias)) {
         if (dweight) {
             const int sp = c3b_wgrad_split(B, H, W, Co, Cin, 1);
             int rc = c3b_wgrad(x0, C0, up0 ? 1 : 0, x1, C1, gp, part, sp, B, Co, H, W, pad_mode, 1, ST);
@@ -1014,7 +1055,10 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
             rc = conv_wreduce(part, nullptr, dweight, nullptr, sp, (int)nW, 0, ST);
             if (rc != DC_OK) return rc;
         }
-        if (dbias) {
+        if (dbias && fused_db) {
+            const int rc = conv_wreduce(nullptr, pbd, nullptr, dbias, gpd_split(Co), 0, Co, ST);
+            if (rc != DC_OK) return rc;
+        } else if (dbias) {
             hipLaunchKernelGGL(conv_dbias_kernel, dim3(Co, DB_SPLIT), dim3(256), 0, ST, gp, pbias, B, Co, H * W);
             DC_CHECK_LAUNCH();
             const int rc = conv_wreduce(nullptr, pbias, nullptr, dbias, DB_SPLIT, 0, Co, ST);
@@ -1023,7 +1067,10 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     } else if (w_dw) {
         const int rc = wino_wgrad_fused(x0, C0, up0 ? 1 : 0, x1, C1, pad_mode, gp, dweight, gws, B, Co, H, W, ST);
         if (rc != DC_OK) return rc;
-        if (dbias) {
+        if (dbias && fused_db) {
+            const int rc2 = conv_wreduce(nullptr, pbd, nullptr, dbias, gpd_split(Co), 0, Co, ST);
+            if (rc2 != DC_OK) return rc2;
+        } else if (dbias) {
             hipLaunchKernelGGL(conv_dbias_kernel, dim3(Co, DB_SPLIT), dim3(256), 0, ST, gp, pb2, B, Co, H * W);
             DC_CHECK_LAUNCH();
             hipLaunchKernelGGL(conv_wreduce_kernel, dim3(ceil_div(Co, 16)), dim3(256), 0, ST, (const float*)nullptr, pb2,

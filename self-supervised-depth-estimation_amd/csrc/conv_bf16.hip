@@ -10,7 +10,9 @@
 // (no Winograd transform, no row-combine epilogue): what bounds them is reading fp32 operands from HBM.
 //
 //   forward / data gradient (c3b_conv_kernel): M = output channels, N = pixels, K = 9 taps x input channels.
-//     A block owns a 16 x 16 (stride 2: 8 x 16) pixel tile x 16*MR output channels; per chunk of 32 input channels the
+//     A block owns an 8 x 32 (stride 2: 4 x 32) pixel tile x 16*MR output channels -- 32 pixels wide so that every row
+//     segment it loads or stores is a whole 128-byte line (16-pixel tiles moved half lines: each line crossed HBM twice and
+//     the kernels sat at 2.2 TB/s); per chunk of 32 input channels the
 //     input patch is staged ONCE as a channel-contiguous bf16 image [pixel][32 ch (+8 pad)] -- the fp32 -> bf16 rounding,
 //     the nearest-x2 upsample, the channel concat and the reflection / zero padding are all index arithmetic of the staging
 //     (16-byte global loads, channel pairs packed by v_cvt_pk_bf16_f32).  One MFMA consumes one tap of all 32 channels: the B
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void c3b_wprep_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // staging of one 32-channel chunk of the input patch:  global fp32 (NCHW) -> registers -> LDS bf16 [pixel][BPX]
-//   S     convolution stride (1 | 2); the patch covers ((TH-1)*S + 3) x (15*S + 3) input pixels
+//   S     convolution stride (1 | 2); the tile is TH x 32 outputs, the patch ((TH-1)*S + 3) x (31*S + 3) input pixels
 //   DPAD  the patch origin is the output tile origin - 2 and out-of-range pixels are zero (data gradient over the padded
 //         domain); otherwise origin - 1 with reflection / zero padding, fused upsample and concat
 // A thread item = (channel pair, patch row, aligned 4-column group) -> two 16-byte loads -> four packed dwords.
@@ -98,13 +100,30 @@ struct PatchSrc {
     int H, W, pad;          // full-resolution input maps
     int dil;                // up0 = 1 only: x0 is DILATED instead of repeated -- full[2y][2x] = x0[y][x], zero elsewhere (the
                             // data gradient of a stride-2 convolution is a stride-1 convolution over the dilated g')
+    unsigned bytes0, bytes1;    // sizes of x0 / x1 (< 2 GiB: the loads are buffer loads with 32-bit offsets)
 };
+
+// Every global load of the staging is a BUFFER load whose offset is either the element's or one past the end of the
+// buffer (the hardware returns 0 for it): padding, tile overhang and ragged item counts need no branch.  A branch around a
+// load makes the compiler wait for that load at the join -- the first version of this file did, and ran its 30 loads per
+// chunk one after the other (13 k cycles per chunk instead of 2.3 k).
+using brsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ brsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ld128(brsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ float ld32(brsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
 
 template <int S, int TH, bool DPAD, int NTHR = 256>
 struct PatchStager {
-    static constexpr int PH = (TH - 1) * S + 3, PW = 15 * S + 3;
+    static constexpr int PH = (TH - 1) * S + 3, PW = 31 * S + 3;
     static constexpr int OFF = DPAD ? 2 : 1;
-    static constexpr int NQ = 4 * S;                              // aligned quads per patch row
+    static constexpr int NQ = 8 * S;                              // aligned quads per patch row
     static constexpr int NE = (S == 1) ? 2 : 1;                   // edge columns per patch row
     static constexpr int NIT = (16 * PH * NQ + NTHR - 1) / NTHR;
     static constexpr int NEI = (16 * PH * NE + NTHR - 1) / NTHR;
@@ -116,79 +135,79 @@ struct PatchStager {
     __device__ __forceinline__ static int edge_col(int e) { return S == 1 ? (DPAD ? e : e * (PW - 1)) : 0; }
 
     __device__ __forceinline__ void prefetch(const PatchSrc& s, int k0, int b, int iy0, int ix0, int tid) {
-        // (iy0, ix0) = input coordinates of patch pixel (0, OFF): ix0 is a multiple of 16
+        // (iy0, ix0) = input coordinates of patch pixel (0, OFF): ix0 is a multiple of 32
         const int K = s.C0 + s.C1;
         const bool upmode = !DPAD && s.up0 && k0 < s.C0;          // this chunk lives in the half-resolution x0
+        const bool from1 = k0 >= s.C0;                            // ... or in x1 (chunks never straddle the concat)
         const int quads = upmode ? NQ / 2 : NQ;
         const int h0 = s.H >> s.up0, w0 = s.W >> s.up0;
+        const brsrc_t rs = from1 ? make_rsrc(s.x1, s.bytes1) : make_rsrc(s.x0, s.bytes0);
+        const int Csrc = from1 ? s.C1 : s.C0, cbase = from1 ? s.C0 : 0;
+        const int sw = from1 ? s.W : w0;                          // row length / plane size of the source
+        const unsigned plane = (unsigned)((from1 ? s.H : h0) * sw);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
+            // consecutive lanes = consecutive channel pairs of one quad: their LDS dwords are consecutive (the commit is free of
+            // bank conflicts; with the quad index fastest 64 lanes hit 8 banks) and 4 lanes still read 64 contiguous bytes
             const int it = tid + i * NTHR;
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-            if (it < 16 * PH * quads) {
-                const int q = it % quads, r = (it / quads) % PH, cp = it / (quads * PH);
-                const int ch = k0 + 2 * cp;
-                bool oky;
-                int yy = iy0 + r;
-                if (DPAD) oky = yy >= 0 && yy < s.H;
-                else yy = pad_index_b(yy, s.H, s.pad, oky);
-                const int xx = ix0 + 4 * q * (upmode ? 2 : 1);
-                if (upmode && s.dil && (yy & 1)) oky = false;          // odd rows of a dilated map are zero
-                if (oky && xx < s.W && ch < K) {
-                    const float* p;
-                    size_t plane;
-                    if (upmode) { p = s.x0 + (((size_t)b * s.C0 + ch) * h0 + (yy >> 1)) * w0 + (xx >> 1); plane = (size_t)h0 * w0; }
-                    else if (ch < s.C0) { p = s.x0 + (((size_t)b * s.C0 + ch) * h0 + yy) * w0 + xx; plane = (size_t)h0 * w0; }
-                    else { p = s.x1 + (((size_t)b * s.C1 + (ch - s.C0)) * s.H + yy) * s.W + xx; plane = (size_t)s.H * s.W; }
-                    v0 = *reinterpret_cast<const float4*>(p);
-                    if (ch + 1 < K) v1 = *reinterpret_cast<const float4*>(p + plane);
-                }
-            }
-            rv[i][0] = v0; rv[i][1] = v1;
+            const int cp = it & 15, q = (it >> 4) % quads, r = (it >> 4) / quads;
+            const int ch = k0 + 2 * cp;
+            bool ok = r < PH && ch < K, oky;
+            int yy = iy0 + r;
+            if (DPAD) oky = yy >= 0 && yy < s.H;
+            else yy = pad_index_b(yy, s.H, s.pad, oky);
+            const int xx = ix0 + 4 * q * (upmode ? 2 : 1);
+            ok = ok && oky && xx < s.W && !(upmode && s.dil && (yy & 1));          // (odd rows of a dilated map are zero)
+            const unsigned off = (((unsigned)(b * Csrc + (ch - cbase)) * plane) +
+                                  (unsigned)((upmode ? (yy >> 1) : yy) * sw + (upmode ? (xx >> 1) : xx))) * 4u;
+            rv[i][0] = ld128(rs, ok ? off : OOB);
+            rv[i][1] = ld128(rs, (ok && ch + 1 < K) ? off + plane * 4u : OOB);
         }
 #pragma unroll
         for (int i = 0; i < NEI; ++i) {
             const int it = tid + i * NTHR;
-            float e0 = 0.f, e1 = 0.f;
-            if (it < 16 * PH * NE) {
-                const int e = it % NE, r = (it / NE) % PH, cp = it / (NE * PH);
-                const int ch = k0 + 2 * cp;
-                bool oky, okx;
-                int yy = iy0 + r;
-                int xx = ix0 - OFF + edge_col(e);
-                if (DPAD) { oky = yy >= 0 && yy < s.H; okx = xx >= 0 && xx < s.W; }
-                else { yy = pad_index_b(yy, s.H, s.pad, oky); xx = pad_index_b(xx, s.W, s.pad, okx); }
-                if (s.dil && ch < s.C0 && ((yy | xx) & 1)) oky = false;
-                if (oky && okx && ch < K) {
-                    const float* p;
-                    size_t plane;
-                    if (ch < s.C0) { p = s.x0 + (((size_t)b * s.C0 + ch) * h0 + (yy >> s.up0)) * w0 + (xx >> s.up0); plane = (size_t)h0 * w0; }
-                    else { p = s.x1 + (((size_t)b * s.C1 + (ch - s.C0)) * s.H + yy) * s.W + xx; plane = (size_t)s.H * s.W; }
-                    e0 = p[0];
-                    if (ch + 1 < K) e1 = p[plane];
-                }
-            }
-            re[i][0] = e0; re[i][1] = e1;
+            const int cp = it & 15, e = (it >> 4) % NE, r = (it >> 4) / NE;
+            const int ch = k0 + 2 * cp;
+            bool ok = r < PH && ch < K, oky, okx;
+            int yy = iy0 + r;
+            int xx = ix0 - OFF + edge_col(e);
+            if (DPAD) { oky = yy >= 0 && yy < s.H; okx = xx >= 0 && xx < s.W; }
+            else { yy = pad_index_b(yy, s.H, s.pad, oky); xx = pad_index_b(xx, s.W, s.pad, okx); }
+            ok = ok && oky && okx && !(upmode && s.dil && ((yy | xx) & 1));
+            const unsigned off = (((unsigned)(b * Csrc + (ch - cbase)) * plane) +
+                                  (unsigned)((upmode ? (yy >> 1) : yy) * sw + (upmode ? (xx >> 1) : xx))) * 4u;
+            re[i][0] = ld32(rs, ok ? off : OOB);
+            re[i][1] = ld32(rs, (ok && ch + 1 < K) ? off + plane * 4u : OOB);
         }
     }
 
-    __device__ __forceinline__ void commit(const PatchSrc& s, int k0, unsigned* img, int tid) const {
+    __device__ __forceinline__ void commit(const PatchSrc& s, int k0, unsigned* img, int ix0, int tid) const {
         const bool upmode = !DPAD && s.up0 && k0 < s.C0;
         const int quads = upmode ? NQ / 2 : NQ;
+        const int qw = upmode ? 8 : 4;
+        // A tile may hang over the right border (W % 32 != 0).  Its outside quads were loaded as zeros; the one value ever
+        // read out there is ReflectionPad's column W (= column W-2): the thread holding the last inside quad stores it.
+        const bool refl_over = !DPAD && s.pad == PAD_REFLECT && !s.dil && ix0 + 32 * S > s.W;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int it = tid + i * NTHR;
             if (it < 16 * PH * quads) {
-                const int q = it % quads, r = (it / quads) % PH, cp = it / (quads * PH);
+                const int cp = it & 15, q = (it >> 4) % quads, r = (it >> 4) / quads;
                 const float4 a = rv[i][0], c = rv[i][1];
                 const unsigned p0 = pack_bf16(a.x, c.x), p1 = pack_bf16(a.y, c.y), p2 = pack_bf16(a.z, c.z), p3 = pack_bf16(a.w, c.w);
-                unsigned* dst = img + (r * PW + OFF + (upmode ? 8 : 4) * q) * (BPX / 2) + cp;
+                unsigned* dst = img + (r * PW + OFF + qw * q) * (BPX / 2) + cp;
+                const int xx = ix0 + qw * q;
+                const bool keep0 = !(refl_over && xx == s.W);
                 if (upmode) {
                     const bool rep = !s.dil;                           // nearest x2: every value twice; dilation: value, zero
-                    dst[0] = p0; dst[BPX / 2] = rep ? p0 : 0u; dst[2 * (BPX / 2)] = p1; dst[3 * (BPX / 2)] = rep ? p1 : 0u;
+                    if (keep0) dst[0] = p0;
+                    dst[BPX / 2] = rep ? p0 : 0u; dst[2 * (BPX / 2)] = p1; dst[3 * (BPX / 2)] = rep ? p1 : 0u;
                     dst[4 * (BPX / 2)] = p2; dst[5 * (BPX / 2)] = rep ? p2 : 0u; dst[6 * (BPX / 2)] = p3; dst[7 * (BPX / 2)] = rep ? p3 : 0u;
+                    if (refl_over && xx + 8 == s.W) dst[8 * (BPX / 2)] = p3;
                 } else {
-                    dst[0] = p0; dst[BPX / 2] = p1; dst[2 * (BPX / 2)] = p2; dst[3 * (BPX / 2)] = p3;
+                    if (keep0) dst[0] = p0;
+                    dst[BPX / 2] = p1; dst[2 * (BPX / 2)] = p2; dst[3 * (BPX / 2)] = p3;
+                    if (refl_over && xx + 4 == s.W) dst[4 * (BPX / 2)] = p2;
                 }
             }
         }
@@ -196,7 +215,7 @@ struct PatchStager {
         for (int i = 0; i < NEI; ++i) {
             const int it = tid + i * NTHR;
             if (it < 16 * PH * NE) {
-                const int e = it % NE, r = (it / NE) % PH, cp = it / (NE * PH);
+                const int cp = it & 15, e = (it >> 4) % NE, r = (it >> 4) / NE;
                 img[(r * PW + edge_col(e)) * (BPX / 2) + cp] = pack_bf16(re[i][0], re[i][1]);
             }
         }
@@ -212,7 +231,7 @@ struct C3bArgs {
     const float* bias;
     float* out;             // (B, M, OH, OW)
     int B, M, K;            // M output channels, K = C0 + C1 reduction channels
-    int OH, OW;
+    int OH, OW, opitch;     // output maps; row pitch of `out` in floats (multiple of 4)
     int act;
     int tiles_x, tiles_y, mblocks, nchunks;
 };
@@ -220,7 +239,7 @@ struct C3bArgs {
 template <int MR, int S, bool DPAD>
 __global__ __launch_bounds__(256, 2) void c3b_conv_kernel(C3bArgs a) {
     constexpr int MT = 16 * MR;
-    constexpr int TH = S == 1 ? 16 : 8, RWV = TH / 4;
+    constexpr int TH = S == 1 ? 8 : 4, RWV = TH / 2;              // RWV: 16-pixel groups per wave (wave = TH/4 rows x two halves)
     using Stager = PatchStager<S, TH, DPAD>;
     constexpr int PW = Stager::PW;
     constexpr int NWI = (36 * MT + 255) / 256;                    // 16-byte weight items per thread and chunk
@@ -235,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void c3b_conv_kernel(C3bArgs a) {
     const int ntiles = a.tiles_x * a.tiles_y;
     const int tile = rest % ntiles, b = rest / ntiles;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int oy0 = ty * TH, ox0 = tx * 32;
     const int m0 = mblk * MT;
     const int iy0 = oy0 * S - Stager::OFF, ix0 = ox0 * S;
 
@@ -247,12 +266,12 @@ __global__ __launch_bounds__(256, 2) void c3b_conv_kernel(C3bArgs a) {
 
     Stager st;
     uint4 rw[NWI];
-    const uint4* wsrc = a.wb + (size_t)mblk * a.nchunks * 36 * MT;
+    const brsrc_t wr = make_rsrc(a.wb + (size_t)mblk * a.nchunks * 36 * MT, (unsigned)(a.nchunks * 36 * MT * 16));
     auto prefetch_w = [&](int c) {
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
             const int it = tid + i * 256;
-            rw[i] = it < 36 * MT ? wsrc[(size_t)c * 36 * MT + it] : make_uint4(0, 0, 0, 0);
+            rw[i] = __builtin_bit_cast(uint4, ld128(wr, it < 36 * MT ? (unsigned)((c * 36 * MT + it) * 16) : OOB));
         }
     };
     auto commit_w = [&]() {
@@ -263,18 +282,26 @@ __global__ __launch_bounds__(256, 2) void c3b_conv_kernel(C3bArgs a) {
         }
     };
 
-    st.prefetch(a.src, 0, b, iy0, ix0, tid);
+#ifndef C3B_ABL
+#define C3B_ABL 0          // diagnostic builds only (tools/abl_bf16.sh): 1 no MFMA, 2 no LDS commit, 4 no stores, 8 no patch loads
+#endif
+    if (!(C3B_ABL & 8)) st.prefetch(a.src, 0, b, iy0, ix0, tid);
     prefetch_w(0);
     const __bf16* pim = reinterpret_cast<const __bf16*>(img);
     for (int c = 0; c < a.nchunks; ++c) {
         __syncthreads();                       // the previous chunk's MFMAs are done with the LDS images
-        st.commit(a.src, c * BC, img, tid);
-        commit_w();
+        if (!(C3B_ABL & 2)) {
+            st.commit(a.src, c * BC, img, ix0, tid);
+            commit_w();
+        } else {
+            asm volatile("" :: "v"(st.rv[0][0].x), "v"(st.rv[Stager::NIT - 1][1].w), "v"(rw[0].x), "v"(rw[NWI - 1].w), "v"(st.re[0][0]));
+        }
         __syncthreads();
         if (c + 1 < a.nchunks) {
-            st.prefetch(a.src, (c + 1) * BC, b, iy0, ix0, tid);
+            if (!(C3B_ABL & 8)) st.prefetch(a.src, (c + 1) * BC, b, iy0, ix0, tid);
             prefetch_w(c + 1);
         }
+        if (C3B_ABL & 1) continue;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ky = t / 3, kx = t - ky * 3;
@@ -282,31 +309,43 @@ __global__ __launch_bounds__(256, 2) void c3b_conv_kernel(C3bArgs a) {
 #pragma unroll
             for (int i = 0; i < MR; ++i) af[i] = __builtin_bit_cast(bf8, wl[(t * 4 + kk) * MT + i * 16 + n]);
 #pragma unroll
-            for (int j = 0; j < RWV; ++j)
-                bfr[j] = *reinterpret_cast<const bf8*>(pim + ((S * (wave * RWV + j) + ky) * PW + S * n + kx) * BPX + kk * 8);
+            for (int j = 0; j < RWV; ++j)          // group j of the wave: tile row wave * TH/4 + j/2, columns 16 (j & 1) .. +15
+                bfr[j] = *reinterpret_cast<const bf8*>(pim + ((S * (wave * (TH / 4) + (j >> 1)) + ky) * PW + S * (16 * (j & 1) + n) + kx) * BPX + kk * 8);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < RWV; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < RWV; ++j)      // D[pixel][channel] = patch fragment (A) x weight fragment (B): see the epilogue
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
-    // ---- epilogue: C/D layout col (pixel x) = lane & 15, row (m) = (lane >> 4) * 4 + reg
-    const int px = ox0 + n;
+    // ---- epilogue.  The pixel index is the ROW of the MFMA result (the patch fragment is the A operand), so a lane holds 4
+    // consecutive pixels of one output channel: C/D layout col (channel) = lane & 15, row (pixel) = (lane >> 4) * 4 + reg.
+    // One 16-byte store per lane and accumulator tile (dword stores, four planes per instruction, cost as much as all the rest
+    // of the kernel on the wide thin decoder levels).  bias + activation first, stores afterwards: a store behind a pending
+    // load makes the compiler wait for everything outstanding.
+    float bv[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        const int m = m0 + i * 16 + n;
+        bv[i] = (!DPAD && a.bias && m < a.M) ? a.bias[m] : 0.f;
+    }
+    if (!DPAD) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < RWV; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv[i], a.act);
+    }
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < RWV; ++j) {
-            const int py = oy0 + wave * RWV + j;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + i * 16 + kk * 4 + r;
-                if (m < a.M && py < a.OH && px < a.OW) {
-                    float v = acc[i][j][r];
-                    if (!DPAD) v = act_fwd(v + (a.bias ? a.bias[m] : 0.f), a.act);
-                    a.out[(((size_t)b * a.M + m) * a.OH + py) * a.OW + px] = v;
-                }
-            }
+            const int py = oy0 + wave * (TH / 4) + (j >> 1), px = ox0 + 16 * (j & 1) + 4 * kk;
+            const int m = m0 + i * 16 + n;
+            // (a.opitch: row pitch of `out`, a multiple of 4 -- OW, or OW rounded up for the padded domain)
+            if (!(C3B_ABL & 4) && m < a.M && py < a.OH && px < a.opitch)
+                *reinterpret_cast<f4*>(a.out + (((size_t)b * a.M + m) * a.OH + py) * a.opitch + px) = acc[i][j];
         }
 }
 
@@ -319,17 +358,18 @@ struct C3bWgArgs {
     PatchSrc src;
     const float* gp;        // g' = gy * act'(y): (B, Co, OH, OW)
     float* part;            // [split][Co][Cin*9]
+    unsigned gbytes;
     int B, Co, OH, OW;
     int tiles_x, tiles_y, split;
 };
 
 template <int S>
 __global__ __launch_bounds__(512, 2) void c3b_wgrad_kernel(C3bWgArgs a) {
-    constexpr int TH = S == 1 ? 16 : 8;
+    constexpr int TH = S == 1 ? 8 : 4;
     using Stager = PatchStager<S, TH, false, 512>;
     constexpr int PW = Stager::PW;
-    constexpr int GLS = TH * 16 + 8;                               // g' row stride in bf16 (528-byte rows: conflict-free b128 reads)
-    constexpr int NG = (64 * TH * 4) / 512;                        // float4 items of the g' tile per thread
+    constexpr int GLS = TH * 32 + 8;                               // g' row stride in bf16 (rows of 16 (2n+1) bytes: conflict-free b128 reads)
+    constexpr int NG = (64 * TH * 8) / 512;                        // float4 items of the g' tile per thread
     __shared__ __attribute__((aligned(16))) unsigned img[Stager::LDS_ELEMS / 2];
     __shared__ __attribute__((aligned(16))) unsigned gl[64 * GLS / 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -346,47 +386,50 @@ __global__ __launch_bounds__(512, 2) void c3b_wgrad_kernel(C3bWgArgs a) {
 
     Stager st;
     float4 rg[NG];
+    const brsrc_t gr = make_rsrc(a.gp, a.gbytes);
+    int cur_ix0 = 0;
     auto prefetch = [&](int tile) {
         const int b = tile / per_img, tt = tile - b * per_img;
         const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
-        const int oy0 = ty * TH, ox0 = tx * 16;
+        const int oy0 = ty * TH, ox0 = tx * 32;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int it = tid + i * 512;
-            const int q = it & 3, r = (it >> 2) % TH, m = it / (4 * TH);
+            const int q = it & 7, r = (it >> 3) % TH, m = it / (8 * TH);
             const int co = m0 + m, yy = oy0 + r, xx = ox0 + 4 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < a.Co && yy < a.OH && xx < a.OW) v = *reinterpret_cast<const float4*>(a.gp + (((size_t)b * a.Co + co) * a.OH + yy) * a.OW + xx);
-            rg[i] = v;
+            const bool ok = co < a.Co && yy < a.OH && xx < a.OW;
+            rg[i] = ld128(gr, ok ? (unsigned)((((b * a.Co + co) * a.OH + yy) * a.OW + xx) * 4) : OOB);
         }
         st.prefetch(a.src, c0, b, oy0 * S - 1, ox0 * S, tid);
+        return ox0 * S;
     };
     auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int it = tid + i * 512;
-            const int q = it & 3, r = (it >> 2) % TH, m = it / (4 * TH);
+            const int q = it & 7, r = (it >> 3) % TH, m = it / (8 * TH);
             const float4 v = rg[i];
-            *reinterpret_cast<uint2*>(gl + (m * GLS + r * 16 + 4 * q) / 2) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+            *reinterpret_cast<uint2*>(gl + (m * GLS + r * 32 + 4 * q) / 2) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
         }
-        st.commit(a.src, c0, img, tid);
+        st.commit(a.src, c0, img, cur_ix0, tid);
     };
 
     const __bf16* gim = reinterpret_cast<const __bf16*>(gl);
     const short* xim = reinterpret_cast<const short*>(img);
     // transposed read of the B operand: lane 4q+p of a 16-lane group supplies the address of pixel row q, channels 4p..4p+3
     const int tq = n >> 2, tp = n & 3;
-    int tile = blockIdx.x;
-    if (tile < ntiles) prefetch(tile);
+    int tile = blockIdx.x, nxt_ix0 = 0;
+    if (tile < ntiles) nxt_ix0 = prefetch(tile);
     for (; tile < ntiles; tile += a.split) {
         __syncthreads();
+        cur_ix0 = nxt_ix0;
         commit();
         __syncthreads();
-        if (tile + a.split < ntiles) prefetch(tile + a.split);
+        if (tile + a.split < ntiles) nxt_ix0 = prefetch(tile + a.split);
 #pragma unroll 2
-        for (int s = 0; s < TH / 2; ++s) {
-            const int trow = 2 * s + (kk >> 1), tcol = 8 * (kk & 1);           // first of this lane's 8 output pixels
-            const bf8 af = *reinterpret_cast<const bf8*>(gim + (cw * 16 + n) * GLS + trow * 16 + tcol);
+        for (int s = 0; s < TH; ++s) {                                         // one tile row (32 pixels) per MFMA
+            const int trow = s, tcol = 8 * kk;                                 // first of this lane's 8 output pixels
+            const bf8 af = *reinterpret_cast<const bf8*>(gim + (cw * 16 + n) * GLS + trow * 32 + tcol);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int ky = t / 3, kx = t - ky * 3;
@@ -417,9 +460,10 @@ static inline size_t al256b(size_t v) { return (v + 255) & ~(size_t)255; }
 static inline int c3b_mr(int M) { return M > 32 ? 4 : (M > 16 ? 2 : 1); }
 
 bool c3b_eligible(int C0, int C1, int up0, int H, int W, int stride) {
-    // 16-byte staging: rows of 16 output pixels, chunks that do not straddle the concat, channel pairs inside one source
-    if (stride == 1) return W % 16 == 0 && H >= 2 && (C1 == 0 || C0 % BC == 0) && (!up0 || ((H | W) & 1) == 0);
-    return stride == 2 && W % 32 == 0 && H % 2 == 0 && C1 == 0 && !up0;
+    // 16-byte staging: whole quads inside a row (W % 4; W % 8 when x0 is read at half resolution), chunks that do not
+    // straddle the concat, channel pairs inside one source
+    if (stride == 1) return W % 4 == 0 && W >= 4 && H >= 2 && (C1 == 0 || C0 % BC == 0) && (!up0 || (W % 8 == 0 && (H & 1) == 0));
+    return stride == 2 && W % 8 == 0 && H % 2 == 0 && C1 == 0 && !up0;
 }
 
 size_t c3b_weights_bytes(int Ci, int Co) {
@@ -429,9 +473,11 @@ size_t c3b_weights_bytes(int Ci, int Co) {
     return al256b(std::max(fwd, dg));
 }
 
+int c3b_dpad_pitch(int W) { return (W + 2 + 3) & ~3; }
+
 int c3b_wgrad_split(int B, int OH, int OW, int Co, int Cin, int stride) {
-    const int TH = stride == 1 ? 16 : 8;
-    const int ntiles = ceil_div(OW, 16) * ceil_div(OH, TH) * B;
+    const int TH = stride == 1 ? 8 : 4;
+    const int ntiles = ceil_div(OW, 32) * ceil_div(OH, TH) * B;
     const int outer = ceil_div(Co, 64) * ceil_div(Cin, BC);
     int split = std::max(1, std::min(ntiles, 1024 / std::max(outer, 1)));
     split = std::min(split, std::max(1, ntiles / 2));
@@ -452,11 +498,14 @@ int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const fl
     hipLaunchKernelGGL(c3b_wprep_kernel, dim3(ceil_div(nitems, 256)), dim3(256), 0, st, weight, wb, Co, Cin, dgrad, MT, mblocks, nchunks);
     DC_CHECK_LAUNCH();
     C3bArgs a{};
-    a.src = PatchSrc{x0, C0, up0 & 1, x1, C1, H, W, pad, (up0 >> 1) & 1};
+    const size_t e0 = (size_t)B * C0 * (H >> (up0 & 1)) * (W >> (up0 & 1)) * 4, e1 = (size_t)B * C1 * H * W * 4;
+    if (e0 >= 0x7fffffffull || e1 >= 0x7fffffffull) return DC_EINVAL;            // 32-bit buffer offsets
+    a.src = PatchSrc{x0, C0, up0 & 1, x1, C1, H, W, pad, (up0 >> 1) & 1, (unsigned)e0, (unsigned)e1};
     a.wb = wb; a.bias = bias; a.out = out; a.B = B; a.M = M; a.K = K; a.act = act;
     a.OH = dpad ? H + 2 : H / stride; a.OW = dpad ? W + 2 : W / stride;
-    const int TH = stride == 1 ? 16 : 8;
-    a.tiles_x = ceil_div(a.OW, 16); a.tiles_y = ceil_div(a.OH, TH); a.mblocks = mblocks; a.nchunks = nchunks;
+    a.opitch = (a.OW + 3) & ~3;          // padded domain: W + 2 rounded up (c3b_dpad_pitch); otherwise OW itself (W % 4 == 0)
+    const int TH = stride == 1 ? 8 : 4;
+    a.tiles_x = ceil_div(a.OW, 32); a.tiles_y = ceil_div(a.OH, TH); a.mblocks = mblocks; a.nchunks = nchunks;
     const long nblk = (long)a.tiles_x * a.tiles_y * mblocks * B;
     if (nblk > 0x7fffffffL) return DC_EINVAL;
     const dim3 grid((unsigned)nblk);
@@ -485,15 +534,19 @@ int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const fl
 int c3b_wgrad(const float* x0, int C0, int up0, const float* x1, int C1, const float* gp, float* part, int split, int B, int Co, int H,
               int W, int pad, int stride, hipStream_t st) {
     C3bWgArgs a{};
-    a.src = PatchSrc{x0, C0, up0, x1, C1, H, W, pad, 0};
+    const size_t e0 = (size_t)B * C0 * (H >> up0) * (W >> up0) * 4, e1 = (size_t)B * C1 * H * W * 4;
+    const size_t eg = (size_t)B * Co * (H / stride) * (W / stride) * 4;
+    if (e0 >= 0x7fffffffull || e1 >= 0x7fffffffull || eg >= 0x7fffffffull) return DC_EINVAL;      // 32-bit buffer offsets
+    a.src = PatchSrc{x0, C0, up0, x1, C1, H, W, pad, 0, (unsigned)e0, (unsigned)e1};
+    a.gbytes = (unsigned)eg;
     a.gp = gp; a.part = part; a.B = B; a.Co = Co; a.OH = H / stride; a.OW = W / stride;
-    const int TH = stride == 1 ? 16 : 8;
-    a.tiles_x = ceil_div(a.OW, 16); a.tiles_y = ceil_div(a.OH, TH); a.split = split;
+    const int TH = stride == 1 ? 8 : 4;
+    a.tiles_x = ceil_div(a.OW, 32); a.tiles_y = ceil_div(a.OH, TH); a.split = split;
     const dim3 grid(split, ceil_div(Co, 64), ceil_div(C0 + C1, BC));
     const int Cin = C0 + C1;
     const double in_elems = (double)B * ((double)C0 * (H >> up0) * (W >> up0) + (double)C1 * H * W);
     hipEvent_t pe = conv_prof_begin(3, 2.0 * (double)B * Co * Cin * 9.0 * a.OH * a.OW,
-                                    2.0 * (double)a.tiles_x * a.tiles_y * B * TH * 16.0 * (grid.y * 64.0) * (grid.z * 32.0) * 9.0,
+                                    2.0 * (double)a.tiles_x * a.tiles_y * B * TH * 32.0 * (grid.y * 64.0) * (grid.z * 32.0) * 9.0,
                                     4.0 * (in_elems + (double)B * Co * a.OH * a.OW) + 36.0 * Co * Cin, st);
     if (stride == 1) hipLaunchKernelGGL((c3b_wgrad_kernel<1>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((c3b_wgrad_kernel<2>), grid, dim3(512), 0, st, a);

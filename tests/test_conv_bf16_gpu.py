@@ -46,6 +46,9 @@ CASES = [
     (1, 64, 1, 64, 64, 20, 32, "elu", "reflect", True),     # H not a multiple of the tile
     (2, 32, 0, 0, 80, 16, 16, "relu", "zero", True),        # Co not a multiple of the channel block (pose-decoder style)
     (1, 4, 0, 0, 4, 16, 32, "tanh", "zero", True),          # Fusion_v3's tiny convolutions
+    (2, 256, 0, 0, 128, 12, 40, "elu", "reflect", True),    # W % 16 != 0: the last tile hangs over the border (192x640 pyramid)
+    (2, 128, 1, 128, 64, 12, 40, "elu", "reflect", True),   # ... with the upsampled half read at W / 2 = 20
+    (1, 512, 0, 0, 64, 6, 20, "none", "zero", False),       # the deepest trunk map
 ]
 
 
@@ -105,7 +108,7 @@ def test_block_forward_and_backward_exact_vs_rounded_operand_oracle(case):
         assert rel_l2(a, c) < (1e-1 if act == "relu" else 2e-2)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 64, 24, 32), (1, 128, 256, 12, 16), (2, 512, 512, 6, 16)])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 24, 32), (1, 128, 256, 12, 16), (2, 512, 512, 6, 16), (2, 256, 256, 12, 40), (1, 512, 512, 6, 20)])
 def test_trunk_entry_points_under_bf16(shape):
     """dc_wino3x3_fwd / _dgrad / _wgrad (the ResNet trunks' stride-1 3x3) route to the bf16 kernels under the policy."""
     from depthcore import ops
@@ -146,7 +149,7 @@ def test_bf16_block_is_deterministic_at_full_size():
         assert torch.equal(a, c) and torch.isfinite(a).all()
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 128, 32, 64), (1, 128, 256, 24, 32), (2, 256, 512, 8, 32)])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 32, 64), (1, 128, 256, 24, 32), (2, 256, 512, 8, 32), (2, 128, 256, 24, 80), (1, 256, 512, 12, 40)])
 def test_stride2_3x3_under_bf16(shape):
     """The trunk's 3x3 / 2 convolutions (dc_convs2_*): forward and weight gradient are the stride-2 instantiation of the
     bf16 kernels, the data gradient is the stride-1 kernel over the DILATED output gradient (zeros between the samples)."""
