@@ -423,16 +423,31 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(ConvArgs a) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fold_at(const float* p, int r, int c, int H, int W, int pad, int PWd) {
     // padded coordinates that map onto (r, c): itself, and with ReflectionPad the mirror row (-1 onto 1, H onto H-2) and the
-    // mirror column.  Branch-free: the mirror terms are always loaded (from the pixel itself when there is none) and
-    // weighted 0 / 1 -- data-dependent branches around the loads made every load wait for the previous one.
-    // (H == 3 would need three sources per axis; H, W >= 4 is enforced by the entry point)
-    const bool refl = pad == PAD_REFLECT;
-    const bool fr = refl && (r == 1 || r == H - 2), fc = refl && (c == 1 || c == W - 2);
-    const int mr = fr ? (r == 1 ? -1 : H) : r, mc = fc ? (c == 1 ? -1 : W) : c;
-    const float* row0 = p + (size_t)(r + 1) * PWd + 1;
-    const float* row1 = p + (size_t)(mr + 1) * PWd + 1;
-    const float v00 = row0[c], v01 = row0[mc], v10 = row1[c], v11 = row1[mc];
-    return v00 + (fc ? v01 : 0.f) + (fr ? v10 : 0.f) + ((fr && fc) ? v11 : 0.f);
+    // mirror column.
+    if (H >= 4 && W >= 4) {
+        // Branch-free: the mirror terms are always loaded (from the pixel itself when there is none) and weighted 0 / 1 --
+        // data-dependent branches around the loads made every load wait for the previous one.
+        const bool refl = pad == PAD_REFLECT;
+        const bool fr = refl && (r == 1 || r == H - 2), fc = refl && (c == 1 || c == W - 2);
+        const int mr = fr ? (r == 1 ? -1 : H) : r, mc = fc ? (c == 1 ? -1 : W) : c;
+        const float* row0 = p + (size_t)(r + 1) * PWd + 1;
+        const float* row1 = p + (size_t)(mr + 1) * PWd + 1;
+        const float v00 = row0[c], v01 = row0[mc], v10 = row1[c], v11 = row1[mc];
+        return v00 + (fc ? v01 : 0.f) + (fr ? v10 : 0.f) + ((fr && fc) ? v11 : 0.f);
+    }
+    // tiny maps (H or W of 2 or 3): row 1 can be the mirror target of both borders -- up to three sources per axis
+    int rs[3], cs[3], nr = 1, nc = 1;
+    rs[0] = r; cs[0] = c;
+    if (pad == PAD_REFLECT) {
+        if (r == 1) rs[nr++] = -1;
+        if (r == H - 2) rs[nr++] = H;
+        if (c == 1) cs[nc++] = -1;
+        if (c == W - 2) cs[nc++] = W;
+    }
+    float v = 0.f;
+    for (int i = 0; i < nr; ++i)
+        for (int j = 0; j < nc; ++j) v += p[(size_t)(rs[i] + 1) * PWd + cs[j] + 1];
+    return v;
 }
 
 // `pitch`: row pitch of dxpad in floats (W + 2, or c3b_dpad_pitch(W) behind the bf16 kernels)

@@ -479,9 +479,10 @@ int c3b_wgrad_split(int B, int OH, int OW, int Co, int Cin, int stride) {
     const int TH = stride == 1 ? 8 : 4;
     const int ntiles = ceil_div(OW, 32) * ceil_div(OH, TH) * B;
     const int outer = ceil_div(Co, 64) * ceil_div(Cin, BC);
-    int split = std::max(1, std::min(ntiles, 1024 / std::max(outer, 1)));
-    split = std::min(split, std::max(1, ntiles / 2));
-    return std::min(split, 512);
+    // one round of 512-thread blocks (two per CU): every extra split is another fp32 slab of the whole weight tensor to write
+    // and to read back (at 512 splits the slabs of a 64 -> 64 layer were 150 MB of traffic, more than its activations)
+    int split = std::max(1, std::min(ntiles, 512 / std::max(outer, 1)));
+    return std::min(split, 256);
 }
 
 // y / dxpad / dx = conv(cat(up2?(x0), x1), weight) on the bf16 matrix cores.
