@@ -31,12 +31,30 @@ class CpuTrainer:
         self.optim = torch.optim.Adam(self.params, lr)
         self.num_ch_enc = [64, 64, 128, 256, 512] if num_layers <= 34 else [64, 256, 512, 1024, 2048]
 
-    def process_batch(self, inputs, noise, kinks=None):
+    def process_batch(self, inputs, noise, kinks=None, nets_autocast=None):
         """`kinks`: {"encoder" | "pose_encoder" | "pose": tape entries recorded by the HIP path (depthcore.ops.KinkTape)} --
         the ReLU / max-pool decisions of those networks are then imposed (oracle/kinks.py); the imposed-vs-own disagreements
-        are left in `self.kink_report`.  The HIP path stacks both pose pairs along the batch: pair i = rows [i*B, (i+1)*B)."""
+        are left in `self.kink_report`.  The HIP path stacks both pose pairs along the batch: pair i = rows [i*B, (i+1)*B).
+        `nets_autocast`: a torch dtype -- the networks are evaluated under torch's own CPU autocast of that type and their
+        outputs cast back to fp32 for the loss: torch's statement of "reduced-precision networks, fp32 loss" (BASELINE
+        configs[4]), the yardstick of tests/test_bf16_policy_gpu.py."""
+        import contextlib
         o = self.opt
-        used = []
+        with (torch.autocast("cpu", dtype=nets_autocast) if nets_autocast is not None else contextlib.nullcontext()):
+            outputs = self._networks(inputs, kinks)
+        if nets_autocast is not None:
+            outputs = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in outputs.items()}
+        R.generate_images_pred(inputs, outputs, o)
+        losses = R.compute_losses(inputs, outputs, o, noise)
+        for _, k in self._used:
+            k.done()
+        self.kink_report = [(name,) + d for name, k in self._used for d in k.disagree]
+        self.kink_objs = self._used
+        return outputs, losses
+
+    def _networks(self, inputs, kinks):
+        o = self.opt
+        used = self._used = []
 
         def forced(name, part=None, parts=1):
             if not kinks or name not in kinks:
@@ -70,13 +88,7 @@ class CpuTrainer:
             pair[1] += 1
             return R.pose_decoder_forward(self.state["pose"], f, 2, kinks=k)
         outputs.update(R.predict_poses(inputs, pose_enc, pose_dec))
-        R.generate_images_pred(inputs, outputs, o)
-        losses = R.compute_losses(inputs, outputs, o, noise)
-        for _, k in used:
-            k.done()
-        self.kink_report = [(name,) + d for name, k in used for d in k.disagree]
-        self.kink_objs = used
-        return outputs, losses
+        return outputs
 
     def train_step(self, inputs, noise):
         outputs, losses = self.process_batch(inputs, noise)
