@@ -237,12 +237,16 @@ struct C3bArgs {
 };
 
 template <int MR, int S, bool DPAD>
-__global__ __launch_bounds__(256, 2) void c3b_conv_kernel(C3bArgs a) {
-    constexpr int MT = 16 * MR;
-    constexpr int TH = S == 1 ? 8 : 4, RWV = TH / 2;              // RWV: 16-pixel groups per wave (wave = TH/4 rows x two halves)
-    using Stager = PatchStager<S, TH, DPAD>;
+__global__ __launch_bounds__(512, 2) void c3b_conv_kernel(C3bArgs a) {
+    // 512 threads: eight waves share the staged images, each owns GPW of the tile's 16-pixel groups.  (With four waves the
+    // staging registers of 256 threads plus 16 accumulator tiles left room for 2 waves per SIMD: load wait, LDS commit, MFMA
+    // phase and stores of a block simply added up.  Half the staging items and half the accumulators per thread -> 4 waves
+    // per SIMD from the same two blocks per CU.)
+    constexpr int MT = 16 * MR, NTHR = 512;
+    constexpr int TH = S == 1 ? 8 : 4, RWV = TH / 4;              // RWV = GPW: 16-pixel groups per wave (TH rows x two halves / 8 waves)
+    using Stager = PatchStager<S, TH, DPAD, NTHR>;
     constexpr int PW = Stager::PW;
-    constexpr int NWI = (36 * MT + 255) / 256;                    // 16-byte weight items per thread and chunk
+    constexpr int NWI = (36 * MT + NTHR - 1) / NTHR;              // 16-byte weight items per thread and chunk
     __shared__ __attribute__((aligned(16))) unsigned img[Stager::LDS_ELEMS / 2];
     __shared__ __attribute__((aligned(16))) uint4 wl[36 * MT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -270,14 +274,14 @@ __global__ __launch_bounds__(256, 2) void c3b_conv_kernel(C3bArgs a) {
     auto prefetch_w = [&](int c) {
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
-            const int it = tid + i * 256;
+            const int it = tid + i * NTHR;
             rw[i] = __builtin_bit_cast(uint4, ld128(wr, it < 36 * MT ? (unsigned)((c * 36 * MT + it) * 16) : OOB));
         }
     };
     auto commit_w = [&]() {
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
-            const int it = tid + i * 256;
+            const int it = tid + i * NTHR;
             if (it < 36 * MT) wl[it] = rw[i];
         }
     };
@@ -309,8 +313,10 @@ __global__ __launch_bounds__(256, 2) void c3b_conv_kernel(C3bArgs a) {
 #pragma unroll
             for (int i = 0; i < MR; ++i) af[i] = __builtin_bit_cast(bf8, wl[(t * 4 + kk) * MT + i * 16 + n]);
 #pragma unroll
-            for (int j = 0; j < RWV; ++j)          // group j of the wave: tile row wave * TH/4 + j/2, columns 16 (j & 1) .. +15
-                bfr[j] = *reinterpret_cast<const bf8*>(pim + ((S * (wave * (TH / 4) + (j >> 1)) + ky) * PW + S * (16 * (j & 1) + n) + kx) * BPX + kk * 8);
+            for (int j = 0; j < RWV; ++j) {        // group g of the tile: row g / 2, columns 16 (g & 1) .. +15
+                const int g = wave * RWV + j;
+                bfr[j] = *reinterpret_cast<const bf8*>(pim + ((S * (g >> 1) + ky) * PW + S * (16 * (g & 1) + n) + kx) * BPX + kk * 8);
+            }
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -341,7 +347,8 @@ __global__ __launch_bounds__(256, 2) void c3b_conv_kernel(C3bArgs a) {
     for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < RWV; ++j) {
-            const int py = oy0 + wave * (TH / 4) + (j >> 1), px = ox0 + 16 * (j & 1) + 4 * kk;
+            const int g = wave * RWV + j;
+            const int py = oy0 + (g >> 1), px = ox0 + 16 * (g & 1) + 4 * kk;
             const int m = m0 + i * 16 + n;
             // (a.opitch: row pitch of `out`, a multiple of 4 -- OW, or OW rounded up for the padded domain)
             if (!(C3B_ABL & 4) && m < a.M && py < a.OH && px < a.opitch)
@@ -516,7 +523,7 @@ int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const fl
     const double in_elems = (double)B * ((double)C0 * (H >> (up0 & 1)) * (W >> (up0 & 1)) + (double)C1 * H * W);
     hipEvent_t pe = conv_prof_begin(2, 2.0 * macs, 2.0 * (double)nblk * (stride == 1 ? 256 : 128) * MT * (double)(nchunks * BC) * 9.0,
                                     4.0 * (in_elems + (double)B * M * a.OH * a.OW) + 36.0 * Co * Cin, st);
-#define C3B_LAUNCH(MRV, SV, DP) hipLaunchKernelGGL((c3b_conv_kernel<MRV, SV, DP>), grid, dim3(256), 0, st, a)
+#define C3B_LAUNCH(MRV, SV, DP) hipLaunchKernelGGL((c3b_conv_kernel<MRV, SV, DP>), grid, dim3(512), 0, st, a)
     if (stride == 2) {
         if (dpad) return DC_EINVAL;
         if (mr == 4) C3B_LAUNCH(4, 2, false); else if (mr == 2) C3B_LAUNCH(2, 2, false); else C3B_LAUNCH(1, 2, false);
