@@ -231,41 +231,32 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
     };
     auto load_x = [&](int c, f2w* dst) {
         if (G == 2 || wave < 2) {
+            // ONE load shape for every kind of chunk -- eight 8-byte buffer loads, the source picked by scalar selects (chunks
+            // never straddle the concat: C0 % PSK == 0, host-checked).  Separate code paths per source (dword loads for the
+            // upsampled half, two descriptors) made the number of outstanding loads path-dependent for the compiler, which then
+            // waited for ALL of them (vmcnt(0)) in front of every LDS commit: the two-chunk prefetch distance was gone in the
+            // decoder's kernels.  The upsampled half reads 8 bytes at x0[iy>>1][ix>>1] and uses the first 4 (commit_x).
             const int ch0 = c * PSK;
-            if (!FUSED || ch0 < C0) {                 // chunks never straddle the concat (C0 % PSK == 0, host-checked)
-                if (FUSED && up0) {
+            const bool from1 = FUSED && ch0 >= C0;
+            const wrsrc_t rs = from1 ? x1r : xr;
+            const unsigned pl = from1 ? plane : plane0, vbase = from1 ? svoff1 : svoff;
+            const int chb = from1 ? ch0 - C0 : ch0, climit = from1 ? a.K - C0 : C0;
 #pragma unroll
-                    for (int k = 0; k < PSK; ++k) {
-                        const int ch = ch0 + k;
-                        const unsigned vo = ch < C0 ? svoff : 0x80000000u;
-                        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)vo, (int)((unsigned)ch * plane0), 0));
-                        dst[k] = f2w{v, v};
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < PSK; ++k) {
-                        const int ch = ch0 + k;
-                        const unsigned vo = ch < C0 ? svoff : 0x80000000u;
-                        dst[k] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)vo, (int)((unsigned)ch * plane0), 0));
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < PSK; ++k) {
-                    const int ch = ch0 + k;
-                    const unsigned vo = ch < a.K ? svoff1 : 0x80000000u;
-                    dst[k] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(x1r, (int)vo, (int)((unsigned)(ch - C0) * plane), 0));
-                }
+            for (int k = 0; k < PSK; ++k) {
+                const int ch = chb + k;
+                const unsigned vo = ch < climit ? vbase : 0x80000000u;
+                dst[k] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)vo, (int)((unsigned)ch * pl), 0));
             }
         }
     };
-    auto commit_x = [&](int buf, const f2w* src) {
+    auto commit_x = [&](int buf, const f2w* src, int c) {
         if (swr) {
             float* xw = xl[buf];
+            const bool dup = FUSED && up0 && c * PSK < C0;        // chunk of the nearest-x2 upsampled source: one value, two columns
 #pragma unroll
             for (int k = 0; k < PSK; ++k) {
                 xw[k * CPS + slds0] = src[k].x;
-                xw[k * CPS + slds1] = src[k].y;
+                xw[k * CPS + slds1] = dup ? src[k].x : src[k].y;
             }
         }
     };
@@ -311,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
         load_u(c_begin, ureg[0]);
         load_x(c_begin, px[0]);
         if (nloc > 1) load_x(c_begin + 1, px[1]);
-        commit_x(0, px[0]);
+        commit_x(0, px[0], c_begin);
         if (nloc > 2) load_x(c_begin + 2, px[0]);
     }
     __syncthreads();
@@ -328,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
         if (i + 1 < nloc) load_u(c_begin + i + 1, unxt);
         DIAG_T(0, compute(i & 1, ucur));
         if (i + 1 < nloc) {
-            DIAG_T(1, commit_x((i + 1) & 1, pxn); DIAG_WAIT());
+            DIAG_T(1, commit_x((i + 1) & 1, pxn, c_begin + i + 1); DIAG_WAIT());
             DIAG_T(2, if (i + 3 < nloc) load_x(c_begin + i + 3, pxn));
         }
         DIAG_T(3, __syncthreads());
