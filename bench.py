@@ -54,6 +54,11 @@ FAMILIES = {
     4: ("dc::g1_* (1x1 convolutions as NCHW fp32-MFMA GEMMs: forward, data gradient, weight gradient)", "mfma"),
 }
 VALU_LANE_OPS_PEAK = 78.6e12   # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: wave-level VALU instructions x 64 lanes per second
+# Issue slots per counted VALU instruction of the photometric kernels' main loops (tools/isa_mix.py on the gfx950 ISA, kept in
+# profiles/round3_photo_isa_mix.txt): SQ_INSTS_VALU counts a packed-fp32 or a transcendental instruction once, the SIMD-32 issues
+# them over twice the cycles (MI355X_MICROARCH.md "vector-instruction ISSUE cost").  backward: 1131 plain + 336 DPP + 16 lane + 2 x
+# (669 packed + 24 transcendental) = 2869 slots per 2176 instructions; forward: 712 + 2 x 60 = 832 per 772.
+VALU_SLOTS_PER_INST = {"bwd": 2869.0 / 2176.0, "fwd": 832.0 / 772.0}
 
 
 # ------------------------------------------------------------------------------------------------ launcher (N > 1)
@@ -227,7 +232,7 @@ def _traffic_for(cfg_key):
     """HBM bytes per launch from the PMC passes kept under profiles/ (separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc
     WRITE_SIZE` runs, tools/pmc_traffic.sh; FETCH_SIZE x2.0 per the gfx950 calibration, WRITE_SIZE x1.0).  They are
     CITED, not measured in this run: a PMC pass serialises the step and cannot share a process with the timed region."""
-    for name in ("round2_traffic_%s.json" % cfg_key, "round1_traffic.json" if cfg_key == "c2" else None):
+    for name in ("round3_traffic_%s.json" % cfg_key, "round2_traffic_%s.json" % cfg_key, "round1_traffic.json" if cfg_key == "c2" else None):
         if not name:
             continue
         tf = os.path.join(REPO, "profiles", name)
@@ -389,6 +394,10 @@ def run_rank(args):
     if rank == 0:
         cfg = (args.num_layers, args.height, args.width, args.batch)
         cfg_key = {(18, 192, 640, 12): "c2", (50, 320, 1024, 8): "c3"}.get(cfg, "other") if args.front == "none" else "other"
+        if args.front == "fusion" and cfg == (18, 192, 640, 12):
+            cfg_key = "c5bf16" if args.nets_dtype == "bf16" else "c5"
+        if args.front == "none" and args.nets_dtype != "f32":
+            cfg_key = "other"
         label = {"c2": "BASELINE configs[1]: ", "c3": "BASELINE configs[2] (per rank): "}.get(cfg_key, "")
         if args.front == "gru":
             label = "BASELINE configs[3] (per rank): ConvGRU v5 temporal fusion, one sequence of %d frames, " % args.len_sequence
@@ -483,6 +492,16 @@ def run_rank(args):
                                          "valu_wave_insts": vb,
                                          "valu_frac_of_peak": round(vb * 64.0 / (bwd_ms * 1e-3) / VALU_LANE_OPS_PEAK, 4)
                                          if vb and bwd_ms > 0 else None,
+                                         # the kernel's floor if every SIMD issued one VALU slot every 2 cycles (needs >= 2 ready waves
+                                         # per SIMD; the kernel holds 2 at 207 VGPRs) -- and what that floor means against HBM
+                                         "valu_issue_floor_ms": round(vb * VALU_SLOTS_PER_INST["bwd"] * 64.0 / VALU_LANE_OPS_PEAK * 1e3, 4)
+                                         if vb else None,
+                                         "valu_issue_frac": round(vb * VALU_SLOTS_PER_INST["bwd"] * 64.0 / VALU_LANE_OPS_PEAK / (bwd_ms * 1e-3), 4)
+                                         if vb and bwd_ms > 0 else None,
+                                         "hbm_frac_at_valu_floor": round(bytes_bwd / (vb * VALU_SLOTS_PER_INST["bwd"] * 64.0 / VALU_LANE_OPS_PEAK)
+                                                                         / 1e9 / HBM_PEAK_GBS, 4) if vb else None,
+                                         "valu_note": "SQ_INSTS_VALU per launch (cited PMC pass) x issue slots per instruction from the ISA "
+                                                      "mix (profiles/round3_photo_isa_mix.txt); 2 cycles per slot per SIMD-32",
                                          "fwd_chain": {"kernel": "identity + smooth + dc::photo_fwd_kernel + finalize",
                                                        "algorithmic_bytes_per_launch": bytes_fwd,
                                                        "avg_chain_ms": round(fwd_chain_ms, 4), "avg_kernel_ms": round(fwd_ms, 4),

@@ -5,8 +5,8 @@
 
 Finds the longest backward-branch loop of every kernel and counts its instructions by issue class; prices them with the
 measured issue costs of MI355X_MICROARCH.md ("vector-instruction ISSUE cost": plain VALU 4 cycles per wave-instruction when one
-wave issues alone, 2 cycles (SIMD-32) when several waves share the SIMD; transcendentals 2x that; DPP adds counted at the plain
-rate) so that a VALU issue floor can be stated from instruction counts instead of from a guess."""
+wave issues alone, 2 cycles (SIMD-32) when several waves share the SIMD; transcendentals and packed-fp32 2x that; DPP adds
+counted at the plain rate) so that a VALU issue floor can be stated from instruction counts instead of from a guess."""
 import collections
 import re
 import sys
@@ -66,7 +66,9 @@ def main():
                 continue
             cls[classify(l)] += 1
         valu = sum(v for k, v in cls.items() if k.startswith("valu"))
-        weighted = valu + cls["valu_trans"]            # a transcendental holds the issue port twice as long
+        # a transcendental and a packed-fp32 instruction hold the issue port twice as long as a plain one (packed fp32 has the
+        # FLOP rate of plain fp32 on gfx950: tools/ubench/valu_rate.hip)
+        weighted = valu + cls["valu_trans"] + cls["valu_packed"]
         print("%s\n  main loop: %d instructions: %s\n  VALU wave-instructions per trip %d (issue-weighted %d): %.0f cycles at 2 cycles "
               "(several waves per SIMD), %.0f at 4 (one wave alone)" % (name, sum(cls.values()), dict(cls), valu, weighted,
                                                                        2.0 * weighted, 4.0 * weighted))

@@ -22,7 +22,9 @@ def main():
         ops.disp_to_depth(big, 0.1, 100.0)
     torch.cuda.synchronize()
     B, H, W, NL = (int(os.environ.get(k, d)) for k, d in (("DC_B", 12), ("DC_H", 192), ("DC_W", 640), ("DC_LAYERS", 18)))
-    inp = synthetic_batch(B, H, W, dev, seed=0)
+    fusion = os.environ.get("DC_FRONT", "") == "fusion"             # BASELINE configs[4] wiring
+    dtype = os.environ.get("DC_DTYPE", "f32")                       # networks' matrix-core precision (f32 | bf16)
+    inp = synthetic_batch(B, H, W, dev, seed=0, frame_ids=(0, -2, -1, 1) if fusion else (0, -1, 1))
     g = torch.Generator(device=dev).manual_seed(0)
     disps = []
     for s in range(4):
@@ -44,7 +46,9 @@ def main():
     torch.cuda.synchronize()
     # two full training steps: the Winograd convolution kernels (mean HBM bytes per launch over all layers)
     import trainer as T
-    tr = T.Trainer(T.default_options(batch_size=B, height=H, width=W, num_layers=NL, overlap_streams=False), device=dev)
+    kw = dict(fusion="v3", frame_ids=[0, -2, -1, 1]) if fusion else {}
+    tr = T.Trainer(T.default_options(batch_size=B, height=H, width=W, num_layers=NL, overlap_streams=False, nets_dtype=dtype, **kw),
+                   device=dev)
     tr.set_train()
     for _ in range(2):
         tr.train_step(inp)
