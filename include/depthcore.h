@@ -277,6 +277,22 @@ int dc_conv1x1_bias_act_fwd(const float* x, const float* weight, const float* bi
                             int stride, int act, void* stream);
 int dc_bias_act_bwd(const float* y, const float* gy, float* gpre, float* dbias, int B, int C, int P, int act, void* stream);
 
+/* The 7x7 / 2 stem reading the RAW frames: `x = (input_image - 0.45) / 0.225` (networks/resnet_encoder.py:89) and, for the
+ * pose encoder, the temporal pair concat `torch.cat([f_a, f_b], 1)` of trainer.py:398-412 are index arithmetic of the
+ * kernels' patch loader (the same two IEEE operations per pixel; conv1's zero padding stays zero), so neither the
+ * normalised image nor the 6-channel pair tensor exists in HBM.
+ *   frames: HOST array of nf device pointers, each (Bf,3,Hi,Wi).  nf = 1: Ci = 3, output batch Bf.  nf = 3: the two pairs
+ *   (f0,f1), (f1,f2) stacked along the batch -- output batch 2*Bf, item b < Bf = cat(f0[b], f1[b]), item Bf + b = cat(f1[b],
+ *   f2[b]) (= trainer.py's pairs (-1,0), (0,+1) for frames (f-1, f0, f+1)).
+ *   weight (64, 3 or 6, 7, 7); y / gy (Bf or 2*Bf, 64, Hi/2, Wi/2); ws: dc_convs2_fwd_workspace / _wgrad_workspace bytes of
+ *   the equivalent dc_convs2_* call (B = output batch, Ci, ksize 7).  Same arithmetic as dc_convs2_fwd / _wgrad on the
+ *   materialised input, bit for bit.  No data gradient (the input is the image). */
+int dc_stem_supported(int nf, int Bf, int Co, int Hi, int Wi);
+int dc_stem_fwd(const float* const* frames, int nf, float mean, float stdv, const float* weight, float* y, void* ws, int Bf, int Hi,
+                int Wi, int Co, void* stream);
+int dc_stem_wgrad(const float* const* frames, int nf, float mean, float stdv, const float* gy, float* dweight, void* ws, int Bf, int Hi,
+                  int Wi, int Co, void* stream);
+
 /* The strided convolutions of the trunks (networks/resnet_encoder.py:87-98 via torchvision): ksize 7 = the 7x7 / 2 stem
  * (padding 3, Ci = 3 or 6), ksize 3 = the 3x3 / 2 first convolution of layer2-4 (padding 1); no bias.  Implicit GEMMs on
  * the fp32 matrix cores straight on NCHW (no im2col tensor, no layout transposes), exact fp32 products, deterministic.

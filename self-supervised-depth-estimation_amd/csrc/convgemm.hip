@@ -535,6 +535,9 @@ __global__ __launch_bounds__(256) void cg_wgrad3_kernel(CgArgs a) {
 constexpr int ST_TH = 2, ST_TW = 64, ST_PW = 68, ST_ROWS = 2 * ST_TH + 5, ST_ROW = 2 * ST_PW;   // one patch row = [E | O]
 struct StemArgs {
     const float* x; const float* w; const float* gy; float* out;
+    // raw-frame mode (dc_stem_fwd / dc_stem_wgrad): nf > 0 frames (Bf,3,Hi,Wi); the network input is (x - mean) / stdv of
+    // frames[0] (nf = 1, Ci = 3) or of the temporal pairs cat(f[p], f[p+1]) stacked along the batch (nf = 3: B = 2 Bf, Ci = 6)
+    const float* f[3]; int nf, Bf; float mean, stdv;
     int B, Ci, Co, Hi, Wi, Ho, Wo, K, Kp;
     int tiles_x, tiles_y, ntiles;     // tiles per row, per image column, total (B * tiles_y * tiles_x)
     int nblocks;                      // weight gradient: blocks that share the tiles
@@ -553,6 +556,7 @@ __device__ __forceinline__ int stem_koff(int k, int K) {
 template <int NV>
 __device__ __forceinline__ void stem_patch_load(const StemArgs& a, cgrsrc_t xr, int b, int oy0, int ox0, int tid, gf4 (&v)[NV]) {
     const int nitems = a.Ci * ST_ROWS * (ST_ROW / 4);
+    const int pr_ = a.nf == 3 ? b / a.Bf : 0, item = b - pr_ * a.Bf;          // raw-frame mode: pair index and item inside it
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int idx = tid + j * 256;
@@ -560,21 +564,40 @@ __device__ __forceinline__ void stem_patch_load(const StemArgs& a, cgrsrc_t xr, 
         const int ci = row / ST_ROWS, pr = row - ci * ST_ROWS;
         const int Y = 2 * oy0 - 3 + pr, X = 2 * ox0 - 4 + 4 * m;
         const bool ok = idx < nitems && (unsigned)Y < (unsigned)a.Hi && (unsigned)X < (unsigned)a.Wi;
-        const unsigned off = ok ? (((unsigned)(b * a.Ci + ci) * a.Hi + Y) * a.Wi + X) * 4u : 0x80000000u;
-        v[j] = __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+        if (a.nf == 0) {
+            const unsigned off = ok ? (((unsigned)(b * a.Ci + ci) * a.Hi + Y) * a.Wi + X) * 4u : 0x80000000u;
+            v[j] = __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+        } else {
+            // channels 0-2 come from frame f[pair], 3-5 from f[pair + 1]: the temporal concat of trainer.py:398-412 is this
+            // pointer select.  Branch-free: an item outside the image reads the frame's first vector and is zeroed at commit.
+            const float* src = (ci >= 3) ? a.f[pr_ + 1] : a.f[pr_];
+            const int c3 = ci >= 3 ? ci - 3 : ci;
+            const size_t off = ok ? (((size_t)(item * 3 + c3) * a.Hi + Y) * a.Wi + X) : 0;
+            v[j] = *reinterpret_cast<const gf4*>(src + off);
+        }
     }
 }
 template <int NV>
-__device__ __forceinline__ void stem_patch_store(const StemArgs& a, float* P, int tid, const gf4 (&v)[NV]) {
+__device__ __forceinline__ void stem_patch_store(const StemArgs& a, float* P, int tid, const gf4 (&v)[NV], int oy0, int ox0) {
     const int nitems = a.Ci * ST_ROWS * (ST_ROW / 4);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int idx = tid + j * 256;
         if (idx >= nitems) continue;
         const int row = idx / (ST_ROW / 4), m = idx - row * (ST_ROW / 4);
+        gf4 w = v[j];
+        if (a.nf) {
+            // (x - mean) / stdv of networks/resnet_encoder.py:89 -- the same two IEEE operations as the tensor expression it
+            // replaces -- on pixels inside the image; the zero padding of conv1 stays zero
+            const int ci = row / ST_ROWS, pr = row - ci * ST_ROWS;
+            const int Y = 2 * oy0 - 3 + pr, X = 2 * ox0 - 4 + 4 * m;
+            const bool ok = (unsigned)Y < (unsigned)a.Hi && (unsigned)X < (unsigned)a.Wi;
+            w.x = ok ? (w.x - a.mean) / a.stdv : 0.f; w.y = ok ? (w.y - a.mean) / a.stdv : 0.f;
+            w.z = ok ? (w.z - a.mean) / a.stdv : 0.f; w.w = ok ? (w.w - a.mean) / a.stdv : 0.f;
+        }
         float* e = P + row * ST_ROW + 2 * m;
-        *reinterpret_cast<gf2*>(e) = gf2{v[j].x, v[j].z};
-        *reinterpret_cast<gf2*>(e + ST_PW) = gf2{v[j].y, v[j].w};
+        *reinterpret_cast<gf2*>(e) = gf2{w.x, w.z};
+        *reinterpret_cast<gf2*>(e + ST_PW) = gf2{w.y, w.w};
     }
 }
 
@@ -607,7 +630,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j]);
     for (int k = tid; k < a.Kp; k += 256) ktab[k] = stem_koff(k, a.K);
-    stem_patch_store<ST_NVP>(a, P, tid, pv);
+    stem_patch_store<ST_NVP>(a, P, tid, pv, oy0, ox0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) store_red4(As + adst[j], ra[j]);
     __syncthreads();
@@ -703,7 +726,11 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemArgs a) {
         }
     };
     auto commit = [&](int tile) {
-        stem_patch_store<ST_NVP>(a, P, tid, pv);
+        {
+            int b_, oy_, ox_;
+            tile_org(tile, b_, oy_, ox_);
+            stem_patch_store<ST_NVP>(a, P, tid, pv, oy_, ox_);
+        }
         if constexpr (PREFETCH_G) {
 #pragma unroll
             for (int j = 0; j < NVG; ++j) gy_store(j, gv[j]);
@@ -971,6 +998,53 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
         hipLaunchKernelGGL(slab_reduce16_kernel<float>, dim3(ceil_div(n, 16)), dim3(256), 0, st, (const float*)ws, dweight, a.splits, n);
         DC_CHECK_LAUNCH();
     }
+    return DC_OK;
+}
+
+// ---- the stem on the RAW frames: normalisation and temporal pair concat folded into the patch loader -------------------------
+static int stem_frames(StemArgs& sa, const float* const* frames, int nf, float mean, float stdv, int Bf, int Hi, int Wi, int Co) {
+    if (!frames || (nf != 1 && nf != 3) || !(stdv > 0.f) || Bf <= 0) return DC_EINVAL;
+    const int B = nf == 3 ? 2 * Bf : Bf, Ci = nf == 3 ? 6 : 3;
+    if (!cg_ok(B, Ci, Co, Hi, Wi, 7) || !stem_ok(Ci, Co, 7)) return DC_EINVAL;
+    for (int i = 0; i < nf; ++i)
+        if (!frames[i]) return DC_EINVAL;
+    sa = stem_args(B, Ci, Co, Hi, Wi);
+    sa.nf = nf; sa.Bf = Bf; sa.mean = mean; sa.stdv = stdv;
+    for (int i = 0; i < 3; ++i) sa.f[i] = frames[i < nf ? i : 0];
+    return DC_OK;
+}
+
+extern "C" int dc_stem_supported(int nf, int Bf, int Co, int Hi, int Wi) {
+    if ((nf != 1 && nf != 3) || Bf <= 0) return 0;
+    const int B = nf == 3 ? 2 * Bf : Bf, Ci = nf == 3 ? 6 : 3;
+    return (cg_ok(B, Ci, Co, Hi, Wi, 7) && stem_ok(Ci, Co, 7)) ? 1 : 0;
+}
+
+extern "C" int dc_stem_fwd(const float* const* frames, int nf, float mean, float stdv, const float* weight, float* y, void* ws, int Bf,
+                           int Hi, int Wi, int Co, void* stream) {
+    StemArgs sa{};
+    if (!weight || !y || !ws || stem_frames(sa, frames, nf, mean, stdv, Bf, Hi, Wi, Co) != DC_OK) return DC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cg_wpad_kernel, dim3(ceil_div(Co * sa.Kp, 256)), dim3(256), 0, st, weight, (float*)ws, Co, sa.K, sa.Kp);
+    DC_CHECK_LAUNCH();
+    sa.w = (const float*)ws; sa.out = y;
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(sa.Ci, sa.Kp), st, sa);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_stem_wgrad(const float* const* frames, int nf, float mean, float stdv, const float* gy, float* dweight, void* ws,
+                             int Bf, int Hi, int Wi, int Co, void* stream) {
+    StemArgs sa{};
+    if (!gy || !dweight || !ws || stem_frames(sa, frames, nf, mean, stdv, Bf, Hi, Wi, Co) != DC_OK) return DC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    sa.gy = gy; sa.out = (float*)ws;
+    const size_t lds = stem_lds_wgrad(sa.Ci);
+    if (sa.Ci == 3) hipLaunchKernelGGL(stem_wgrad_kernel<5>, dim3(sa.nblocks), dim3(256), lds, st, sa);
+    else hipLaunchKernelGGL(stem_wgrad_kernel<10>, dim3(sa.nblocks), dim3(256), lds, st, sa);
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stem_wreduce_kernel, dim3(ceil_div(64 * sa.K, 16)), dim3(256), 0, st, (const float*)ws, dweight, sa.nblocks, sa.K, sa.Kp);
+    DC_CHECK_LAUNCH();
     return DC_OK;
 }
 

@@ -114,6 +114,9 @@ def _sig(lib):
         "dc_conv_profile_collect": (i, [i, p, p, p, p, p]),
         "dc_wino3x3_wgrad_workspace": (z, [i, i, i, i, i]),
         "dc_wino3x3_wgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
+        "dc_stem_supported": (i, [i, i, i, i, i]),
+        "dc_stem_fwd": (i, [p, i, f, f, p, p, p, i, i, i, i, p]),
+        "dc_stem_wgrad": (i, [p, i, f, f, p, p, p, i, i, i, i, p]),
         "dc_convs2_supported": (i, [i, i, i, i, i, i]),
         "dc_convs2_fwd_workspace": (z, [i, i, i, i, i, i]),
         "dc_convs2_fwd": (i, [p, p, p, p, i, i, i, i, i, i, p]),

@@ -888,6 +888,65 @@ def conv_s2(x, weight):
 
 
 # ----------------------------------------------------------------------------------------------
+# a1 the stem on the raw frames: (image - mean) / std and the pose pairs' concat inside the kernels' patch loader
+#                                   (reference networks/resnet_encoder.py:89-90, trainer.py:398-412)
+# ----------------------------------------------------------------------------------------------
+def stem_supported(frames, weight):
+    f0 = frames[0]
+    return (f0.is_cuda and f0.dtype == torch.float32 and len(frames) in (1, 3) and f0.shape[1] == 3
+            and tuple(weight.shape[1:]) == (3 * (2 if len(frames) == 3 else 1), 7, 7)
+            and all(t.shape == f0.shape and not t.requires_grad for t in frames)
+            and bool(_lib.lib().dc_stem_supported(len(frames), f0.shape[0], weight.shape[0], f0.shape[2], f0.shape[3])))
+
+
+class _StemConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, mean, std, *frames):
+        L = _lib.lib()
+        fr = [_c(t.detach()) for t in frames]
+        ww = _c(weight.detach())
+        nf = len(fr)
+        Bf, _, Hi, Wi = fr[0].shape
+        Co = ww.shape[0]
+        B, Ci = (2 * Bf, 6) if nf == 3 else (Bf, 3)
+        ptrs = (ctypes.c_void_p * nf)(*[ptr(t) for t in fr])
+        y = torch.empty(B, Co, Hi // 2, Wi // 2, dtype=torch.float32, device=ww.device)
+        _use_precision(_lib.PREC_F32)                      # (the stem has no reduced-precision kernel: 3 / 6 input channels)
+        ws = torch.empty(L.dc_convs2_fwd_workspace(B, Ci, Co, Hi, Wi, 7), dtype=torch.uint8, device=ww.device)
+        check(L.dc_stem_fwd(ptrs, nf, float(mean), float(std), ptr(ww), ptr(y), ws.data_ptr(), Bf, Hi, Wi, Co, stream(ww)),
+              "dc_stem_fwd")
+        ctx.save_for_backward(ww, *fr)
+        ctx.cfg = (float(mean), float(std))
+        ctx.slot = _slot(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        ww, *fr = ctx.saved_tensors
+        nf = len(fr)
+        Bf, _, Hi, Wi = fr[0].shape
+        Co = ww.shape[0]
+        B, Ci = (2 * Bf, 6) if nf == 3 else (Bf, 3)
+        g_c = _c(gy)
+        gw = None
+        if ctx.needs_input_grad[0]:
+            gw = _grad_dst(ctx.slot, ww)
+            ptrs = (ctypes.c_void_p * nf)(*[ptr(t) for t in fr])
+            ws = torch.empty(L.dc_convs2_wgrad_workspace(B, Ci, Co, Hi, Wi, 7), dtype=torch.uint8, device=ww.device)
+            check(L.dc_stem_wgrad(ptrs, nf, ctx.cfg[0], ctx.cfg[1], ptr(g_c), ptr(gw), ws.data_ptr(), Bf, Hi, Wi, Co, stream(ww)),
+                  "dc_stem_wgrad")
+        return (gw, None, None) + (None,) * nf
+
+
+def stem_conv(frames, weight, mean=0.45, std=0.225):
+    """conv2d((x - mean) / std, weight, stride 2, padding 3) with x = frames[0] (one frame) or, for three frames (f-1, f0, f+1),
+    the two temporal pairs cat(f-1, f0), cat(f0, f+1) stacked along the batch -- neither the normalised image nor the pair
+    tensor is materialised.  Frames are inputs (no gradient)."""
+    return _StemConv.apply(weight, mean, std, *frames)
+
+
+# ----------------------------------------------------------------------------------------------
 # f1 ResidualAttentionUnit of the Fusion_v3 front-end (reference networks/fusion_v2.py:46-137)
 # ----------------------------------------------------------------------------------------------
 PLAIN, PIXEL_SHUFFLE2 = "plain", "ps2"

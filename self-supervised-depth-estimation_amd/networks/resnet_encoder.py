@@ -31,11 +31,13 @@ def _bn_act(x, bn, res=None, relu=True, groups=1):
 CONV_S2 = True        # 7x7 / 2 stem and 3x3 / 2 convolutions on depthcore's implicit-GEMM kernels (GPU)
 GEMM_1X1 = True       # 1x1 stride-2 `downsample` convolutions on depthcore's NCHW MFMA GEMM (GPU)
 WINO_TRUNK = True     # stride-1 3x3 trunk convolutions on depthcore's fused Winograd kernel (GPU, even widths)
+STEM_FUSED = True     # input normalisation (and the pose pairs' concat) inside the stem kernels' loader (dc_stem_*)
 
 
 def _conv(conv, x):
-    """nn.Conv2d call of the trunk; the stride-1 3x3 ones (84 % of the trunk's multiplies) run on
-    dc_wino3x3_fwd / dc_wino3x3_dgrad, the rest (7x7 stem, stride-2 3x3, 1x1) on the library convolution."""
+    """nn.Conv2d call of the trunk: stride-1 3x3 on dc_wino3x3_* (84 % of a ResNet-18 trunk's multiplies), 1x1 on dc_conv1x1_*,
+    the 7x7 / 2 stem and the 3x3 / 2 convolutions on dc_convs2_*; only shapes outside those kernels' 16-byte staging (odd or
+    tiny maps in tests) reach the framework's convolution."""
     if (WINO_TRUNK and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and x.shape[-1] % 2 == 0
             and x.dtype == torch.float32):
@@ -175,15 +177,32 @@ class ResnetEncoder(nn.Module):
         self._nbt = None            # tensors may be re-created by .to() / .cuda()
         return super()._apply(fn, *a, **k)
 
+    def forward_pairs(self, f_prev, f_cur, f_next):
+        """Both temporally ordered pairs of the pose network in ONE pass: equals `forward(cat([cat([f_prev, f_cur], 1),
+        cat([f_cur, f_next], 1)], 0), bn_groups=2)` (trainer.py:398-419: pairs (-1, 0) and (0, +1)), with the concatenations
+        and the input normalisation done by the stem kernel's loader when the shapes allow."""
+        frames = (f_prev, f_cur, f_next)
+        if STEM_FUSED and _ops.stem_supported(frames, self.encoder.conv1.weight):
+            return self._trunk(_ops.stem_conv(frames, self.encoder.conv1.weight), 2)
+        pairs = torch.cat([torch.cat([f_prev, f_cur], 1), torch.cat([f_cur, f_next], 1)], 0)
+        return self.forward(pairs, bn_groups=2)
+
     def forward(self, input_image, bn_groups=1):
         """networks/resnet_encoder.py:87-98.  `bn_groups` > 1: `input_image` stacks that many independent
         sub-batches along dim 0; BatchNorm statistics (and running-stat updates) are kept per sub-batch, so the
         result equals `bn_groups` separate calls -- used to push both pose pairs through the trunk at once."""
         e = self.encoder
+        if STEM_FUSED and input_image.shape[1] == 3 and _ops.stem_supported((input_image,), e.conv1.weight):
+            return self._trunk(_ops.stem_conv((input_image,), e.conv1.weight), bn_groups)     # normalisation inside the loader
+        x = (input_image - 0.45) / 0.225
+        return self._trunk(_conv(e.conv1, x), bn_groups)
+
+    def _trunk(self, x, bn_groups):
+        """everything behind conv1; x = conv1((input - 0.45) / 0.225)"""
+        e = self.encoder
         e._g[0] = int(bn_groups)
         self.features = []
-        x = (input_image - 0.45) / 0.225
-        x = _bn_act(_conv(e.conv1, x), e.bn1, groups=e._g[0])
+        x = _bn_act(x, e.bn1, groups=e._g[0])
         self.features.append(x)
         self.features.append(e.layer1(_ops.maxpool3x3s2(x) if x.is_cuda else e.maxpool(x)))
         self.features.append(e.layer2(self.features[-1]))

@@ -257,9 +257,9 @@ class Trainer:
         arithmetic of the reference's two sequential passes (trainer.py:398-419) at twice the GEMM N."""
         outputs = {}
         pose_feats = {f: inputs[("color_aug", f, 0)] for f in (-1, 0, 1)}
-        pairs = [torch.cat([pose_feats[-1], pose_feats[0]], 1), torch.cat([pose_feats[0], pose_feats[1]], 1)]
-        B = pairs[0].shape[0]
-        feats = self.models["pose_encoder"](torch.cat(pairs, 0), bn_groups=2)
+        B = pose_feats[0].shape[0]
+        # (the pair tensors cat([f-1, f0], 1), cat([f0, f+1], 1) of trainer.py:398-412 are formed by the stem kernel's loader)
+        feats = self.models["pose_encoder"].forward_pairs(pose_feats[-1], pose_feats[0], pose_feats[1])
         axisangle, translation = self.models["pose"]([feats])
         for i, f in enumerate((-1, 1)):
             aa, tr = axisangle[i * B:(i + 1) * B], translation[i * B:(i + 1) * B]

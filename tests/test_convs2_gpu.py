@@ -80,3 +80,45 @@ def test_encoder_runs_without_library_convolutions(monkeypatch):
         feats = enc(x)
         sum(f.mean() for f in feats).backward()
         assert calls == [], "library convolution entered for %r" % calls[:3]
+
+
+@pytest.mark.parametrize("nf,Bf,H,W", [(1, 3, 64, 128), (3, 2, 64, 128), (3, 2, 96, 192), (1, 1, 192, 640)])
+def test_stem_on_raw_frames_equals_stem_on_materialised_input(nf, Bf, H, W):
+    """dc_stem_fwd / dc_stem_wgrad: `(x - 0.45) / 0.225` (networks/resnet_encoder.py:89) and the pose pairs' concat
+    (trainer.py:398-412) inside the patch loader -- bit for bit the result of dc_convs2_* on the tensors it replaces."""
+    from depthcore import ops
+    g = torch.Generator().manual_seed(nf * 10 + Bf)
+    frames = [torch.rand(Bf, 3, H, W, generator=g).cuda() for _ in range(nf)]
+    w = (torch.randn(64, 3 * (2 if nf == 3 else 1), 7, 7, generator=g) * 0.05).cuda().requires_grad_()
+    assert ops.stem_supported(frames, w)
+    y = ops.stem_conv(frames, w)
+    if nf == 3:
+        x = torch.cat([torch.cat([frames[0], frames[1]], 1), torch.cat([frames[1], frames[2]], 1)], 0)
+    else:
+        x = frames[0]
+    xn = (x - 0.45) / 0.225
+    y_ref = ops.conv_s2(xn, w)
+    assert y.shape == y_ref.shape and torch.equal(y, y_ref)
+    gy = torch.randn(y.shape, generator=g).cuda()
+    (gw,) = torch.autograd.grad(y, w, gy)
+    (gw_ref,) = torch.autograd.grad(y_ref, w, gy)
+    assert torch.equal(gw, gw_ref)
+
+
+def test_pose_encoder_forward_pairs_equals_stacked_forward():
+    import networks
+    torch.manual_seed(0)
+    enc = networks.ResnetEncoder(18, False, num_input_images=2).cuda()
+    enc.train()
+    g = torch.Generator().manual_seed(3)
+    f = [torch.rand(2, 3, 64, 128, generator=g).cuda() for _ in range(3)]
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    a = enc.forward_pairs(*f)
+    ga = torch.autograd.grad(sum(t.square().sum() for t in a), enc.encoder.conv1.weight)[0]
+    enc.load_state_dict(sd)                      # (training-mode BatchNorm advanced the running statistics)
+    x = torch.cat([torch.cat([f[0], f[1]], 1), torch.cat([f[1], f[2]], 1)], 0)
+    b = enc(x, bn_groups=2)
+    gb = torch.autograd.grad(sum(t.square().sum() for t in b), enc.encoder.conv1.weight)[0]
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert torch.equal(ga, gb)
