@@ -83,17 +83,17 @@ def test_all_parameter_gradients_vs_oracle(fusion):
     from depthcore import ops
     tapes = {}
 
-    def taped(name):
-        mod, orig = tr.models[name], tr.models[name].forward
+    def taped(name, method="forward"):
+        mod, orig = tr.models[name], getattr(tr.models[name], method)
 
         def fwd(*a, **k):
             with ops.KinkTape() as t:
                 out = orig(*a, **k)
             tapes[name] = t.entries
             return out
-        mod.forward = fwd
-    for name in ("encoder", "pose_encoder", "pose"):
-        taped(name)
+        setattr(mod, method, fwd)
+    for name, method in (("encoder", "forward"), ("pose_encoder", "forward_pairs"), ("pose", "forward")):
+        taped(name, method)
     torch.manual_seed(1234)
     tr.buckets.zero()
     dev_in = {k: v.to(DEV) for k, v in inputs.items()}
