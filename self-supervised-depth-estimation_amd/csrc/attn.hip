@@ -67,16 +67,39 @@ struct AttnP {           // parameters in registers (uniform across the block: t
 // ---- stage r = relu?(x) of a (RH x RW) region whose top-left image coordinate is (y0, x0) into LDS [pix][C]; 0 outside
 template <int C, int RH, int RW>
 __device__ __forceinline__ void attn_stage_x(const AttnArgs& a, int b, int y0, int x0, float* xs) {
-    for (int i = threadIdx.x; i < RH * RW * C; i += 256) {
-        const int c = i / (RH * RW), p = i - c * (RH * RW);
+    // All loads of the region are issued back to back from CLAMPED coordinates (always a valid address) and zeroed at the
+    // commit: the earlier `if (inside) v = ptr[c][...]` with a run-time channel index was a dependent pointer load plus a
+    // branch around every element -- ten serialised round trips per block in front of the arithmetic.
+    constexpr int NPX = RH * RW, IT = (NPX + 255) / 256;
+    float v[C][IT];
+    const int h2 = a.H >> 1, w2 = a.W >> 1;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float* base = a.x.ptr[c] + (size_t)b * (size_t)a.x.batch_stride[c];
+        const bool ps = a.x.mode[c] == DC_ATTN_PIXEL_SHUFFLE2;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int p = (int)threadIdx.x + k * 256;
+            const int ry = p / RW, rx = p - ry * RW;
+            const int gy_ = min(max(y0 + ry, 0), a.H - 1), gx_ = min(max(x0 + rx, 0), a.W - 1);
+            const size_t off = ps ? (size_t)((gy_ & 1) * 2 + (gx_ & 1)) * h2 * w2 + (size_t)(gy_ >> 1) * w2 + (gx_ >> 1)
+                                  : (size_t)gy_ * a.W + gx_;
+            v[c][k] = base[off];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int p = (int)threadIdx.x + k * 256;
+        if (p >= NPX) continue;
         const int ry = p / RW, rx = p - ry * RW;
         const int gy_ = y0 + ry, gx_ = x0 + rx;
-        float v = 0.f;
-        if (gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W) {
-            v = a.x.ptr[c][attn_off(a.x, c, b, gy_, gx_, a.H, a.W)];
-            if (a.relu_in) v = fmaxf(v, 0.f);
+        const bool inside = gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float t = v[c][k];
+            if (a.relu_in) t = fmaxf(t, 0.f);
+            xs[p * C + c] = inside ? t : 0.f;
         }
-        xs[p * C + c] = v;
     }
 }
 // ---- k, v of every pixel of the staged region -> LDS kv[pix][2C] = {k[0..C), v[0..C)}
@@ -121,6 +144,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         const int py = ty0 + ly, px = tx0 + lx;
         if (py >= a.H || px >= a.W) continue;
         const int pc = (ly + 1) * RW + lx + 1;                  // region index of the pixel itself
+        // the residual input of the pixel, fetched before the arithmetic (a load next to the stores below made each store
+        // wait for the previous one)
+        float rres[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) rres[c] = 0.f;
+        if (a.res.ptr[0]) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) rres[c] = a.res.ptr[c][attn_off(a.res, c, b, py, px, a.H, a.W)];
+        }
         float r[C], q[C];
 #pragma unroll
         for (int i = 0; i < C; ++i) r[i] = xs[pc * C + i];
@@ -142,6 +174,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     vt[c][dy * 3 + dx] = e[C + c];
                 }
             }
+        float out[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float m = lg[c][0];
@@ -155,13 +188,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 o = fmaf(e, vt[c][k], o);
             }
             o = o / s;
-            const size_t off = ((size_t)b * C + c) * plane + (size_t)py * a.W + px;
-            if (a.res.ptr[0]) {
-                const float rr = a.res.ptr[c][attn_off(a.res, c, b, py, px, a.H, a.W)];
-                o += a.relu_res ? fmaxf(rr, 0.f) : rr;
-            }
-            a.y[off] = o;
+            if (a.res.ptr[0]) o += a.relu_res ? fmaxf(rres[c], 0.f) : rres[c];
+            out[c] = o;
         }
+#pragma unroll
+        for (int c = 0; c < C; ++c) a.y[((size_t)b * C + c) * plane + (size_t)py * a.W + px] = out[c];
     }
 }
 
@@ -208,6 +239,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     float dq[C], dK[C], dV[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) dq[c] = dK[c] = dV[c] = 0.f;
+    // everything this thread reads from HBM besides the staged region, fetched up front from clamped coordinates (used only
+    // where the pixel is inside): the output gradient, the gradient to add to dx, the residual input of the ReLU mask
+    const int cy = min(max(py, 0), a.H - 1), cx = min(max(px, 0), a.W - 1);
+    float gpix[C], dxadd[C], resv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const size_t off = ((size_t)b * C + c) * plane + (size_t)cy * a.W + cx;
+        gpix[c] = a.gy[off];
+        dxadd[c] = a.dx_add ? a.dx_add[off] : 0.f;
+        resv[c] = (a.dres.ptr[0] && a.relu_res) ? a.res.ptr[c][attn_off(a.res, c, b, cy, cx, a.H, a.W)] : 1.f;
+    }
 
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -241,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
             }
             const float inv = 1.f / s;
             o *= inv;
-            const float g = a.gy[((size_t)b * C + c) * plane + (size_t)py * a.W + px];
+            const float g = gpix[c];
             float dqc = 0.f, sdk = 0.f, drh[3] = {0.f, 0.f, 0.f}, drw[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
@@ -298,14 +340,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
                 pg[O_WK + c * C + i] = fmaf(dK[c], r, pg[O_WK + c * C + i]);
                 pg[O_WV + c * C + i] = fmaf(dV[c], r, pg[O_WV + c * C + i]);
             }
-            const size_t off = ((size_t)b * C + i) * plane + (size_t)py * a.W + px;
             if (a.relu_in && !(r > 0.f)) d = 0.f;               // r = relu(x): r > 0 <=> x > 0
-            if (a.dx_add) d += a.dx_add[off];
+            d += dxadd[i];
             const_cast<float*>(a.dx.ptr[i])[attn_off(a.dx, i, b, py, px, a.H, a.W)] = d;
             if (a.dres.ptr[0]) {
-                const float g = a.gy[off];
-                const bool dead = a.relu_res && !(a.res.ptr[i][attn_off(a.res, i, b, py, px, a.H, a.W)] > 0.f);
-                const_cast<float*>(a.dres.ptr[i])[attn_off(a.dres, i, b, py, px, a.H, a.W)] = dead ? 0.f : g;
+                const bool dead = a.relu_res && !(resv[i] > 0.f);
+                const_cast<float*>(a.dres.ptr[i])[attn_off(a.dres, i, b, py, px, a.H, a.W)] = dead ? 0.f : gpix[i];
             }
         }
     }

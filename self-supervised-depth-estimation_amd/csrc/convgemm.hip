@@ -553,10 +553,15 @@ __device__ __forceinline__ int stem_koff(int k, int K) {
 
 // the patch of tile (b, ty, tx): 16-byte loads of rows 2*oy0-3 .. +8, columns 2*ox0-4 .. +135; rows / columns outside
 // the image come back as zeros from the buffer descriptor
-template <int NV>
+template <int NV, bool FR>
 __device__ __forceinline__ void stem_patch_load(const StemArgs& a, cgrsrc_t xr, int b, int oy0, int ox0, int tid, gf4 (&v)[NV]) {
     const int nitems = a.Ci * ST_ROWS * (ST_ROW / 4);
-    const int pr_ = a.nf == 3 ? b / a.Bf : 0, item = b - pr_ * a.Bf;          // raw-frame mode: pair index and item inside it
+    // raw-frame mode (FR): pair index and item inside it; channels 0-2 come from frame f[pair], 3-5 from f[pair + 1] -- the
+    // temporal concat of trainer.py:398-412 is a pointer select (scalar selects on the three kernel arguments: indexing the
+    // argument array with a run-time index is a dependent memory load in front of every patch load)
+    const int pr_ = (FR && a.nf == 3) ? b / a.Bf : 0, item = b - pr_ * a.Bf;
+    const float* const fa = pr_ ? a.f[1] : a.f[0];
+    const float* const fb = pr_ ? a.f[2] : a.f[1];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int idx = tid + j * 256;
@@ -564,20 +569,19 @@ __device__ __forceinline__ void stem_patch_load(const StemArgs& a, cgrsrc_t xr, 
         const int ci = row / ST_ROWS, pr = row - ci * ST_ROWS;
         const int Y = 2 * oy0 - 3 + pr, X = 2 * ox0 - 4 + 4 * m;
         const bool ok = idx < nitems && (unsigned)Y < (unsigned)a.Hi && (unsigned)X < (unsigned)a.Wi;
-        if (a.nf == 0) {
+        if (!FR) {
             const unsigned off = ok ? (((unsigned)(b * a.Ci + ci) * a.Hi + Y) * a.Wi + X) * 4u : 0x80000000u;
             v[j] = __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
         } else {
-            // channels 0-2 come from frame f[pair], 3-5 from f[pair + 1]: the temporal concat of trainer.py:398-412 is this
-            // pointer select.  Branch-free: an item outside the image reads the frame's first vector and is zeroed at commit.
-            const float* src = (ci >= 3) ? a.f[pr_ + 1] : a.f[pr_];
+            // branch-free: an item outside the image reads the frame's first vector and is zeroed at commit
+            const float* src = (ci >= 3) ? fb : fa;
             const int c3 = ci >= 3 ? ci - 3 : ci;
             const size_t off = ok ? (((size_t)(item * 3 + c3) * a.Hi + Y) * a.Wi + X) : 0;
             v[j] = *reinterpret_cast<const gf4*>(src + off);
         }
     }
 }
-template <int NV>
+template <int NV, bool FR>
 __device__ __forceinline__ void stem_patch_store(const StemArgs& a, float* P, int tid, const gf4 (&v)[NV], int oy0, int ox0) {
     const int nitems = a.Ci * ST_ROWS * (ST_ROW / 4);
 #pragma unroll
@@ -586,7 +590,7 @@ __device__ __forceinline__ void stem_patch_store(const StemArgs& a, float* P, in
         if (idx >= nitems) continue;
         const int row = idx / (ST_ROW / 4), m = idx - row * (ST_ROW / 4);
         gf4 w = v[j];
-        if (a.nf) {
+        if (FR) {
             // (x - mean) / stdv of networks/resnet_encoder.py:89 -- the same two IEEE operations as the tensor expression it
             // replaces -- on pixels inside the image; the zero padding of conv1 stays zero
             const int ci = row / ST_ROWS, pr = row - ci * ST_ROWS;
@@ -603,6 +607,7 @@ __device__ __forceinline__ void stem_patch_store(const StemArgs& a, float* P, in
 
 // ---- forward: block = tile x 64 output channels; 4 waves = (channel half wm) x (tile row wn); MT = 2, NT = 4 ------------
 constexpr int ST_NVP = 8;        // ceil(6 * 9 * 34 / 256) patch vectors per thread
+template <bool FR>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
     constexpr int KC = GKC, MT = 2, NT = 4, ASZ = 64 * (KC + RP);
     float* const As = g1_smem;                       // [2][64][KC + RP]
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
     const cgrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
 
     gf4 pv[ST_NVP];
-    stem_patch_load<ST_NVP>(a, xr, b, oy0, ox0, tid, pv);
+    stem_patch_load<ST_NVP, FR>(a, xr, b, oy0, ox0, tid, pv);
     const float* asrc[2];
     int adst[2];
 #pragma unroll
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j]);
     for (int k = tid; k < a.Kp; k += 256) ktab[k] = stem_koff(k, a.K);
-    stem_patch_store<ST_NVP>(a, P, tid, pv, oy0, ox0);
+    stem_patch_store<ST_NVP, FR>(a, P, tid, pv, oy0, ox0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) store_red4(As + adst[j], ra[j]);
     __syncthreads();
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
 // 4 waves = (channel half wm) x (column half wn); a wave owns 32 channels x Kp/2 columns = MT 2 x NT (5 or 10) tiles.
 // Reduction = the tile's 128 pixels in octets of 8 along a row: A = gy[co][pixel] (reduction-contiguous image, as the
 // GEMM kernels), B[k][pixel] = patch[koff[k] + r * 2 * ROW + c] with koff fixed per lane for the whole kernel.
-template <int NT>
+template <int NT, bool FR>
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemArgs a) {
     constexpr int MT = 2, GS = 128 + RP, NVG = 8;
     float* const G = g1_smem;                        // [64][128 + RP]   gy of the tile, pixel = r * 64 + c
@@ -692,6 +697,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemArgs a) {
     const int per = (a.ntiles + a.nblocks - 1) / a.nblocks;
     const int t0 = blockIdx.x * per, t1 = min(t0 + per, a.ntiles);
     const int per_img = a.tiles_y * a.tiles_x, P2 = a.Ho * a.Wo;
+    const cgrsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), (short)0, (int)((size_t)a.B * a.Co * P2 * 4), 0x00020000);
     int koff[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) koff[t] = stem_koff(wn * 16 * NT + 16 * t + i, a.K);
@@ -709,8 +715,10 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemArgs a) {
     auto gy_vec = [&](int b, int oy0, int ox0, int j) {          // gy: 64 channels x 2 rows x 16 float4
         const int idx = tid + j * 256, co = idx >> 5, rr = (idx >> 4) & 1, c4 = idx & 15;
         const int oy = oy0 + rr, ox = ox0 + c4 * 4;
-        return (oy < a.Ho && ox < a.Wo) ? *reinterpret_cast<const gf4*>(a.gy + ((size_t)b * a.Co + co) * P2 + (size_t)oy * a.Wo + ox)
-                                        : gf4{0.f, 0.f, 0.f, 0.f};
+        // buffer load with an out-of-range offset for the zeros: a select around the load made the compiler wait for each
+        // of these eight loads before issuing the next
+        const unsigned off = (oy < a.Ho && ox < a.Wo) ? (unsigned)(((b * a.Co + co) * P2 + oy * a.Wo + ox) * 4) : 0x80000000u;
+        return __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(gr, (int)off, 0, 0));
     };
     auto gy_store = [&](int j, gf4 v) {
         const int idx = tid + j * 256, co = idx >> 5, rr = (idx >> 4) & 1, c4 = idx & 15;
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemArgs a) {
     auto gload = [&](int tile) {
         int b, oy0, ox0;
         tile_org(tile, b, oy0, ox0);
-        stem_patch_load<ST_NVP>(a, xr, b, oy0, ox0, tid, pv);
+        stem_patch_load<ST_NVP, FR>(a, xr, b, oy0, ox0, tid, pv);
         if constexpr (PREFETCH_G) {
 #pragma unroll
             for (int j = 0; j < NVG; ++j) gv[j] = gy_vec(b, oy0, ox0, j);
@@ -729,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemArgs a) {
         {
             int b_, oy_, ox_;
             tile_org(tile, b_, oy_, ox_);
-            stem_patch_store<ST_NVP>(a, P, tid, pv, oy_, ox_);
+            stem_patch_store<ST_NVP, FR>(a, P, tid, pv, oy_, ox_);
         }
         if constexpr (PREFETCH_G) {
 #pragma unroll
@@ -911,7 +919,7 @@ extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void
     if (stem_ok(Ci, Co, ksize)) {
         StemArgs sa = stem_args(B, Ci, Co, Hi, Wi);
         sa.x = x; sa.w = a.w; sa.out = y;
-        hipLaunchKernelGGL(stem_fwd_kernel, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(Ci, sa.Kp), st, sa);
+        hipLaunchKernelGGL(stem_fwd_kernel<false>, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(Ci, sa.Kp), st, sa);
         DC_CHECK_LAUNCH();
         return DC_OK;
     }
@@ -971,8 +979,8 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
         StemArgs sa = stem_args(B, Ci, Co, Hi, Wi);
         sa.x = x; sa.gy = gy; sa.out = (float*)ws;
         const size_t lds = stem_lds_wgrad(Ci);
-        if (Ci == 3) hipLaunchKernelGGL(stem_wgrad_kernel<5>, dim3(sa.nblocks), dim3(256), lds, st, sa);
-        else hipLaunchKernelGGL(stem_wgrad_kernel<10>, dim3(sa.nblocks), dim3(256), lds, st, sa);
+        if (Ci == 3) hipLaunchKernelGGL((stem_wgrad_kernel<5, false>), dim3(sa.nblocks), dim3(256), lds, st, sa);
+        else hipLaunchKernelGGL((stem_wgrad_kernel<10, false>), dim3(sa.nblocks), dim3(256), lds, st, sa);
         DC_CHECK_LAUNCH();
         hipLaunchKernelGGL(stem_wreduce_kernel, dim3(ceil_div(64 * sa.K, 16)), dim3(256), 0, st, (const float*)ws, dweight, sa.nblocks, sa.K, sa.Kp);
         DC_CHECK_LAUNCH();
@@ -1028,7 +1036,7 @@ extern "C" int dc_stem_fwd(const float* const* frames, int nf, float mean, float
     hipLaunchKernelGGL(cg_wpad_kernel, dim3(ceil_div(Co * sa.Kp, 256)), dim3(256), 0, st, weight, (float*)ws, Co, sa.K, sa.Kp);
     DC_CHECK_LAUNCH();
     sa.w = (const float*)ws; sa.out = y;
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(sa.Ci, sa.Kp), st, sa);
+    hipLaunchKernelGGL(stem_fwd_kernel<true>, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(sa.Ci, sa.Kp), st, sa);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -1040,8 +1048,8 @@ extern "C" int dc_stem_wgrad(const float* const* frames, int nf, float mean, flo
     hipStream_t st = (hipStream_t)stream;
     sa.gy = gy; sa.out = (float*)ws;
     const size_t lds = stem_lds_wgrad(sa.Ci);
-    if (sa.Ci == 3) hipLaunchKernelGGL(stem_wgrad_kernel<5>, dim3(sa.nblocks), dim3(256), lds, st, sa);
-    else hipLaunchKernelGGL(stem_wgrad_kernel<10>, dim3(sa.nblocks), dim3(256), lds, st, sa);
+    if (sa.Ci == 3) hipLaunchKernelGGL((stem_wgrad_kernel<5, true>), dim3(sa.nblocks), dim3(256), lds, st, sa);
+    else hipLaunchKernelGGL((stem_wgrad_kernel<10, true>), dim3(sa.nblocks), dim3(256), lds, st, sa);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(stem_wreduce_kernel, dim3(ceil_div(64 * sa.K, 16)), dim3(256), 0, st, (const float*)ws, dweight, sa.nblocks, sa.K, sa.Kp);
     DC_CHECK_LAUNCH();

@@ -117,19 +117,15 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
             const int chb = kb * WG_KT + xcg;               // wave-uniform: xcg = wave
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
+                // ONE load shape for every channel: an 8-byte buffer load, source picked by scalar selects (ch is wave-uniform).
+                // Per-source code paths -- and `px[q] = {v, v}`, a USE of the value, for the upsampled half -- made the compiler
+                // wait for these loads at their issue / in front of every commit (see wino.hip load_x).  The upsampled half
+                // reads 8 bytes at x0[y>>1][x>>1] and uses the first 4 (commit).
                 const int ch = chb + 4 * q;
-                if (!FUSED || ch < C0) {
-                    const unsigned vo = ok ? (unsigned)(b * C0 + ch) * plane0 + pix0 : 0x80000000u;
-                    if (FUSED && up0) {
-                        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)vo, 0, 0));
-                        px[q] = f2w{v, v};
-                    } else {
-                        px[q] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)vo, 0, 0));
-                    }
-                } else {
-                    const unsigned vo = ok ? (unsigned)(b * (a.K - C0) + (ch - C0)) * plane + pix1 : 0x80000000u;
-                    px[q] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(x1r, (int)vo, 0, 0));
-                }
+                const bool from1 = FUSED && ch >= C0;
+                const wrsrc_t rs = from1 ? x1r : xr;
+                const unsigned base = from1 ? (unsigned)(b * (a.K - C0) + (ch - C0)) * plane + pix1 : (unsigned)(b * C0 + ch) * plane0 + pix0;
+                px[q] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(ok ? base : 0x80000000u), 0, 0));
             }
         }
     };
@@ -141,8 +137,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
         if (x_in) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
+                const bool dup = FUSED && up0 && (kb * WG_KT + xcg + 4 * q) < C0;      // nearest-x2 source: one value, two columns
                 xl[buf][xlds0 + 4 * q * WG_XPS] = px[q].x;      // (pair 0: the discarded column lands on, and is overwritten by, .y)
-                xl[buf][xlds1 + 4 * q * WG_XPS] = px[q].y;
+                xl[buf][xlds1 + 4 * q * WG_XPS] = dup ? px[q].x : px[q].y;
             }
         }
     };
