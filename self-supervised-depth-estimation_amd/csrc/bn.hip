@@ -358,18 +358,27 @@ __global__ __launch_bounds__(256) void maxpool_fwd2_kernel(const float* __restri
     const float* p = x + plane * H * W;
     float ba = -INFINITY, bb = -INFINITY;
     int ca = 0, cb = 0;
+    // the three window rows are fetched together from clamped rows (a `continue` / `if` around the loads made each row wait
+    // for the previous one) and rows / the left column outside the image are skipped in the comparisons
+    float4 f[3];
+    float e[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = min(max(oy * 2 - 1 + ky, 0), H - 1);
+        const float* row = p + (size_t)yy * W + 2 * ox0;
+        f[ky] = *reinterpret_cast<const float4*>(row);
+        e[ky] = row[ox0 > 0 ? -1 : 0];
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int yy = oy * 2 - 1 + ky;
         if (yy < 0 || yy >= H) continue;
-        const float* row = p + (size_t)yy * W + 2 * ox0;
-        const float4 f = *reinterpret_cast<const float4*>(row);
-        if (ox0 > 0) { const float e = row[-1]; if (e > ba || e != e) { ba = e; ca = ky * 3; } }
-        if (f.x > ba || f.x != f.x) { ba = f.x; ca = ky * 3 + 1; }
-        if (f.y > ba || f.y != f.y) { ba = f.y; ca = ky * 3 + 2; }
-        if (f.y > bb || f.y != f.y) { bb = f.y; cb = ky * 3; }
-        if (f.z > bb || f.z != f.z) { bb = f.z; cb = ky * 3 + 1; }
-        if (f.w > bb || f.w != f.w) { bb = f.w; cb = ky * 3 + 2; }
+        if (ox0 > 0) { if (e[ky] > ba || e[ky] != e[ky]) { ba = e[ky]; ca = ky * 3; } }
+        if (f[ky].x > ba || f[ky].x != f[ky].x) { ba = f[ky].x; ca = ky * 3 + 1; }
+        if (f[ky].y > ba || f[ky].y != f[ky].y) { ba = f[ky].y; ca = ky * 3 + 2; }
+        if (f[ky].y > bb || f[ky].y != f[ky].y) { bb = f[ky].y; cb = ky * 3; }
+        if (f[ky].z > bb || f[ky].z != f[ky].z) { bb = f[ky].z; cb = ky * 3 + 1; }
+        if (f[ky].w > bb || f[ky].w != f[ky].w) { bb = f[ky].w; cb = ky * 3 + 2; }
     }
     const size_t o = plane * Ho * Wo + (size_t)oy * Wo + ox0;
     *reinterpret_cast<float2*>(y + o) = make_float2(ba, bb);

@@ -68,9 +68,12 @@ __global__ __launch_bounds__(256) void dispconv_fwd_kernel(const float* __restri
 
 // folded g' window of pixel (qy, qx): G[ky][kx] = sum over padded rows r in Ry(qy), columns c in Rx(qx) of g'[r+1-ky][c+1-kx]
 __device__ __forceinline__ float gprime_at(const float* gy, const float* y, int H, int W, int r, int c, int act) {
-    if (r < 0 || r >= H || c < 0 || c >= W) return 0.f;
-    const size_t o = (size_t)r * W + c;
-    return gy[o] * act_bwd(y[o], act);
+    // branch-free: load from the clamped position, select afterwards (an early return around the loads made the compiler
+    // wait for each of the 18 loads of a window before issuing the next)
+    const bool ok = r >= 0 && r < H && c >= 0 && c < W;
+    const size_t o = (size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1);
+    const float v = gy[o] * act_bwd(y[o], act);
+    return ok ? v : 0.f;
 }
 
 // grid (ceil(H*W / 256), B): one thread per pixel, loops over the channels (coalesced plane writes)
@@ -95,10 +98,11 @@ __global__ __launch_bounds__(256) void dispconv_dx_kernel(const float* __restric
         if (qx == W - 2) rx[nx++] = W;
     }
     float G[9];
+    // the pixel's own window first, all 18 loads in flight together; the mirrored rows / columns (border pixels only) after it
 #pragma unroll
-    for (int t = 0; t < 9; ++t) G[t] = 0.f;
+    for (int t = 0; t < 9; ++t) G[t] = gprime_at(g, yy, H, W, qy + 1 - t / 3, qx + 1 - t % 3, act);
     for (int a = 0; a < ny; ++a)
-        for (int c = 0; c < nx; ++c) {
+        for (int c = (a == 0 ? 1 : 0); c < nx; ++c) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) G[t] += gprime_at(g, yy, H, W, ry[a] + 1 - t / 3, rx[c] + 1 - t % 3, act);
         }
