@@ -62,16 +62,22 @@ __device__ __forceinline__ size_t pix_group_off(int n, int N, int P, int Wo, int
     return (size_t)b * C * Hi * Wi + (size_t)(py * s) * Wi + px * s;
 }
 // 4 output pixels of one channel plane (stride-2: every other element of 8 consecutive ones)
-__device__ __forceinline__ gf4 load_pix4(const float* plane_ptr, int s) {
-    if (s == 1) return *reinterpret_cast<const gf4*>(plane_ptr);
-    const gf4 u = *reinterpret_cast<const gf4*>(plane_ptr), v = *reinterpret_cast<const gf4*>(plane_ptr + 4);
-    return gf4{u.x, u.z, v.x, v.z};
+// (the stride is a TEMPLATE parameter: as a run-time `if` it put a branch around every B-operand load, and the compiler
+// waited for all outstanding loads -- vmcnt(0) -- right behind each, i.e. before the MFMAs the loads were meant to overlap)
+template <int S>
+__device__ __forceinline__ gf4 load_pix4(const float* plane_ptr) {
+    if constexpr (S == 1) {
+        return *reinterpret_cast<const gf4*>(plane_ptr);
+    } else {
+        const gf4 u = *reinterpret_cast<const gf4*>(plane_ptr), v = *reinterpret_cast<const gf4*>(plane_ptr + 4);
+        return gf4{u.x, u.z, v.x, v.z};
+    }
 }
 
 // =====================================================================================================================
 // forward.  A = w [co][ci] (reduction-contiguous), B = x [ci][n] (index-contiguous).  Ci % KC == 0.
 // =====================================================================================================================
-template <int MT, int NT, bool EPI>
+template <int MT, int NT, bool EPI, int S>
 __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
     constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SB = IdxStride<NT, BN>::v;
     constexpr int NA = BM * KC / 1024, NB = KC * BN / 1024;          // float4 per thread per chunk
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int idx = tid + j * 256, k = idx / (BN / 4), c4 = idx % (BN / 4);
-        bsrc[j] = a.x + pix_group_off(n0 + c4 * 4, N, P, a.Wo, a.Ci, a.Hi, a.Wi, a.s) + (size_t)k * plane;
+        bsrc[j] = a.x + pix_group_off(n0 + c4 * 4, N, P, a.Wo, a.Ci, a.Hi, a.Wi, S) + (size_t)k * plane;
         bdst[j] = k * SB + c4 * 4;
     }
     gf4 ra[NA], rb[NB];
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j] + k0);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) rb[j] = load_pix4(bsrc[j] + (size_t)k0 * plane, a.s);
+        for (int j = 0; j < NB; ++j) rb[j] = load_pix4<S>(bsrc[j] + (size_t)k0 * plane);
     };
     auto commit = [&](int buf) {
 #pragma unroll
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
 // reduction-contiguous.  blockIdx.y = split: a contiguous range of chunks (its successive 128-byte row segments stay in one
 // L2); writes slab[split][co][ci] (or dw itself when there is one split).
 // =====================================================================================================================
-template <int MT, int NT>
+template <int MT, int NT, int S>
 __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
     constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC;
     constexpr int NA = BM * KC / 1024, NB = BN * KC / 1024;
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
         const int n = ch * KC + kq * 4;
         const int b = n / P, p = n - b * P;
         size_t pix;
-        if (a.s == 1) {
+        if constexpr (S == 1) {
             pix = p;
         } else {
             const int py = p / a.Wo, px = p - py * a.Wo;
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const gf4*>(ga + arow[j]);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) rb[j] = load_pix4(xb + brow[j], a.s);
+        for (int j = 0; j < NB; ++j) rb[j] = load_pix4<S>(xb + brow[j]);
     };
     auto commit = [&](int buf) {
 #pragma unroll
@@ -449,14 +455,21 @@ extern "C" int dc_gemm1x1_fwd(const float* x, const float* weight, const float* 
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = g1_lds_fwd(t);
     const bool epi = bias || act != ACT_NONE;
-    static const bool attr = g1_set_lds(g1_fwd_kernel<4, 4, false>, g1_lds_fwd({4, 4})) &&
-                             g1_set_lds(g1_fwd_kernel<4, 4, true>, g1_lds_fwd({4, 4}));
+    static const bool attr = g1_set_lds(g1_fwd_kernel<4, 4, false, 1>, g1_lds_fwd({4, 4})) &&
+                             g1_set_lds(g1_fwd_kernel<4, 4, true, 1>, g1_lds_fwd({4, 4})) &&
+                             g1_set_lds(g1_fwd_kernel<4, 4, false, 2>, g1_lds_fwd({4, 4})) &&
+                             g1_set_lds(g1_fwd_kernel<4, 4, true, 2>, g1_lds_fwd({4, 4}));
     if (!attr) return DC_ELAUNCH;
     hipEvent_t pe = conv_prof_begin(4, 2.0 * (double)B * Co * Ci * a.Ho * a.Wo, 2.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * Ci, 4.0 * ((double)B * Ci * a.Ho * a.Wo + (double)B * Co * a.Ho * a.Wo + (double)Co * Ci), st);
 #define G1_FWD(MT, NT)                                                                            \
     do {                                                                                          \
-        if (epi) hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, true>), grid, dim3(256), lds, st, a);  \
-        else hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, false>), grid, dim3(256), lds, st, a);     \
+        if (stride == 1) {                                                                            \
+            if (epi) hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, true, 1>), grid, dim3(256), lds, st, a);   \
+            else hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, false, 1>), grid, dim3(256), lds, st, a);      \
+        } else {                                                                                      \
+            if (epi) hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, true, 2>), grid, dim3(256), lds, st, a);   \
+            else hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, false, 2>), grid, dim3(256), lds, st, a);      \
+        }                                                                                             \
     } while (0)
     if (t.mt == 4) G1_FWD(4, 4);
     else if (t.nt == 4) G1_FWD(2, 4);
@@ -512,11 +525,16 @@ extern "C" int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight,
     const dim3 grid(a.mtiles * a.ntiles, a.splits);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = g1_lds_wgrad(t);
-    static const bool attr = g1_set_lds(g1_wgrad_kernel<4, 4>, g1_lds_wgrad({4, 4}));
+    static const bool attr = g1_set_lds(g1_wgrad_kernel<4, 4, 1>, g1_lds_wgrad({4, 4})) && g1_set_lds(g1_wgrad_kernel<4, 4, 2>, g1_lds_wgrad({4, 4}));
     if (!attr) return DC_ELAUNCH;
     hipEvent_t pe = conv_prof_begin(4, 2.0 * (double)B * Co * Ci * a.Ho * a.Wo, 2.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * (double)a.chunks * GKC, 4.0 * ((double)B * Ci * a.Ho * a.Wo + (double)B * Co * a.Ho * a.Wo + (double)Co * Ci), st);
-    if (t.mt == 4) hipLaunchKernelGGL((g1_wgrad_kernel<4, 4>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((g1_wgrad_kernel<2, 2>), grid, dim3(256), lds, st, a);
+    if (stride == 1) {
+        if (t.mt == 4) hipLaunchKernelGGL((g1_wgrad_kernel<4, 4, 1>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((g1_wgrad_kernel<2, 2, 1>), grid, dim3(256), lds, st, a);
+    } else {
+        if (t.mt == 4) hipLaunchKernelGGL((g1_wgrad_kernel<4, 4, 2>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((g1_wgrad_kernel<2, 2, 2>), grid, dim3(256), lds, st, a);
+    }
     conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     if (a.splits > 1) {
