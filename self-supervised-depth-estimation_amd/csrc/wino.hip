@@ -132,15 +132,19 @@ struct WinoPsArgs {
     unsigned xbytes;
     size_t slab_stride;               // floats between the K-split slabs
     int mblocks, tblocks, m_fast;
-    unsigned long long* diag;         // WINO_DIAG builds only: per block {compute, commit(+load wait), issue, barrier, total} cycles
+    unsigned long long* diag;         // WINO_DIAG builds only: per block {compute, commit(+load wait), issue, barrier, loop, prologue, epilogue, start time} cycles
 };
 
 template <int MR, int NR, bool FUSED>
-__global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
+__global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) void wino_ps_kernel(WinoPsArgs a) {
     constexpr int MT = 16 * MR, G = NR / 2;
     constexpr int UF4 = PSK * 4 * MT;                 // f4 items of one U chunk in global memory
     static_assert(NR % 2 == 0 && NR * 2048 <= 2 * PSK * G * PSUB, "the row exchange aliases the slab double buffer");
     __shared__ float xl[2][PSK * G * PSUB];
+#ifdef WINO_DIAG
+    const unsigned long long dg_start = __builtin_amdgcn_s_memtime();
+    const unsigned long long dg_rstart = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kk = lane >> 4;
     const int H = a.H, W = a.W, RH = a.RH, RW = a.RW, RS = a.RS, SUBS = a.SUBS;
@@ -154,8 +158,12 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
     const int c_begin = blockIdx.z * a.chunks_per_split;
     const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
 
-    // ---- staging role: thread -> (sub-region, slab row, column pair), all PSK channels of the chunk
-    const int sg_ = tid >> 7, sp = tid & 127;
+    // ---- staging role: thread -> (sub-region, slab row, column pair) and PK channels of the chunk.  G = 2: the two thread
+    // halves take the two sub-regions, all PSK channels each.  G = 1: they take the two channel halves of the one sub-region
+    // (with waves 0-1 staging everything, waves 2-3 sat at the barrier for the length of 16 LDS writes and 8 load issues per chunk)
+    constexpr int PK = G == 1 ? PSK / 2 : PSK;
+    const int sg_ = G == 1 ? 0 : tid >> 7, sp = tid & 127;
+    const int kh0 = G == 1 ? (wave >> 1) * PK : 0;       // first channel of the chunk this thread stages
     const int PR = RW + 2, SR = 2 * RH + 2;
     const int ssub = tblk * G + sg_;
     const bool s_act = sg_ < G && ssub < a.nsub && sp < SR * PR;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[i][j][q] = f4{0.f, 0.f, 0.f, 0.f};
 
-    f2w px[2][PSK];                                  // x of chunk c lives in px[(c - c_begin) & 1], two chunks in flight
+    f2w px[2][PK];                                   // x of chunk c lives in px[(c - c_begin) & 1], two chunks in flight
     // A operands: the four waves need DISJOINT quarters of a U chunk (wave = Winograd row = pq), so U never goes through
     // LDS: each lane loads its own 16 bytes per k-step and 16-channel block straight into the registers the MFMAs read,
     // one chunk ahead (16 lanes x 16 B = 256-byte rows; the other tile blocks of this channel block find them in L2)
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
                 dst[ks][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ur, uoff + (ks * 16 * MT + i * 16) * 16, c * (UF4 * 16), 0));
     };
     auto load_x = [&](int c, f2w* dst) {
-        if (G == 2 || wave < 2) {
+        {
             // ONE load shape for every kind of chunk -- eight 8-byte buffer loads, the source picked by scalar selects (chunks
             // never straddle the concat: C0 % PSK == 0, host-checked).  Separate code paths per source (dword loads for the
             // upsampled half, two descriptors) made the number of outstanding loads path-dependent for the compiler, which then
@@ -240,9 +248,9 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
             const bool from1 = FUSED && ch0 >= C0;
             const wrsrc_t rs = from1 ? x1r : xr;
             const unsigned pl = from1 ? plane : plane0, vbase = from1 ? svoff1 : svoff;
-            const int chb = from1 ? ch0 - C0 : ch0, climit = from1 ? a.K - C0 : C0;
+            const int chb = (from1 ? ch0 - C0 : ch0) + kh0, climit = from1 ? a.K - C0 : C0;
 #pragma unroll
-            for (int k = 0; k < PSK; ++k) {
+            for (int k = 0; k < PK; ++k) {
                 const int ch = chb + k;
                 const unsigned vo = ch < climit ? vbase : 0x80000000u;
                 dst[k] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)vo, (int)((unsigned)ch * pl), 0));
@@ -254,9 +262,9 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
             float* xw = xl[buf];
             const bool dup = FUSED && up0 && c * PSK < C0;        // chunk of the nearest-x2 upsampled source: one value, two columns
 #pragma unroll
-            for (int k = 0; k < PSK; ++k) {
-                xw[k * CPS + slds0] = src[k].x;
-                xw[k * CPS + slds1] = dup ? src[k].x : src[k].y;
+            for (int k = 0; k < PK; ++k) {
+                xw[(kh0 + k) * CPS + slds0] = src[k].x;
+                xw[(kh0 + k) * CPS + slds1] = dup ? src[k].x : src[k].y;
             }
         }
     };
@@ -309,6 +317,8 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
 #ifdef WINO_DIAG
     unsigned long long dg[5] = {0, 0, 0, 0, 0};
     const unsigned long long dg0 = __builtin_amdgcn_s_memtime();
+#endif
+#if defined(WINO_DIAG) && WINO_DIAG == 1             // WINO_DIAG=2: only prologue / loop / epilogue (the inner timers cost ~20 % themselves)
 #define DIAG_T(k, stmt) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stmt; dg[k] += __builtin_amdgcn_s_memtime() - t_; }
 #define DIAG_WAIT() __builtin_amdgcn_s_waitcnt(0xc07f)   /* lgkmcnt(0): charge the LDS writes to the commit phase */
 #else
@@ -330,9 +340,8 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
     }
 
 #ifdef WINO_DIAG
-    dg[4] = __builtin_amdgcn_s_memtime() - dg0;
-    if (a.diag && lane == 0 && wave == 0)
-        for (int q = 0; q < 5; ++q) a.diag[(size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 5 + q] = dg[q];
+    const unsigned long long dg_loop_end = __builtin_amdgcn_s_memtime();
+    dg[4] = dg_loop_end - dg0;
 #endif
     // ---- combine the four rows: wave a contributes z[a][jj] = sum_b M[a][b] A[b][jj]; Y[0] = z0+z1+z2, Y[1] = z1-z2-z3
     float* ex = &xl[0][0];                                       // [wave][(j*4 + r)*2 + jj][lane]  (the slabs are dead now)
@@ -387,6 +396,24 @@ __global__ __launch_bounds__(256, 2) void wino_ps_kernel(WinoPsArgs a) {
             }
         }
     }
+#ifdef WINO_DIAG
+    if (a.diag && lane == 0 && wave == 0) {
+        unsigned long long* o = a.diag + (size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8;
+        for (int q = 0; q < 5; ++q) o[q] = dg[q];
+        o[5] = dg0 - dg_start;                                  // prologue (index setup, first loads, first commit)
+        o[6] = __builtin_amdgcn_s_memtime() - dg_loop_end;      // epilogue (row combine through LDS, stores issued)
+        o[7] = dg_start;
+#if WINO_DIAG == 2
+        o[7] = dg_rstart;                                       // s_memrealtime: 100 MHz, the same counter on every CU (s_memtime is per CU)
+        o[0] = __builtin_amdgcn_s_memrealtime();                // block end: (start, end) of every block -> residency timeline
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        o[1] = hwid;                                            // [11:8] CU, [15:13]... which SIMD/CU/SE the block ran on
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hwid));
+        o[2] = hwid;
+#endif
+    }
+#endif
 }
 
 // y = act(sum of the K-split slabs (fixed order) + bias)
@@ -499,6 +526,27 @@ void conv_prof_end(hipEvent_t e, hipStream_t st) {
     if (e) (void)hipEventRecord(e, st);
 }
 
+// Predicted duration (us) of one wino_ps_kernel launch, used to pick the tile variant v (0: 16 ch x 32 tiles, 4 blocks per
+// CU; 1: 32 x 32, 3 per CU; 2: 32 x 64, 2 per CU) and the reduction split.  Per-block timelines (-DWINO_DIAG=2,
+// tools/diag_wino.py) showed what the old rule ("32 x 64 while that fills 512 slots") missed: the launch runs in ROUNDS of
+// 256 x blocks-per-CU blocks, the blocks of a round move in lock-step (same start, same length), and a last round that is
+// 40 % full still costs 65 % of a full one (720 blocks of the 32 x 64 variant: 27 us + 18 us).  Model: a block takes
+// P + chunks * (a + b * o) with o = blocks resident per CU; full rounds at o = blocks-per-CU, the remainder at its own o;
+// a split adds the slab sum.  {P, a, b} fitted to the 132 measurements of tools/sweep_wino.py (22 step shapes x 6
+// choices, rms error 7 %); the model's pick is within 0.3 % of the best measured choice summed over those shapes, 9 %
+// below the old rule's.  Deterministic in the shape, so every rank takes the same summation order.
+static double wino_ps_cost(int v, int ksplit, int nsub, int M, int nchunks, size_t nout) {
+    static const double P[3] = {3.28, 3.51, 4.05}, A[3] = {0.614, 0.598, 0.835}, Bc[3] = {0.213, 0.460, 0.929};
+    static const int bpc[3] = {4, 3, 2}, mt[3] = {16, 32, 32}, g[3] = {1, 1, 2};
+    const long blocks = (long)ceil_div(nsub, g[v]) * ceil_div(M, mt[v]) * ksplit;
+    const int chunks = ceil_div(nchunks, ksplit);
+    const long slots = 256L * bpc[v], full = blocks / slots, rem = blocks % slots;
+    double t = (double)full * (P[v] + chunks * (A[v] + Bc[v] * bpc[v]));
+    if (rem) t += P[v] + chunks * (A[v] + Bc[v] * (double)ceil_div((int)rem, 256));
+    if (ksplit > 1) t += 6.5 + 0.124 * (double)nout * 12.0 * 1e-6;
+    return t;
+}
+
 // One convolution launch: reduction over K = C0 + C1 source channels, M output channels.
 struct WinoLaunch {
     const float* src0; int C0; int up0; const float* src1; int C1;     // input = cat(up2?(src0), src1), maps H x W
@@ -524,14 +572,26 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     a.SUBS = (2 * a.RH + 2) * a.RS;
     a.regs_x = ceil_div(TW, a.RW); a.regs_y = ceil_div(TH, a.RH); a.nsub = a.regs_x * a.regs_y * d.B;
     a.nchunks = ceil_div(K, PSK);
-    // 32 channels x 64 tiles per block while that fills 256 CUs x 2; otherwise 16 x 32, and on the deepest layers
-    // (few tiles, many channels) the reduction is split as well (measured per trunk shape, tools/bench_wino.py)
-    const bool small = M <= 16 || (long)ceil_div(a.nsub, 2) * ceil_div(M, 32) < 512;
-    const int MT = small ? 16 : 32, G = small ? 1 : 2;
-    const int Mp = ceil_div(M, MT) * MT, Kp = a.nchunks * PSK;
-    const int blocks = ceil_div(a.nsub, G) * (Mp / MT);
+    // Tile variant and reduction split: the cheapest of {16x32, 32x32, 32x64} x {1, 2 slabs} under wino_ps_cost (below)
+    int MT = 32, G = 2, ksplit = 1;
     const size_t nout = (size_t)d.B * M * Ho * Wo;
-    const int ksplit = (blocks < 512 && a.nchunks >= 8 && (Ho * Wo) % 4 == 0) ? 2 : 1;
+    {
+        const bool can_split = (Ho * Wo) % 4 == 0 && a.nchunks >= 2;
+        double best = 1e30;
+        for (int v = 0; v < 3; ++v)
+            for (int ks = 1; ks <= (can_split ? 2 : 1); ++ks) {
+                const double t = wino_ps_cost(v, ks, a.nsub, M, a.nchunks, nout);
+                if (t < best) { best = t; MT = v == 0 ? 16 : 32; G = v == 2 ? 2 : 1; ksplit = ks; }
+            }
+        if (const char* f = getenv("DC_WINO_FORCE")) {       // experiments: "MR,NR,ksplit" (tools/sweep_wino.py)
+            int mr = 0, nr = 0, fks = 0;
+            if (sscanf(f, "%d,%d,%d", &mr, &nr, &fks) >= 2 && (mr == 1 || mr == 2) && (nr == 2 || nr == 4) && !(mr == 1 && nr == 4)) {
+                MT = 16 * mr; G = nr / 2;
+                if (fks > 0) ksplit = can_split ? std::min(fks, 2) : 1;
+            }
+        }
+    }
+    const int Mp = ceil_div(M, MT) * MT, Kp = a.nchunks * PSK;
     a.chunks_per_split = ceil_div(a.nchunks, ksplit);
     float* slabs = (float*)((char*)d.ws + wino_uhat_bytes(d.Ci, d.Co));
     a.y = ksplit > 1 ? slabs : d.out;
@@ -556,10 +616,12 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
                                     2.0 * 16.0 * (double)a.nsub * 32.0 * (double)Mp * Kp,
                                     (double)b0 + (double)b1 + 4.0 * (double)nout + 36.0 * d.Co * d.Ci, st);
     if (d.fused) {
-        if (small) hipLaunchKernelGGL((wino_ps_kernel<1, 2, true>), grid, dim3(256), 0, st, a);
+        if (MT == 16) hipLaunchKernelGGL((wino_ps_kernel<1, 2, true>), grid, dim3(256), 0, st, a);
+        else if (G == 1) hipLaunchKernelGGL((wino_ps_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wino_ps_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
     } else {
-        if (small) hipLaunchKernelGGL((wino_ps_kernel<1, 2, false>), grid, dim3(256), 0, st, a);
+        if (MT == 16) hipLaunchKernelGGL((wino_ps_kernel<1, 2, false>), grid, dim3(256), 0, st, a);
+        else if (G == 1) hipLaunchKernelGGL((wino_ps_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wino_ps_kernel<2, 4, false>), grid, dim3(256), 0, st, a);
     }
     conv_prof_end(pe, st);

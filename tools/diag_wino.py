@@ -22,17 +22,24 @@ def main():
         w = torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05
         y = torch.empty(B, Co, H, W, device="cuda")
         ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device="cuda")
-        diag = torch.zeros(5 * 200000, dtype=torch.int64, device="cuda")
+        diag = torch.zeros(8 * 200000, dtype=torch.int64, device="cuda")
         raw.dc_wino_set_diag(diag.data_ptr())
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(50):
             L.dc_wino3x3_fwd(ptr(x), ptr(w), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, st)
         torch.cuda.synchronize()
-        d = diag.cpu().view(-1, 5)
-        d = d[d[:, 4] > 0].double()
+        d = diag.cpu().view(-1, 8)
+        d = d[d[:, 4] > 0]
+        if os.environ.get("WINO_DIAG_DUMP"):
+            import numpy as np
+            np.save(os.path.join(os.environ["WINO_DIAG_DUMP"], "wino_blocks_%s.npy" % spec.replace(",", "_")), d.numpy())
+        span = int(d[:, 7].max() - d[:, 7].min())               # first to last block start (s_memtime ticks)
+        d = d.double()
         m = d.mean(0)
-        print("%s: blocks %d | cycles/block: compute %.0f commit+wait %.0f issue %.0f barrier %.0f total(loop) %.0f | frac %s"
-              % (spec, d.shape[0], m[0], m[1], m[2], m[3], m[4], ["%.2f" % (v / m[4]) for v in m[:4]]))
+        print("%s: blocks %d | cycles/block: compute %.0f commit+wait %.0f issue %.0f barrier %.0f total(loop) %.0f | frac %s | "
+              "prologue %.0f epilogue %.0f (%.2f / %.2f of the block) | block starts span %d"
+              % (spec, d.shape[0], m[0], m[1], m[2], m[3], m[4], ["%.2f" % (v / m[4]) for v in m[:4]], m[5], m[6],
+                 m[5] / (m[4] + m[5] + m[6]), m[6] / (m[4] + m[5] + m[6]), span))
 
 
 if __name__ == "__main__":
