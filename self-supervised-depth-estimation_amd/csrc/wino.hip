@@ -500,6 +500,7 @@ static const float* wc_lookup(const float* w, int Ci, int Co, bool dgrad, int MT
 #ifdef WINO_DIAG
 static unsigned long long* g_wino_diag = nullptr;
 extern "C" void dc_wino_set_diag(void* p) { g_wino_diag = (unsigned long long*)p; }
+unsigned long long* wino_diag_ptr() { return g_wino_diag; }
 #endif
 
 // ---- measurement hook ---------------------------------------------------------------------------------

@@ -51,13 +51,18 @@ struct WinoWgArgs {
     int regs_x, regs_y, nsub;
     int splits, kblocks, mblocks;
     unsigned xbytes, gbytes;
+    unsigned long long* diag;         // -DWINO_DIAG builds: per block {end, hw id, xcc, -, loop, prologue, epilogue, start} (tools/diag_wino.py)
 };
+unsigned long long* wino_diag_ptr();
 
 template <bool FUSED>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     constexpr int MR = WG_MR, KR = WG_KR;
     __shared__ float gl[2][WG_MT * WG_GPS];
     __shared__ float xl[2][WG_KT * WG_XPS];
+#ifdef WINO_DIAG
+    const unsigned long long dg_start = __builtin_amdgcn_s_memtime(), dg_rstart = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, tq = lane >> 4;          // channel within a 16-block, tile within a k-step
     const int H = a.H, W = a.W, RH = a.RH, RW = a.RW, GRS = a.GRS, XRS = a.XRS;
@@ -227,6 +232,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
         if (sub + a.splits < a.nsub) prefetch(sub + a.splits);
     }
     __syncthreads();
+#ifdef WINO_DIAG
+    const unsigned long long dg0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = 0; sub < a.nsub; sub += a.splits, ++it) {
         compute(it & 1);
         if (sub + a.splits < a.nsub) {
@@ -236,6 +244,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
         __syncthreads();
     }
 
+#ifdef WINO_DIAG
+    const unsigned long long dg1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- q[a][.] = (sigma dU)[a][.] G and the slab write (lane-contiguous):
     // slab[((((blk*4 + a)*MR + i)*KR + j)*4 + r)*3 + qq][lane],  blk = split * nmk + mk
     const float sa = wave == 3 ? -1.f : 1.f;
@@ -254,6 +265,18 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
                 d[64] = 0.5f * (u1 - u2);
                 d[128] = h + u3;
             }
+#ifdef WINO_DIAG
+    if (a.diag && lane == 0 && wave == 0) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0): the slab stores have left the wave
+        unsigned long long* o = a.diag + (size_t)blockIdx.x * 8;
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[1] = hwid; o[2] = xcc; o[3] = 0; o[4] = dg1 - dg0; o[5] = dg0 - dg_start;
+        o[6] = __builtin_amdgcn_s_memtime() - dg1; o[7] = dg_rstart;
+        o[0] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // dw[m][k][3x3] = G^T (sum over splits of q), fixed order.  One block per (m-block, k-block, i, j, r): 64 lanes x 16
@@ -329,6 +352,10 @@ static WgPlan wg_plan(int B, int Ci, int Co, int H, int W) {
     const int nmk = p.mblocks * p.kblocks;
     // 256 CUs x 2 blocks; at least two chunks per block so that the pipeline has something to overlap
     p.splits = std::max(1, std::min(std::max(1, p.nsub / 2), ceil_div(512, nmk)));
+    if (const char* f = getenv("DC_WGRAD_BLOCKS")) {         // experiments (tools/sweep_wgrad.py): target block count
+        const int tb = atoi(f);
+        if (tb > 0) p.splits = std::max(1, std::min(std::max(1, p.nsub / 2), ceil_div(tb, nmk)));
+    }
     return p;
 }
 
@@ -344,6 +371,9 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
     a.RH = p.RH; a.RW = p.RW; a.GRS = p.GRS; a.XRS = p.XRS;
     a.regs_x = p.regs_x; a.regs_y = p.regs_y; a.nsub = p.nsub; a.splits = p.splits; a.kblocks = p.kblocks; a.mblocks = p.mblocks;
     a.xbytes = (unsigned)b0; a.x1bytes = (unsigned)b1; a.gbytes = (unsigned)gb;
+#ifdef WINO_DIAG
+    a.diag = wino_diag_ptr();
+#endif
     const int nmk = p.mblocks * p.kblocks;
     hipEvent_t pe = conv_prof_begin(1, 2.0 * B * (double)Co * Ci * 9.0 * H * W,
                                     2.0 * 16.0 * (double)p.nsub * 16.0 * (double)(p.mblocks * WG_MT) * (p.kblocks * WG_KT),

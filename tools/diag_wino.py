@@ -25,14 +25,21 @@ def main():
         diag = torch.zeros(8 * 200000, dtype=torch.int64, device="cuda")
         raw.dc_wino_set_diag(diag.data_ptr())
         st = torch.cuda.current_stream().cuda_stream
-        for _ in range(50):
-            L.dc_wino3x3_fwd(ptr(x), ptr(w), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, st)
+        if os.environ.get("WINO_DIAG_KERNEL") == "wgrad":          # the weight-gradient kernel instead (mode 2 fields only)
+            gy = torch.randn(B, Co, H, W, device="cuda")
+            dw = torch.empty_like(w)
+            ws = torch.empty(L.dc_wino3x3_wgrad_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device="cuda")
+            for _ in range(50):
+                L.dc_wino3x3_wgrad(ptr(x), ptr(gy), ptr(dw), ws.data_ptr(), B, Ci, Co, H, W, st)
+        else:
+            for _ in range(50):
+                L.dc_wino3x3_fwd(ptr(x), ptr(w), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, st)
         torch.cuda.synchronize()
         d = diag.cpu().view(-1, 8)
         d = d[d[:, 4] > 0]
         if os.environ.get("WINO_DIAG_DUMP"):
             import numpy as np
-            np.save(os.path.join(os.environ["WINO_DIAG_DUMP"], "wino_blocks_%s.npy" % spec.replace(",", "_")), d.numpy())
+            np.save(os.path.join(os.environ["WINO_DIAG_DUMP"], "%s_blocks_%s.npy" % (os.environ.get("WINO_DIAG_KERNEL", "wino"), spec.replace(",", "_"))), d.numpy())
         span = int(d[:, 7].max() - d[:, 7].min())               # first to last block start (s_memtime ticks)
         d = d.double()
         m = d.mean(0)
