@@ -282,7 +282,7 @@ def run_rank(args):
     elif args.front == "fusion":     # BASELINE configs[4]: frames [-2, -1, 0] stacked through encoder + decoder, then Fusion_v3
         front = dict(fusion="v3", frame_ids=[0, -2, -1, 1])
     opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
-                            nets_dtype=args.nets_dtype,
+                            nets_dtype=args.nets_dtype, torch_adam=args.torch_adam,
                             cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap,
                             wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph) and world == 1, **front)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
@@ -545,6 +545,7 @@ def main():
     ap.add_argument("--front", choices=["none", "gru", "fusion"], default="none",
                     help="sequence front-end: gru = ConvGRU v5 (configs[3], batch 1 x --len-sequence frames), fusion = Fusion_v3 (configs[4])")
     ap.add_argument("--len-sequence", type=int, default=3)
+    ap.add_argument("--torch-adam", action="store_true", help="A/B: ATen's fused Adam instead of dc_adam_step")
     ap.add_argument("--nets-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: the reduced-precision-networks policy of BASELINE configs[4] (convolution operands rounded to bf16 "
                          "for the matrix cores, fp32 accumulate; tensors, master weights, BatchNorm and the loss stay fp32); "

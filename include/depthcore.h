@@ -293,6 +293,23 @@ int dc_stem_fwd(const float* const* frames, int nf, float mean, float stdv, cons
 int dc_stem_wgrad(const float* const* frames, int nf, float mean, float stdv, const float* gy, float* dweight, void* ws, int Bf, int Hi,
                   int Wi, int Co, void* stream);
 
+/* Adam update of all trainable tensors of a step (reference trainer.py:110-113 `optim.Adam(self.parameters_to_train,
+ * self.opt.learning_rate)` and `self.model_optimizer.step()` at trainer.py:238): torch.optim.Adam arithmetic in fp32 -- no
+ * weight decay, no amsgrad -- one streaming pass, 28 bytes per parameter.
+ *   slots_dev   device array of ntensors records {float* param, float* exp_avg, float* exp_avg_sq, float* step, int64 numel}
+ *               (40 bytes each; `step` points at the tensor's step count, a float in device memory, as torch's capturable
+ *               Adam keeps it);
+ *   chunks_dev  device array of int32 pairs {tensor, first element}: every tensor cut into pieces of dc_adam_chunk()
+ *               elements, sorted by tensor;  chunk_start_host[t] = index of tensor t's first pair (ntensors + 1 entries, host);
+ *   grads_host  host array of ntensors device pointers: this step's gradients (contiguous fp32), NULL = the tensor got no
+ *               gradient: it is skipped and its step count does not advance.
+ * beta1 / beta2 are doubles: the scalar factors (1 - beta, the bias corrections) are formed in double as torch forms them.
+ * Both tables are static for a model; only grads_host changes per step.  Capturable in a hipGraph (nothing step-dependent
+ * is baked into the launch except the gradient addresses and lr). */
+int dc_adam_chunk(void);
+int dc_adam_step(const void* slots_dev, const void* chunks_dev, const int* chunk_start_host, const void* const* grads_host,
+                 int ntensors, float lr, double beta1, double beta2, float eps, void* stream);
+
 /* The strided convolutions of the trunks (networks/resnet_encoder.py:87-98 via torchvision): ksize 7 = the 7x7 / 2 stem
  * (padding 3, Ci = 3 or 6), ksize 3 = the 3x3 / 2 first convolution of layer2-4 (padding 1); no bias.  Implicit GEMMs on
  * the fp32 matrix cores straight on NCHW (no im2col tensor, no layout transposes), exact fp32 products, deterministic.

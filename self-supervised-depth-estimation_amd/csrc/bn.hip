@@ -25,33 +25,75 @@ __device__ __forceinline__ float block_sum256(float v, float* sm) {
 // Small planes (layer3 / layer4: 480 / 120 elements): a block per (channel, sample) spends its life on the prologue -- 12 K
 // blocks of 120 elements ran 9-16 us for 6-18 MB.  `ns` > 1 gives a block `ns` consecutive samples of its channel (same
 // BatchNorm group; one plane per wave and pass, so the ReLU mask's per-wave ballot layout is unchanged) and one partial.
-struct BnSpan { int n_first, n_step, i_first, i_step; };
-__device__ __forceinline__ BnSpan bn_span(int ns) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    return ns > 1 ? BnSpan{wave, 4, lane * 4, 256} : BnSpan{0, 1, (int)threadIdx.x * 4, 1024};
+// The float4 items of one thread in its block's span, visited BN_U at a time so that every load of a batch is issued before
+// the first use (one load -> use -> store per loop iteration left a single 16-byte load in flight per thread: the passes ran
+// at 3.1-3.7 TB/s where a plain elementwise pass over tensors of this size reaches 6-7, tools/ubench/ew_bw.py).
+//   ns == 1: the 256 threads stride the chunk [lo, hi) by 1024 elements (item k -> i = lo + 4 tid + 1024 k);
+//   ns  > 1: wave w takes samples w, w + 4, ...; its lanes stride a plane by 256 elements (item k -> sample w + 4 (k / ipp),
+//            i = 4 lane + 256 (k % ipp)).  Either way a wave's 64 lanes cover 256 consecutive elements of one plane, which
+//            is the layout of the ReLU bit mask (4 ballots per wave item).
+constexpr int BN_U = 4;
+struct BnItems {
+    int wave, lane, ipp, nitems, lo, hi, ns, HW;
+    __device__ __forceinline__ BnItems(int ns_, int HW_, int lo_, int hi_) : lo(lo_), hi(hi_), ns(ns_), HW(HW_) {
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); lane = threadIdx.x & 63;
+        if (ns > 1) { ipp = (HW + 255) >> 8; nitems = ((ns - wave + 3) >> 2) * ipp; }
+        else { ipp = 1; nitems = (hi - lo + 1023) >> 10; }
+    }
+    // item k -> sample offset nn (wave-uniform) and element offset i; false past the end (nn, i then point at a valid item)
+    __device__ __forceinline__ bool at(int k, int& nn, int& i) const {
+        bool ok;
+        if (ns > 1) {
+            const int a = k / ipp, b = k - a * ipp;
+            nn = wave + 4 * a; i = lane * 4 + 256 * b;
+            ok = k < nitems && i < HW;
+            if (!(k < nitems)) nn = wave < ns ? wave : 0;
+        } else {
+            nn = 0; i = lo + (int)threadIdx.x * 4 + 1024 * k;
+            ok = i < hi;
+        }
+        if (!ok) i = 0;
+        return ok;
+    }
+};
+
+// both block sums behind one pair of barriers
+__device__ __forceinline__ void block_sum256x2(float& a, float& b, float* sm8) {
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { sm8[threadIdx.x >> 6] = a; sm8[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    a = (sm8[0] + sm8[1]) + (sm8[2] + sm8[3]);
+    b = (sm8[4] + sm8[5]) + (sm8[6] + sm8[7]);
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, float* part, int C, int HW, int ns) {
-    __shared__ float sm[4];
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int C, int HW, int ns) {
+    __shared__ float sm[8];
     const int c = blockIdx.y, n0 = blockIdx.z * ns;
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     float s = 0.f, q = 0.f;
     if ((HW & 3) == 0) {
-        const BnSpan sp = bn_span(ns);
-        for (int nn = sp.n_first; nn < ns; nn += sp.n_step) {
-            const float* p = x + ((size_t)(n0 + nn) * C + c) * HW;
-            for (int i = lo + sp.i_first; i < hi; i += sp.i_step) {
-                const float4 v = *reinterpret_cast<const float4*>(p + i);
-                s += (v.x + v.y) + (v.z + v.w);
-                q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        const BnItems it(ns, HW, lo, hi);
+        for (int k0 = 0; k0 < it.nitems; k0 += BN_U) {
+            float4 v[BN_U];
+            bool ok[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                int nn, i;
+                ok[u] = it.at(k0 + u, nn, i);
+                v[u] = *reinterpret_cast<const float4*>(x + ((size_t)(n0 + nn) * C + c) * HW + i);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                const float4 w = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                s += (w.x + w.y) + (w.z + w.w);
+                q += (w.x * w.x + w.y * w.y) + (w.z * w.z + w.w * w.w);
             }
         }
     } else {
         const float* p = x + ((size_t)n0 * C + c) * HW;
         for (int i = lo + threadIdx.x; i < hi; i += 256) { const float v = p[i]; s += v; q += v * v; }
     }
-    s = block_sum256(s, sm);
-    q = block_sum256(q, sm);
+    block_sum256x2(s, q, sm);
     if (threadIdx.x == 0) {
         float* o = part + (((size_t)c * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * 2;
         o[0] = s; o[1] = q;
@@ -61,15 +103,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, float* pa
 // Per-(group, channel) statistics from the partial sums, recomputed by every block that needs them (a few dozen
 // L2-resident floats; cheaper than a separate finalize launch per layer).  Fixed summation order -> every block
 // gets bit-identical values.
-__device__ __forceinline__ void bn_reduce_partials(const float* part, int c, int nparts, int per, int gidx, float* sm,
-                                                   float& s, float& q) {
+__device__ __forceinline__ void bn_reduce_partials(const float* __restrict__ part, int c, int nparts, int per, int gidx, float& s, float& q) {
+    // every WAVE reduces the partials by itself (lane-strided sums, then the wave tree): no barrier in front of the streaming
+    // loop, and the four waves -- like every block -- get bit-identical values
+    const float2* p2 = reinterpret_cast<const float2*>(part) + (size_t)c * nparts + (size_t)gidx * per;
     float a = 0.f, b = 0.f;
-    for (int i = threadIdx.x; i < per; i += 256) {
-        a += part[((size_t)c * nparts + gidx * per + i) * 2];
-        b += part[((size_t)c * nparts + gidx * per + i) * 2 + 1];
-    }
-    s = block_sum256(a, sm);
-    q = block_sum256(b, sm);
+    for (int i = threadIdx.x & 63; i < per; i += 64) { const float2 v = p2[i]; a += v.x; b += v.y; }
+    s = wave_sum(a);
+    q = wave_sum(b);
 }
 
 // grid (chunks, C, N), block 256: y = relu?((x - mean)*invstd*gamma + beta [+ res]); block (0, c, first sample of
@@ -79,13 +120,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
                                                        const float* gamma, const float* beta, float* y, int C, int HW,
                                                        int relu, int n_per_group, int groups, float eps, float momentum,
                                                        unsigned long long* mask, int ns) {
-    __shared__ float sm[4];
     const int c = blockIdx.y, n0 = blockIdx.z * ns, n = n0;
     const int nparts = gridDim.z * gridDim.x, per = nparts / groups;
     const int gidx = n / n_per_group;
     const float count = (float)n_per_group * (float)HW;
     float s, q;
-    bn_reduce_partials(part, c, nparts, per, gidx, sm, s, q);
+    bn_reduce_partials(part, c, nparts, per, gidx, s, q);
     const float m = s / count;
     const float var = fmaxf(q / count - m * m, 0.f);          // biased (used to normalise)
     const float is = rsqrtf(var + eps);
@@ -95,7 +135,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
         float rm = run_mean[c], rv = run_var[c];
         for (int g2 = 0; g2 < groups; ++g2) {
             float s2, q2;
-            bn_reduce_partials(part, c, nparts, per, g2, sm, s2, q2);
+            bn_reduce_partials(part, c, nparts, per, g2, s2, q2);
             const float m2 = s2 / count, v2 = fmaxf(q2 / count - m2 * m2, 0.f);
             rm = (1.f - momentum) * rm + momentum * m2;
             rv = (1.f - momentum) * rv + momentum * v2 * (count / fmaxf(count - 1.f, 1.f));
@@ -105,33 +145,46 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
     const float a = is * gamma[c], b = beta[c] - m * a;
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     if ((HW & 3) == 0) {
-      const BnSpan sp = bn_span(ns);
-      for (int nn = sp.n_first; nn < ns; nn += sp.n_step) {
-        const int n = n0 + nn;
-        const size_t base = ((size_t)n * C + c) * HW;
-        for (int i = lo + sp.i_first; i < hi; i += sp.i_step) {
-            float4 v = *reinterpret_cast<const float4*>(x + base + i);
-            v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
-            if (res) {
-                const float4 r = *reinterpret_cast<const float4*>(res + base + i);
-                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        const BnItems it(ns, HW, lo, hi);
+        const float* rsrc = res ? res : x;                      // one code shape with or without the residual (the loads stay unconditional)
+        for (int k0 = 0; k0 < it.nitems; k0 += BN_U) {
+            float4 v[BN_U], r[BN_U];
+            size_t off[BN_U];
+            bool ok[BN_U];
+            int iu[BN_U], nu[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                ok[u] = it.at(k0 + u, nu[u], iu[u]);
+                off[u] = ((size_t)(n0 + nu[u]) * C + c) * HW + iu[u];
+                v[u] = *reinterpret_cast<const float4*>(x + off[u]);
             }
-            if (relu) {
-                if (mask) {
-                    // ReLU mask for the backward as bits: the 256 elements of this wave iteration -> 4 ballots (one per
-                    // float4 component), 32 bytes instead of the 1 KiB of y the backward kernels would re-read twice
-                    const unsigned long long b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f),
-                                             b3 = __ballot(v.w > 0.f);
-                    if ((threadIdx.x & 63) == 0) {
-                        unsigned long long* mw = mask + (((size_t)n * C + c) * ((HW + 255) >> 8) + (i >> 8)) * 4;
-                        mw[0] = b0; mw[1] = b1; mw[2] = b2; mw[3] = b3;
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) r[u] = *reinterpret_cast<const float4*>(rsrc + off[u]);
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                float4 w = v[u];
+                w.x = fmaf(w.x, a, b); w.y = fmaf(w.y, a, b); w.z = fmaf(w.z, a, b); w.w = fmaf(w.w, a, b);
+                if (res) { w.x += r[u].x; w.y += r[u].y; w.z += r[u].z; w.w += r[u].w; }
+                if (relu) {
+                    if (mask) {
+                        // ReLU mask for the backward as bits: the 256 elements of this wave item -> 4 ballots (one per
+                        // float4 component), 32 bytes instead of the 1 KiB of y the backward kernels would re-read twice.
+                        // (lanes past the end of the plane contribute 0 bits; a wave whose item is entirely past the end
+                        // writes nothing)
+                        const unsigned long long b0 = __ballot(ok[u] && w.x > 0.f), b1 = __ballot(ok[u] && w.y > 0.f),
+                                                 b2 = __ballot(ok[u] && w.z > 0.f), b3 = __ballot(ok[u] && w.w > 0.f);
+                        const bool any = __ballot(ok[u]) != 0ull;
+                        if (any && (threadIdx.x & 63) == 0) {
+                            // lane 0 is valid whenever any lane of the wave item is (items are lane-ascending)
+                            unsigned long long* mw = mask + (((size_t)(n0 + nu[u]) * C + c) * ((HW + 255) >> 8) + (iu[u] >> 8)) * 4;
+                            mw[0] = b0; mw[1] = b1; mw[2] = b2; mw[3] = b3;
+                        }
                     }
+                    w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
                 }
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                if (ok[u]) *reinterpret_cast<float4*>(y + off[u]) = w;
             }
-            *reinterpret_cast<float4*>(y + base + i) = v;
         }
-      }
     } else {
         const size_t base = ((size_t)n * C + c) * HW;
         for (int i = lo + threadIdx.x; i < hi; i += 256) {
@@ -142,54 +195,70 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
     }
 }
 
-// the masked gradient of one float4: bits from the forward's ballots (lane bit of the wave-iteration's 4 words) or y > 0
-__device__ __forceinline__ float4 bn_mask_grad(float4 g, const unsigned long long* mask, const float* y, size_t plane, int C_unused,
-                                               int HW, size_t base, int i) {
-    if (mask) {
-        const unsigned long long* mw = mask + (plane * ((HW + 255) >> 8) + (i >> 8)) * 4;
-        const int l = threadIdx.x & 63;
-        g.x = ((mw[0] >> l) & 1ull) ? g.x : 0.f; g.y = ((mw[1] >> l) & 1ull) ? g.y : 0.f;
-        g.z = ((mw[2] >> l) & 1ull) ? g.z : 0.f; g.w = ((mw[3] >> l) & 1ull) ? g.w : 0.f;
-    } else {
-        const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
-        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
-    }
+// The ReLU decisions of one float4 as 4 bits (x, y, z, w): from the forward's ballots (this lane's bit of the wave item's 4
+// words -- `mw` loaded by the caller together with the batch's other loads) or from y > 0.
+__device__ __forceinline__ float4 bn_apply_bits(float4 g, unsigned bits) {
+    g.x = (bits & 1u) ? g.x : 0.f; g.y = (bits & 2u) ? g.y : 0.f; g.z = (bits & 4u) ? g.z : 0.f; g.w = (bits & 8u) ? g.w : 0.f;
     return g;
 }
+struct BnMaskWords { unsigned long long w[4]; };
+__device__ __forceinline__ unsigned bn_bits_of(const BnMaskWords& m) {
+    const int l = threadIdx.x & 63;
+    return (unsigned)((m.w[0] >> l) & 1ull) | ((unsigned)((m.w[1] >> l) & 1ull) << 1) | ((unsigned)((m.w[2] >> l) & 1ull) << 2) |
+           ((unsigned)((m.w[3] >> l) & 1ull) << 3);
+}
+__device__ __forceinline__ unsigned bn_bits_of(float4 yv) {
+    return (yv.x > 0.f ? 1u : 0u) | (yv.y > 0.f ? 2u : 0u) | (yv.z > 0.f ? 4u : 0u) | (yv.w > 0.f ? 8u : 0u);
+}
 
-// backward stats: partial {sum g, sum g*x_hat}, g = gy*[y>0] when relu
-__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const float* y, const float* gy,
-                                                           const float* mean, const float* invstd, float* part, int C,
-                                                           int HW, int relu, int n_per_group, const unsigned long long* mask, int ns) {
-    __shared__ float sm[4];
+// backward stats: partial {sum g, sum g*x_hat}, g = gy*[y>0] when relu.  MODE: 0 no ReLU, 1 bit mask, 2 saved output y
+// (a template parameter so that each instantiation has ONE set of unconditional loads per batch)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ part, int C,
+                                                           int HW, int n_per_group, const unsigned long long* __restrict__ mask, int ns) {
+    __shared__ float sm[8];
     const int c = blockIdx.y, n0 = blockIdx.z * ns;
     const int gc = (n0 / n_per_group) * C + c;
     const float m = mean[gc], is = invstd[gc];
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     float s = 0.f, q = 0.f;
     if ((HW & 3) == 0) {
-      const BnSpan sp = bn_span(ns);
-      for (int nn = sp.n_first; nn < ns; nn += sp.n_step) {
-        const int n = n0 + nn;
-        const size_t base = ((size_t)n * C + c) * HW;
-        for (int i = lo + sp.i_first; i < hi; i += sp.i_step) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
-            float4 g = *reinterpret_cast<const float4*>(gy + base + i);
-            if (relu) g = bn_mask_grad(g, mask, y, (size_t)n * C + c, C, HW, base, i);
-            s += (g.x + g.y) + (g.z + g.w);
-            q += (g.x * (xv.x - m) + g.y * (xv.y - m)) + (g.z * (xv.z - m) + g.w * (xv.w - m));
+        const BnItems it(ns, HW, lo, hi);
+        for (int k0 = 0; k0 < it.nitems; k0 += BN_U) {
+            float4 xv[BN_U], g[BN_U], yv[BN_U];
+            BnMaskWords mw[BN_U];
+            bool ok[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                int nn, i;
+                ok[u] = it.at(k0 + u, nn, i);
+                const size_t plane = (size_t)(n0 + nn) * C + c, off = plane * HW + i;
+                xv[u] = *reinterpret_cast<const float4*>(x + off);
+                g[u] = *reinterpret_cast<const float4*>(gy + off);
+                if (MODE == 1) mw[u] = *reinterpret_cast<const BnMaskWords*>(mask + (plane * ((HW + 255) >> 8) + (i >> 8)) * 4);
+                if (MODE == 2) yv[u] = *reinterpret_cast<const float4*>(y + off);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                float4 gg = g[u];
+                if (MODE == 1) gg = bn_apply_bits(gg, bn_bits_of(mw[u]));
+                if (MODE == 2) gg = bn_apply_bits(gg, bn_bits_of(yv[u]));
+                if (!ok[u]) gg = make_float4(0.f, 0.f, 0.f, 0.f);
+                s += (gg.x + gg.y) + (gg.z + gg.w);
+                q += (gg.x * (xv[u].x - m) + gg.y * (xv[u].y - m)) + (gg.z * (xv[u].z - m) + gg.w * (xv[u].w - m));
+            }
         }
-      }
     } else {
         const size_t base = ((size_t)n0 * C + c) * HW;
         for (int i = lo + threadIdx.x; i < hi; i += 256) {
             float g = gy[base + i];
-            if (relu && !(y[base + i] > 0.f)) g = 0.f;
+            if (MODE != 0 && !(y[base + i] > 0.f)) g = 0.f;
             s += g; q += g * (x[base + i] - m);
         }
     }
-    s = block_sum256(s, sm);
-    q = block_sum256(q, sm) * is;
+    block_sum256x2(s, q, sm);
+    q *= is;
     if (threadIdx.x == 0) {
         float* o = part + (((size_t)c * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * 2;
         o[0] = s; o[1] = q;
@@ -197,24 +266,24 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const
 }
 
 // dx = gamma*invstd*(g - mean(g) - x_hat*mean(g*x_hat)); dres = g.  The two means come from the partials (reduced
-// by every block, see bn_reduce_partials); block (0, c, 0) also writes dgamma / dbeta (sums over all groups).
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const float* y, const float* gy,
-                                                           const float* mean, const float* invstd, const float* gamma,
-                                                           const float* part, float* dgamma, float* dbeta, float* dx,
-                                                           float* dres, int C, int HW, int relu, int n_per_group,
-                                                           int groups, const unsigned long long* mask, int ns) {
-    __shared__ float sm[4];
+// by every wave, see bn_reduce_partials); block (0, c, 0) also writes dgamma / dbeta (sums over all groups).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dx,
+                                                           float* __restrict__ dres, int C, int HW, int n_per_group,
+                                                           int groups, const unsigned long long* __restrict__ mask, int ns) {
     const int c = blockIdx.y, n0 = blockIdx.z * ns, n = n0;
     const int nparts = gridDim.z * gridDim.x, per = nparts / groups;
     const int gidx = n / n_per_group;
     const float count = (float)n_per_group * (float)HW;
     float s, q;
-    bn_reduce_partials(part, c, nparts, per, gidx, sm, s, q);
+    bn_reduce_partials(part, c, nparts, per, gidx, s, q);
     if (blockIdx.x == 0 && n == 0) {
         float ts = 0.f, tq = 0.f;
         for (int g2 = 0; g2 < groups; ++g2) {
             float s2, q2;
-            bn_reduce_partials(part, c, nparts, per, g2, sm, s2, q2);
+            bn_reduce_partials(part, c, nparts, per, g2, s2, q2);
             ts += s2; tq += q2;
         }
         if (threadIdx.x == 0) {
@@ -226,26 +295,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
     const float m = mean[gc], is = invstd[gc], k = gamma[c] * is, a = s / count, bq = (q / count) * is;
     const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
     if ((HW & 3) == 0) {
-      const BnSpan sp = bn_span(ns);
-      for (int nn = sp.n_first; nn < ns; nn += sp.n_step) {
-        const int n = n0 + nn;
-        const size_t base = ((size_t)n * C + c) * HW;
-        for (int i = lo + sp.i_first; i < hi; i += sp.i_step) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
-            float4 g = *reinterpret_cast<const float4*>(gy + base + i);
-            if (relu) g = bn_mask_grad(g, mask, y, (size_t)n * C + c, C, HW, base, i);
-            if (dres) *reinterpret_cast<float4*>(dres + base + i) = g;
-            float4 d;
-            d.x = k * (g.x - a - (xv.x - m) * bq); d.y = k * (g.y - a - (xv.y - m) * bq);
-            d.z = k * (g.z - a - (xv.z - m) * bq); d.w = k * (g.w - a - (xv.w - m) * bq);
-            *reinterpret_cast<float4*>(dx + base + i) = d;
+        const BnItems it(ns, HW, lo, hi);
+        for (int k0 = 0; k0 < it.nitems; k0 += BN_U) {
+            float4 xv[BN_U], g[BN_U], yv[BN_U];
+            BnMaskWords mw[BN_U];
+            size_t off[BN_U];
+            bool ok[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                int nn, i;
+                ok[u] = it.at(k0 + u, nn, i);
+                const size_t plane = (size_t)(n0 + nn) * C + c;
+                off[u] = plane * HW + i;
+                xv[u] = *reinterpret_cast<const float4*>(x + off[u]);
+                g[u] = *reinterpret_cast<const float4*>(gy + off[u]);
+                if (MODE == 1) mw[u] = *reinterpret_cast<const BnMaskWords*>(mask + (plane * ((HW + 255) >> 8) + (i >> 8)) * 4);
+                if (MODE == 2) yv[u] = *reinterpret_cast<const float4*>(y + off[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                float4 gg = g[u];
+                if (MODE == 1) gg = bn_apply_bits(gg, bn_bits_of(mw[u]));
+                if (MODE == 2) gg = bn_apply_bits(gg, bn_bits_of(yv[u]));
+                float4 d;
+                d.x = k * (gg.x - a - (xv[u].x - m) * bq); d.y = k * (gg.y - a - (xv[u].y - m) * bq);
+                d.z = k * (gg.z - a - (xv[u].z - m) * bq); d.w = k * (gg.w - a - (xv[u].w - m) * bq);
+                if (ok[u]) {
+                    if (dres) *reinterpret_cast<float4*>(dres + off[u]) = gg;
+                    *reinterpret_cast<float4*>(dx + off[u]) = d;
+                }
+            }
         }
-      }
     } else {
         const size_t base = ((size_t)n * C + c) * HW;
         for (int i = lo + threadIdx.x; i < hi; i += 256) {
             float g = gy[base + i];
-            if (relu && !(y[base + i] > 0.f)) g = 0.f;
+            if (MODE != 0 && !(y[base + i] > 0.f)) g = 0.f;
             if (dres) dres[base + i] = g;
             dx[base + i] = k * (g - a - (x[base + i] - m) * bq);
         }
@@ -304,12 +389,21 @@ extern "C" int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, c
     if (groups < 1 || N % groups) return DC_EINVAL;
     const int chunks = ceil_div(HW, BN_CHUNK), ns = bn_ns(N / groups, HW);
     float* part = (float*)ws;
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(chunks, C, N / ns), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, part, C,
-                       HW, relu, N / groups, mk, ns);
-    DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chunks, C, N / ns), dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, gamma,
-                       (const float*)part, dgamma, dbeta, dx, dres, C, HW, relu, N / groups, groups, mk, ns);
-    DC_CHECK_LAUNCH();
+    const dim3 grid(chunks, C, N / ns);
+    const int mode = !relu ? 0 : (mk ? 1 : 2);
+#define BN_BWD(MODE)                                                                                                             \
+    do {                                                                                                                         \
+        hipLaunchKernelGGL(bn_bwd_stats_kernel<MODE>, grid, dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, part, C, HW,      \
+                           N / groups, mk, ns);                                                                                  \
+        DC_CHECK_LAUNCH();                                                                                                       \
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<MODE>, grid, dim3(256), 0, ST, x, y, gy, save_mean, save_invstd, gamma,            \
+                           (const float*)part, dgamma, dbeta, dx, dres, C, HW, N / groups, groups, mk, ns);                      \
+        DC_CHECK_LAUNCH();                                                                                                       \
+    } while (0)
+    if (mode == 0) BN_BWD(0);
+    else if (mode == 1) BN_BWD(1);
+    else BN_BWD(2);
+#undef BN_BWD
     return DC_OK;
 }
 

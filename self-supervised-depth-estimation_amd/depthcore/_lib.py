@@ -117,6 +117,8 @@ def _sig(lib):
         "dc_stem_supported": (i, [i, i, i, i, i]),
         "dc_stem_fwd": (i, [p, i, f, f, p, p, p, i, i, i, i, p]),
         "dc_stem_wgrad": (i, [p, i, f, f, p, p, p, i, i, i, i, p]),
+        "dc_adam_chunk": (i, []),
+        "dc_adam_step": (i, [p, p, p, p, i, f, c_double, c_double, f, p]),
         "dc_convs2_supported": (i, [i, i, i, i, i, i]),
         "dc_convs2_fwd_workspace": (z, [i, i, i, i, i, i]),
         "dc_convs2_fwd": (i, [p, p, p, p, i, i, i, i, i, i, p]),

@@ -95,6 +95,7 @@ _BUILD = [
     ("fusion", str, None, [None, "v3"]),         # front-end of trainer_fusion_v3.py
     ("hip_graph", int, 0, [0, 1]),               # single-GPU: capture the whole step (fwd + bwd + Adam) in one hipGraph and replay it
     ("wino_weight_cache", int, 1, [0, 1]),       # all 3x3 weights -> Winograd domain once per step (one launch)
+    ("torch_adam", int, 0, [0, 1]),              # 1: torch.optim.Adam(fused=True) instead of the depthcore Adam kernel (A/B)
     ("nets_dtype", str, "f32", ["f32", "bf16"]),  # matrix-core precision of the networks' convolutions (bf16: BASELINE configs[4] policy; the loss stays fp32)
     ("imagenet_weights", str, None, None),       # weights_init=pretrained: path of the torchvision resnet{N}-*.pth (no download here)
     ("gru", str, None, [None, "v5"]),            # front-end of trainer_gru.py (run_gru_v5; sequences of len_sequence frames)

@@ -130,8 +130,14 @@ class Trainer:
         self.graph_enabled = bool(getattr(self.opt, "hip_graph", False)) and self.device.type == "cuda" and world_size == 1
         if self.graph_enabled and self.opt.cpu_tiebreak_noise:
             raise ValueError("hip_graph replays cannot include the reference's CPU randn + host-to-device copy (cpu_tiebreak_noise)")
-        self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate,
-                                          fused=self.device.type == "cuda", capturable=self.graph_enabled)
+        # reference trainer.py:110-113: one Adam over every trainable tensor.  On the GPU the depthcore kernel (one streaming
+        # pass, step counts in device memory so the launch is capturable); `opt.torch_adam` keeps ATen's fused kernel (A/B)
+        if self.device.type == "cuda" and not getattr(self.opt, "torch_adam", False):
+            from depthcore.optim import Adam as DepthcoreAdam
+            self.model_optimizer = DepthcoreAdam(self.parameters_to_train, self.opt.learning_rate)
+        else:
+            self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate,
+                                              fused=self.device.type == "cuda", capturable=self.graph_enabled)
         self._seed_dev = torch.full((1,), rank, dtype=torch.int64, device=self.device) if self.graph_enabled else None
         self._graphs, self._graph, self._graph_warm, self._graph_stream = {}, None, {}, None
         self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
