@@ -886,7 +886,7 @@ static inline bool wino_dx(int C0, int C1, int B, int Co, int H, int W, int act)
     return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && wino_gp_ok(B, Co, H, W, act) && wino_fits(B, C0, C1, Co, H, W);
 }
 static inline bool wino_dw(int C0, int C1, int B, int Co, int H, int W, int act) {
-    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && Co >= 64 && wino_gp_ok(B, Co, H, W, act) &&
+    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && Co >= 32 && wino_gp_ok(B, Co, H, W, act) &&
            wino_fits(B, C0, C1, Co, H, W);
 }
 

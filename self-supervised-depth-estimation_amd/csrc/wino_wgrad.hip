@@ -34,11 +34,11 @@ using f4 = __attribute__((ext_vector_type(4))) float;
 using f2w = __attribute__((ext_vector_type(2))) float;
 using wrsrc_t = __amdgpu_buffer_rsrc_t;
 
-constexpr int WG_MR = 4, WG_KR = 2;                    // 16-channel tiles per wave: gy side, x side
-constexpr int WG_MT = 16 * WG_MR, WG_KT = 16 * WG_KR;  // channels per block
+constexpr int WG_MR = 4, WG_KR = 2;                    // 16-channel tiles per wave: gy side (WG_MR; 2 for the thin 32-channel layers), x side
+constexpr int WG_KT = 16 * WG_KR;                      // x-side channels per block (gy side: 16 MR)
 constexpr int WG_GPS = 66;                             // gy slab channel stride (floats), = 2 mod 32, >= 64
 constexpr int WG_XPS = 130;                            // x slab channel stride, = 2 mod 32, >= 120
-constexpr int WG_SLAB = 4 * WG_MR * WG_KR * 4 * 3 * 64;   // floats one block writes
+constexpr int WG_SLAB = 4 * WG_MR * WG_KR * 4 * 3 * 64;   // floats one block writes (MR = 4; half of it for MR = 2)
 
 struct WinoWgArgs {
     const float* x; const float* gy; float* slab;
@@ -55,10 +55,10 @@ struct WinoWgArgs {
 };
 unsigned long long* wino_diag_ptr();
 
-template <bool FUSED>
+template <bool FUSED, int MR>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
-    constexpr int MR = WG_MR, KR = WG_KR;
-    __shared__ float gl[2][WG_MT * WG_GPS];
+    constexpr int KR = WG_KR, MT = 16 * MR, NGQ = MT / 8;       // NGQ: gy channels staged per thread
+    __shared__ float gl[2][MT * WG_GPS];
     __shared__ float xl[2][WG_KT * WG_XPS];
 #ifdef WINO_DIAG
     const unsigned long long dg_start = __builtin_amdgcn_s_memtime(), dg_rstart = __builtin_amdgcn_s_memrealtime();
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     const bool x_in = xslot < (2 * RH + 2) * XPR;
     const int xlds0 = xcg * WG_XPS + xrow * XRS + max(2 * xcp - 1, 0), xlds1 = xcg * WG_XPS + xrow * XRS + 2 * xcp;
 
-    f2w pg[8], px[8];
+    f2w pg[NGQ], px[8];
     auto prefetch = [&](int sub) {
         const int b = sub / per_img, rq = sub - b * per_img;
         const int ry = rq / a.regs_x, rx = rq - ry * a.regs_x;
@@ -102,9 +102,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
         {
             const int y = Y0 + grow, xx = X0 + 2 * gcp;
             const bool ok = g_in && y < H && xx < W;
-            const unsigned vo = ok ? ((unsigned)(b * a.M + mb * WG_MT + gcg) * plane + (unsigned)(y * W + xx) * 4u) : 0x80000000u;
+            const unsigned vo = ok ? ((unsigned)(b * a.M + mb * MT + gcg) * plane + (unsigned)(y * W + xx) * 4u) : 0x80000000u;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < NGQ; ++q)
                 pg[q] = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(gr, (int)vo, (int)((unsigned)(8 * q) * plane), 0));
         }
         {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     auto commit = [&](int buf) {
         if (g_in) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) *reinterpret_cast<f2w*>(&gl[buf][glds + 8 * q * WG_GPS]) = pg[q];
+            for (int q = 0; q < NGQ; ++q) *reinterpret_cast<f2w*>(&gl[buf][glds + 8 * q * WG_GPS]) = pg[q];
         }
         if (x_in) {
 #pragma unroll
@@ -283,9 +283,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
 // split groups; a group sums its contiguous range of splits, the 16 partial sums are then added in order through LDS.
 constexpr int WR_GROUPS = 16;
 __global__ __launch_bounds__(64 * WR_GROUPS) void wino_wreduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                                      int splits, int nmk, int kblocks, int M, int K) {
-    constexpr int MR = WG_MR, KR = WG_KR;
-    constexpr size_t WAVE_SLAB = (size_t)MR * KR * 4 * 3 * 64;       // floats one wave (row a) of one block wrote
+                                                                      int splits, int nmk, int kblocks, int M, int K, int MR) {
+    constexpr int KR = WG_KR;
+    const size_t WAVE_SLAB = (size_t)MR * KR * 4 * 3 * 64;           // floats one wave (row a) of one block wrote
     __shared__ float part[WR_GROUPS][12][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     int e = blockIdx.x;                                 // ((mk*MR + i)*KR + j)*4 + r
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64 * WR_GROUPS) void wino_wreduce_kernel(const floa
             q[w][c] = t;
         }
     const int mbk = mk / kblocks, kbk = mk - mbk * kblocks;
-    const int m = mbk * WG_MT + i * 16 + (lane >> 4) * 4 + r, k = kbk * WG_KT + j * 16 + (lane & 15);
+    const int m = mbk * (16 * MR) + i * 16 + (lane >> 4) * 4 + r, k = kbk * WG_KT + j * 16 + (lane & 15);
     if (m >= M || k >= K) return;
     float* out = dw + ((size_t)m * K + k) * 9;
 #pragma unroll
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64 * WR_GROUPS) void wino_wreduce_kernel(const floa
     }
 }
 
-struct WgPlan { int RH, RW, GRS, XRS, regs_x, regs_y, nsub, mblocks, kblocks, splits; };
+struct WgPlan { int RH, RW, GRS, XRS, regs_x, regs_y, nsub, mblocks, kblocks, splits, mr; };
 
 static WgPlan wg_plan(int B, int Ci, int Co, int H, int W) {
     WgPlan p{};
@@ -348,7 +348,10 @@ static WgPlan wg_plan(int B, int Ci, int Co, int H, int W) {
         if (util > best + 1e-9) { best = util; p.RH = c[0]; p.RW = c[1]; p.GRS = c[2]; p.XRS = c[3]; }
     }
     p.regs_x = ceil_div(TW, p.RW); p.regs_y = ceil_div(TH, p.RH); p.nsub = p.regs_x * p.regs_y * B;
-    p.mblocks = ceil_div(Co, WG_MT); p.kblocks = ceil_div(Ci, WG_KT);
+    // 64 output channels per block; 32 (MR = 2) where the last 64-block would be at most half used --
+    // the 32-channel decoder levels ran on the direct kernel at 65 TFLOP/s before (96 -> 32 at 96 x 320: 311 us)
+    p.mr = (Co % 64 != 0 && Co % 64 <= 32) ? 2 : 4;
+    p.mblocks = ceil_div(Co, 16 * p.mr); p.kblocks = ceil_div(Ci, WG_KT);
     const int nmk = p.mblocks * p.kblocks;
     // 256 CUs x 2 blocks; at least two chunks per block so that the pipeline has something to overlap
     p.splits = std::max(1, std::min(std::max(1, p.nsub / 2), ceil_div(512, nmk)));
@@ -376,21 +379,26 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
 #endif
     const int nmk = p.mblocks * p.kblocks;
     hipEvent_t pe = conv_prof_begin(1, 2.0 * B * (double)Co * Ci * 9.0 * H * W,
-                                    2.0 * 16.0 * (double)p.nsub * 16.0 * (double)(p.mblocks * WG_MT) * (p.kblocks * WG_KT),
+                                    2.0 * 16.0 * (double)p.nsub * 16.0 * (double)(p.mblocks * 16 * p.mr) * (p.kblocks * WG_KT),
                                     (double)b0 + (double)b1 + (double)gb + 36.0 * Co * Ci, st);
-    if (fused) hipLaunchKernelGGL(wino_wgrad_kernel<true>, dim3(p.splits * nmk), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wino_wgrad_kernel<false>, dim3(p.splits * nmk), dim3(256), 0, st, a);
+    if (p.mr == 4) {
+        if (fused) hipLaunchKernelGGL((wino_wgrad_kernel<true, 4>), dim3(p.splits * nmk), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 4>), dim3(p.splits * nmk), dim3(256), 0, st, a);
+    } else {
+        if (fused) hipLaunchKernelGGL((wino_wgrad_kernel<true, 2>), dim3(p.splits * nmk), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 2>), dim3(p.splits * nmk), dim3(256), 0, st, a);
+    }
     conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wino_wreduce_kernel, dim3(nmk * WG_MR * WG_KR * 4), dim3(64 * std::min(WR_GROUPS, std::max(1, p.splits / 2))), 0, st,
-                       (const float*)ws, dweight, p.splits, nmk, p.kblocks, Co, Ci);
+    hipLaunchKernelGGL(wino_wreduce_kernel, dim3(nmk * p.mr * WG_KR * 4), dim3(64 * std::min(WR_GROUPS, std::max(1, p.splits / 2))), 0, st,
+                       (const float*)ws, dweight, p.splits, nmk, p.kblocks, Co, Ci, p.mr);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
 
 size_t wino_wgrad_ws_bytes(int B, int Ci, int Co, int H, int W) {
     const WgPlan p = wg_plan(B, Ci, Co, H, W);
-    return (size_t)p.splits * p.mblocks * p.kblocks * WG_SLAB * sizeof(float);
+    return (size_t)p.splits * p.mblocks * p.kblocks * (WG_SLAB / WG_MR * p.mr) * sizeof(float);
 }
 
 int wino_wgrad_fused(const float* x0, int C0, int up0, const float* x1, int C1, int pad, const float* gp, float* dweight, void* ws,
