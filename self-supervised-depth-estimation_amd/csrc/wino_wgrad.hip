@@ -55,15 +55,25 @@ struct WinoWgArgs {
 };
 unsigned long long* wino_diag_ptr();
 
-template <bool FUSED, int MR>
-__global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
+// NG = 2: a block is TWO such 4-wave groups (512 threads, one block per CU instead of two).  They take alternate sub-regions
+// of the block's split with their own LDS slabs, and at the end group 1 hands its q values to group 0 through LDS (the
+// staging slabs are dead by then): one slab write per CU instead of two -- the slabs were 50 MB written and 50 MB read
+// back per launch whatever the layer (512 blocks x 96 KB), ~13 % of the kernel + reduce time -- at the same 8 waves per CU.
+template <bool FUSED, int MR, int NG>
+__global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     constexpr int KR = WG_KR, MT = 16 * MR, NGQ = MT / 8;       // NGQ: gy channels staged per thread
-    __shared__ float gl[2][MT * WG_GPS];
-    __shared__ float xl[2][WG_KT * WG_XPS];
+    constexpr int GL = MT * WG_GPS, XL = WG_KT * WG_XPS, GROUP_LDS = 2 * GL + 2 * XL;
+    static_assert(NG == 1 || NG * GROUP_LDS >= 4 * MR * KR * 4 * 3 * 64, "the q exchange aliases the staging slabs");
+    extern __shared__ float wg_smem[];
 #ifdef WINO_DIAG
     const unsigned long long dg_start = __builtin_amdgcn_s_memtime(), dg_rstart = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = NG == 1 ? 0 : wave_all >> 2, wave = wave_all & 3, tid = threadIdx.x & 255;     // group, Winograd row, thread of the group
+    float* const gl0 = wg_smem + grp * GROUP_LDS;
+    float* const xl0 = gl0 + 2 * GL;
+    auto gl = [&](int buf) { return gl0 + buf * GL; };
+    auto xl = [&](int buf) { return xl0 + buf * XL; };
     const int cl = lane & 15, tq = lane >> 4;          // channel within a 16-block, tile within a k-step
     const int H = a.H, W = a.W, RH = a.RH, RW = a.RW, GRS = a.GRS, XRS = a.XRS;
     // flat grid, XCD-aware: the nmk = mblocks * kblocks blocks of one split (same sub-regions: gy shared across the k-blocks,
@@ -137,14 +147,14 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     auto commit = [&](int buf) {
         if (g_in) {
 #pragma unroll
-            for (int q = 0; q < NGQ; ++q) *reinterpret_cast<f2w*>(&gl[buf][glds + 8 * q * WG_GPS]) = pg[q];
+            for (int q = 0; q < NGQ; ++q) *reinterpret_cast<f2w*>(gl(buf) + glds + 8 * q * WG_GPS) = pg[q];
         }
         if (x_in) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const bool dup = FUSED && up0 && (kb * WG_KT + xcg + 4 * q) < C0;      // nearest-x2 source: one value, two columns
-                xl[buf][xlds0 + 4 * q * WG_XPS] = px[q].x;      // (pair 0: the discarded column lands on, and is overwritten by, .y)
-                xl[buf][xlds1 + 4 * q * WG_XPS] = dup ? px[q].x : px[q].y;
+                xl(buf)[xlds0 + 4 * q * WG_XPS] = px[q].x;      // (pair 0: the discarded column lands on, and is overwritten by, .y)
+                xl(buf)[xlds1 + 4 * q * WG_XPS] = dup ? px[q].x : px[q].y;
             }
         }
     };
@@ -180,8 +190,8 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
             for (int q = 0; q < 4; ++q) acc[i][j][q] = f4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
-        const float* gs_ = gl[buf];
-        const float* xs_ = xl[buf];
+        const float* gs_ = gl(buf);
+        const float* xs_ = xl(buf);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             // the two B sets (x side) of this k-step
@@ -224,22 +234,26 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
         }
     };
 
-    // ---- reduction over this block's sub-regions: split, split + splits, ...
-    int sub = split0;
+    // ---- reduction over this block's sub-regions: split, split + splits, ... (NG = 2: alternately to the two groups; the
+    // barriers are the block's, so a group that runs out of work keeps pace without computing)
+    const int stride = NG * a.splits;
+    int sub = split0 + grp * a.splits;
     if (sub < a.nsub) {
         prefetch(sub);
         commit(0);
-        if (sub + a.splits < a.nsub) prefetch(sub + a.splits);
+        if (sub + stride < a.nsub) prefetch(sub + stride);
     }
     __syncthreads();
 #ifdef WINO_DIAG
     const unsigned long long dg0 = __builtin_amdgcn_s_memtime();
 #endif
-    for (int it = 0; sub < a.nsub; sub += a.splits, ++it) {
-        compute(it & 1);
-        if (sub + a.splits < a.nsub) {
-            commit((it + 1) & 1);
-            if (sub + 2 * a.splits < a.nsub) prefetch(sub + 2 * a.splits);
+    for (int it = 0, lead = split0; lead < a.nsub; lead += stride, sub += stride, ++it) {     // `lead`: group 0's sub-region (block-uniform trip count)
+        if (sub < a.nsub) {
+            compute(it & 1);
+            if (sub + stride < a.nsub) {
+                commit((it + 1) & 1);
+                if (sub + 2 * stride < a.nsub) prefetch(sub + 2 * stride);
+            }
         }
         __syncthreads();
     }
@@ -251,22 +265,44 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     // slab[((((blk*4 + a)*MR + i)*KR + j)*4 + r)*3 + qq][lane],  blk = split * nmk + mk
     const float sa = wave == 3 ? -1.f : 1.f;
     float* dst = a.slab + ((size_t)(split0 * nmk + mk) * 4 + wave) * (MR * KR * 4 * 3 * 64) + lane;
+    float* ex = wg_smem + (size_t)wave * (MR * KR * 4 * 3 * 64) + lane;       // NG = 2: group 1 -> group 0, same layout as the slab
+    if (NG == 2 && grp == 1) {
 #pragma unroll
-    for (int i = 0; i < MR; ++i)
+        for (int i = 0; i < MR; ++i)
 #pragma unroll
-        for (int j = 0; j < KR; ++j)
+            for (int j = 0; j < KR; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float u0 = sa * acc[i][j][0][r], u1 = sa * acc[i][j][1][r], u2 = sa * acc[i][j][2][r];
-                const float u3 = -sa * acc[i][j][3][r];
-                const float h = 0.5f * (u1 + u2);
-                float* d = dst + (size_t)(((i * KR + j) * 4 + r) * 3) * 64;
-                d[0] = u0 + h;
-                d[64] = 0.5f * (u1 - u2);
-                d[128] = h + u3;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const float u0 = sa * acc[i][j][0][r], u1 = sa * acc[i][j][1][r], u2 = sa * acc[i][j][2][r];
+                    const float u3 = -sa * acc[i][j][3][r];
+                    const float h = 0.5f * (u1 + u2);
+                    float* d = ex + (((i * KR + j) * 4 + r) * 3) * 64;
+                    d[0] = u0 + h;
+                    d[64] = 0.5f * (u1 - u2);
+                    d[128] = h + u3;
+                }
+    }
+    if (NG == 2) __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < KR; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u0 = sa * acc[i][j][0][r], u1 = sa * acc[i][j][1][r], u2 = sa * acc[i][j][2][r];
+                    const float u3 = -sa * acc[i][j][3][r];
+                    const float h = 0.5f * (u1 + u2);
+                    const int e = (((i * KR + j) * 4 + r) * 3) * 64;
+                    float q0 = u0 + h, q1 = 0.5f * (u1 - u2), q2 = h + u3;
+                    if (NG == 2) { q0 += ex[e]; q1 += ex[e + 64]; q2 += ex[e + 128]; }     // fixed order: group 0 + group 1
+                    dst[e] = q0;
+                    dst[e + 64] = q1;
+                    dst[e + 128] = q2;
+                }
+    }
 #ifdef WINO_DIAG
-    if (a.diag && lane == 0 && wave == 0) {
+    if (a.diag && lane == 0 && wave_all == 0) {
         __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0): the slab stores have left the wave
         unsigned long long* o = a.diag + (size_t)blockIdx.x * 8;
         unsigned hwid, xcc;
@@ -335,7 +371,13 @@ __global__ __launch_bounds__(64 * WR_GROUPS) void wino_wreduce_kernel(const floa
     }
 }
 
-struct WgPlan { int RH, RW, GRS, XRS, regs_x, regs_y, nsub, mblocks, kblocks, splits, mr; };
+static inline size_t wg_lds(int mr, int ng) { return (size_t)ng * (2 * 16 * mr * WG_GPS + 2 * WG_KT * WG_XPS) * sizeof(float); }
+template <typename K>
+static bool wg_set_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
+struct WgPlan { int RH, RW, GRS, XRS, regs_x, regs_y, nsub, mblocks, kblocks, splits, mr, ng; };
 
 static WgPlan wg_plan(int B, int Ci, int Co, int H, int W) {
     WgPlan p{};
@@ -351,13 +393,19 @@ static WgPlan wg_plan(int B, int Ci, int Co, int H, int W) {
     // 64 output channels per block; 32 (MR = 2) where the last 64-block would be at most half used --
     // the 32-channel decoder levels ran on the direct kernel at 65 TFLOP/s before (96 -> 32 at 96 x 320: 311 us)
     p.mr = (Co % 64 != 0 && Co % 64 <= 32) ? 2 : 4;
+    if (const char* f = getenv("DC_WGRAD_MR")) { const int v = atoi(f); if (v == 2 || v == 4) p.mr = v; }      // experiments
     p.mblocks = ceil_div(Co, 16 * p.mr); p.kblocks = ceil_div(Ci, WG_KT);
     const int nmk = p.mblocks * p.kblocks;
     // 256 CUs x 2 blocks; at least two chunks per block so that the pipeline has something to overlap
-    p.splits = std::max(1, std::min(std::max(1, p.nsub / 2), ceil_div(512, nmk)));
+    // 256 CUs x 8 waves: 512 one-group blocks, or -- 64-channel tiles with at least two sub-regions for each of the 512
+    // groups -- 256 two-group blocks (half the slab traffic); at least two chunks per group so that the pipeline has
+    // something to overlap
+    p.ng = (p.mr == 4 && p.nsub >= 4 * ceil_div(256, nmk)) ? 2 : 1;
+    if (const char* f = getenv("DC_WGRAD_NG")) { const int v = atoi(f); if (v == 1 || (v == 2 && p.mr == 4)) p.ng = v; }      // experiments
+    p.splits = std::max(1, std::min(std::max(1, p.nsub / (2 * p.ng)), ceil_div(512 / p.ng, nmk)));
     if (const char* f = getenv("DC_WGRAD_BLOCKS")) {         // experiments (tools/sweep_wgrad.py): target block count
         const int tb = atoi(f);
-        if (tb > 0) p.splits = std::max(1, std::min(std::max(1, p.nsub / 2), ceil_div(tb, nmk)));
+        if (tb > 0) p.splits = std::max(1, std::min(std::max(1, p.nsub / (2 * p.ng)), ceil_div(tb, nmk)));
     }
     return p;
 }
@@ -381,12 +429,21 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
     hipEvent_t pe = conv_prof_begin(1, 2.0 * B * (double)Co * Ci * 9.0 * H * W,
                                     2.0 * 16.0 * (double)p.nsub * 16.0 * (double)(p.mblocks * 16 * p.mr) * (p.kblocks * WG_KT),
                                     (double)b0 + (double)b1 + (double)gb + 36.0 * Co * Ci, st);
-    if (p.mr == 4) {
-        if (fused) hipLaunchKernelGGL((wino_wgrad_kernel<true, 4>), dim3(p.splits * nmk), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 4>), dim3(p.splits * nmk), dim3(256), 0, st, a);
+    static const bool attr = wg_set_lds(wino_wgrad_kernel<true, 4, 1>, wg_lds(4, 1)) && wg_set_lds(wino_wgrad_kernel<false, 4, 1>, wg_lds(4, 1)) &&
+                             wg_set_lds(wino_wgrad_kernel<true, 4, 2>, wg_lds(4, 2)) && wg_set_lds(wino_wgrad_kernel<false, 4, 2>, wg_lds(4, 2)) &&
+                             wg_set_lds(wino_wgrad_kernel<true, 2, 1>, wg_lds(2, 1)) && wg_set_lds(wino_wgrad_kernel<false, 2, 1>, wg_lds(2, 1));
+    if (!attr) return DC_ELAUNCH;
+    const dim3 grid(p.splits * nmk);
+    const size_t lds = wg_lds(p.mr, p.ng);
+    if (p.mr == 4 && p.ng == 2) {
+        if (fused) hipLaunchKernelGGL((wino_wgrad_kernel<true, 4, 2>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 2>), grid, dim3(512), lds, st, a);
+    } else if (p.mr == 4) {
+        if (fused) hipLaunchKernelGGL((wino_wgrad_kernel<true, 4, 1>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 1>), grid, dim3(256), lds, st, a);
     } else {
-        if (fused) hipLaunchKernelGGL((wino_wgrad_kernel<true, 2>), dim3(p.splits * nmk), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 2>), dim3(p.splits * nmk), dim3(256), 0, st, a);
+        if (fused) hipLaunchKernelGGL((wino_wgrad_kernel<true, 2, 1>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 2, 1>), grid, dim3(256), lds, st, a);
     }
     conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
