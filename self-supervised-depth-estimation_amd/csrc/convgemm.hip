@@ -1075,7 +1075,8 @@ extern "C" int dc_convs2_dgrad(const float* gy, const float* weight, float* dx, 
     a.w = (const float*)ws; a.gy = gy; a.out = dx; a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
     const int N = B * a.Ho * a.Wo;
     // both column parities live in registers: 2 x (MT x NT) accumulator tiles -> 64 x 128 and 64 x 64 blocks only
-    const CgTile t = ((long)ceil_div(Ci, 64) * ceil_div(N, 128) * 2 >= 300) ? CgTile{2, 4} : CgTile{2, 2};
+    CgTile t = ((long)ceil_div(Ci, 64) * ceil_div(N, 128) * 2 >= 300) ? CgTile{2, 4} : CgTile{2, 2};
+    if (const char* f = getenv("DC_DGRAD3_NT")) { const int v = atoi(f); if (v == 2 || v == 4) t = CgTile{2, v}; }      // experiments
     a.mtiles = ceil_div(Ci, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
     const dim3 grid(a.mtiles * a.ntiles, 2);
     const size_t lds = cg_lds_dgrad(t);
