@@ -264,12 +264,13 @@ __global__ __launch_bounds__(256) void cg_dgrad3_kernel(CgArgs a) {
     const float* gb = a.gy + (size_t)b * a.Co * P;
     // chunk list of this row parity: dy = 0 -> ky = 1; dy = 1 -> ky = 0 (reads gy row oy+1) and ky = 2 (row oy)
     const int nky = dy ? 2 : 1;
-    const int cpt = a.Co / KC;                 // chunks per tap
+    const int cpt = a.Co / KC / (int)gridDim.z;        // chunks per tap of THIS reduction slab (blockIdx.z: a range of output channels)
+    const int cz0 = blockIdx.z * cpt;
     const int nchunk = nky * 3 * cpt;
     gf4 ra[NA], rb[NB];
     auto tap_of = [&](int c, int& ky, int& kx, int& co0) {
         const int t = c / cpt;
-        co0 = (c - t * cpt) * KC;
+        co0 = (cz0 + c - t * cpt) * KC;
         ky = dy ? (t / 3) * 2 : 1;
         kx = t % 3;
     };
@@ -340,12 +341,24 @@ __global__ __launch_bounds__(256) void cg_dgrad3_kernel(CgArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int ci = m0 + wm * 16 * MT + ((lane >> 4) * 4 + r) * MT + mt;
             if (ci >= a.Ci) continue;
-            float* dst = a.out + ((size_t)bo * a.Ci + ci) * plane + (size_t)(2 * qy + dy) * a.Wi + 2 * qx;
+            float* dst = a.out + (size_t)blockIdx.z * a.B * a.Ci * plane + ((size_t)bo * a.Ci + ci) * plane + (size_t)(2 * qy + dy) * a.Wi + 2 * qx;
 #pragma unroll
             for (int h = 0; h < NT / 2; ++h)
                 *reinterpret_cast<gf4*>(dst + 4 * h) =
                     gf4{acc[0][mt][2 * h][r], acc[1][mt][2 * h][r], acc[0][mt][2 * h + 1][r], acc[1][mt][2 * h + 1][r]};
         }
+}
+
+// dx = slab 0 + slab 1 (+ ...), fixed order (the reduction slabs of cg_dgrad3_kernel)
+__global__ __launch_bounds__(256) void cg_slabsum_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n4, int splits) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256ull) {
+        gf4 v = reinterpret_cast<const gf4*>(slabs)[i];
+        for (int z = 1; z < splits; ++z) {
+            const gf4 t = reinterpret_cast<const gf4*>(slabs)[i + (size_t)z * n4];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        reinterpret_cast<gf4*>(out)[i] = v;
+    }
 }
 
 // =====================================================================================================================
@@ -1056,9 +1069,24 @@ extern "C" int dc_stem_wgrad(const float* const* frames, int nf, float mean, flo
     return DC_OK;
 }
 
+// The data gradient's grid: 64 x 64 tiles (both column parities in registers: 2 x (MT x NT) accumulator tiles) x 2 row
+// parities, and -- on the deep layers, where that is fewer blocks than the chip has slots and each block walks up to 96
+// chunks -- the output channels split into 2 or 4 reduction slabs summed in fixed order.  (64 x 128 tiles were measured
+// slower on every trunk shape: the row-parity-1 blocks carry 6 taps against 3, so fewer, larger blocks only lengthen the
+// critical path; tools/bench_convs2.py.)
+static int cg_dgrad3_splits(int B, int Ci, int Co, int Hi, int Wi) {
+    const long blocks = (long)ceil_div(Ci, 64) * ceil_div(B * (Hi / 2) * (Wi / 2), 64) * 2;
+    int s = 1;
+    while (s < 4 && blocks * s * 2 <= 768 && (Co / GKC) % (s * 2) == 0 && (Co / GKC) / (s * 2) >= 2) s *= 2;
+    if (const char* f = getenv("DC_DGRAD3_SPLIT")) { const int v = atoi(f); if ((v == 1 || v == 2 || v == 4) && (Co / GKC) % v == 0) s = v; }   // experiments
+    return s;
+}
+
 extern "C" size_t dc_convs2_dgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize) {
     if (!cg_ok(B, Ci, Co, Hi, Wi, ksize) || ksize != 3 || (Ci & 3) || Co % GKC) return 0;
-    return std::max((size_t)9 * Co * Ci * sizeof(float), c3b_weights_bytes(Ci, Co));
+    const int sp = cg_dgrad3_splits(B, Ci, Co, Hi, Wi);
+    const size_t wt = ((size_t)9 * Co * Ci * sizeof(float) + 255) & ~(size_t)255;
+    return std::max(wt + (sp > 1 ? (size_t)sp * B * Ci * Hi * Wi * sizeof(float) : 0), c3b_weights_bytes(Ci, Co));
 }
 
 extern "C" int dc_convs2_dgrad(const float* gy, const float* weight, float* dx, void* ws, int B, int Ci, int Co, int Hi, int Wi,
@@ -1074,14 +1102,19 @@ extern "C" int dc_convs2_dgrad(const float* gy, const float* weight, float* dx, 
     CgArgs a{};
     a.w = (const float*)ws; a.gy = gy; a.out = dx; a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
     const int N = B * a.Ho * a.Wo;
-    // both column parities live in registers: 2 x (MT x NT) accumulator tiles -> 64 x 128 and 64 x 64 blocks only
-    CgTile t = ((long)ceil_div(Ci, 64) * ceil_div(N, 128) * 2 >= 300) ? CgTile{2, 4} : CgTile{2, 2};
-    if (const char* f = getenv("DC_DGRAD3_NT")) { const int v = atoi(f); if (v == 2 || v == 4) t = CgTile{2, v}; }      // experiments
+    const int sp = cg_dgrad3_splits(B, Ci, Co, Hi, Wi);
+    float* slabs = (float*)((char*)ws + (((size_t)9 * Co * Ci * sizeof(float) + 255) & ~(size_t)255));
+    if (sp > 1) a.out = slabs;
+    const CgTile t{2, 2};
     a.mtiles = ceil_div(Ci, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
-    const dim3 grid(a.mtiles * a.ntiles, 2);
+    const dim3 grid(a.mtiles * a.ntiles, 2, sp);
     const size_t lds = cg_lds_dgrad(t);
-    if (t.nt == 4) hipLaunchKernelGGL((cg_dgrad3_kernel<2, 4>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((cg_dgrad3_kernel<2, 2>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((cg_dgrad3_kernel<2, 2>), grid, dim3(256), lds, st, a);
+    if (sp > 1) {
+        DC_CHECK_LAUNCH();
+        const size_t n4 = (size_t)B * Ci * Hi * Wi / 4;
+        hipLaunchKernelGGL(cg_slabsum_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, st, (const float*)slabs, dx, n4, sp);
+    }
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
