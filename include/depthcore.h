@@ -233,6 +233,12 @@ int dc_wino3x3_fwd(const float* x, const float* weight, float* y, void* ws, int 
                    void* stream);
 int dc_wino3x3_dgrad(const float* gy, const float* weight, float* gx, void* ws, int B, int Ci, int Co, int H, int W,
                      void* stream);
+/* gx = data gradient + addend (addend: same shape as gx, may be NULL).  For a tensor with two consumers -- the input of a
+ * residual block feeds conv1 AND the skip connection (torchvision BasicBlock / Bottleneck behind
+ * networks/resnet_encoder.py:74-98) -- autograd sums the two gradients in a separate pass; here the skip's gradient is
+ * added in the store epilogue of conv1's data-gradient kernel. */
+int dc_wino3x3_dgrad_add(const float* gy, const float* weight, float* gx, const float* addend, void* ws, int B, int Ci, int Co,
+                         int H, int W, void* stream);
 
 /* Measurement hook for the convolution kernels (bench.py `roofline`): when enabled, every Winograd launch brackets its
  * main kernel with hipEvents on the launch stream.  kind 0 = wino_ps_kernel (forward / data gradient of the trunk and
@@ -263,6 +269,10 @@ int dc_wino3x3_wgrad(const float* x, const float* gy, float* dweight, void* ws, 
 int dc_conv1x1_fwd(const float* x, const float* weight, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride, void* stream);
 int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride,
                      void* stream);
+/* dx = data gradient + addend (see dc_wino3x3_dgrad_add); in the store epilogue of the tiled GEMM for stride 1, a separate
+ * in-place pass otherwise. */
+int dc_conv1x1_dgrad_add(const float* gy, const float* weight, float* dx, const float* addend, int B, int Ci, int Co, int Hi, int Wi,
+                         int stride, void* stream);
 size_t dc_conv1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride);
 int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
                      void* stream);

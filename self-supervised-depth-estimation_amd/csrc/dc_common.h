@@ -119,6 +119,10 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
     return 1.f;
 }
 
+// y += a (n floats; float4 body + scalar tail), pointwise.hip.  For the data-gradient paths that cannot take the second
+// gradient of a residual fork in their epilogue (dc_*_dgrad_add): stride-2 1x1, the general 1x1 kernels, the bf16 policy.
+int add_inplace(float* y, const float* a, size_t n, hipStream_t st);
+
 }  // namespace dc
 
 #define DC_CHECK_LAUNCH()                          \

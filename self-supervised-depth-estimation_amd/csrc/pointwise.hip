@@ -250,15 +250,44 @@ extern "C" int dc_conv1x1_fwd(const float* x, const float* weight, float* y, int
     return dc_conv1x1_bias_act_fwd(x, weight, nullptr, y, B, Ci, Co, Hi, Wi, stride, ACT_NONE, stream);
 }
 
-extern "C" int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride,
-                                void* stream) {
+namespace dc {
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ a, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256ull) {
+        float4 v = reinterpret_cast<float4*>(y)[i];
+        const float4 t = reinterpret_cast<const float4*>(a)[i];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] += a[n4 * 4 + threadIdx.x];
+}
+int add_inplace(float* y, const float* a, size_t n, hipStream_t st) {
+    if ((((size_t)y | (size_t)a) & 15) != 0) return DC_EINVAL;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)std::min<size_t>((n / 4 + 255) / 256 + 1, 4096)), dim3(256), 0, st, y, a, n);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+}  // namespace dc
+
+extern "C" int dc_conv1x1_dgrad_add(const float* gy, const float* weight, float* dx, const float* addend, int B, int Ci, int Co, int Hi,
+                                    int Wi, int stride, void* stream) {
     if (!gy || !weight || !dx || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
-    if (dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) return dc_gemm1x1_dgrad(gy, weight, dx, B, Ci, Co, Hi, Wi, stride, stream);
+    if (dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) {
+        // the tiled GEMM adds it in its store epilogue (stride 1: dx is written once, densely)
+        const int rc = dc_gemm1x1_dgrad(gy, weight, dx, stride == 1 ? addend : nullptr, B, Ci, Co, Hi, Wi, stride, stream);
+        if (rc != DC_OK || stride == 1 || !addend) return rc;
+        return add_inplace(dx, addend, (size_t)B * Ci * Hi * Wi, (hipStream_t)stream);
+    }
     PwArgs a{};
     a.a = weight; a.b = gy; a.out = dx; a.B = B; a.M = Co; a.K = Ci; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;
     hipLaunchKernelGGL(pw_dgrad_kernel, dim3(ceil_div(a.Ho * a.Wo, PT), ceil_div(Ci, PT), B), dim3(256), 0, (hipStream_t)stream, a);
     DC_CHECK_LAUNCH();
-    return DC_OK;
+    return addend ? add_inplace(dx, addend, (size_t)B * Ci * Hi * Wi, (hipStream_t)stream) : DC_OK;
+}
+
+extern "C" int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                                void* stream) {
+    return dc_conv1x1_dgrad_add(gy, weight, dx, nullptr, B, Ci, Co, Hi, Wi, stride, stream);
 }
 
 extern "C" int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,

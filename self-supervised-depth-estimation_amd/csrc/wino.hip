@@ -124,6 +124,7 @@ struct WinoPsArgs {
     int Ho, Wo;                       // output map (H x W, or (H+2) x (W+2) for the full correlation P = 2)
     // FUSED only: x = cat(up2?(x0), x1) along channels, padding mode, patch origin = output - P, bias + activation
     const float* x1; const float* bias;
+    const float* addend;              // !FUSED only: same shape as y, added in the store epilogue (the other gradient of a residual fork)
     int C0, up0, pad, P, act;
     unsigned x1bytes;
     int RH, RW, RS, SUBS;             // sub-region shape in tiles, LDS row stride, plane floats (rows * RS)
@@ -371,6 +372,19 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
                 ex[((wave * NR * 4 + j * 4 + r) * 2 + 0) * 64 + lane] = m0 + m1 + m2;
                 ex[((wave * NR * 4 + j * 4 + r) * 2 + 1) * 64 + lane] = m1 - m2 - m3;
             }
+        // (plain launches) the other gradient of a residual fork: loaded before the barrier, so that the loads fly while the
+        // rows are exchanged, and added below
+        f2w ad[4][2];
+        const bool has_add = !FUSED && a.addend && gridDim.z == 1;
+        if (has_add) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = min(mblk * MT + i * 16 + kk * 4 + r, a.M - 1);
+                const size_t o = (((size_t)ob * a.M + m) * Ho + min(oy, Ho - 1)) * Wo + min(ox, Wo - 2);
+                ad[r][0] = *reinterpret_cast<const f2w*>(a.addend + o);
+                ad[r][1] = *reinterpret_cast<const f2w*>(a.addend + o + (oy + 1 < Ho ? Wo : 0));
+            }
+        }
         __syncthreads();
         if (o_ok) {
 #pragma unroll
@@ -390,7 +404,9 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
                     y00 = act_fwd(y00 + bv, a.act); y01 = act_fwd(y01 + bv, a.act);
                     y10 = act_fwd(y10 + bv, a.act); y11 = act_fwd(y11 + bv, a.act);
                 }
-                float* dst = yout + (((size_t)ob * a.M + m) * Ho + oy) * Wo + ox;
+                const size_t o = (((size_t)ob * a.M + m) * Ho + oy) * Wo + ox;
+                if (has_add) { y00 += ad[r][0].x; y01 += ad[r][0].y; y10 += ad[r][1].x; y11 += ad[r][1].y; }
+                float* dst = yout + o;
                 *reinterpret_cast<f2w*>(dst) = f2w{y00, y01};
                 if (oy + 1 < Ho) *reinterpret_cast<f2w*>(dst + Wo) = f2w{y10, y11};
             }
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
 // y = act(sum of the K-split slabs (fixed order) + bias)
 __global__ __launch_bounds__(256) void wino_ysum_kernel(const float* __restrict__ slabs, float* __restrict__ y, size_t n4,
                                                         size_t stride4, int ksplit, const float* __restrict__ bias, int act,
-                                                        int plane4, int M) {
+                                                        int plane4, int M, const float* __restrict__ addend) {
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256ull) {
         float4 v = reinterpret_cast<const float4*>(slabs)[i];
         for (int s = 1; s < ksplit; ++s) {
@@ -429,6 +445,10 @@ __global__ __launch_bounds__(256) void wino_ysum_kernel(const float* __restrict_
         if (bias || act != ACT_NONE) {
             const float bv = bias ? bias[(i / plane4) % M] : 0.f;
             v.x = act_fwd(v.x + bv, act); v.y = act_fwd(v.y + bv, act); v.z = act_fwd(v.z + bv, act); v.w = act_fwd(v.w + bv, act);
+        }
+        if (addend) {
+            const float4 t = reinterpret_cast<const float4*>(addend)[i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
         reinterpret_cast<float4*>(y)[i] = v;
     }
@@ -553,6 +573,7 @@ struct WinoLaunch {
     const float* src0; int C0; int up0; const float* src1; int C1;     // input = cat(up2?(src0), src1), maps H x W
     const float* weight; int Co, Ci; bool dgrad;                         // nn.Conv2d weight (Co,Ci,3,3) and the transform
     const float* bias; int act, pad, P;                                  // FUSED options (P: 1 same, 2 full correlation)
+    const float* addend;                                                 // plain launches: added to the result (may be null)
     float* out; void* ws;
     int B, H, W, M;
     bool fused;
@@ -564,7 +585,7 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     const size_t b0 = (size_t)d.B * d.C0 * (H >> d.up0) * (W >> d.up0) * 4, b1 = (size_t)d.B * d.C1 * H * W * 4;
     if (b0 >= 0x7fffffffull || b1 >= 0x7fffffffull) return DC_EINVAL;      // 32-bit buffer offsets
     WinoPsArgs a{};
-    a.x = d.src0; a.x1 = d.src1; a.uhat = (const float*)d.ws; a.bias = d.bias;
+    a.x = d.src0; a.x1 = d.src1; a.uhat = (const float*)d.ws; a.bias = d.bias; a.addend = d.fused ? nullptr : d.addend;
     a.B = d.B; a.K = K; a.M = M; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
     a.C0 = d.C0; a.up0 = d.up0; a.pad = d.pad; a.P = d.P; a.act = d.act;
     a.xbytes = (unsigned)b0; a.x1bytes = (unsigned)b1;
@@ -631,7 +652,7 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
         const size_t n4 = nout / 4;
         hipLaunchKernelGGL(wino_ysum_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, slabs,
                            d.out, n4, n4, ksplit, d.fused ? d.bias : (const float*)nullptr, d.fused ? d.act : (int)ACT_NONE,
-                           Ho * Wo / 4, M);
+                           Ho * Wo / 4, M, d.fused ? (const float*)nullptr : d.addend);
         DC_CHECK_LAUNCH();
     }
     return DC_OK;
@@ -665,16 +686,19 @@ int wino_conv_full_dgrad(const float* gp, const float* weight, float* dxpad, voi
     return wino_launch(d, st);
 }
 
-static int wino_run(const float* x, const float* w, float* y, void* ws, int B, int Ci, int Co, int H, int W, bool dgrad,
-                    hipStream_t st) {
+static int wino_run(const float* x, const float* w, float* y, const float* addend, void* ws, int B, int Ci, int Co, int H, int W,
+                    bool dgrad, hipStream_t st) {
     if (!x || !w || !y || !ws || B <= 0 || Ci <= 0 || Co <= 0 || H < 1 || W < 2 || (W & 1)) return DC_EINVAL;
     // reduced-precision policy: direct implicit GEMM on the bf16 matrix cores (conv_bf16.hip; the data gradient of a
     // zero-padded convolution is the convolution with the rotated, transposed filter)
-    if (matrix_precision() == DC_PREC_BF16 && c3b_eligible(dgrad ? Co : Ci, 0, 0, H, W, 1))
-        return c3b_conv(x, dgrad ? Co : Ci, 0, nullptr, 0, w, Co, Ci, dgrad ? 1 : 0, 0, nullptr, y, ws, B, H, W, ACT_NONE, PAD_ZERO, 1, st);
+    if (matrix_precision() == DC_PREC_BF16 && c3b_eligible(dgrad ? Co : Ci, 0, 0, H, W, 1)) {
+        const int rc = c3b_conv(x, dgrad ? Co : Ci, 0, nullptr, 0, w, Co, Ci, dgrad ? 1 : 0, 0, nullptr, y, ws, B, H, W, ACT_NONE, PAD_ZERO, 1, st);
+        if (rc != DC_OK || !addend) return rc;
+        return add_inplace(y, addend, (size_t)B * (dgrad ? Ci : Co) * H * W, st);
+    }
     WinoLaunch d{};
     d.src0 = x; d.C0 = dgrad ? Co : Ci; d.weight = w; d.Co = Co; d.Ci = Ci; d.dgrad = dgrad; d.act = ACT_NONE; d.pad = PAD_ZERO;
-    d.P = 1; d.out = y; d.ws = ws; d.B = B; d.H = H; d.W = W; d.M = dgrad ? Ci : Co; d.fused = false;
+    d.P = 1; d.out = y; d.ws = ws; d.B = B; d.H = H; d.W = W; d.M = dgrad ? Ci : Co; d.fused = false; d.addend = addend;
     return wino_launch(d, st);
 }
 
@@ -821,10 +845,16 @@ extern "C" size_t dc_wino3x3_workspace(int B, int Ci, int Co, int H, int W) {
 
 extern "C" int dc_wino3x3_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int H, int W,
                               void* stream) {
-    return wino_run(x, weight, y, ws, B, Ci, Co, H, W, false, (hipStream_t)stream);
+    return wino_run(x, weight, y, nullptr, ws, B, Ci, Co, H, W, false, (hipStream_t)stream);
 }
 
 extern "C" int dc_wino3x3_dgrad(const float* gy, const float* weight, float* gx, void* ws, int B, int Ci, int Co, int H,
                                 int W, void* stream) {
-    return wino_run(gy, weight, gx, ws, B, Ci, Co, H, W, true, (hipStream_t)stream);
+    return wino_run(gy, weight, gx, nullptr, ws, B, Ci, Co, H, W, true, (hipStream_t)stream);
+}
+
+extern "C" int dc_wino3x3_dgrad_add(const float* gy, const float* weight, float* gx, const float* addend, void* ws, int B, int Ci,
+                                    int Co, int H, int W, void* stream) {
+    if (addend && (((size_t)addend | (size_t)gx) & 15)) return DC_EINVAL;
+    return wino_run(gy, weight, gx, addend, ws, B, Ci, Co, H, W, true, (hipStream_t)stream);
 }

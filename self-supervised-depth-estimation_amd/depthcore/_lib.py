@@ -104,10 +104,12 @@ def _sig(lib):
         "dc_wino3x3_workspace": (z, [i, i, i, i, i]),
         "dc_wino3x3_fwd": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_wino3x3_dgrad": (i, [p, p, p, p, i, i, i, i, i, p]),
+        "dc_wino3x3_dgrad_add": (i, [p, p, p, p, p, i, i, i, i, i, p]),
         "dc_conv1x1_fwd": (i, [p, p, p, i, i, i, i, i, i, p]),
         "dc_conv1x1_bias_act_fwd": (i, [p, p, p, p, i, i, i, i, i, i, i, p]),
         "dc_bias_act_bwd": (i, [p, p, p, p, i, i, i, i, p]),
         "dc_conv1x1_dgrad": (i, [p, p, p, i, i, i, i, i, i, p]),
+        "dc_conv1x1_dgrad_add": (i, [p, p, p, p, i, i, i, i, i, i, p]),
         "dc_conv1x1_wgrad_workspace": (z, [i, i, i, i, i, i]),
         "dc_conv1x1_wgrad": (i, [p, p, p, p, i, i, i, i, i, i, p]),
         "dc_conv_profile_enable": (i, [i, i]),

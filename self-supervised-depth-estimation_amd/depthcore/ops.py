@@ -586,11 +586,41 @@ def conv3x3_block(x0, x1, weight, bias, up0=False, act=ACT_NONE, pad=PAD_REFLECT
 
 
 # ----------------------------------------------------------------------------------------------
+# a1 the gradient of a residual block's input: summed inside conv1's data-gradient kernel, not by autograd
+# ----------------------------------------------------------------------------------------------
+class GradFork:
+    """The input x of a residual block without a downsample branch has two consumers: conv1 and the skip connection into the
+    last BatchNorm (+ add + ReLU).  Autograd would add their two gradients in a separate elementwise pass (31 such passes per
+    C2 step, 42 at C3).  With a GradFork shared by the two ops, the last BatchNorm's backward -- which always runs first:
+    conv1's output feeds it -- parks the skip's gradient here and reports NO gradient for its `res` input; conv1's backward
+    picks it up and its data-gradient kernel adds it in the store epilogue (dc_wino3x3_dgrad_add / dc_conv1x1_dgrad_add), so
+    x receives the complete gradient from conv1 alone.  One backward pass per forward (no double backward / retain_graph
+    replays): a fork that is asked twice, or whose parked gradient is never collected, raises."""
+    __slots__ = ("addend", "armed")
+
+    def __init__(self):
+        self.addend = None
+        self.armed = True
+
+    def park(self, dres):
+        if not self.armed or self.addend is not None:
+            raise _lib.DepthcoreError("GradFork: the skip gradient was produced twice (a second backward through the same block?)")
+        self.addend = dres
+
+    def take(self):
+        if not self.armed:
+            raise _lib.DepthcoreError("GradFork: conv1's backward ran twice for one forward")
+        self.armed = False
+        a, self.addend = self.addend, None
+        return a
+
+
+# ----------------------------------------------------------------------------------------------
 # a1 training-mode BatchNorm2d (+ residual add) (+ ReLU), fused  (ResNet BasicBlock / Bottleneck / stem)
 # ----------------------------------------------------------------------------------------------
 class _BNReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum, relu, groups):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum, relu, groups, fork=None):
         L = _lib.lib()
         xx = _c(x.detach())
         rr = _c(res.detach()) if res is not None else None
@@ -610,6 +640,7 @@ class _BNReLU(torch.autograd.Function):
             _record_kink("relu", y)
         ctx.cfg = (int(relu), res is not None, int(groups))
         ctx.slots = (_slot(gamma), _slot(beta))
+        ctx.fork = fork if (fork is not None and res is not None and res.requires_grad) else None
         return y
 
     @staticmethod
@@ -627,15 +658,18 @@ class _BNReLU(torch.autograd.Function):
         check(L.dc_bn_relu_bwd(ptr(xx), ptr(y), ptr(g_c), ptr(g), ptr(mean), ptr(invstd), ptr(dx), ptr(dres), ptr(dgamma),
                                ptr(dbeta), ws.data_ptr(), mask.data_ptr() if mask is not None else None, N, C, H * W, relu,
                                groups, stream(xx)), "dc_bn_relu_bwd")
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+        if ctx.fork is not None and dres is not None:
+            ctx.fork.park(dres)             # conv1's data-gradient kernel adds it (GradFork)
+            dres = None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def bn_relu(x, bn, res=None, relu=True, groups=1):
+def bn_relu(x, bn, res=None, relu=True, groups=1, fork=None):
     """y = relu?(bn(x) [+ res]) with `bn` an nn.BatchNorm2d in training mode (batch statistics; updates its
     running_mean / running_var in place; `num_batches_tracked` is advanced by the caller).  `groups` > 1:
     the batch is that many independent sub-batches (statistics and running-stat updates per sub-batch)."""
     mom = 0.1 if bn.momentum is None else bn.momentum
-    return _BNReLU.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu, groups)
+    return _BNReLU.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu, groups, fork)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -676,7 +710,7 @@ def maxpool3x3s2(x):
 # ----------------------------------------------------------------------------------------------
 class _WinoConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, fork=None):
         L = _lib.lib()
         xx, ww = _c(x.detach()), _c(weight.detach())
         B, Ci, H, W = xx.shape
@@ -687,6 +721,7 @@ class _WinoConv(torch.autograd.Function):
         check(L.dc_wino3x3_fwd(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, stream(xx)), "dc_wino3x3_fwd")
         ctx.save_for_backward(xx, ww)
         ctx.slot = _slot(weight)
+        ctx.fork = fork if x.requires_grad else None
         return y
 
     @staticmethod
@@ -698,26 +733,42 @@ class _WinoConv(torch.autograd.Function):
         g_c = _c(gy)
         gx = gw = None
         _use_precision(ctx.prec)
+        add = _fork_addend(ctx, xx)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xx)
             ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
-            check(L.dc_wino3x3_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), B, Ci, Co, H, W, stream(g_c)),
-                  "dc_wino3x3_dgrad")
+            check(L.dc_wino3x3_dgrad_add(ptr(g_c), ptr(ww), ptr(gx), ptr(add), ws.data_ptr(), B, Ci, Co, H, W, stream(g_c)),
+                  "dc_wino3x3_dgrad_add")
         if ctx.needs_input_grad[1]:
             gw = _grad_dst(ctx.slot, ww)
             ws = torch.empty(L.dc_wino3x3_wgrad_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
             check(L.dc_wino3x3_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, H, W, stream(xx)),
                   "dc_wino3x3_wgrad")
-        return gx, gw
+        return gx, gw, None
 
 
-def wino_conv3x3(x, weight):
+def _fork_addend(ctx, xx):
+    """The skip gradient parked for this convolution's input (GradFork), or None."""
+    if ctx.fork is None:
+        return None
+    add = ctx.fork.take()
+    if add is not None and not ctx.needs_input_grad[0]:
+        raise _lib.DepthcoreError("GradFork: a skip gradient is waiting but the convolution's input gradient was not requested")
+    if add is not None and (add.shape != xx.shape or not add.is_contiguous()):
+        raise _lib.DepthcoreError("GradFork: skip gradient %s does not match the block input %s" % (tuple(add.shape), tuple(xx.shape)))
+    return add
+
+
+def wino_conv3x3(x, weight, fork=None):
     """F.conv2d(x, weight, None, 1, 1) for 3x3 kernels on even-width maps (fused Winograd on the matrix cores).
     The Winograd kernels use 32-bit buffer offsets: a tensor of 2 GiB or more takes the direct implicit-GEMM kernels of
     the fused conv block (same arithmetic contract, size_t indexing) instead."""
     if max(x.numel(), x.numel() // x.shape[1] * weight.shape[0]) * 4 >= 0x7fffffff:
+        if fork is not None:
+            fork.armed = False          # (the direct kernels have no addend: the caller falls back to autograd's sum)
+            raise _lib.DepthcoreError("GradFork is not available on the >= 2 GiB path; call without a fork")
         return conv3x3_block(x, None, weight, None, False, ACT_NONE, PAD_ZERO)
-    return _WinoConv.apply(x, weight)
+    return _WinoConv.apply(x, weight, fork)
 
 
 # ---- transformed-weight cache of the Winograd kernels (include/depthcore.h: dc_wino_cache_*) ----------------------
@@ -779,7 +830,7 @@ class WinoWeightCache:
 # ----------------------------------------------------------------------------------------------
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, act):
+    def forward(ctx, x, weight, bias, stride, act, fork=None):
         L = _lib.lib()
         xx, ww = _c(x.detach()), _c(weight.detach())
         bs = _c(bias.detach()) if bias is not None else None
@@ -796,6 +847,7 @@ class _Conv1x1(torch.autograd.Function):
         ctx.save_for_backward(xx, ww, None if plain else y)
         ctx.cfg = (int(stride), int(act), bias is not None)
         ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
+        ctx.fork = fork if x.requires_grad else None
         return y
 
     @staticmethod
@@ -817,20 +869,21 @@ class _Conv1x1(torch.autograd.Function):
             check(L.dc_bias_act_bwd(ptr(y), ptr(g_c), ptr(gpre), ptr(gb), B, Co, P, act, stream(xx)), "dc_bias_act_bwd")
             if gpre is not None:
                 g_c = gpre
+        add = _fork_addend(ctx, xx)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xx)
-            check(L.dc_conv1x1_dgrad(ptr(g_c), ptr(ww), ptr(gx), B, Ci, Co, Hi, Wi, s_, stream(xx)), "dc_conv1x1_dgrad")
+            check(L.dc_conv1x1_dgrad_add(ptr(g_c), ptr(ww), ptr(gx), ptr(add), B, Ci, Co, Hi, Wi, s_, stream(xx)), "dc_conv1x1_dgrad_add")
         if ctx.needs_input_grad[1]:
             gw = _grad_dst(ctx.slots[0], ww)
             ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
             check(L.dc_conv1x1_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream(xx)),
                   "dc_conv1x1_wgrad")
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
-def conv1x1(x, weight, stride=1, bias=None, act=ACT_NONE):
-    """act(F.conv2d(x, weight, bias, stride)) for (Co,Ci,1,1) weights; stride 2 needs even H, W."""
-    return _Conv1x1.apply(x, weight, bias, stride, act)
+def conv1x1(x, weight, stride=1, bias=None, act=ACT_NONE, fork=None):
+    """act(F.conv2d(x, weight, bias, stride)) for (Co,Ci,1,1) weights; stride 2 needs even H, W.  `fork`: GradFork."""
+    return _Conv1x1.apply(x, weight, bias, stride, act, fork)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -15,13 +15,13 @@ import torch.nn.functional as F
 from depthcore import ops as _ops
 
 
-def _bn_act(x, bn, res=None, relu=True, groups=1):
+def _bn_act(x, bn, res=None, relu=True, groups=1, fork=None):
     """BatchNorm2d (+ residual) (+ ReLU).  Training mode (the hot path) is one fused depthcore launch chain and has no
     fallback: a CPU tensor raises DepthcoreError.  Eval mode (running statistics; validation / export, not on the
     training path) uses the stock functional ops.
     `groups`: number of independent sub-batches stacked along dim 0 (statistics per sub-batch)."""
     if bn.training:
-        return _ops.bn_relu(x, bn, res, relu, groups)
+        return _ops.bn_relu(x, bn, res, relu, groups, fork)
     y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, bn.momentum or 0.1, bn.eps)
     if res is not None:
         y = y + res
@@ -34,26 +34,47 @@ WINO_TRUNK = True     # stride-1 3x3 trunk convolutions on depthcore's fused Win
 STEM_FUSED = True     # input normalisation (and the pose pairs' concat) inside the stem kernels' loader (dc_stem_*)
 
 
-def _conv(conv, x):
+GRAD_FORK = True      # residual blocks without a downsample branch: the skip's gradient is added inside conv1's data-gradient kernel
+
+
+def _fork_for(block, x):
+    """A GradFork for this call of a residual block, or None: training on the GPU, identity skip, an input that needs a
+    gradient, conv1 on a kernel with the addend epilogue (stride-1 3x3 Winograd or 1x1 GEMM) and a map below 2 GiB."""
+    c = block.conv1
+    if not (GRAD_FORK and block.downsample is None and block.training and x.is_cuda and x.requires_grad and x.dtype == torch.float32
+            and torch.is_grad_enabled() and c.stride == (1, 1) and c.groups == 1 and c.bias is None and x.numel() * 4 < 0x7fffffff):
+        return None
+    if c.kernel_size == (3, 3) and WINO_TRUNK and c.padding == (1, 1) and c.dilation == (1, 1) and x.shape[-1] % 2 == 0:
+        return _ops.GradFork()
+    if c.kernel_size == (1, 1) and GEMM_1X1 and c.padding == (0, 0):
+        return _ops.GradFork()
+    return None
+
+
+def _conv(conv, x, fork=None):
     """nn.Conv2d call of the trunk: stride-1 3x3 on dc_wino3x3_* (84 % of a ResNet-18 trunk's multiplies), 1x1 on dc_conv1x1_*,
     the 7x7 / 2 stem and the 3x3 / 2 convolutions on dc_convs2_*; only shapes outside those kernels' 16-byte staging (odd or
     tiny maps in tests) reach the framework's convolution."""
     if (WINO_TRUNK and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and x.shape[-1] % 2 == 0
             and x.dtype == torch.float32):
-        return _ops.wino_conv3x3(x, conv.weight)
+        return _ops.wino_conv3x3(x, conv.weight, fork)
     if (GEMM_1X1 and x.is_cuda and conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
             and conv.bias is None and conv.stride in ((1, 1), (2, 2)) and x.dtype == torch.float32
             and (conv.stride == (1, 1) or (x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0))):
         # Bottleneck conv1 / conv3 and every `downsample` branch: NCHW fp32-MFMA GEMMs (dc_conv1x1_*), no layout transposes
-        return _ops.conv1x1(x, conv.weight, conv.stride[0])
+        return _ops.conv1x1(x, conv.weight, conv.stride[0], fork=fork)
     if (CONV_S2 and x.is_cuda and conv.stride == (2, 2) and conv.kernel_size in ((3, 3), (7, 7)) and conv.groups == 1
             and conv.padding == (conv.kernel_size[0] // 2,) * 2 and conv.dilation == (1, 1) and conv.bias is None
             and x.dtype == torch.float32 and _ops.conv_s2_supported(x, conv.weight)
             and ((conv.kernel_size == (7, 7) and not x.requires_grad)        # (the stem kernels have no data gradient)
                  or (conv.kernel_size == (3, 3) and conv.in_channels % 4 == 0 and conv.out_channels % 32 == 0))):
         # 7x7 / 2 stem and the 3x3 / 2 convolutions: implicit GEMMs on the matrix cores (dc_convs2_*)
+        if fork is not None:
+            raise _ops.DepthcoreError("GradFork handed to a strided convolution")
         return _ops.conv_s2(x, conv.weight)
+    if fork is not None:  # (_fork_for mirrors the two conditions above; a fork nobody collects would lose the skip's gradient)
+        raise _ops.DepthcoreError("GradFork handed to a convolution that does not run on a kernel with the addend epilogue")
     return conv(x)      # shapes outside the kernels' 16-byte staging (odd or tiny maps in tests): the framework's convolution
 
 
@@ -73,8 +94,9 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         g = self._g[0]
         idt = x if self.downsample is None else _bn_act(_conv(self.downsample[0], x), self.downsample[1], relu=False, groups=g)
-        out = _bn_act(_conv(self.conv1, x), self.bn1, groups=g)
-        return _bn_act(_conv(self.conv2, out), self.bn2, res=idt, groups=g)   # relu(bn2(conv2) + identity), one pass
+        fork = _fork_for(self, x)
+        out = _bn_act(_conv(self.conv1, x, fork), self.bn1, groups=g)
+        return _bn_act(_conv(self.conv2, out), self.bn2, res=idt, groups=g, fork=fork)   # relu(bn2(conv2) + identity), one pass
 
 
 class Bottleneck(nn.Module):
@@ -95,9 +117,10 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         g = self._g[0]
         idt = x if self.downsample is None else _bn_act(_conv(self.downsample[0], x), self.downsample[1], relu=False, groups=g)
-        out = _bn_act(_conv(self.conv1, x), self.bn1, groups=g)
+        fork = _fork_for(self, x)
+        out = _bn_act(_conv(self.conv1, x, fork), self.bn1, groups=g)
         out = _bn_act(_conv(self.conv2, out), self.bn2, groups=g)
-        return _bn_act(_conv(self.conv3, out), self.bn3, res=idt, groups=g)
+        return _bn_act(_conv(self.conv3, out), self.bn3, res=idt, groups=g, fork=fork)
 
 
 _CFG = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3)),

@@ -1,0 +1,62 @@
+"""GradFork (depthcore.ops): the gradient of a residual block's input -- conv1's data gradient + the skip's gradient -- summed in
+the store epilogue of conv1's data-gradient kernel (dc_wino3x3_dgrad_add / dc_conv1x1_dgrad_add) instead of by an autograd
+add (torchvision BasicBlock / Bottleneck behind reference networks/resnet_encoder.py:74-98).  One fp32 addition either way,
+so the results must be IDENTICAL to the un-forked path's, for the input and for every parameter."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(block_cls, inplanes, planes, shape, fork, seed=0):
+    from networks import resnet_encoder as RE
+    torch.manual_seed(seed)
+    blk = block_cls(inplanes, planes).to(DEV).train()
+    x = torch.randn(*shape, device=DEV).requires_grad_()
+    cot = torch.randn(shape[0], planes * block_cls.expansion, shape[2], shape[3], device=DEV)
+    old = RE.GRAD_FORK
+    RE.GRAD_FORK = fork
+    try:
+        made = []
+        orig = RE._ops.GradFork
+        RE._ops.GradFork = lambda: made.append(orig()) or made[-1]
+        y = blk(x * 1.0)                       # (x * 1.0: the block input is a non-leaf, as inside the trunk)
+        (y * cot).sum().backward()
+    finally:
+        RE.GRAD_FORK = old
+        RE._ops.GradFork = orig
+    torch.cuda.synchronize()
+    return x.grad.clone(), {n: p.grad.clone() for n, p in blk.named_parameters()}, y.detach().clone(), made
+
+
+@pytest.mark.parametrize("kind,shape", [("basic", (4, 64, 24, 80)), ("basic", (2, 128, 12, 40)), ("basic", (12, 512, 6, 20)),
+                                        ("bottleneck", (2, 256, 16, 64)), ("bottleneck", (4, 512, 8, 32))])
+def test_forked_block_gradients_equal_autograd_sum(kind, shape):
+    from networks import resnet_encoder as RE
+    cls = RE.BasicBlock if kind == "basic" else RE.Bottleneck
+    planes = shape[1] // cls.expansion
+    gx1, gp1, y1, made1 = _run(cls, shape[1], planes, shape, True)
+    gx0, gp0, y0, made0 = _run(cls, shape[1], planes, shape, False)
+    assert len(made1) == 1 and not made0                                     # the fork was really used / really off
+    assert made1[0].addend is None and not made1[0].armed                     # parked and collected exactly once
+    assert torch.equal(y1, y0)
+    assert torch.equal(gx1, gx0), float((gx1 - gx0).abs().max())
+    for n in gp0:
+        assert torch.equal(gp1[n], gp0[n]), n
+
+
+def test_block_with_downsample_or_eval_gets_no_fork_and_second_backward_raises():
+    from depthcore._lib import DepthcoreError
+    from networks import resnet_encoder as RE
+    import torch.nn as nn
+    x = torch.randn(2, 64, 16, 32, device=DEV).requires_grad_()
+    ds = nn.Sequential(nn.Conv2d(64, 128, 1, 2, bias=False), nn.BatchNorm2d(128))
+    assert RE._fork_for(RE.BasicBlock(64, 128, 2, ds).to(DEV).train(), x) is None      # downsample branch: two convolutions share x
+    assert RE._fork_for(RE.BasicBlock(64, 64).to(DEV).eval(), x) is None
+    assert RE._fork_for(RE.BasicBlock(64, 64).to(DEV).train(), x.detach()) is None     # nothing upstream needs the gradient
+    blk = RE.BasicBlock(64, 64).to(DEV).train()
+    y = blk(x * 1.0)
+    y.sum().backward(retain_graph=True)
+    with pytest.raises(DepthcoreError):
+        y.sum().backward()                                                             # one backward per forward
