@@ -17,8 +17,10 @@
 //     The four waves need DISJOINT quarters of a chunk (row = wave), so U bypasses LDS: a lane loads the 16 bytes that
 //     are its A operands for the 4 positions of one k-step and 16-channel block straight into registers (256-byte rows
 //     per 16 lanes, L2 hits for every tile block but the first of an XCD), one chunk ahead.
-//   * a wave keeps 4*MR*NR accumulator tiles (MR,NR = 2,4: 32 output channels x 64 tiles per block, 128 VGPRs);
-//     the four rows are combined at the end through LDS (Y = A^T M A is linear in the rows of M), 8-byte stores.
+//   * a wave keeps 4*MR*NR accumulator tiles; three tile variants -- (MR,NR) = (1,2): 16 output channels x 32 tiles, 4 blocks
+//     per CU; (2,2): 32 x 32, 3 per CU; (2,4): 32 x 64, 2 per CU -- and a K split, picked per launch by wino_ps_cost (a model
+//     of the lock-step ROUNDS a launch runs in, fitted to per-block timelines; below).  The four rows are combined at the
+//     end through LDS (Y = A^T M A is linear in the rows of M), 8-byte stores.
 //   * tiles are grouped in sub-regions of <= 32 (RH x RW chosen per map so that it divides evenly: 4x8, 2x16,
 //     3x10, 8x4); a block takes NR/2 consecutive sub-regions, which may lie in different images.
 //   * pipeline: the slab is double-buffered in LDS (one barrier per chunk of 8 channels); while chunk c is
@@ -26,8 +28,9 @@
 //   * block order puts the readers of the larger stream (x across channel blocks, or U across tile blocks) next to
 //     each other ON ONE XCD (xcd_logical_block) so that the re-reads are L2 hits; small maps split the reduction
 //     over gridDim.z and sum the partial outputs in fixed order (wino_ysum_kernel).
-// Measured phase split of the previous revision, which staged U through LDS (-DWINO_DIAG build, tools/diag_wino.sh,
-// B=24 256->64 48x160): MFMA phase 61 %, LDS commit incl. load wait 15 %, load issue 14 %, barrier 4 % of the loop.
+// Measured (-DWINO_DIAG builds, tools/diag_wino.sh): mode 1 = phase split inside the loop (an earlier revision, B=24 256->64
+// 48x160: MFMA phase 61 %, LDS commit incl. load wait 15 %, load issue 14 %, barrier 4 %; the timers cost ~20 % themselves);
+// mode 2 = per-block start / end (s_memrealtime) and prologue / loop / epilogue lengths -> DESIGN 4a "block timelines".
 // dgrad is the same kernel on the 180-degree-rotated, transposed weights (wino_weights_kernel<DGRAD>).
 // Requires even W (8-byte row alignment); H arbitrary.
 #include "dc_common.h"
