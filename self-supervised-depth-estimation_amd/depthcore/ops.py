@@ -596,11 +596,22 @@ class GradFork:
     picks it up and its data-gradient kernel adds it in the store epilogue (dc_wino3x3_dgrad_add / dc_conv1x1_dgrad_add), so
     x receives the complete gradient from conv1 alone.  One backward pass per forward (no double backward / retain_graph
     replays): a fork that is asked twice, or whose parked gradient is never collected, raises."""
-    __slots__ = ("addend", "armed")
+    __slots__ = ("addend", "armed", "pair", "arrived")
 
-    def __init__(self):
+    def __init__(self, pair=False):
         self.addend = None
         self.armed = True
+        # pair: x feeds TWO convolutions with the addend epilogue (Bottleneck conv1 and the 1x1 `downsample`): whichever
+        # backward runs first parks its data gradient and reports none, the second adds it (no assumption about the order)
+        self.pair = pair
+        self.arrived = 0
+
+    def arrive(self):
+        """pair forks: 0 for the first convolution backward to get here, 1 for the second."""
+        if not self.pair or self.arrived >= 2:
+            raise _lib.DepthcoreError("GradFork: more backward calls than the two convolutions that share the input")
+        self.arrived += 1
+        return self.arrived - 1
 
     def park(self, dres):
         if not self.armed or self.addend is not None:
@@ -612,6 +623,8 @@ class GradFork:
             raise _lib.DepthcoreError("GradFork: conv1's backward ran twice for one forward")
         self.armed = False
         a, self.addend = self.addend, None
+        if self.pair and a is None:
+            raise _lib.DepthcoreError("GradFork: the first convolution's data gradient was never parked")
         return a
 
 
@@ -869,10 +882,16 @@ class _Conv1x1(torch.autograd.Function):
             check(L.dc_bias_act_bwd(ptr(y), ptr(g_c), ptr(gpre), ptr(gb), B, Co, P, act, stream(xx)), "dc_bias_act_bwd")
             if gpre is not None:
                 g_c = gpre
-        add = _fork_addend(ctx, xx)
+        first_of_pair = ctx.fork is not None and ctx.fork.pair and ctx.fork.arrive() == 0
+        add = None if first_of_pair else _fork_addend(ctx, xx)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xx)
             check(L.dc_conv1x1_dgrad_add(ptr(g_c), ptr(ww), ptr(gx), ptr(add), B, Ci, Co, Hi, Wi, s_, stream(xx)), "dc_conv1x1_dgrad_add")
+            if first_of_pair:
+                ctx.fork.park(gx)          # the other convolution of the pair adds it and returns the sum
+                gx = None
+        elif first_of_pair:
+            raise _lib.DepthcoreError("GradFork: the shared input needs no gradient")
         if ctx.needs_input_grad[1]:
             gw = _grad_dst(ctx.slots[0], ww)
             ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)

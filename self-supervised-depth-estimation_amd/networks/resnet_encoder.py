@@ -51,6 +51,16 @@ def _fork_for(block, x):
     return None
 
 
+def _pair_fork_for(block, x):
+    """A pair GradFork for a Bottleneck with a downsample branch (both consumers of x are 1x1 GEMM convolutions), or None."""
+    c, d = block.conv1, block.downsample[0]
+    ok = (GRAD_FORK and GEMM_1X1 and block.training and x.is_cuda and x.requires_grad and x.dtype == torch.float32
+          and torch.is_grad_enabled() and x.numel() * 4 < 0x7fffffff
+          and all(m.kernel_size == (1, 1) and m.padding == (0, 0) and m.groups == 1 and m.bias is None for m in (c, d))
+          and c.stride == (1, 1) and d.stride in ((1, 1), (2, 2)) and (d.stride == (1, 1) or (x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0)))
+    return _ops.GradFork(pair=True) if ok else None
+
+
 def _conv(conv, x, fork=None):
     """nn.Conv2d call of the trunk: stride-1 3x3 on dc_wino3x3_* (84 % of a ResNet-18 trunk's multiplies), 1x1 on dc_conv1x1_*,
     the 7x7 / 2 stem and the 3x3 / 2 convolutions on dc_convs2_*; only shapes outside those kernels' 16-byte staging (odd or
@@ -116,11 +126,20 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         g = self._g[0]
-        idt = x if self.downsample is None else _bn_act(_conv(self.downsample[0], x), self.downsample[1], relu=False, groups=g)
         fork = _fork_for(self, x)
-        out = _bn_act(_conv(self.conv1, x, fork), self.bn1, groups=g)
+        if self.downsample is None:
+            out = _bn_act(_conv(self.conv1, x, fork), self.bn1, groups=g)
+            out = _bn_act(_conv(self.conv2, out), self.bn2, groups=g)
+            return _bn_act(_conv(self.conv3, out), self.bn3, res=x, groups=g, fork=fork)
+        # conv1 and the 1x1 `downsample` both read x: a pair fork sums their two data gradients in the second one's epilogue
+        pair = _pair_fork_for(self, x)
+        out = _bn_act(_conv(self.conv1, x, pair), self.bn1, groups=g)
         out = _bn_act(_conv(self.conv2, out), self.bn2, groups=g)
-        return _bn_act(_conv(self.conv3, out), self.bn3, res=idt, groups=g, fork=fork)
+        out = _conv(self.conv3, out)
+        # (the skip branch is evaluated last so that its backward runs first: the stride-1 conv1 -- whose kernel adds in its
+        # store epilogue -- is then the second of the pair; either order is correct)
+        idt = _bn_act(_conv(self.downsample[0], x, pair), self.downsample[1], relu=False, groups=g)
+        return _bn_act(out, self.bn3, res=idt, groups=g)
 
 
 _CFG = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3)),

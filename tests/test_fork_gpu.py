@@ -9,18 +9,23 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _run(block_cls, inplanes, planes, shape, fork, seed=0):
+def _run(block_cls, inplanes, planes, shape, fork, seed=0, ds_stride=0):
+    import torch.nn as nn
     from networks import resnet_encoder as RE
     torch.manual_seed(seed)
-    blk = block_cls(inplanes, planes).to(DEV).train()
+    ds = None
+    if ds_stride:       # a downsample branch as ResNetTrunk._make_layer builds it (v1.5: the block's stride sits on conv2)
+        ds = nn.Sequential(nn.Conv2d(inplanes, planes * block_cls.expansion, 1, ds_stride, bias=False), nn.BatchNorm2d(planes * block_cls.expansion))
+    blk = (block_cls(inplanes, planes, ds_stride, ds) if ds_stride else block_cls(inplanes, planes)).to(DEV).train()
     x = torch.randn(*shape, device=DEV).requires_grad_()
-    cot = torch.randn(shape[0], planes * block_cls.expansion, shape[2], shape[3], device=DEV)
+    so = ds_stride or 1
+    cot = torch.randn(shape[0], planes * block_cls.expansion, shape[2] // so, shape[3] // so, device=DEV)
     old = RE.GRAD_FORK
     RE.GRAD_FORK = fork
     try:
         made = []
         orig = RE._ops.GradFork
-        RE._ops.GradFork = lambda: made.append(orig()) or made[-1]
+        RE._ops.GradFork = lambda **kw: made.append(orig(**kw)) or made[-1]
         y = blk(x * 1.0)                       # (x * 1.0: the block input is a non-leaf, as inside the trunk)
         (y * cot).sum().backward()
     finally:
@@ -60,3 +65,17 @@ def test_block_with_downsample_or_eval_gets_no_fork_and_second_backward_raises()
     y.sum().backward(retain_graph=True)
     with pytest.raises(DepthcoreError):
         y.sum().backward()                                                             # one backward per forward
+
+
+@pytest.mark.parametrize("shape,planes,ds_stride", [((2, 64, 16, 64), 64, 1), ((2, 256, 16, 64), 128, 2), ((4, 512, 8, 32), 256, 2)])
+def test_pair_fork_of_bottleneck_with_downsample_equals_autograd_sum(shape, planes, ds_stride):
+    """x feeds conv1 AND the 1x1 `downsample` (layer1.0: stride 1; layer2-4.0: stride 2): whichever data gradient is computed
+    second adds the first (in its store epilogue for stride 1, by the library's in-place pass for stride 2)."""
+    from networks import resnet_encoder as RE
+    gx1, gp1, y1, made1 = _run(RE.Bottleneck, shape[1], planes, shape, True, ds_stride=ds_stride)
+    gx0, gp0, y0, made0 = _run(RE.Bottleneck, shape[1], planes, shape, False, ds_stride=ds_stride)
+    assert len(made1) == 1 and made1[0].pair and made1[0].arrived == 2 and made1[0].addend is None and not made0
+    assert torch.equal(y1, y0)
+    assert torch.equal(gx1, gx0), float((gx1 - gx0).abs().max())
+    for n in gp0:
+        assert torch.equal(gp1[n], gp0[n]), n
