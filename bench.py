@@ -451,7 +451,7 @@ def run_rank(args):
         fams.sort(key=lambda e: -e["ms_per_step"])
         dom = dict(fams[0]) if fams else {"kernel": None, "bound": "mfma", "achieved": 0.0, "peak": MFMA_F32_PEAK_TFLOPS,
                                           "unit": "TFLOP/s", "frac": 0.0}
-        dom_key = {0: "dc::wino_ps_kernel", 1: "dc::wino_wgrad_kernel", 2: "dc::c3b_conv_kernel", 3: "dc::c3b_wgrad_kernel"}.get(dom.get("family"))
+        dom_key = {0: "dc::wino_ps_kernel", 1: "dc::wino_wgrad_kernel", 2: "dc::c3b_conv_kernel", 3: "dc::c3b_wgrad_kernel", 4: "dc::g1_*"}.get(dom.get("family"))
         vb = valu("dc::photo_bwd_kernel")
         out = {
             "metric": "training images/sec at %dx%d bs%d (resnet%d depth+pose, 4-scale photometric+smoothness)"

@@ -15,6 +15,8 @@ def load(d):
         n = r["Kernel_Name"].split("(")[0].replace("void ", "")
         n = n.split("<")[0] if ("wino_" in n or "c3b_" in n) else n     # all instantiations of a convolution kernel together
         agg[n].append(float(r["Counter_Value"]))
+        if any(t in n for t in ("g1_fwd_kernel", "g1_dgrad_kernel", "g1_wgrad_kernel")):
+            agg["dc::g1_*"].append(float(r["Counter_Value"]))          # the 1x1 GEMM family of bench.py (mean over all its launches)
     return {k: sum(v) / len(v) for k, v in agg.items()}
 fe, wr, va = load(sys.argv[1] + "/fetch"), load(sys.argv[1] + "/write"), load(sys.argv[1] + "/valu")
 cal = [k for k in fe if "d2d_fwd" in k][0]
