@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void cg_fwd_kernel(CgArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
                 if (m >= a.Co) continue;
-                float* dst = a.out + ((size_t)bo * a.Co + m) * P + p;
+                float* dst = a.out + (size_t)blockIdx.y * a.B * a.Co * P + ((size_t)bo * a.Co + m) * P + p;
                 if constexpr (NT == 4) *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
                 else *reinterpret_cast<gf2*>(dst) = gf2{acc[mt][0][r], acc[mt][1][r]};
             }
@@ -435,9 +435,12 @@ __global__ __launch_bounds__(256) void cg_fwd3_kernel(CgArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
-    const int nsc = a.K / KC3;
-    gload(0);
-    for (int sc = 0; sc < nsc; ++sc) {
+    // gridDim.y > 1: the reduction (super-chunks of 96 rows) is split into slabs summed in fixed order by cg_slabsum_kernel --
+    // the deep layers have fewer 64 x 64 tiles than the chip has slots and 24-48 super-chunks per tile
+    const int nsc_all = a.K / KC3, per = (nsc_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int sc0 = blockIdx.y * per, nsc = min(sc0 + per, nsc_all);
+    if (sc0 < nsc) gload(sc0);
+    for (int sc = sc0; sc < nsc; ++sc) {
         commit();
         __syncthreads();
         if (sc + 1 < nsc) gload(sc + 1);
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void cg_fwd3_kernel(CgArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
                 if (m >= a.Co) continue;
-                float* dst = a.out + ((size_t)bo * a.Co + m) * P + p;
+                float* dst = a.out + (size_t)blockIdx.y * a.B * a.Co * P + ((size_t)bo * a.Co + m) * P + p;
                 if constexpr (NT == 4) *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
                 else *reinterpret_cast<gf2*>(dst) = gf2{acc[mt][0][r], acc[mt][1][r]};
             }
@@ -905,11 +908,29 @@ static int cg_kp(int Ci, int ks) { return ceil_div(Ci * ks * ks, GKC) * GKC; }
 
 extern "C" int dc_convs2_supported(int B, int Ci, int Co, int Hi, int Wi, int ksize) { return cg_ok(B, Ci, Co, Hi, Wi, ksize) ? 1 : 0; }
 
+// 3x3 / 2 forward (triple-gather kernel): tile and reduction split.  Returns the number of slabs (1: straight into y).
+static int cg_fwd3_plan(int B, int Ci, int Co, int Hi, int Wi, CgTile& t) {
+    const int N = B * (Hi / 2) * (Wi / 2);
+    t = ((long)ceil_div(Co, 64) * ceil_div(N, 128) >= 300 || N >= 8 * Co) ? CgTile{2, 4} : CgTile{2, 2};
+    const long blocks = (long)ceil_div(Co, 64) * ceil_div(N, 32 * t.nt);
+    const int nsc = Ci * 9 / 96;
+    int s = 1;
+    while (s < 4 && blocks * s * 2 <= 768 && nsc / (s * 2) >= 3) s *= 2;
+    if (const char* f = getenv("DC_FWD3_SPLIT")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4) s = std::min(v, std::max(1, nsc)); }   // experiments
+    return s;
+}
+
 extern "C" size_t dc_convs2_fwd_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksize) {
     if (!cg_ok(B, Ci, Co, Hi, Wi, ksize)) return 0;
     const int K = Ci * ksize * ksize, Kp = cg_kp(Ci, ksize);
     const size_t b16 = ksize == 3 ? c3b_weights_bytes(Ci, Co) : 0;
-    return std::max(Kp == K ? (size_t)16 : (size_t)Co * Kp * sizeof(float), b16);
+    size_t slabs = 0;
+    if (trip_ok(Ci, ksize)) {
+        CgTile t;
+        const int sp = cg_fwd3_plan(B, Ci, Co, Hi, Wi, t);
+        if (sp > 1) slabs = (size_t)sp * B * Co * (Hi / 2) * (Wi / 2) * sizeof(float);
+    }
+    return std::max(std::max(Kp == K ? (size_t)16 : (size_t)Co * Kp * sizeof(float), b16), slabs);
 }
 
 extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int Hi, int Wi, int ksize,
@@ -938,14 +959,22 @@ extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void
     }
     const int N = B * a.Ho * a.Wo;
     if (trip_ok(Ci, ksize)) {
-        const CgTile t = ((long)ceil_div(Co, 64) * ceil_div(N, 128) >= 300 || N >= 8 * Co) ? CgTile{2, 4} : CgTile{2, 2};
+        CgTile t;
+        const int sp = cg_fwd3_plan(B, Ci, Co, Hi, Wi, t);
+        if (sp > 1) a.out = (float*)ws;            // (Kp == K for the 3x3: the workspace holds nothing else on this path)
         a.mtiles = ceil_div(Co, 64); a.ntiles = ceil_div(N, 32 * t.nt);
         const size_t lds3 = ((size_t)64 * (96 + RP) + (size_t)96 * (t.nt == 4 ? 128 : 80)) * sizeof(float);
         static const bool attr3 = cg_set_lds(cg_fwd3_kernel<2, 4>, ((size_t)64 * (96 + RP) + (size_t)96 * 128) * sizeof(float));
         if (!attr3) return DC_ELAUNCH;
-        if (t.nt == 4) hipLaunchKernelGGL((cg_fwd3_kernel<2, 4>), dim3(a.mtiles * a.ntiles), dim3(256), lds3, st, a);
-        else hipLaunchKernelGGL((cg_fwd3_kernel<2, 2>), dim3(a.mtiles * a.ntiles), dim3(256), lds3, st, a);
+        const dim3 grid(a.mtiles * a.ntiles, sp);
+        if (t.nt == 4) hipLaunchKernelGGL((cg_fwd3_kernel<2, 4>), grid, dim3(256), lds3, st, a);
+        else hipLaunchKernelGGL((cg_fwd3_kernel<2, 2>), grid, dim3(256), lds3, st, a);
         DC_CHECK_LAUNCH();
+        if (sp > 1) {
+            const size_t n4 = (size_t)B * Co * a.Ho * a.Wo / 4;
+            hipLaunchKernelGGL(cg_slabsum_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, st, (const float*)ws, y, n4, sp);
+            DC_CHECK_LAUNCH();
+        }
         return DC_OK;
     }
     const CgTile t = cg_pick(Co, N);
