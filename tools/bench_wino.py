@@ -61,8 +61,16 @@ def main():
         t_dl = timed(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0],
                                                                  1, [True, False, False]))
         gflop = 2.0 * B * C * C * 9 * H * W / 1e9
-        print("B=%d C=%d %dx%d: fwd %.1f us (lib %.1f) err %.1e | dgrad %.1f us (lib %.1f) err %.1e | %.0f TF direct-equiv"
-              % (B, C, H, W, t_f, t_fl, err_f, t_d, t_dl, err_d, gflop / t_f * 1e3), flush=True)
+        # weight gradient (kernel + slab reduce) on the same shape
+        wws = torch.empty(L.dc_wino3x3_wgrad_workspace(B, C, C, H, W), dtype=torch.uint8, device="cuda")
+        dw = torch.empty_like(w)
+        t_w = timed(lambda: L.dc_wino3x3_wgrad(ptr(x), ptr(gy), ptr(dw), wws.data_ptr(), B, C, C, H, W, st))
+        # issued = the 16 Winograd-domain GEMMs actually sent to the matrix cores = 16/36 of the direct convolution's MACs
+        iss = [gflop * 16.0 / 36.0 / t * 1e3 for t in (t_f, t_d, t_w)]
+        print("B=%d C=%d %dx%d: fwd %.1f us (lib %.1f) err %.1e | dgrad %.1f us (lib %.1f) err %.1e | wgrad+reduce %.1f us | direct-equiv "
+              "%.0f / %.0f / %.0f TFLOP/s | issued %.0f / %.0f / %.0f TFLOP/s = %.2f / %.2f / %.2f of the fp32 matrix peak (157.3)"
+              % (B, C, H, W, t_f, t_fl, err_f, t_d, t_dl, err_d, t_w, gflop / t_f * 1e3, gflop / t_d * 1e3, gflop / t_w * 1e3,
+                 iss[0], iss[1], iss[2], iss[0] / 157.3, iss[1] / 157.3, iss[2] / 157.3), flush=True)
 
 
 if __name__ == "__main__":
