@@ -420,12 +420,19 @@ static G1Tile g1_pick(int M, int N, size_t (*lds)(G1Tile)) {
 // (128 x 128 tiles for every shape with both extents >= 128 -- half the operand traffic of the HBM-heavy 64 x 64 launches --
 // were measured: 60 -> 80 us per launch in isolation, no change of the C3 step; the small tiles keep more blocks in flight.)
 static G1Tile g1_wpick(int M, int K) {
-    if (M > 64 && K > 64 && (long)ceil_div(M, 128) * ceil_div(K, 128) >= 32) return {4, 4};
+    if (const char* f = getenv("DC_G1_WTILE")) { const int v = atoi(f); if (v == 4) return {4, 4}; if (v == 2) return {2, 2}; }      // experiments
+    // 128 x 128 tiles wherever both dimensions fill one (half the operand re-reads per MAC), 64 x 64 otherwise; split
+    // targets 512 / 1024 blocks (2 / 4 resident per CU).  Measured on the 26 resnet50 shapes of C3 (tools/sweep_g1wgrad.py):
+    // 13 % less time in total than the round-2 rule (128 x 128 only from 32 tiles on, 768 blocks for both); in the two-stream
+    // step that is +0.6 % at C3 and within noise at C2.
+    if (M >= 128 && K >= 128) return {4, 4};
     return {2, 2};
 }
 static int g1_wsplits(int M, int K, int chunks, G1Tile t) {
     const int tiles = ceil_div(M, 32 * t.mt) * ceil_div(K, 32 * t.nt);
-    int s = std::max(1, std::min({chunks, ceil_div(768, tiles), 512}));
+    int target = t.mt == 4 ? 512 : 1024;
+    if (const char* f = getenv("DC_G1_WBLOCKS")) { const int v = atoi(f); if (v > 0) target = v; }      // experiments
+    int s = std::max(1, std::min({chunks, ceil_div(target, tiles), 512}));   // (a floor on chunks per block measured slower, C2)
     return ceil_div(chunks, ceil_div(chunks, s));        // no empty split: every slab gets written
 }
 
