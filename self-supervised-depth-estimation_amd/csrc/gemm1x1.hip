@@ -400,6 +400,10 @@ static size_t g1_lds_fwd(G1Tile t) { return (size_t)2 * (32 * t.mt * (GKC + RP) 
 static size_t g1_lds_dgrad(G1Tile t) { return (size_t)2 * GKC * ((t.mt == 4 ? 128 : 80) + (t.nt == 4 ? 128 : 80)) * sizeof(float); }
 static size_t g1_lds_wgrad(G1Tile t) { return (size_t)2 * 32 * (t.mt + t.nt) * (GKC + RP) * sizeof(float); }
 static G1Tile g1_pick(int M, int N, size_t (*lds)(G1Tile)) {
+    if (const char* f = getenv("DC_G1_TILE")) {                 // experiments (tools/sweep_g1.py): "MT,NT"
+        int mt = 0, nt = 0;
+        if (sscanf(f, "%d,%d", &mt, &nt) == 2 && ((mt == 4 && nt == 4 && M > 64) || (mt == 2 && (nt == 4 || nt == 2)))) return {mt, nt};
+    }
     const G1Tile cand[3] = {{4, 4}, {2, 4}, {2, 2}};
     const double penalty[3] = {1.0, 1.12, 1.3};          // relative cost per MFMA (operand re-reads, shorter MFMA runs)
     double best = 1e300;
