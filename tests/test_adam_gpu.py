@@ -105,7 +105,7 @@ def test_trainer_steps_with_depthcore_adam_match_torch_adam():
         l1, l2 = t1.train_step(dict(inputs))[1], t2.train_step(dict(inputs))[1]
         torch.cuda.synchronize()
         v1, v2 = float(l1["loss"].detach()), float(l2["loss"].detach())
-        assert abs(v1 - v2) <= (0.0 if step < 2 else 1e-5) * abs(v2), (step, v1, v2)        # steps 0 / 1: the same forward to the bit
+        assert abs(v1 - v2) <= (0.0 if step == 0 else 1e-5) * abs(v2), (step, v1, v2)       # step 0: the same forward to the bit
         for k in t1.models:
             for (n, p1), (_, p2) in zip(t1.models[k].named_parameters(), t2.models[k].named_parameters()):
                 d = float((p1.detach() - p2.detach()).abs().max())
