@@ -136,6 +136,7 @@ struct WinoPsArgs {
     unsigned xbytes;
     size_t slab_stride;               // floats between the K-split slabs
     int mblocks, tblocks, m_fast;
+    unsigned mg_mblocks, mg_tblocks, mg_per_img, mg_regs_x, mg_PR, mg_RW;   // fdiv magics of the divisors the kernel divides by
     unsigned long long* diag;         // WINO_DIAG builds only: per block {compute, commit(+load wait), issue, barrier, loop, prologue, epilogue, start time} cycles
 };
 
@@ -156,8 +157,9 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     // block -> (tile block, channel block): the faster index is the one whose operand is the larger stream, so that
     // its other readers find it in L2
     const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);       // neighbours in this order share an XCD (one L2)
-    const int mblk = a.m_fast ? lbid % a.mblocks : lbid / a.tblocks;
-    const int tblk = a.m_fast ? lbid / a.mblocks : lbid % a.tblocks;
+    const int q_m = fdiv(lbid, a.mg_mblocks), q_t = fdiv(lbid, a.mg_tblocks);
+    const int mblk = a.m_fast ? lbid - q_m * a.mblocks : q_t;
+    const int tblk = a.m_fast ? q_m : lbid - q_t * a.tblocks;
     const int per_img = a.regs_x * a.regs_y;
     const int c_begin = blockIdx.z * a.chunks_per_split;
     const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
@@ -172,9 +174,9 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     const int ssub = tblk * G + sg_;
     const bool s_act = sg_ < G && ssub < a.nsub && sp < SR * PR;
     const int sq = s_act ? ssub : 0;
-    const int sb = sq / per_img, srq = sq - sb * per_img;
-    const int sry = srq / a.regs_x, srx = srq - sry * a.regs_x;
-    const int sr = sp / PR, scp = sp - sr * PR;
+    const int sb = fdiv(sq, a.mg_per_img), srq = sq - sb * per_img;
+    const int sry = fdiv(srq, a.mg_regs_x), srx = srq - sry * a.regs_x;
+    const int sr = fdiv(sp, a.mg_PR), scp = sp - sr * PR;
     // image position of this thread's column pair (ix even) and the source it is read from:
     //   plain: zero padding, P = 1.  FUSED: ReflectionPad2d(1) folds row -1 -> 1, H -> H-2 and redirects the two border
     //   pairs to the aligned pair that holds the mirrored column (pair (-2,-1) -> (0,1): .y lands on slab column 0;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     for (int h = 0; h < 2; ++h) {
         const int local = n + 16 * h;
         const int tl = local < RH * RW ? local : 0;
-        const int ty = tl / RW, tx = tl - ty * RW;
+        const int ty = fdiv(tl, a.mg_RW), tx = tl - ty * RW;
         offA[h] = kk * CPS + (2 * ty + ra) * RS + 2 * tx;
         offB[h] = kk * CPS + (2 * ty + rb) * RS + 2 * tx;
     }
@@ -356,10 +358,10 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     const int olocal = n + 16 * (oj & 1);
     const bool o_act = wave < NR && osub < a.nsub && olocal < RH * RW;
     const int oq = o_act ? osub : 0;
-    const int ob = oq / per_img, orq = oq - ob * per_img;
-    const int ory = orq / a.regs_x, orx = orq - ory * a.regs_x;
+    const int ob = fdiv(oq, a.mg_per_img), orq = oq - ob * per_img;
+    const int ory = fdiv(orq, a.mg_regs_x), orx = orq - ory * a.regs_x;
     const int otl = o_act ? olocal : 0;
-    const int oty = otl / RW, otx = otl - oty * RW;
+    const int oty = fdiv(otl, a.mg_RW), otx = otl - oty * RW;
     const int oy = ory * RH * 2 + 2 * oty, ox = orx * RW * 2 + 2 * otx;
     const int Ho = FUSED ? a.Ho : H, Wo = FUSED ? a.Wo : W;
     const bool o_ok = o_act && oy < Ho && ox < Wo;
@@ -634,6 +636,11 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     a.diag = g_wino_diag;
 #endif
     a.tblocks = ceil_div(a.nsub, G); a.mblocks = Mp / MT;
+    a.mg_mblocks = fdiv_magic(a.mblocks); a.mg_tblocks = fdiv_magic(a.tblocks); a.mg_per_img = fdiv_magic(a.regs_x * a.regs_y);
+    a.mg_regs_x = fdiv_magic(a.regs_x); a.mg_PR = fdiv_magic(a.RW + 2); a.mg_RW = fdiv_magic(a.RW);
+    // fdiv is exact for dividend * divisor < 2^32: block index by mblocks / tblocks, sub-region index by per_img / regs_x
+    if ((unsigned long long)a.tblocks * a.mblocks * (unsigned)std::max(a.mblocks, a.tblocks) >= 0xffffffffull ||
+        (unsigned long long)(a.nsub + 2 * G) * (unsigned)(a.regs_x * a.regs_y) >= 0xffffffffull) return DC_EINVAL;
     a.m_fast = (size_t)d.B * H * W >= (size_t)M * 16 ? 1 : 0;     // x stream (per reduction channel) vs U stream
     const dim3 grid(a.tblocks * a.mblocks, 1, ksplit);
     // algorithmic = 2 MAC of the direct convolution; executed = the 16 Winograd-domain GEMMs incl. tile padding

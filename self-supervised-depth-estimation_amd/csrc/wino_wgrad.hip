@@ -51,6 +51,7 @@ struct WinoWgArgs {
     int regs_x, regs_y, nsub;
     int splits, kblocks, mblocks;
     unsigned xbytes, gbytes;
+    unsigned mg_nmk, mg_kblocks, mg_RW, mg_XPR, mg_per_img, mg_regs_x;      // fdiv magics (dc_common.h)
     unsigned long long* diag;         // -DWINO_DIAG builds: per block {end, hw id, xcc, -, loop, prologue, epilogue, start} (tools/diag_wino.py)
 };
 unsigned long long* wino_diag_ptr();
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     // x across the m-blocks) get adjacent logical indices, i.e. one XCD and its L2
     const int nmk = a.mblocks * a.kblocks;
     const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);
-    const int split0 = lbid / nmk, mk = lbid - split0 * nmk;
-    const int mb = mk / a.kblocks, kb = mk - mb * a.kblocks;
+    const int split0 = fdiv(lbid, a.mg_nmk), mk = lbid - split0 * nmk;
+    const int mb = fdiv(mk, a.mg_kblocks), kb = mk - mb * a.kblocks;
     const int per_img = a.regs_x * a.regs_y;
     const unsigned plane = (unsigned)(H * W) * 4u;
     const wrsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), (short)0, (int)a.gbytes, 0x00020000);
@@ -94,20 +95,20 @@ __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     // ---- staging roles
     // gy: 32 pair slots per channel (rows 2RH x column pairs RW), thread -> (slot, channels cg + 8q)
     const int gslot = tid & 31, gcg = tid >> 5;
-    const int grow = gslot / RW, gcp = gslot - grow * RW;
+    const int grow = fdiv(gslot, a.mg_RW), gcp = gslot - grow * RW;
     const bool g_in = gslot < 2 * RH * RW;
     const int glds = gcg * WG_GPS + grow * GRS + 2 * gcp;
     // x: 64 pair slots per channel (rows 2RH+2 x column pairs RW+2), thread -> (slot, channels cg + 4q)
     const int xslot = tid & 63, xcg = tid >> 6;
     const int XPR = RW + 2;
-    const int xrow = xslot / XPR, xcp = xslot - xrow * XPR;
+    const int xrow = fdiv(xslot, a.mg_XPR), xcp = xslot - xrow * XPR;
     const bool x_in = xslot < (2 * RH + 2) * XPR;
     const int xlds0 = xcg * WG_XPS + xrow * XRS + max(2 * xcp - 1, 0), xlds1 = xcg * WG_XPS + xrow * XRS + 2 * xcp;
 
     f2w pg[NGQ], px[8];
     auto prefetch = [&](int sub) {
-        const int b = sub / per_img, rq = sub - b * per_img;
-        const int ry = rq / a.regs_x, rx = rq - ry * a.regs_x;
+        const int b = fdiv(sub, a.mg_per_img), rq = sub - b * per_img;
+        const int ry = fdiv(rq, a.mg_regs_x), rx = rq - ry * a.regs_x;
         const int Y0 = ry * RH * 2, X0 = rx * RW * 2;
         {
             const int y = Y0 + grow, xx = X0 + 2 * gcp;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
         const int t = ks * 4 + tq;
         const bool v = t < RH * RW;
         const int tl = v ? t : 0;
-        const int ty = tl / RW, tx = tl - ty * RW;
+        const int ty = fdiv(tl, a.mg_RW), tx = tl - ty * RW;
         tvalid |= v ? (1u << ks) : 0u;
         goffA[ks] = cl * WG_GPS + (2 * ty + ga) * GRS + 2 * tx;
         goffB[ks] = cl * WG_GPS + (2 * ty + gb) * GRS + 2 * tx;
@@ -422,6 +423,14 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
     a.RH = p.RH; a.RW = p.RW; a.GRS = p.GRS; a.XRS = p.XRS;
     a.regs_x = p.regs_x; a.regs_y = p.regs_y; a.nsub = p.nsub; a.splits = p.splits; a.kblocks = p.kblocks; a.mblocks = p.mblocks;
     a.xbytes = (unsigned)b0; a.x1bytes = (unsigned)b1; a.gbytes = (unsigned)gb;
+    {
+        const int nmk_ = p.mblocks * p.kblocks, per_img = p.regs_x * p.regs_y;
+        a.mg_nmk = fdiv_magic(nmk_); a.mg_kblocks = fdiv_magic(p.kblocks); a.mg_RW = fdiv_magic(p.RW); a.mg_XPR = fdiv_magic(p.RW + 2);
+        a.mg_per_img = fdiv_magic(per_img); a.mg_regs_x = fdiv_magic(p.regs_x);
+        // exact while dividend * divisor < 2^32: block index by nmk, sub-region index by per_img
+        if ((unsigned long long)p.splits * nmk_ * (unsigned)nmk_ >= 0xffffffffull || (unsigned long long)p.nsub * (unsigned)per_img >= 0xffffffffull)
+            return DC_EINVAL;
+    }
 #ifdef WINO_DIAG
     a.diag = wino_diag_ptr();
 #endif
