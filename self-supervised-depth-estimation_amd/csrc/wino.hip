@@ -352,11 +352,13 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     // ---- combine the four rows: wave a contributes z[a][jj] = sum_b M[a][b] A[b][jj]; Y[0] = z0+z1+z2, Y[1] = z1-z2-z3
     float* ex = &xl[0][0];                                       // [wave][(j*4 + r)*2 + jj][lane]  (the slabs are dead now)
     float* yout = a.y + (size_t)blockIdx.z * a.slab_stride;
-    // the (sub-region, tile) this lane stores in the exchange round: slot j = wave
-    const int oj = wave < NR ? wave : 0;
+    // the (sub-region, tile) this lane stores in the exchange round: slot j = wave % NR, and -- NR = 2: the four waves share
+    // the two slots -- the RPW = NR of the four r (channel) values starting at (wave / NR) * NR; every wave stores
+    constexpr int RPW = NR;
+    const int oj = wave % NR, r0 = (wave / NR) * RPW;
     const int osub = tblk * G + (oj >> 1);
     const int olocal = n + 16 * (oj & 1);
-    const bool o_act = wave < NR && osub < a.nsub && olocal < RH * RW;
+    const bool o_act = osub < a.nsub && olocal < RH * RW;
     const int oq = o_act ? osub : 0;
     const int ob = fdiv(oq, a.mg_per_img), orq = oq - ob * per_img;
     const int ory = fdiv(orq, a.mg_regs_x), orx = orq - ory * a.regs_x;
@@ -379,21 +381,22 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
             }
         // (plain launches) the other gradient of a residual fork: loaded before the barrier, so that the loads fly while the
         // rows are exchanged, and added below
-        f2w ad[4][2];
+        f2w ad[RPW][2];
         const bool has_add = !FUSED && a.addend && gridDim.z == 1;
         if (has_add) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = min(mblk * MT + i * 16 + kk * 4 + r, a.M - 1);
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int m = min(mblk * MT + i * 16 + kk * 4 + r0 + rr, a.M - 1);
                 const size_t o = (((size_t)ob * a.M + m) * Ho + min(oy, Ho - 1)) * Wo + min(ox, Wo - 2);
-                ad[r][0] = *reinterpret_cast<const f2w*>(a.addend + o);
-                ad[r][1] = *reinterpret_cast<const f2w*>(a.addend + o + (oy + 1 < Ho ? Wo : 0));
+                ad[rr][0] = *reinterpret_cast<const f2w*>(a.addend + o);
+                ad[rr][1] = *reinterpret_cast<const f2w*>(a.addend + o + (oy + 1 < Ho ? Wo : 0));
             }
         }
         __syncthreads();
         if (o_ok) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int r = r0 + rr;
                 const int m = mblk * MT + i * 16 + kk * 4 + r;
                 if (m >= a.M) continue;
                 float z[4][2];
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
                     y10 = act_fwd(y10 + bv, a.act); y11 = act_fwd(y11 + bv, a.act);
                 }
                 const size_t o = (((size_t)ob * a.M + m) * Ho + oy) * Wo + ox;
-                if (has_add) { y00 += ad[r][0].x; y01 += ad[r][0].y; y10 += ad[r][1].x; y11 += ad[r][1].y; }
+                if (has_add) { y00 += ad[rr][0].x; y01 += ad[rr][0].y; y10 += ad[rr][1].x; y11 += ad[rr][1].y; }
                 float* dst = yout + o;
                 *reinterpret_cast<f2w*>(dst) = f2w{y00, y01};
                 if (oy + 1 < Ho) *reinterpret_cast<f2w*>(dst + Wo) = f2w{y10, y11};
