@@ -163,6 +163,20 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     const int per_img = a.regs_x * a.regs_y;
     const int c_begin = blockIdx.z * a.chunks_per_split;
     const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
+    // A operands (comment at `px` below).  The first chunk's U is requested HERE, before the ~300 instructions of staging
+    // index arithmetic: it depends on the block's channel tile only
+    f4 ureg[2][PSK / 4][MR];
+    const wrsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.uhat) + (size_t)mblk * a.nchunks * UF4 * 4, (short)0, (int)((size_t)a.nchunks * UF4 * 16), 0x00020000);
+    const int uoff = ((kk * 4 + wave) * MT + n) * 16;
+    auto load_u = [&](int c, f4 (*dst)[MR]) {
+#pragma unroll
+        for (int ks = 0; ks < PSK / 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                dst[ks][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ur, uoff + (ks * 16 * MT + i * 16) * 16, c * (UF4 * 16), 0));
+    };
+    if (c_begin < c_end) load_u(c_begin, ureg[0]);
 
     // ---- staging role: thread -> (sub-region, slab row, column pair) and PK channels of the chunk.  G = 2: the two thread
     // halves take the two sub-regions, all PSK channels each.  G = 1: they take the two channel halves of the one sub-region
@@ -232,17 +246,6 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     // A operands: the four waves need DISJOINT quarters of a U chunk (wave = Winograd row = pq), so U never goes through
     // LDS: each lane loads its own 16 bytes per k-step and 16-channel block straight into the registers the MFMAs read,
     // one chunk ahead (16 lanes x 16 B = 256-byte rows; the other tile blocks of this channel block find them in L2)
-    f4 ureg[2][PSK / 4][MR];
-    const wrsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.uhat) + (size_t)mblk * a.nchunks * UF4 * 4, (short)0, (int)((size_t)a.nchunks * UF4 * 16), 0x00020000);
-    const int uoff = ((kk * 4 + wave) * MT + n) * 16;
-    auto load_u = [&](int c, f4 (*dst)[MR]) {
-#pragma unroll
-        for (int ks = 0; ks < PSK / 4; ++ks)
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-                dst[ks][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ur, uoff + (ks * 16 * MT + i * 16) * 16, c * (UF4 * 16), 0));
-    };
     auto load_x = [&](int c, f2w* dst) {
         {
             // ONE load shape for every kind of chunk -- eight 8-byte buffer loads, the source picked by scalar selects (chunks
@@ -313,7 +316,6 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     // multiplied: U of c+1 (L2-resident) and x of c+1 and c+2 (first touch comes from HBM).
     const int nloc = c_end - c_begin;
     if (nloc > 0) {
-        load_u(c_begin, ureg[0]);
         load_x(c_begin, px[0]);
         if (nloc > 1) load_x(c_begin + 1, px[1]);
         commit_x(0, px[0], c_begin);
