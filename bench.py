@@ -58,7 +58,7 @@ VALU_LANE_OPS_PEAK = 78.6e12   # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: wave-le
 # profiles/round3_photo_isa_mix.txt): SQ_INSTS_VALU counts a packed-fp32 or a transcendental instruction once, the SIMD-32 issues
 # them over twice the cycles (MI355X_MICROARCH.md "vector-instruction ISSUE cost").  backward: 1131 plain + 336 DPP + 16 lane + 2 x
 # (669 packed + 24 transcendental) = 2869 slots per 2176 instructions; forward: 712 + 2 x 60 = 832 per 772.
-VALU_SLOTS_PER_INST = {"bwd": 2869.0 / 2176.0, "fwd": 832.0 / 772.0}
+VALU_SLOTS_PER_INST = {"bwd": 1.0, "fwd": 1.0}    # refreshed from profiles/round4_photo_isa_mix.txt below
 
 
 # ------------------------------------------------------------------------------------------------ launcher (N > 1)
@@ -125,15 +125,16 @@ def host_info():
     return model, os.cpu_count() or usable, usable
 
 
-def cpu_baseline(opt, trainer, seconds_budget=45.0):
-    """SURVEY 8d protocol on a BOUNDED sample: the CPU oracle (oracle/train_step.py, kind "port") runs the same step
-    (fwd + bwd + Adam) from the GPU trainer's weights on the same kind of synthetic batch.  All usable cores: one warm-up
-    step, then >= 3 timed steps at the largest batch <= opt.batch_size a timed B=2 probe predicts to fit the budget
-    (the full batch on the GPU box) -> median and min.  1 thread: one timed B=1 step."""
+def cpu_baseline(opt, trainer, timed_steps=10, allcore_steps=3):
+    """SURVEY 8d protocol: the CPU oracle (oracle/train_step.py, kind "port") runs the same step (fwd + bwd + Adam) from the
+    GPU trainer's weights on the same kind of synthetic batch at the FULL per-rank batch: warm-up (B=1, B=2, one full batch),
+    then `timed_steps` (>= 10) timed steps at 64 torch threads -> median (the headline `value`: torch's intra-op pool stops
+    scaling long before 100+ threads on these convolutions, so 64 is the faster setting on the GPU boxes' hosts), then
+    `allcore_steps` timed steps with one thread per usable core (reported beside it, even when slower), then one B=1 step on
+    one thread.  About 60-80 s of CPU work on the GPU box's host."""
     from oracle import ref_cpu as R
     from oracle.train_step import CpuTrainer
     model, logical, usable = host_info()
-    # torch's intra-op pool stops scaling long before 100+ threads on these convolutions; the thread count used is stated
     threads = max(1, min(usable, 64))
     state = {k: {n: t.detach().cpu() for n, t in m.state_dict().items()} for k, m in trainer.models.items()}
     H, W = opt.height, opt.width
@@ -146,28 +147,64 @@ def cpu_baseline(opt, trainer, seconds_budget=45.0):
         ct.train_step(inputs, noise)
         return time.perf_counter() - t0
 
+    def note(msg):
+        print("cpu_baseline: " + msg, file=sys.stderr, flush=True)     # one line per step: a silent minute reads as a hang
+
     torch.set_num_threads(threads)
     step(1, 2)                                      # pages the oracle in
     t2 = step(2, 1)
-    nsteps = 3
-    bs = int(max(1, min(opt.batch_size, seconds_budget / nsteps / (t2 / 2.0))))
-    print("cpu_baseline: %s, %d logical / %d usable cores, %d threads; B=2 probe %.2f s -> B=%d x %d timed steps"
-          % (model, logical, usable, threads, t2, bs, nsteps), file=sys.stderr, flush=True)
-    step(bs, 3)                                     # warm-up at the timed size
-    ts = [step(bs, 10 + i) for i in range(nsteps)]
+    bs = opt.batch_size
+    note("%s, %d logical / %d usable cores, %d threads; B=2 probe %.2f s" % (model, logical, usable, threads, t2))
+    tw = step(bs, 3)                                # warm-up at the timed size; also sizes the sample
+    # >= 10 timed steps wherever they fit ~75 s; a host much slower than the GPU boxes' keeps the run bounded
+    nsteps = timed_steps if tw * timed_steps <= 75.0 else max(3, int(75.0 / tw))
+    note("B=%d warm-up step %.2f s -> %d timed steps" % (bs, tw, nsteps))
+    ts = []
+    for i in range(nsteps):
+        ts.append(step(bs, 10 + i))
+        note("step %d/%d %.2f s" % (i + 1, nsteps, ts[-1]))
+    allc = None
+    if usable > threads:
+        # one thread per usable core: reported beside the headline even when slower (torch's intra-op pool stops scaling long
+        # before 100+ threads here).  Sized by a B=2 probe so that it cannot run away: full-batch steps if they fit ~40 s,
+        # otherwise the probe itself is the sample (and says so)
+        torch.set_num_threads(usable)
+        step(1, 6)
+        p1 = step(1, 8)
+        note("all %d cores: B=1 probe %.2f s" % (usable, p1))
+        p2 = step(2, 7) if p1 <= 5.0 else None
+        if p2 is not None:
+            note("all %d cores: B=2 probe %.2f s" % (usable, p2))
+        if p2 is None:
+            allc = {"value": round(1.0 / p1, 4), "unit": "images/s", "cores": usable, "step_seconds_median": round(p1, 3),
+                    "timed_steps": 1, "sample_batch": 1,
+                    "note": "one B=1 step after a B=1 warm-up: larger batches at this thread count would not fit the run"}
+        elif p2 / 2.0 * bs * (allcore_steps + 1) <= 40.0:
+            step(bs, 5)
+            ta = []
+            for i in range(allcore_steps):
+                ta.append(step(bs, 40 + i))
+                note("all-core step %d/%d %.2f s" % (i + 1, allcore_steps, ta[-1]))
+            allc = {"value": round(bs / statistics.median(ta), 4), "unit": "images/s", "cores": usable,
+                    "step_seconds_median": round(statistics.median(ta), 3), "timed_steps": allcore_steps, "sample_batch": bs}
+        else:
+            allc = {"value": round(2.0 / p2, 4), "unit": "images/s", "cores": usable, "step_seconds_median": round(p2, 3),
+                    "timed_steps": 1, "sample_batch": 2,
+                    "note": "one B=2 step after a B=1 warm-up: full-batch steps at this thread count would not fit the run"}
     torch.set_num_threads(1)
     t1 = step(1, 4)
     torch.set_num_threads(threads)
     med, best = statistics.median(ts), min(ts)
-    print("cpu_baseline: steps %s s; 1 thread B=1 %.2f s" % (["%.2f" % t for t in ts], t1), file=sys.stderr, flush=True)
+    note("steps %s s; all %d cores: %s; 1 thread B=1 %.2f s" % (["%.2f" % t for t in ts], usable, allc, t1))
     return {"value": round(bs / med, 4), "unit": "images/s", "cores": threads, "kind": "port",
             "value_best": round(bs / best, 4), "step_seconds_median": round(med, 3), "step_seconds_min": round(best, 3),
             "timed_steps": nsteps, "sample_batch": bs, "cpu_model": model, "host_logical_cores": logical,
-            "host_usable_cores": usable, "one_thread": {"value": round(1.0 / t1, 4), "unit": "images/s", "cores": 1,
-                                                         "sample": "one B=1 step"},
-            "sample": "%d timed full training steps (fwd+bwd+Adam; median) of the CPU oracle at B=%d (of %d), %dx%d, "
-                      "resnet%d, fp32, torch intra-op threads = %d, after a B=1, a B=2 and one B=%d warm-up step"
-                      % (nsteps, bs, opt.batch_size, H, W, opt.num_layers, threads, bs)}
+            "host_usable_cores": usable, "all_usable_cores": allc,
+            "one_thread": {"value": round(1.0 / t1, 4), "unit": "images/s", "cores": 1, "sample": "one B=1 step"},
+            "sample": "%d timed full training steps (fwd+bwd+Adam; median) of the CPU oracle at B=%d (the full per-rank batch), "
+                      "%dx%d, resnet%d, fp32, torch intra-op threads = %d, after a B=1, a B=2 and one B=%d warm-up step; "
+                      "`all_usable_cores`: %d more timed steps at one thread per usable core"
+                      % (nsteps, bs, H, W, opt.num_layers, threads, bs, allcore_steps if allc else 0)}
 
 
 # ------------------------------------------------------------------------------------------------ rehearsal stand-in
@@ -232,7 +269,7 @@ def _traffic_for(cfg_key):
     """HBM bytes per launch from the PMC passes kept under profiles/ (separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc
     WRITE_SIZE` runs, tools/pmc_traffic.sh; FETCH_SIZE x2.0 per the gfx950 calibration, WRITE_SIZE x1.0).  They are
     CITED, not measured in this run: a PMC pass serialises the step and cannot share a process with the timed region."""
-    for name in ("round3_traffic_%s.json" % cfg_key, "round2_traffic_%s.json" % cfg_key, "round1_traffic.json" if cfg_key == "c2" else None):
+    for name in ("round4_traffic_%s.json" % cfg_key, "round3_traffic_%s.json" % cfg_key):
         if not name:
             continue
         tf = os.path.join(REPO, "profiles", name)
@@ -434,11 +471,16 @@ def run_rank(args):
                  "algorithmic_flops_per_launch": round(d["flops"] / d["launches"], 0),
                  "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 0)}
             if bound == "mfma":
-                e.update({"achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                          "flops_definition": "SURVEY 8d algorithmic: 2 MAC of the direct convolution, summed over the launches",
-                          "issued_to_matrix_cores_tflops": round(ex, 2),
-                          "issued_frac_of_peak": round(ex / MFMA_F32_PEAK_TFLOPS, 4)})
+                # `achieved` / `frac` = what the matrix pipe does (<= 1): FLOPs actually issued to the MFMA units.  For the
+                # Winograd kernels that is 16/36 of SURVEY 8d's algorithmic count (2 MAC of the direct convolution), which is
+                # kept beside it as the direct-convolution equivalent; for a direct GEMM the two are the same number
+                e.update({"achieved": round(ex, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(ex / MFMA_F32_PEAK_TFLOPS, 4),
+                          "flops_definition": "FLOPs issued to the matrix cores (Winograd F(2x2,3x3): 16/36 of the direct "
+                                              "convolution's 2 MAC; GEMMs: all of them), summed over the launches",
+                          "issued_frac_of_peak": round(ex / MFMA_F32_PEAK_TFLOPS, 4),
+                          "direct_conv_equivalent_tflops": round(tf, 2),
+                          "direct_conv_equivalent_frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
             else:
                 gbs = d["bytes"] / sec / 1e9
                 e.update({"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -452,7 +494,44 @@ def run_rank(args):
         dom = dict(fams[0]) if fams else {"kernel": None, "bound": "mfma", "achieved": 0.0, "peak": MFMA_F32_PEAK_TFLOPS,
                                           "unit": "TFLOP/s", "frac": 0.0}
         dom_key = {0: "dc::wino_ps_kernel", 1: "dc::wino_wgrad_kernel", 2: "dc::c3b_conv_kernel", 3: "dc::c3b_wgrad_kernel", 4: "dc::g1_*"}.get(dom.get("family"))
-        vb = valu("dc::photo_bwd_kernel")
+        # ---- BASELINE metric 2: the fused warp + SSIM + smoothness kernels against HBM.  Round 4 moved the SSIM derivative, its
+        # transposed 3x3 spread and the contraction with d(warped)/d(coords) into the TRAINING FORWARD (dc::photo_fwdg_kernel emits
+        # du, dv per frame: 16 B per pixel and scale); the backward (dc::photo_bwdg_kernel) is pointwise.  The honest figure is
+        # therefore the PAIR: SURVEY 8d's algorithmic bytes of forward + backward over the time of both launch chains; each
+        # chain is also given on its own (the backward's own fraction flatters it: part of its work now runs in the forward).
+        def chain(bytes_, ms):
+            gbs = bytes_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"algorithmic_bytes_per_launch": bytes_, "avg_chain_ms": round(ms, 4), "achieved": round(gbs, 1),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+        def kern(name, ms, bytes_, slots):
+            v = valu(name)
+            e = {"kernel": name, "avg_kernel_ms": round(ms, 4), "traffic": tr_bytes(name), "valu_wave_insts": v}
+            if v and ms > 0:
+                floor_s = v * slots * 64.0 / VALU_LANE_OPS_PEAK
+                e.update({"valu_issue_floor_ms": round(floor_s * 1e3, 4), "valu_issue_frac": round(floor_s / (ms * 1e-3), 4),
+                          "hbm_frac_at_valu_floor": round(bytes_ / floor_s / 1e9 / HBM_PEAK_GBS, 4)})
+            return e
+        pair_ms = fwd_chain_ms + bwd_chain_ms
+        pair = chain(bytes_fwd + bytes_bwd, pair_ms)
+        photometric = dict(pair, **{
+            "kernel": "fused warp + SSIM + L1 + automask + smoothness, forward AND backward launch chains of a step (4 scales x 2 "
+                      "frames): identity + smooth + dc::photo_fwdg_kernel + finalize | dc::photo_bwdg_kernel + disp_grad (incl. the "
+                      "pose-gradient reduction)",
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "traffic": (tr_bytes("dc::identity_kernel") or 0) + (tr_bytes("dc::photo_fwdg_kernel") or 0) + (tr_bytes("dc::smooth_fwd_kernel") or 0)
+                       + (tr_bytes("dc::photo_bwdg_kernel") or 0) + (tr_bytes("dc::disp_grad_kernel") or 0)
+                       if tr_bytes("dc::photo_fwdg_kernel") else None,
+            "traffic_source": traffic_src, "launches": prof["bwd_launches"],
+            "bytes_definition": "SURVEY 8d: forward sum_s 36 N + 16 n_s, backward sum_s 36 N + 20 n_s (fp32, N = B H W)",
+            "forward_chain": dict(chain(bytes_fwd, fwd_chain_ms), **kern("dc::photo_fwdg_kernel", fwd_ms, bytes_fwd, VALU_SLOTS_PER_INST["fwd"])),
+            "backward_chain": dict(chain(bytes_bwd, bwd_chain_ms), **kern("dc::photo_bwdg_kernel", bwd_ms, bytes_bwd, VALU_SLOTS_PER_INST["bwd"])),
+            "round3": {"forward_chain_ms": 0.17, "backward_chain_ms": 0.2487, "pair_frac": 0.148,
+                       "note": "forward without gradient emission + the window backward (profiles/round3_c2_bench_n1.json)"},
+            "limiter": "the training forward is VALU-issue bound (2 waves per SIMD at 203 VGPRs); the pointwise backward and the "
+                       "transposed upsample are latency / HBM bound",
+            "valu_note": "SQ_INSTS_VALU per launch (cited PMC pass) x issue slots per instruction from the ISA mix "
+                         "(profiles/round4_photo_isa_mix.txt); 2 cycles per slot per SIMD-32"})
         out = {
             "metric": "training images/sec at %dx%d bs%d (resnet%d depth+pose, 4-scale photometric+smoothness)"
                       % (args.height, args.width, args.batch, args.num_layers),
@@ -475,40 +554,11 @@ def run_rank(args):
                          "selection": "the instrumented kernel family with the largest GPU time per step; all of them under `families`",
                          "timed_region_note": "two-stream overlap: a launch shares the GPU with the other branch's kernels "
                                               "(sampled every 7th launch); rocprofv3 serialises dispatches and matches avg_kernel_ms",
-                         "note": "Winograd kernels issue 16/36 of the algorithmic MACs to the matrix cores: for them `frac` follows the "
-                                 "SURVEY 8d definition and can exceed what the pipe does; `issued_frac_of_peak` is the fraction of the "
-                                 "fp32 MFMA peak actually used",
+                         "note": "`frac` is the fraction of the fp32 MFMA peak the pipe actually delivers (issued FLOPs); the Winograd "
+                                 "kernels issue 16/36 of SURVEY 8d's algorithmic MACs, so their direct-convolution equivalent "
+                                 "(`direct_conv_equivalent_frac`) is 2.25x that and may exceed 1",
                          "families": fams[1:],
-                         "photometric": {"kernel": "fused warp+SSIM+L1+automask+smoothness BACKWARD, whole chain of a step "
-                                                   "(dc::photo_bwd_kernel + disp_grad_kernel + pose_grad_kernel; 4 scales x 2 frames)",
-                                         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr_bytes("dc::photo_bwd_kernel"),
-                                         "traffic_source": traffic_src,
-                                         "algorithmic_bytes_per_launch": bytes_bwd, "avg_chain_ms": round(bwd_chain_ms, 4),
-                                         "avg_kernel_ms": round(bwd_ms, 4), "launches": prof["bwd_launches"],
-                                         "dominant_kernel_frac": round(bytes_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                         if bwd_ms > 0 else 0.0,
-                                         "limiter": "VALU issue, not HBM (SQ_INSTS_VALU per launch under valu_wave_insts)",
-                                         "valu_wave_insts": vb,
-                                         "valu_frac_of_peak": round(vb * 64.0 / (bwd_ms * 1e-3) / VALU_LANE_OPS_PEAK, 4)
-                                         if vb and bwd_ms > 0 else None,
-                                         # the kernel's floor if every SIMD issued one VALU slot every 2 cycles (needs >= 2 ready waves
-                                         # per SIMD; the kernel holds 2 at 207 VGPRs) -- and what that floor means against HBM
-                                         "valu_issue_floor_ms": round(vb * VALU_SLOTS_PER_INST["bwd"] * 64.0 / VALU_LANE_OPS_PEAK * 1e3, 4)
-                                         if vb else None,
-                                         "valu_issue_frac": round(vb * VALU_SLOTS_PER_INST["bwd"] * 64.0 / VALU_LANE_OPS_PEAK / (bwd_ms * 1e-3), 4)
-                                         if vb and bwd_ms > 0 else None,
-                                         "hbm_frac_at_valu_floor": round(bytes_bwd / (vb * VALU_SLOTS_PER_INST["bwd"] * 64.0 / VALU_LANE_OPS_PEAK)
-                                                                         / 1e9 / HBM_PEAK_GBS, 4) if vb else None,
-                                         "valu_note": "SQ_INSTS_VALU per launch (cited PMC pass) x issue slots per instruction from the ISA "
-                                                      "mix (profiles/round3_photo_isa_mix.txt); 2 cycles per slot per SIMD-32",
-                                         "fwd_chain": {"kernel": "identity + smooth + dc::photo_fwd_kernel + finalize",
-                                                       "algorithmic_bytes_per_launch": bytes_fwd,
-                                                       "avg_chain_ms": round(fwd_chain_ms, 4), "avg_kernel_ms": round(fwd_ms, 4),
-                                                       "achieved": round(bytes_fwd / (fwd_chain_ms * 1e-3) / 1e9, 1)
-                                                       if fwd_chain_ms > 0 else 0.0,
-                                                       "frac": round(bytes_fwd / (fwd_chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                                       if fwd_chain_ms > 0 else 0.0}}}),
+                         "photometric": photometric}),
             "phases_ms": {"forward": round(ph[0], 3), "backward_incl_overlapped_exchange": round(ph[1], 3),
                           "exposed_exchange_wait": round(ph[2], 3), "adam": round(ph[3], 3),
                           "note": "host-synchronised between phases (slower than the pipelined step); %d steps after the "
@@ -558,6 +608,9 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: let ranks share GPUs (use with DC_DIST_BACKEND=gloo)")
     ap.add_argument("--rehearse", action="store_true", help="rehearsal: CPU stand-in step over gloo (launcher / exchange plumbing only)")
     args = ap.parse_args()
+    from depthcore import _lib as _dc_lib
+    if _dc_lib.IS_VARIANT:          # tuning / ablation builds are for the sweep scripts under tools/ only
+        raise SystemExit("bench.py measures the product library; unset DEPTHCORE_LIB (%s)" % _dc_lib.LIB_PATH)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

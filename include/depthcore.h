@@ -38,10 +38,16 @@ extern "C" {
 #define DC_OPT_AVG_REPROJ 2u    /* opt.avg_reprojection */
 #define DC_OPT_NO_SSIM 4u       /* opt.no_ssim */
 #define DC_OPT_ALIGN_CORNERS 8u /* grid_sample(align_corners=True); default False = installed-torch default */
+#define DC_OPT_NO_GRAD 16u      /* dc_photo_fwd only: evaluation -- the forward does not emit d(loss)/d(warped), the workspace
+                                   is smaller and dc_photo_bwd on this descriptor returns DC_EINVAL */
 
 const char* dc_version(void);
 /* Compiled-for architecture string, e.g. "gfx950". */
 const char* dc_arch(void);
+/* Reads and clears HIP's per-thread last-error code (returned as an int, 0 = none).  The dc_* entry points detect a failed
+ * launch through that code; call this after an error that was NOT theirs (e.g. a hipGraph capture that was invalidated) so
+ * that the next launch does not report it as DC_ELAUNCH. */
+int dc_clear_error(void);
 
 /* ------------------------------------------------------------------ a5 */
 /* layers.py:28-103 transformation_from_parameters (+rot_from_axisangle, get_translation_matrix).
@@ -409,24 +415,30 @@ int dc_get_matrix_precision(void);
 /* Every stride-1 3x3 convolution on the Winograd kernels (dc_wino3x3_fwd / _dgrad and the Winograd branch of
  * dc_conv3x3_fwd / _bwd) starts by transforming its filter (U = G g G^T; the data gradient uses the rotated, transposed
  * filter): one small launch in front of every convolution, although the weights only change in the optimiser step.
- *   dc_wino_cache_register(weight, Ci, Co): `weight` (Co,Ci,3,3) stays at this address for the life of the model.
- *   dc_wino_cache_refresh(stream): ONE launch that transforms every (weight, pass, tile layout) variant the kernels have
- *     asked for so far; from then on those launches read the cached U.  Call it at the start of a training step, after
- *     the weights were last written, on a stream every consumer stream waits for.
- *   dc_wino_cache_invalidate(): the cached transforms are stale (call after the step's backward, before the optimiser).
- *   dc_wino_cache_unregister(weight): forget one weight.  Its buffers are parked, not freed -- a captured hipGraph of the
- *     former owner may still name them -- until dc_wino_cache_clear().
- *   dc_wino_cache_clear(): drop ALL registrations and free every buffer (device-synchronising; only when no captured
- *     graph that used the cache will be replayed again).
- *   dc_wino_cache_variants(): number of cached variants (diagnostics / tests).
+ *   dc_wino_cache_new_owner(): an id for one model (one Trainer).  Every owner has its OWN descriptor table: a refresh
+ *     transforms -- and a hipGraph that captured it replays the transform of -- that owner's weights only, never memory
+ *     whose lifetime belongs to another model.
+ *   dc_wino_cache_register(owner, weight, Ci, Co): `weight` (Co,Ci,3,3) stays at this address, alive, until the owner is
+ *     released.
+ *   dc_wino_cache_refresh(owner, stream): ONE launch that transforms every (weight, pass, tile layout) variant the kernels
+ *     have asked for so far among the owner's weights; from then on those launches read the cached U.  Call it at the
+ *     start of a training step, after the weights were last written, on a stream every consumer stream waits for.
+ *   dc_wino_cache_invalidate(owner): the owner's cached transforms are stale (call after the step's backward, before the
+ *     optimiser).
+ *   dc_wino_cache_release_owner(owner): forget the owner and all its weights.  Tables and buffers are parked, not freed --
+ *     a captured hipGraph of the owner may still name them -- until dc_wino_cache_clear().
+ *   dc_wino_cache_clear(): drop ALL owners and free every buffer (device-synchronising; only when no captured graph that
+ *     used the cache will be replayed again).
+ *   dc_wino_cache_variants(): number of cached variants over all owners (diagnostics / tests).
  * A convolution whose weight is not registered, or met before the first refresh, transforms in place exactly as before:
  * the cache changes launch counts, never results (the transform is the same device function).  Nothing here allocates,
  * synchronises or copies while `stream` is being captured into a hipGraph: a variant first met inside a capture keeps its
- * per-launch transform, and a refresh inside a capture launches the descriptor table as it stood before the capture. */
-int dc_wino_cache_register(const float* weight, int Ci, int Co);
-int dc_wino_cache_unregister(const float* weight);
-int dc_wino_cache_refresh(void* stream);
-void dc_wino_cache_invalidate(void);
+ * per-launch transform, and a refresh inside a capture launches the owner's table as it stood before the capture. */
+int dc_wino_cache_new_owner(void);
+int dc_wino_cache_register(int owner, const float* weight, int Ci, int Co);
+int dc_wino_cache_release_owner(int owner);
+int dc_wino_cache_refresh(int owner, void* stream);
+int dc_wino_cache_invalidate(int owner);
 int dc_wino_cache_clear(void);
 int dc_wino_cache_variants(void);
 

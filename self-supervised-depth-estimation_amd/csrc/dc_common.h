@@ -89,6 +89,7 @@ __device__ __forceinline__ Bilin bilin_setup(float x, float y, int H, int W) {
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 
 // ---- XCD-aware block order ---------------------------------------------------------------------------
 // The hardware hands consecutive workgroup ids to the 8 XCDs round-robin, and every XCD has its own L2.  This maps the

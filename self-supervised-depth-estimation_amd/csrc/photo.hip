@@ -9,14 +9,16 @@
 //     rows are fetched from HBM once and re-served by L1/L2 to the other waves;
 //   * nothing of the reference's ~25 intermediate (B,3,H,W) tensors is materialised: the warped
 //     image exists only in registers (it is written out only when the log tensors are requested);
-//   * backward recomputes the warp (halo 2) instead of saving it, routes the min() gradient by the
-//     1-byte argmin map the forward wrote, and reduces the pose gradient per wave -> per block ->
-//     fixed-order final sum (no float atomics, bitwise reproducible);
-//   * the SSIM derivative of the backward is evaluated for ONE source frame per pixel, the one the argmin map routes the
-//     gradient to (the other frame's coefficients are exactly zero), except under avg_reprojection where both get half.
-//     (Tried and dropped: target window statistics precomputed once per step by identity_kernel and loaded by the eight
-//     scale-wave passes -- 20 % fewer VALU instructions in the backward, but the 48 B/pixel side stream made the forward
-//     chain 40 us slower than the backward gained.)
+//   * round 4: the TRAINING forward (photo_fwdg_kernel) also emits d(loss)/d(source coordinates) -- it already holds the
+//     window moments, the argmin and the taps, so the SSIM derivative (evaluated for the ONE frame the min() selected; the
+//     other frame's coefficients are exactly zero, except under avg_reprojection where both get half), its transposed 3x3
+//     spread and the contraction with d(warped)/d(coords) happen once, in the same march -- and the backward
+//     (photo_bwdg_kernel) is pointwise: no window, no halo, no gather; it chains (du, dv) through the projection and reduces
+//     the pose gradient per wave -> per block -> fixed-order final sum (no float atomics, bitwise reproducible).  The
+//     evaluation forward (photo_fwd_kernel, DC_OPT_NO_GRAD) emits nothing.  The round-3 backward recomputed the warp and
+//     the window sums of both frames (halo 2, 207 VGPRs): 199 us against 35 + 12 us moved into the forward now.
+//     (Tried and dropped earlier: target window statistics precomputed once per step by identity_kernel and loaded by the
+//     eight scale-wave passes -- the 48 B/pixel side stream made the forward chain 40 us slower than the backward gained.)
 #include <mutex>
 #include <vector>
 
@@ -27,7 +29,6 @@ namespace dc {
 #ifndef FWD_WAVES
 #define FWD_WAVES 3
 #endif
-constexpr int BWD_BLOCKS_PER_CU = 2;   // __launch_bounds__ of the backward / forward kernels (256-thread blocks per CU)
 constexpr int FWD_BLOCKS_PER_CU = FWD_WAVES;
 constexpr float kC1 = 0.01f * 0.01f;  // layers.py:231-232
 constexpr float kC2 = 0.03f * 0.03f;
@@ -53,7 +54,7 @@ struct PhotoArgs {
     const unsigned long long* seed_ptr;   // when set: the seed is read from device memory at run time (hipGraph replays)
     float* idl;                        // identity losses, pixel-interleaved (B, H, W, 2|1)
     float* pk[3];                      // pixel-interleaved RGBx copies (B,H,W,4) of target / source -1 / source +1
-    int rows_f, rows_b;                // image rows a wave produces in the forward / backward march (even)
+    int rows_f;                        // image rows a wave produces in the evaluation forward's march (even)
     uint8_t* argmin[DC_MAX_SCALES];
     float* depth[DC_MAX_SCALES];
     float* sample[DC_MAX_SCALES][2];
@@ -68,6 +69,8 @@ struct PhotoArgs {
     float* part_smooth;  // [ns][B][nchunk][3]
     float* stats;        // [ns][B][3]  (mean disp, Sx, Sy)
     float* gdup[DC_MAX_SCALES];   // full-res d(upsampled disp)
+    float* gw[DC_MAX_SCALES];     // d(sum of to_optimise) / d(source coords): (B,H,W,[du-1, dv-1, du+1, dv+1]) written by the forward
+    int rows_g, rows_p;           // rows per block of the gradient-emitting forward / the pointwise backward
     float* part_dP;      // [ns][2][B][nblk_b_per_image][12]
     int nblk_f, nchunk, nblk_b_img;
 };
@@ -212,7 +215,7 @@ struct Taps {
     f3 t;                // target pixel (RGB)
     f3 tap[2][4];        // [frame][nw, ne, sw, se] RGB pixels
     float wx1[2], wy1[2];
-    float sx[2], sy[2];  // backward only: d(ix)/du, d(iy)/dv incl. the border-clamp zero
+    float sx[2], sy[2];  // training forward only: d(ix)/du, d(iy)/dv incl. the border-clamp zero
 };
 struct RowLog {          // forward, only when the log tensors are requested
     float gx[2], gy[2], depth;
@@ -237,11 +240,9 @@ __device__ __forceinline__ TapOff tap_offsets(float x, float y, int H, int W) {
     return t;
 }
 
-// MODE 0: forward (fills `lg` when LOGS); MODE 1: backward (fills r.sx/sy and parks u,v,zi,depth -- what
-// stage C needs two rows later -- straight into the per-lane LDS slot `park`, stride 64 floats).
-template <int MODE, bool LOGS>
-__device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, float disp, int x, int y, RowLog& lg,
-                                          float* park) {
+// GRAD false: evaluation forward; true: the training forward (also fills r.sx / r.sy).  `lg` is filled when LOGS.
+template <bool GRAD, bool LOGS>
+__device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, float disp, int x, int y, RowLog& lg) {
     r.t = bload3(c.ptg, (unsigned)(y * c.W + x) * 16u);
     const float scaled = c.min_disp + c.disp_range * disp;
     const float depth = frcp(scaled);
@@ -254,8 +255,7 @@ __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, f
         ray = ray + g.iK[i * 3 + 2];
         cam[i] = depth * ray;
     }
-    if (MODE == 0 && LOGS) lg.depth = depth;
-    if (MODE == 1) park[6 * 64] = depth;
+    if (LOGS) lg.depth = depth;
     TapOff to[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -273,11 +273,10 @@ __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, f
         const float ixu = fmaf(u, c.ax, c.bx), iyu = fmaf(v, c.ay, c.by);
         const float hx = (float)(c.W - 1), hy = (float)(c.H - 1);
         const float ix = fminf(fmaxf(ixu, 0.f), hx), iy = fminf(fmaxf(iyu, 0.f), hy);
-        if (MODE == 0 && LOGS) { lg.gx[f] = (u * c.inv_Wm1 - 0.5f) * 2.f; lg.gy[f] = (v * c.inv_Hm1 - 0.5f) * 2.f; }
-        if (MODE == 1) {
+        if (LOGS) { lg.gx[f] = (u * c.inv_Wm1 - 0.5f) * 2.f; lg.gy[f] = (v * c.inv_Hm1 - 0.5f) * 2.f; }
+        if (GRAD) {
             r.sx[f] = (ixu > 0.f && ixu < hx) ? c.ax : 0.f;      // d(ix)/du
             r.sy[f] = (iyu > 0.f && iyu < hy) ? c.ay : 0.f;
-            park[(f * 3 + 0) * 64] = u; park[(f * 3 + 1) * 64] = v; park[(f * 3 + 2) * 64] = zi;
         }
         to[f] = tap_offsets(ix, iy, c.H, c.W);
         r.wx1[f] = to[f].wx1;
@@ -505,7 +504,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
         Row cur;
         blend_row(tp, cur);
         if (LOGS) lg_cur = lg_nxt;
-        issue_row<0, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), lg_nxt, nullptr);
+        issue_row<false, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), lg_nxt);
         {   // identity loss + tie-break noise of the row the NEXT step outputs (row yy)
             const unsigned px = (unsigned)(min(max(yy, 0), H - 1) * W + xr);
             const f2 id2 = bload2(idl, px * idl_px);       // avg: .x is the value (the .y read is discarded)
@@ -568,7 +567,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
     };
 
     disp_issue(dt, c, xr, reflect_clamp(y0 - 1, H));
-    issue_row<0, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(y0 - 1, H), lg_nxt, nullptr);
+    issue_row<false, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(y0 - 1, H), lg_nxt);
     disp_issue(dt, c, xr, reflect_clamp(y0, H));
 #pragma unroll 1
     for (int i = 0; i < R_ROWS + 2; i += 2) {
@@ -680,193 +679,249 @@ __global__ __launch_bounds__(1024) void finalize_kernel(PhotoArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// backward: wave = scale s, both frames, halo 2.  grid (strips60, rowblocks, B), block 64*ns.
-//
-// Per march step (row yy):  A: blend the taps of row yy (value + coordinate derivatives);
-//   B: SSIM derivative coefficients of output pixel row p = yy-1, spread (transposed 3x3 with the
-//      ReflectionPad fold-back) onto the pending gradient accumulators of rows yy-2, yy-1, yy;
-//   C: row q = yy-2 is now complete: chain it through grid_sample / Project3D / BackprojectDepth /
-//      disp_to_depth, accumulate the pose gradient, store d(upsampled disp).
-// What C needs from A two rows earlier (dw/dcoords, projection) waits in a per-lane LDS ring; nothing
-// is recomputed and nothing but the final d(disp) is written to HBM.
-// ------------------------------------------------------------------------------------------------
-constexpr int RING_VALS = 12;   // Dx[2][3], Dy[2][3]          3 slots (written at A, read at C two rows later)
-constexpr int PARK_VALS = 7;    // (u, v, zi) x 2 + depth      4 slots (written one row ahead by issue_row)
-constexpr int BWD_LDS_PER_WAVE = (3 * RING_VALS + 4 * PARK_VALS) * 64;
+constexpr int RING_VALS = 12;   // d(warped)/d(x), d(warped)/d(y) of [2 frames][3 channels]: 3 slots (written at A, read at C two rows later)
 
 struct GAcc {
     float g[2][3];
 };
 
-__global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [ns waves][BWD_LDS_PER_WAVE]
+// ------------------------------------------------------------------------------------------------
+// Training forward: the forward pass that ALSO emits d(sum_p to_optimise(p)) / d(source coordinates u, v) of both source
+// frames (16 B per pixel and scale).  It already holds what that derivative is made of -- the window moments of both
+// frames, the argmin and the bilinear taps -- so the SSIM derivative, its transposed 3x3 spread (ReflectionPad fold-back
+// included), the L1 sign term and the contraction with d(warped)/d(coords) happen here, once, in the same row march
+// (halo 2, like the round-3 backward), and the backward below needs no window, no target, no argmin and no gather.
+// d(warped)/d(coords) of a row is formed when its taps are blended (stage A) and waits two rows in a per-lane LDS ring.
+// wave = scale s, both frames.  grid (strips60, rowblocks, B), block 64*ns.
+//   step i (row yy = y0-2+i):  A: blend row yy;  B: pixel row p = yy-1: values, min / argmin, loss sum, derivative
+//   coefficients of the selected frame, spread onto rows yy-2..yy;  C: row q = yy-2 is complete -> store.
+// ------------------------------------------------------------------------------------------------
+#ifndef FWDG_BLOCKS_PER_CU
+#define FWDG_BLOCKS_PER_CU 2
+#endif
+
+// SPEC >= 0: the option flags are compile-time constants (bit 0 no_ssim, 1 avg_reprojection, 2 automasking, 3 external noise
+// tensors) -- the default training configuration gets straight-line code the scheduler can interleave across channels and
+// frames; SPEC = -1 reads them at run time (every other combination).
+template <bool LOGS, int SPEC>
+__global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(PhotoArgs p) {
     const int lane = threadIdx.x & 63;
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
     const int x = blockIdx.x * 60 - 2 + lane;
-    const int R_ROWS = p.rows_b;
+    const int R_ROWS = p.rows_g;
     const int y0 = blockIdx.y * R_ROWS;
     const int H = p.H, W = p.W;
     const int xr = reflect_clamp(x, W);
     Ctx c;
     make_ctx(c, p, b, s);
     const unsigned plane = c.plane4 / 4;
-    const bool no_ssim = p.flags & DC_OPT_NO_SSIM;
-    const bool automask = !(p.flags & DC_OPT_NO_AUTOMASK);
-    const bool avg = p.flags & DC_OPT_AVG_REPROJ;
+    const unsigned long long seedv = p.seed_ptr ? *p.seed_ptr : p.seed;
+    const bool no_ssim = SPEC >= 0 ? bool(SPEC & 1) : bool(p.flags & DC_OPT_NO_SSIM);
+    const bool automask = SPEC >= 0 ? bool(SPEC & 4) : !(p.flags & DC_OPT_NO_AUTOMASK);
+    const bool avg = SPEC >= 0 ? bool(SPEC & 2) : bool(p.flags & DC_OPT_AVG_REPROJ);
     const bool col_ok = x >= 0 && x < W;
     const bool q_lane = lane >= 2 && lane <= 61 && col_ok;
     Geo g;
     load_geo(g, p, b);
-    const rsrc_t am = make_rsrc(p.argmin[s] + (size_t)b * plane, plane);
-    // d loss / d to_optimise(pixel) for this scale: mean over B*H*W, total = mean over scales
-    const float wgt = uni((p.g_losses[s] + p.g_losses[p.ns] / (float)p.ns) / ((float)p.B * H * W));
+    const unsigned nch4 = (avg ? 1u : 2u) * c.plane4;
+    const bool ext_noise = SPEC >= 0 ? bool(SPEC & 8) : p.noise[s] != nullptr;
+    const rsrc_t nz = make_rsrc(ext_noise ? p.noise[s] + (size_t)b * (avg ? 1 : 2) * plane : p.idl, ext_noise ? nch4 : 0u);
+    const rsrc_t idl = make_rsrc(p.idl + (size_t)b * (avg ? 1 : 2) * plane, automask ? nch4 : 0u);
+    const unsigned idl_px = avg ? 4u : 8u;
+    uint8_t* am = p.argmin[s] + (size_t)b * plane;
+    float* isel = p.idsel[s] ? p.idsel[s] + (size_t)b * plane : nullptr;
+    __shared__ float dring[DC_MAX_SCALES][3 * RING_VALS * 64];       // [wave][slot i%3][(f*3+ch)*2 + {x,y}][lane]
+    float* ring = dring[s] + lane;
+    const rsrc_t gwb = make_rsrc(p.gw[s] + (size_t)b * plane * 4, plane * 16u);
     const float g_ssim = no_ssim ? 0.f : 0.85f / 3.f;
-    const float g_l1 = no_ssim ? 1.f / 3.f : 0.15f / 3.f;
-    // argmin value that routes the gradient to frame -1 / +1
-    const int selv[2] = {avg ? 1 : (automask ? 2 : 0), avg ? 1 : (automask ? 3 : 1)};
-    const float sel_val = (avg ? 0.5f : 1.f) * wgt;
-    const bool sel_all = avg && !automask;   // single channel: to_optimise = combined
-    float* ring = lds + (size_t)s * BWD_LDS_PER_WAVE + lane;
-    float* park = ring + 3 * RING_VALS * 64;
-    float* gout = p.gdup[s] + (size_t)b * plane;
+    const float g_l1 = (no_ssim ? 1.f / 3.f : 0.15f / 3.f) * (avg ? 0.5f : 1.f);
+    const float sel_val = avg ? 0.5f : 1.f;
     const float fl = (x == 1) ? 2.f : 1.f, fr = (x == W - 2) ? 2.f : 1.f;   // ReflectionPad fold-back, x
 
     Row rA = {}, rB = {};        // rows yy-2 / yy-1 (ping-pong)
     GAcc gA = {}, gB = {};       // pending d/d(warped) of rows yy-2 / yy-1
-    int mA = 0, mB = 0, m_in = 0;
-    // pose-gradient accumulators; the lane's column x is constant along the march, so
-    //   sum dq_r*cam_j = (iK_j0*x + iK_j2) * sum(dq_r*depth) + iK_j1 * sum(dq_r*depth*y)
-    float accA[2][3], accB[2][3], accC[2][3];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) accA[f][k] = accB[f][k] = accC[f][k] = 0.f;
+    int m_prev = -1;             // frame the min() routed pixel row yy-2 to (decided one step ago): -1 none, 0 / 1, 2 = both (avg)
+    float idnA[4] = {0.f, 0.f, 0.f, 0.f}, idnB[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc = 0.f;
     Taps tp;
     DispTaps dt;
-    RowLog nolog;
+    RowLog lg_cur = {}, lg_nxt = {};
     int slot3 = 0;   // i % 3
 
-    auto body = [&](int i, Row& r_old, const Row& r_new, GAcc& g_old, GAcc& g_new, int& m_old, const int& m_new) {
+    auto body = [&](int i, Row& r_old, const Row& r_new, GAcc& g_old, GAcc& g_new, const float* idn_cur, float* idn_nxt) {
         const int yy = y0 - 2 + i;
-        // ---------------- stage A: warped values + their coordinate derivatives on (reflected) row yy
+        // ---------------- stage A: blend row yy (+ d(warped)/d(coords) -> ring), then every load of the step in one phase
         Row cur;
-        float* rs = ring + (size_t)slot3 * RING_VALS * 64;
+        blend_row(tp, cur);
+        {
+            float* rs = ring + (size_t)slot3 * RING_VALS * 64;
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const float wx1 = tp.wx1[f], wy1 = tp.wy1[f];
+            for (int f = 0; f < 2; ++f) {
+                const float wx1 = tp.wx1[f], wy1 = tp.wy1[f];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float nw = tp.tap[f][0][ch], ne = tp.tap[f][1][ch], sw = tp.tap[f][2][ch], se = tp.tap[f][3][ch];
-                const float top = fmaf(ne - nw, wx1, nw), bot = fmaf(se - sw, wx1, sw);
-                cur.w[f][ch] = fmaf(bot - top, wy1, top);
-                const float Dx = fmaf((se - sw) - (ne - nw), wy1, ne - nw) * tp.sx[f];
-                const float Dy = (bot - top) * tp.sy[f];
-                rs[((f * 3 + ch) * 2 + 0) * 64] = Dx;
-                rs[((f * 3 + ch) * 2 + 1) * 64] = Dy;
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float nw = tp.tap[f][0][ch], ne = tp.tap[f][1][ch], sw = tp.tap[f][2][ch], se = tp.tap[f][3][ch];
+                    const float dn = ne - nw, ds = se - sw;
+                    const float top = fmaf(dn, wx1, nw), bot = fmaf(ds, wx1, sw);
+                    rs[((f * 3 + ch) * 2 + 0) * 64] = fmaf(ds - dn, wy1, dn) * tp.sx[f];
+                    rs[((f * 3 + ch) * 2 + 1) * 64] = (bot - top) * tp.sy[f];
+                }
             }
         }
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) cur.t[ch] = tp.t[ch];
-        const int m_cur = m_in;
-        // ---------------- all loads of the step: row yy+1 (taps, target, argmin) and disparity of row yy+2
-        issue_row<1, false>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), nolog,
-                            park + (size_t)((i + 1) & 3) * PARK_VALS * 64);
-        m_in = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(am, min(max(yy + 1, 0), H - 1) * W + xr, 0, 0);
+        if (LOGS) lg_cur = lg_nxt;
+        issue_row<true, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), lg_nxt);
+        {   // identity loss + tie-break noise of the pixel row the NEXT step decides (row yy)
+            const unsigned px = (unsigned)(min(max(yy, 0), H - 1) * W + xr);
+            const f2 id2 = bload2(idl, px * idl_px);
+            idn_nxt[0] = id2.x;
+            idn_nxt[1] = id2.y;
+            idn_nxt[2] = bload(nz, px * 4u, 0);
+            idn_nxt[3] = bload(nz, px * 4u, c.plane4);
+        }
         disp_issue(dt, c, xr, reflect_clamp(yy + 2, H));
+        if (LOGS && i >= 2 && i <= R_ROWS + 1 && yy < H && q_lane) {
+            const unsigned o = (unsigned)(yy * W + x);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                if (float* col = p.color[s][f]) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) col[((size_t)b * 3 + ch) * plane + o] = cur.w[f][ch];
+                }
+                if (float* smp = p.sample[s][f])
+                    reinterpret_cast<float2*>(smp)[(size_t)b * plane + o] = make_float2(lg_cur.gx[f], lg_cur.gy[f]);
+            }
+            if (float* dep = p.depth[s]) dep[(size_t)b * plane + o] = lg_cur.depth;
+        }
 
-        // ---------------- stage B: SSIM derivative coefficients at row p = yy-1 (window rows yy-2, yy-1, yy)
+        // ---------------- stage B: pixel row p = yy-1 (window rows yy-2, yy-1, yy)
         float g_tmp[2][3];
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) g_tmp[f][ch] = 0.f;
-        if (i >= 2) {            // (the first two steps only fill the window)
+        int m_p = -1;
+        if (i >= 2) {
             const int py = yy - 1;
             const bool p_ok = py >= 0 && py < H && col_ok;
-            const float fu = (yy == 1) ? 2.f : 1.f;          // fold-back for q = yy   (p = q-1)
-            const float fd = (yy - 2 == H - 2) ? 2.f : 1.f;  // fold-back for q = yy-2 (p = q+1)
-            // derivative coefficients of one (channel, frame) from its window statistics
-            auto coeffs = [&](const TStat& ts, const WStat& t, float gsel, float& a, float& bb, float& cc) {
-                const float n = t.n1 * t.n2;
-                const float id = frcp(t.d1 * t.d2);
-                const float nid = n * id;
-                const float v = fmaf(-0.5f, nid, 0.5f);
-                // clamp(.,0,1) passes the gradient inclusively
-                const float G = (v >= 0.f && v <= 1.f) ? gsel : 0.f;
-                const float Gid = G * id;
-                // d/d mu_x | d/d E[xx] | d/d E[xy]   (E[.] held fixed for mu_x)
-                a = Gid * fmaf(nid * t.mu_x, t.d2 - t.d1, -ts.mu_y * (t.n2 - t.n1));
-                bb = 0.5f * Gid * nid * t.d1;
-                cc = -Gid * t.n1;
-            };
-            // transposed 3x3: along x across lanes, along y onto the pending rows q = p-1 (= yy-2), p (= yy-1), p+1 (= yy)
-            auto spread = [&](int f, int ch, float a, float bb, float cc) {
-                const float ka = fmaf(fr, from_right(a), fmaf(fl, from_left(a), a));
-                const float kb = fmaf(fr, from_right(bb), fmaf(fl, from_left(bb), bb));
-                const float kc = fmaf(fr, from_right(cc), fmaf(fl, from_left(cc), cc));
-                const float kb2 = kb + kb;
-                g_old.g[f][ch] = fmaf(fd, fmaf(r_old.t[ch], kc, fmaf(r_old.w[f][ch], kb2, ka)), g_old.g[f][ch]);
-                g_new.g[f][ch] += fmaf(r_new.t[ch], kc, fmaf(r_new.w[f][ch], kb2, ka));
-                g_tmp[f][ch] = fu * fmaf(cur.t[ch], kc, fmaf(cur.w[f][ch], kb2, ka));   // fresh accumulator of row yy
-            };
-            if (sel_all || avg) {
-                // avg_reprojection: both frames carry half of the gradient
-                float gs[2];
+            // ---- values of both frames (the window sums and target statistics stay live for the derivative)
+            TStat ts[3];
+            WSums ws[3][2];
+            float ss[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};
 #pragma unroll
-                for (int f = 0; f < 2; ++f) gs[f] = (p_ok && (sel_all || m_new == selv[f])) ? sel_val * g_ssim : 0.f;
+            for (int ch = 0; ch < 3; ++ch) {
+                if (!no_ssim) ts[ch] = target_stat(r_old.t[ch], r_new.t[ch], cur.t[ch]);
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const TStat ts = target_stat(r_old.t[ch], r_new.t[ch], cur.t[ch]);
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        const WStat t = warp_stat(ts, r_old.w[f][ch], r_new.w[f][ch], cur.w[f][ch], r_old.t[ch], r_new.t[ch],
-                                                  cur.t[ch]);
-                        float a, bb, cc;
-                        coeffs(ts, t, gs[f], a, bb, cc);
-                        spread(f, ch, a, bb, cc);
+                for (int f = 0; f < 2; ++f) {
+                    l1[f] += fabsf(r_new.t[ch] - r_new.w[f][ch]);
+                    if (!no_ssim) {
+                        ws[ch][f] = warp_sums(r_old.w[f][ch], r_new.w[f][ch], cur.w[f][ch], r_old.t[ch], r_new.t[ch], cur.t[ch]);
+                        const WStat st = warp_from_sums(ts[ch], ws[ch][f].sx, ws[ch][f].sxx, ws[ch][f].sxy);
+                        const float v = fmaf(-(st.n1 * st.n2), 0.5f * frcp(st.d1 * st.d2), 0.5f);
+                        ss[f] += fminf(fmaxf(v, 0.f), 1.f);
                     }
                 }
-            } else {
-                // min(): the argmin map routes the gradient of pixel p to at most ONE frame; the other frame's coefficients
-                // are exactly zero.  The window sums are taken for both frames (a pixel's window spans lanes that may have
-                // chosen the other frame), the statistics and the derivative only for the selected one.
-                const bool s1 = m_new == selv[1];
-                const float gsel = (p_ok && (s1 || m_new == selv[0])) ? sel_val * g_ssim : 0.f;
+            }
+            float r[2];
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const TStat ts = target_stat(r_old.t[ch], r_new.t[ch], cur.t[ch]);
-                    const WSums w0 = warp_sums(r_old.w[0][ch], r_new.w[0][ch], cur.w[0][ch], r_old.t[ch], r_new.t[ch], cur.t[ch]);
-                    const WSums w1 = warp_sums(r_old.w[1][ch], r_new.w[1][ch], cur.w[1][ch], r_old.t[ch], r_new.t[ch], cur.t[ch]);
-                    const WStat t = warp_from_sums(ts, s1 ? w1.sx : w0.sx, s1 ? w1.sxx : w0.sxx, s1 ? w1.sxy : w0.sxy);
-                    float a, bb, cc;
-                    coeffs(ts, t, gsel, a, bb, cc);
-                    spread(0, ch, s1 ? 0.f : a, s1 ? 0.f : bb, s1 ? 0.f : cc);
-                    spread(1, ch, s1 ? a : 0.f, s1 ? bb : 0.f, s1 ? cc : 0.f);
+            for (int f = 0; f < 2; ++f)
+                r[f] = no_ssim ? l1[f] * (1.f / 3.f) : fmaf(0.85f / 3.f, ss[f], (0.15f / 3.f) * l1[f]);
+            // ---- min over [identity(-1), identity(+1), reproj(-1), reproj(+1)]  (trainer.py:592-610)
+            const unsigned o = (unsigned)(min(max(py, 0), H - 1) * W + xr);
+            float best;
+            int idx = 0;
+            if (avg) {
+                const float rr = (r[0] + r[1]) * 0.5f;
+                best = rr;
+                m_p = 2;
+                if (automask) {
+                    const float n0 = ext_noise ? idn_cur[2] : rng_normal(seedv, b * plane + o, s * 2);
+                    const float id = __fadd_rn(idn_cur[0], __fmul_rn(n0, 0.00001f));
+                    best = id;
+                    m_p = -1;
+                    if (rr < best) { best = rr; idx = 1; m_p = 2; }
+                }
+            } else if (automask) {
+                const float n0 = ext_noise ? idn_cur[2] : rng_normal(seedv, b * plane + o, s * 2);
+                const float n1 = ext_noise ? idn_cur[3] : rng_normal(seedv, b * plane + o, s * 2 + 1);
+                const float i0 = __fadd_rn(idn_cur[0], __fmul_rn(n0, 0.00001f));
+                const float i1 = __fadd_rn(idn_cur[1], __fmul_rn(n1, 0.00001f));
+                best = i0;
+                if (i1 < best) { best = i1; idx = 1; }
+                if (r[0] < best) { best = r[0]; idx = 2; m_p = 0; }
+                if (r[1] < best) { best = r[1]; idx = 3; m_p = 1; }
+            } else {
+                best = r[0];
+                m_p = 0;
+                if (r[1] < best) { best = r[1]; idx = 1; m_p = 1; }
+            }
+            if (!p_ok) m_p = -1;
+            if (i >= 3 && i <= R_ROWS + 2 && py < H && q_lane) {      // rows / columns this block owns
+                acc += best;
+                am[o] = (uint8_t)idx;
+                if (isel && automask) isel[o] = (idx > (avg ? 0 : 1)) ? 1.f : 0.f;
+            }
+            // ---- derivative coefficients of the selected frame, spread (transposed 3x3) onto rows yy-2, yy-1, yy
+            if (!no_ssim && __builtin_amdgcn_ballot_w64(m_p >= 0) != 0ull) {
+                const float fu = (yy == 1) ? 2.f : 1.f;          // fold-back for q = yy   (p = q-1)
+                const float fd = (yy - 2 == H - 2) ? 2.f : 1.f;  // fold-back for q = yy-2 (p = q+1)
+                auto coeffs = [&](const TStat& tq, const WStat& t, float gsel, float& a, float& bb, float& cc) {
+                    const float n = t.n1 * t.n2;
+                    const float id = frcp(t.d1 * t.d2);
+                    const float nid = n * id;
+                    const float v = fmaf(-0.5f, nid, 0.5f);
+                    const float G = (v >= 0.f && v <= 1.f) ? gsel : 0.f;      // clamp(.,0,1) passes inclusively
+                    const float Gid = G * id;
+                    a = Gid * fmaf(nid * t.mu_x, t.d2 - t.d1, -tq.mu_y * (t.n2 - t.n1));
+                    bb = 0.5f * Gid * nid * t.d1;
+                    cc = -Gid * t.n1;
+                };
+                auto spread = [&](int f, int ch, float a, float bb, float cc) {
+                    const float ka = fmaf(fr, from_right(a), fmaf(fl, from_left(a), a));
+                    const float kb = fmaf(fr, from_right(bb), fmaf(fl, from_left(bb), bb));
+                    const float kc = fmaf(fr, from_right(cc), fmaf(fl, from_left(cc), cc));
+                    const float kb2 = kb + kb;
+                    g_old.g[f][ch] = fmaf(fd, fmaf(r_old.t[ch], kc, fmaf(r_old.w[f][ch], kb2, ka)), g_old.g[f][ch]);
+                    g_new.g[f][ch] += fmaf(r_new.t[ch], kc, fmaf(r_new.w[f][ch], kb2, ka));
+                    g_tmp[f][ch] = fu * fmaf(cur.t[ch], kc, fmaf(cur.w[f][ch], kb2, ka));
+                };
+                if (avg) {
+                    const float gsel = (m_p == 2) ? sel_val * g_ssim : 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) {
+                            const WStat t = warp_from_sums(ts[ch], ws[ch][f].sx, ws[ch][f].sxx, ws[ch][f].sxy);
+                            float a, bb, cc;
+                            coeffs(ts[ch], t, gsel, a, bb, cc);
+                            spread(f, ch, a, bb, cc);
+                        }
+                } else {
+                    const bool s1 = m_p == 1;
+                    const float gsel = (m_p >= 0) ? sel_val * g_ssim : 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const WStat t = warp_from_sums(ts[ch], s1 ? ws[ch][1].sx : ws[ch][0].sx, s1 ? ws[ch][1].sxx : ws[ch][0].sxx,
+                                                       s1 ? ws[ch][1].sxy : ws[ch][0].sxy);
+                        float a, bb, cc;
+                        coeffs(ts[ch], t, gsel, a, bb, cc);
+                        spread(0, ch, s1 ? 0.f : a, s1 ? 0.f : bb, s1 ? 0.f : cc);
+                        spread(1, ch, s1 ? a : 0.f, s1 ? bb : 0.f, s1 ? cc : 0.f);
+                    }
                 }
             }
         }
-        // ---------------- stage C: gradient at row q = yy-2 (its stage-A data comes back from the LDS ring)
+        // ---------------- stage C: row q = yy-2 has every contribution: add the L1 term, contract with the row's
+        // d(warped)/d(coords) from the ring, store (du, dv) of both frames
         if (i >= 4) {
             const int qy = yy - 2;
-            if (qy < H) {
+            if (qy < H && q_lane) {
                 const int s2 = (slot3 == 0) ? 1 : ((slot3 == 1) ? 2 : 0);   // (i-2) % 3
                 const float* rq = ring + (size_t)s2 * RING_VALS * 64;
-                const float* pk = park + (size_t)((i - 2) & 3) * PARK_VALS * 64;
-                const float qdepth = pk[6 * 64];
-                const float xf = (float)xr, yf = (float)qy;
-                float ray[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    float t = g.iK[r * 3 + 0] * xf;
-                    t = fmaf(g.iK[r * 3 + 1], yf, t);
-                    ray[r] = t + g.iK[r * 3 + 2];
-                }
-                float dcam[3] = {0.f, 0.f, 0.f};
+                float duv[2][2];
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
-                    const float gl = (q_lane && (sel_all || m_old == selv[f])) ? sel_val * g_l1 : 0.f;
+                    const float gl = (m_prev == f || m_prev == 2) ? g_l1 : 0.f;
                     float du = 0.f, dv = 0.f;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
@@ -876,25 +931,9 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
                         du = fmaf(gw, rq[((f * 3 + ch) * 2 + 0) * 64], du);
                         dv = fmaf(gw, rq[((f * 3 + ch) * 2 + 1) * 64], dv);
                     }
-                    if (!q_lane) { du = 0.f; dv = 0.f; }
-                    const float qu = pk[(f * 3 + 0) * 64], qv = pk[(f * 3 + 1) * 64], qzi = pk[(f * 3 + 2) * 64];
-                    float dq[3];
-                    dq[0] = du * qzi;
-                    dq[1] = dv * qzi;
-                    dq[2] = -fmaf(du, qu, dv * qv) * qzi;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const float dqd = dq[r] * qdepth;
-                        accA[f][r] += dqd;
-                        accB[f][r] = fmaf(dqd, yf, accB[f][r]);
-                        accC[f][r] += dq[r];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) dcam[j] = fmaf(dq[r], g.P[f][r * 4 + j], dcam[j]);
-                    }
+                    duv[f][0] = du; duv[f][1] = dv;
                 }
-                const float dd = fmaf(dcam[0], ray[0], fmaf(dcam[1], ray[1], dcam[2] * ray[2]));
-                const float gd = -dd * qdepth * qdepth * p.disp_range;
-                if (q_lane) gout[(unsigned)(qy * W + x)] = gd;
+                bstore4(gwb, (unsigned)(qy * W + x) * 16u, duv[0][0], duv[0][1], duv[1][0], duv[1][1]);
             }
         }
         // rotate: the slots of row yy-2 now take row yy
@@ -903,22 +942,150 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) g_old.g[f][ch] = g_tmp[f][ch];
         r_old = cur;
-        m_old = m_cur;
+        m_prev = m_p;           // stage C of the next step finishes the row this step decided
         slot3 = (slot3 == 2) ? 0 : slot3 + 1;
     };
 
     disp_issue(dt, c, xr, reflect_clamp(y0 - 2, H));
-    issue_row<1, false>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(y0 - 2, H), nolog, park + 0 * PARK_VALS * 64);
-    m_in = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(am, min(max(y0 - 2, 0), H - 1) * W + xr, 0, 0);
+    issue_row<true, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(y0 - 2, H), lg_nxt);
     disp_issue(dt, c, xr, reflect_clamp(y0 - 1, H));
 #pragma unroll 1
     for (int i = 0; i < R_ROWS + 4; i += 2) {
-        body(i, rA, rB, gA, gB, mA, mB);
-        body(i + 1, rB, rA, gB, gA, mB, mA);
+        body(i, rA, rB, gA, gB, idnA, idnB);
+        body(i + 1, rB, rA, gB, gA, idnB, idnA);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        p.part_photo[(size_t)s * p.nblk_f + blk] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pointwise backward: d(loss)/d(source coordinates) comes from the training forward (gw: du, dv per frame), so a pixel
+// needs nothing from its neighbours and nothing from the images -- no window, no halo, no gather, no LDS.  Per pixel
+// and scale: re-derive the projection (disp -> depth -> cam -> both frames' u, v, 1/z), chain (du, dv) through
+// Project3D / BackprojectDepth / disp_to_depth, accumulate the pose-gradient sums.
+// wave = scale s, lane = column, marching down rows_p rows.  grid (strips64, rowblocks, B), block 64*ns.
+// ------------------------------------------------------------------------------------------------
+#ifndef BWDG_BLOCKS_PER_CU
+#define BWDG_BLOCKS_PER_CU 4
+#endif
+
+struct ProjQ {
+    float u[2], v[2], zi[2], depth;
+};
+
+__device__ __forceinline__ void project_q(ProjQ& q, const Geo& g, const Ctx& c, float disp, int x, int y) {
+    const float scaled = c.min_disp + c.disp_range * disp;
+    const float depth = frcp(scaled);
+    const float xf = (float)x, yf = (float)y;
+    float cam[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float ray = g.iK[i * 3 + 0] * xf;
+        ray = fmaf(g.iK[i * 3 + 1], yf, ray);
+        ray = ray + g.iK[i * 3 + 2];
+        cam[i] = depth * ray;
+    }
+    q.depth = depth;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        float w[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float a = g.P[f][i * 4 + 0] * cam[0];
+            a = fmaf(g.P[f][i * 4 + 1], cam[1], a);
+            a = fmaf(g.P[f][i * 4 + 2], cam[2], a);
+            w[i] = a + g.P[f][i * 4 + 3];
+        }
+        const float zi = frcp(w[2] + 1e-7f);
+        q.u[f] = w[0] * zi; q.v[f] = w[1] * zi; q.zi[f] = zi;
+    }
+}
+
+constexpr int BWDG_UNROLL = 4;     // rows whose loads are in flight together
+
+__global__ __launch_bounds__(256, BWDG_BLOCKS_PER_CU) void photo_bwdg_kernel(PhotoArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + lane;
+    const int R_ROWS = p.rows_p;
+    const int y0 = blockIdx.y * R_ROWS;
+    const int H = p.H, W = p.W;
+    const int xr = min(x, W - 1);
+    const bool col_ok = x < W;
+    Ctx c;
+    make_ctx(c, p, b, s);
+    const unsigned plane = c.plane4 / 4;
+    Geo g;
+    load_geo(g, p, b);
+    const rsrc_t gwb = make_rsrc(p.gw[s] + (size_t)b * plane * 4, plane * 16u);
+    // d loss / d to_optimise(pixel) for this scale: mean over B*H*W, total = mean over scales
+    const float wgt = col_ok ? uni((p.g_losses[s] + p.g_losses[p.ns] / (float)p.ns) / ((float)p.B * H * W)) : 0.f;
+    float* gout = p.gdup[s] + (size_t)b * plane;
+    // pose-gradient accumulators; the lane's column x is constant along the march, so
+    //   sum dq_r*cam_j = (iK_j0*x + iK_j2) * sum(dq_r*depth) + iK_j1 * sum(dq_r*depth*y)
+    float accA[2][3], accB[2][3], accC[2][3];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) accA[f][k] = accB[f][k] = accC[f][k] = 0.f;
+    const int yend = min(y0 + R_ROWS, H);
+    const float xf = (float)xr;
+
+#pragma unroll 1
+    for (int qy0 = y0; qy0 < yend; qy0 += BWDG_UNROLL) {
+        // ---- every load of BWDG_UNROLL rows in one batch (rows past the block: clamped, loaded, never stored)
+        DispTaps dt[BWDG_UNROLL];
+        f4v gq[BWDG_UNROLL];
+#pragma unroll
+        for (int k = 0; k < BWDG_UNROLL; ++k) {
+            const int qy = min(qy0 + k, H - 1);
+            disp_issue(dt[k], c, xr, qy);
+            gq[k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(gwb, (int)((unsigned)(qy * W + xr) * 16u), 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < BWDG_UNROLL; ++k) {
+            const int qy = qy0 + k;
+            ProjQ cq;
+            project_q(cq, g, c, disp_value(dt[k], c), xr, min(qy, H - 1));
+            const float m = (qy < yend) ? wgt : 0.f;
+            const float du[2] = {gq[k].x * m, gq[k].z * m}, dv[2] = {gq[k].y * m, gq[k].w * m};
+            // ---- Project3D / BackprojectDepth / disp_to_depth backward, pose sums
+            const float yf = (float)qy;
+            float ray[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float t = g.iK[r * 3 + 0] * xf;
+                t = fmaf(g.iK[r * 3 + 1], yf, t);
+                ray[r] = t + g.iK[r * 3 + 2];
+            }
+            float dcam[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                float dq[3];
+                dq[0] = du[f] * cq.zi[f];
+                dq[1] = dv[f] * cq.zi[f];
+                dq[2] = -fmaf(du[f], cq.u[f], dv[f] * cq.v[f]) * cq.zi[f];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float dqd = dq[r] * cq.depth;
+                    accA[f][r] += dqd;
+                    accB[f][r] = fmaf(dqd, yf, accB[f][r]);
+                    accC[f][r] += dq[r];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) dcam[j] = fmaf(dq[r], g.P[f][r * 4 + j], dcam[j]);
+                }
+            }
+            const float dd = fmaf(dcam[0], ray[0], fmaf(dcam[1], ray[1], dcam[2] * ray[2]));
+            const float gd = -dd * cq.depth * cq.depth * p.disp_range;
+            if (col_ok && qy < yend) gout[(unsigned)(qy * W + x)] = gd;
+        }
     }
     // pose-gradient partials: per wave, fixed shuffle tree
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-    const float xf = (float)xr;
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         float* o = p.part_dP + ((((size_t)s * 2 + f) * p.B + b) * p.nblk_b_img + blk) * 12;
@@ -936,13 +1103,17 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_kernel(PhotoArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// d_disp[s] = bilinear-upsample^T(gdup[s]) + smoothness gradient.
-// grid (tiles_x, tiles_y, ns*B), block 256.  A block owns a (128/K) x (32/K) tile of scale-s pixels: it
-// stages the (128+K) x (32+K) full-resolution footprint in LDS with coalesced row reads, then applies
-// the transposed interpolation separably (x, then y).  The 1-D tap weights are re-derived with the
-// forward's own `lin_tap`, so forward and backward cannot disagree about a tap.
+// d_disp[s] = bilinear-upsample^T(gdup[s]) + smoothness gradient, and (in the same launch) the pose-gradient reduction.
+// grid (tiles of all scales + 2 pose blocks, B), block 256.
+//   scale 0: the upsample is the identity -- a block owns a 128 x 8 tile, four pixels per thread, pointwise.
+//   scale s >= 1 (K = 2^s): a block owns a (128/K) x (32/K) tile of scale-s pixels: it stages the (128+K) x (32+K)
+//     full-resolution footprint in LDS, then applies the transposed interpolation separably (x, then y).  The 1-D tap
+//     weights are re-derived with the forward's own `lin_tap`, so forward and backward cannot disagree about a tap.
+// Every global load of a block is issued in ONE batch before the first use (footprint, then the disparity / colour
+// neighbourhoods of the smoothness term): round 3's version loaded and committed element by element -- 21 dependent HBM
+// round trips per block, 38 us for 30 MB.
 // ------------------------------------------------------------------------------------------------
-constexpr int DG_W = 128, DG_H = 32;          // full-resolution core footprint of one block
+constexpr int DG_W = 128, DG_H = 32, DG_H0 = 8;   // full-resolution core footprint of one block (scale >= 1 / scale 0)
 constexpr int DG_MAXK = 8;
 constexpr int DG_RW = DG_W + DG_MAXK, DG_RH = DG_H + DG_MAXK;
 
@@ -951,112 +1122,178 @@ __device__ __forceinline__ float tapw(int dst, float ratio, int n_in, int j) {
     return (t.i0 == j ? 1.f - t.w1 : 0.f) + (t.i1 == j ? t.w1 : 0.f);
 }
 
-__global__ __launch_bounds__(256) void disp_grad_kernel(PhotoArgs p) {
-    __shared__ float reg[DG_RH * DG_RW];                 // full-res footprint
-    __shared__ float hs[DG_RH * (DG_W / 2)];             // after the x pass: [footprint row][tile column]
-    const int s = blockIdx.z / p.B, b = blockIdx.z - s * p.B;
-    const int K = 1 << s;
-    const int h = p.hs[s], w = p.ws[s], n = h * w;
+// the disparity / colour neighbourhood of one scale-s pixel (loads only), and the smoothness gradient from it
+struct SmNb {
+    float d[5];        // centre, right, left, down, up
+    float im[3][5];
+};
+__device__ __forceinline__ void smooth_issue(SmNb& n, rsrc_t rd, rsrc_t rim, int x, int y, int w, int h, unsigned plane4) {
+    const unsigned inv = 0x80000000u;     // out of range: the descriptor returns 0 (never used: masked by the edge tests)
+    const unsigned i = (unsigned)(y * w + x) * 4u;
+    const unsigned o[5] = {i, x < w - 1 ? i + 4u : inv, x > 0 ? i - 4u : inv, y < h - 1 ? i + (unsigned)w * 4u : inv,
+                           y > 0 ? i - (unsigned)w * 4u : inv};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        n.d[k] = bload(rd, o[k], 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) n.im[c][k] = bload(rim, o[k], c * plane4);
+    }
+}
+__device__ __forceinline__ float smooth_grad(const SmNb& n, int x, int y, int w, int h, float cx_, float cy_) {
+    auto sgn = [](float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); };
+    auto ex = [&](int k) {
+        const float gi = (fabsf(n.im[0][0] - n.im[0][k]) + fabsf(n.im[1][0] - n.im[1][k]) + fabsf(n.im[2][0] - n.im[2][k])) * (1.f / 3.f);
+        return __expf(-gi);
+    };
+    float gx = 0.f, gy = 0.f;
+    if (x < w - 1) gx += sgn(n.d[0] - n.d[1]) * ex(1);
+    if (x > 0) gx -= sgn(n.d[2] - n.d[0]) * ex(2);
+    if (y < h - 1) gy += sgn(n.d[0] - n.d[3]) * ex(3);
+    if (y > 0) gy -= sgn(n.d[4] - n.d[0]) * ex(4);
+    return cx_ * gx + cy_ * gy;
+}
+
+template <int S>
+__device__ __forceinline__ void disp_grad_tile(const PhotoArgs& p, int b, int tile, float* reg, float* hsm) {
+    constexpr int K = 1 << S;
+    constexpr int TW = DG_W / K, TH = (S == 0 ? DG_H0 : DG_H / K);      // tile size in scale-s pixels
+    constexpr int PX = (TW * TH + 255) / 256;                           // pixels per thread: 4, 4, 1, 1
+    const int h = p.hs[S], w = p.ws[S], n = h * w;
     const int H = p.H, W = p.W;
-    const int tw = DG_W / K, th = DG_H / K;              // tile size in scale-s pixels
-    const int tx0 = blockIdx.x * tw, ty0 = blockIdx.y * th;
-    if (tx0 >= w || ty0 >= h) return;
-    const float* gu = p.gdup[s] + (size_t)b * H * W;
-    float up = 0.f;
-    const int lx = threadIdx.x % tw, ly0 = threadIdx.x / tw;   // this thread's tile cells: (lx, ly0 + k*rows)
-    const int rows_per_pass = 256 / tw;
-    if (K == 1) {
-        // scale 0: the upsample is the identity
-    } else {
-        const int fx0 = tx0 * K - K / 2, fy0 = ty0 * K - K / 2;   // footprint origin (may be negative)
-        const int rw = DG_W + K, rh = DG_H + K;
-        for (int k = threadIdx.x; k < rw * rh; k += 256) {
-            const int ry = k / rw, rx = k - ry * rw;
+    const int ntx = ceil_div_dev(w, TW);
+    const int tyi = tile / ntx, txi = tile - tyi * ntx;
+    const int tx0 = txi * TW, ty0 = tyi * TH;
+    const int tid = threadIdx.x;
+    const rsrc_t rgu = make_rsrc(p.gdup[S] + (size_t)b * H * W, (unsigned)(H * W) * 4u);
+    const rsrc_t rd = make_rsrc(p.disp[S] + (size_t)b * n, (unsigned)n * 4u);
+    const rsrc_t rim = make_rsrc(p.color_s[S] + (size_t)b * 3 * n, (unsigned)n * 12u);
+    const int lx = tid % TW, ly0 = tid / TW;
+    constexpr int RPP = 256 / TW;                                       // tile rows per pass of the block
+    // ---- every load of the block, one batch
+    constexpr int RW = DG_W + K, RH = (S == 0 ? 0 : DG_H + K);
+    constexpr int NF = (RW * RH + 255) / 256;
+    const int fx0 = tx0 * K - K / 2, fy0 = ty0 * K - K / 2;             // footprint origin (may be negative)
+    float fv[NF > 0 ? NF : 1];
+    if (S > 0) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int k = tid + 256 * j;
+            const int ry = k / RW, rx = k - ry * RW;
             const int gy = fy0 + ry, gx = fx0 + rx;
-            reg[ry * DG_RW + rx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gu[(size_t)gy * W + gx] : 0.f;
+            const bool ok = k < RW * RH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            fv[j] = bload(rgu, ok ? (unsigned)(gy * W + gx) * 4u : 0x80000000u, 0);
+        }
+    }
+    SmNb nb[PX];
+    float up[PX];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const int x = min(tx0 + lx, w - 1), y = min(ty0 + ly0 + k * RPP, h - 1);
+        smooth_issue(nb[k], rd, rim, x, y, w, h, (unsigned)n * 4u);
+        if (S == 0) up[k] = bload(rgu, (unsigned)(y * w + x) * 4u, 0);
+    }
+    if (S > 0) {
+        // ---- commit the footprint, x pass (a thread's cells share one tile column: 2K weights, computed once)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int k = tid + 256 * j;
+            if (k < RW * RH) { const int ry = k / RW; reg[ry * DG_RW + (k - ry * RW)] = fv[j]; }
+        }
+        float wt[2 * K];
+        {
+            const int jx = tx0 + lx;
+#pragma unroll
+            for (int t = 0; t < 2 * K; ++t) {
+                const int gx = fx0 + lx * K + t;
+                wt[t] = (jx < w && gx >= 0 && gx < W) ? tapw(gx, p.rx[S], w, jx) : 0.f;
+            }
         }
         __syncthreads();
-        // x pass: cell column cx gathers the 2K footprint columns [cx*K, cx*K + 2K)
-        for (int k = threadIdx.x; k < rh * tw; k += 256) {
-            const int ry = k / tw, cx = k - ry * tw;
-            const int jx = tx0 + cx;
+        for (int ry = ly0; ry < RH; ry += RPP) {
             float acc = 0.f;
-            if (jx < w) {
-                for (int t = 0; t < 2 * K; ++t) {
-                    const int rx = cx * K + t, gx = fx0 + rx;
-                    if (gx >= 0 && gx < W) acc = fmaf(tapw(gx, p.rx[s], w, jx), reg[ry * DG_RW + rx], acc);
-                }
-            }
-            hs[ry * (DG_W / 2) + cx] = acc;
+#pragma unroll
+            for (int t = 0; t < 2 * K; ++t) acc = fmaf(wt[t], reg[ry * DG_RW + lx * K + t], acc);
+            hsm[ry * (DG_W / 2) + lx] = acc;
         }
         __syncthreads();
     }
-    // y pass + smoothness gradient, one scale-s pixel per iteration
-    const float gsm = (p.g_losses[s] + p.g_losses[p.ns] / (float)p.ns) * p.smoothness / (float)(1 << s);
-    const float* st = p.stats + ((size_t)s * p.B + b) * 3;
+    // ---- y pass + smoothness gradient
+    const float gsm = (p.g_losses[S] + p.g_losses[p.ns] / (float)p.ns) * p.smoothness / (float)(1 << S);
+    const float* st = p.stats + ((size_t)S * p.B + b) * 3;
     const float A = 1.f / (st[0] + 1e-7f);
     const float cx_ = 1.f / ((float)p.B * h * (w - 1)), cy_ = 1.f / ((float)p.B * (h - 1) * w);
-    const float* d = p.disp[s] + (size_t)b * n;
-    const float* im = p.color_s[s] + (size_t)b * 3 * n;
-    auto sgn = [](float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); };
-    auto ex = [&](int i0, int i1) {
-        const float gi = (fabsf(im[i0] - im[i1]) + fabsf(im[n + i0] - im[n + i1]) +
-                          fabsf(im[2 * n + i0] - im[2 * n + i1])) * (1.f / 3.f);
-        return __expf(-gi);
-    };
-    for (int cy = ly0; cy < th; cy += rows_per_pass) {
+    const float mean_term = A * A * (cx_ * st[1] + cy_ * st[2]) / (float)n;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const int cy = ly0 + k * RPP;
         const int x = tx0 + lx, y = ty0 + cy;
-        if (x >= w || y >= h) continue;
-        const int i = y * w + x;
-        if (K == 1) {
-            up = gu[i];
+        if (cy >= TH || x >= w || y >= h) continue;
+        float u;
+        if (S == 0) {
+            u = up[k];
         } else {
-            const int fy0 = ty0 * K - K / 2;
-            up = 0.f;
+            u = 0.f;
+#pragma unroll
             for (int t = 0; t < 2 * K; ++t) {
                 const int ry = cy * K + t, gy = fy0 + ry;
-                if (gy >= 0 && gy < H) up = fmaf(tapw(gy, p.ry[s], h, y), hs[ry * (DG_W / 2) + lx], up);
+                if (gy >= 0 && gy < H) u = fmaf(tapw(gy, p.ry[S], h, y), hsm[ry * (DG_W / 2) + lx], u);
             }
         }
         // smoothness:  L = A*(cx*Sx + cy*Sy),  A = 1/(mean+eps)
-        const float dv = d[i];
-        float gx = 0.f, gy = 0.f;
-        if (x < w - 1) gx += sgn(dv - d[i + 1]) * ex(i, i + 1);
-        if (x > 0) gx -= sgn(d[i - 1] - dv) * ex(i - 1, i);
-        if (y < h - 1) gy += sgn(dv - d[i + w]) * ex(i, i + w);
-        if (y > 0) gy -= sgn(d[i - w] - dv) * ex(i - w, i);
-        const float gs = A * (cx_ * gx + cy_ * gy) - A * A * (cx_ * st[1] + cy_ * st[2]) / (float)n;
-        p.d_disp[s][(size_t)b * n + i] = up + gsm * gs;
+        const float gs = A * smooth_grad(nb[k], x, y, w, h, cx_, cy_) - mean_term;
+        p.d_disp[S][(size_t)b * n + y * w + x] = u + gsm * gs;
     }
 }
 
-// d_T[f][b] = K[b][:3,:]^T @ sum_{s,blk} dP      grid (B, 2), block 64
-__global__ __launch_bounds__(64) void pose_grad_kernel(PhotoArgs p) {
-    __shared__ float dPs[12];
-    const int b = blockIdx.x, f = blockIdx.y;
-    const int lane = threadIdx.x;
+// d_T[f][b] = K[b][:3,:]^T @ sum_{s,blk} dP, one 256-thread block per (b, f): fixed-order sums
+__device__ __forceinline__ void pose_grad_block(const PhotoArgs& p, int b, int f, float* sm) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     for (int s = 0; s < p.ns; ++s) {
         const float* q = p.part_dP + (((size_t)s * 2 + f) * p.B + b) * p.nblk_b_img * 12;
-        for (int k = lane; k < p.nblk_b_img; k += 64) {
+        for (int k = threadIdx.x; k < p.nblk_b_img; k += 256) {
 #pragma unroll
             for (int j = 0; j < 12; ++j) acc[j] += q[k * 12 + j];
         }
     }
 #pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) dPs[k] = acc[k];
+    for (int k = 0; k < 12; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) sm[wv * 12 + k] = v;
     }
     __syncthreads();
-    if (lane < 16) {
-        const int r = lane >> 2, c = lane & 3;   // d_T[r][c] = sum_i K[i][r] * dP[i][c]
+    if (threadIdx.x < 16) {
+        const int r = threadIdx.x >> 2, c = threadIdx.x & 3;   // d_T[r][c] = sum_i K[i][r] * dP[i][c]
         const float* K = p.K + b * 16;
-        float v = K[0 * 4 + r] * dPs[0 * 4 + c] + K[1 * 4 + r] * dPs[1 * 4 + c] + K[2 * 4 + r] * dPs[2 * 4 + c];
-        p.d_T[f][b * 16 + lane] = v;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float dp = (sm[0 * 12 + i * 4 + c] + sm[1 * 12 + i * 4 + c]) + (sm[2 * 12 + i * 4 + c] + sm[3 * 12 + i * 4 + c]);
+            v = (i == 0) ? K[i * 4 + r] * dp : v + K[i * 4 + r] * dp;
+        }
+        p.d_T[f][b * 16 + threadIdx.x] = v;
+    }
+}
+
+struct DgPlan { int start[DC_MAX_SCALES + 1]; };   // first block of scale s; start[ns] = the two pose blocks
+
+__global__ __launch_bounds__(256) void disp_grad_kernel(PhotoArgs p, DgPlan pl) {
+    __shared__ float reg[DG_RH * DG_RW];                 // full-res footprint
+    __shared__ float hsm[DG_RH * (DG_W / 2)];            // after the x pass: [footprint row][tile column]
+    const int b = blockIdx.y;
+    const int blk = blockIdx.x;
+    if (blk >= pl.start[p.ns]) {
+        pose_grad_block(p, b, blk - pl.start[p.ns], reg);
+    } else if (blk < pl.start[1]) {
+        disp_grad_tile<0>(p, b, blk, reg, hsm);
+    } else if (blk < pl.start[2]) {
+        disp_grad_tile<1>(p, b, blk - pl.start[1], reg, hsm);
+    } else if (blk < pl.start[3]) {
+        disp_grad_tile<2>(p, b, blk - pl.start[2], reg, hsm);
+    } else {
+        disp_grad_tile<3>(p, b, blk - pl.start[3], reg, hsm);
     }
 }
 
@@ -1064,8 +1301,9 @@ __global__ __launch_bounds__(64) void pose_grad_kernel(PhotoArgs p) {
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Carve {
-    size_t idl, pk[3], part_photo, part_smooth, stats, gdup[DC_MAX_SCALES], part_dP, total;
-    int nblk_f, nchunk, nblk_b_img, strips_f, strips_b, rows_f, rows_b, rowblocks_f, rowblocks_b;
+    size_t idl, pk[3], part_photo, part_smooth, stats, gdup[DC_MAX_SCALES], gw[DC_MAX_SCALES], part_dP, total;
+    int nblk_f, nchunk, nblk_b_img, strips_f, strips_b, rows_f, rowblocks_f;
+    int strips_p, rows_g, rows_p, rowblocks_g, rowblocks_p;   // training forward (60-lane strips) / pointwise backward
 };
 
 // Rows a wave marches per block.  Taller blocks spend fewer steps on the halo rows (a block costs rows + halo row-steps),
@@ -1073,11 +1311,17 @@ struct Carve {
 // least 1.5 blocks per resident slot (256 CUs x blocks per CU) keeps the chip full for most of the launch.  (Measured at
 // 192 x 640, B = 12: 64-row blocks -- 396 blocks on 512 slots -- dropped the VALU pipe from 90 % to 67 % busy.)
 static int pick_rows(int H, int strips, int B, int halo, int blocks_per_cu) {
-    static const int cand[] = {16, 24, 32, 48, 64};
+    static const int cand[] = {8, 12, 16, 24, 32, 48, 64};
     const long slots = 256L * blocks_per_cu;
+    if (!halo) {     // pointwise backward: no halo to amortise -- the tallest of {16, 12, 8} that still fills every slot once
+        for (int r : {16, 12, 8})
+            if ((long)strips * ceil_div(H, r) * B >= slots) return r;
+        return 8;
+    }
     int best = 16;
-    long best_work = (long)strips * ceil_div(H, 16) * B * (16 + halo);
+    long best_work = (long)strips * ceil_div(H, best) * B * (best + halo);
     for (int r : cand) {
+        if (r < 16) continue;
         const long blocks = (long)strips * ceil_div(H, r) * B;
         if (2 * blocks < 3 * slots) continue;
         const long work = blocks * (r + halo);
@@ -1092,11 +1336,15 @@ static Carve carve(const dc_photo_desc* d) {
     c.strips_f = ceil_div(d->W, 62);
     c.strips_b = ceil_div(d->W, 60);
     c.rows_f = pick_rows(d->H, c.strips_f, d->B, 2, FWD_BLOCKS_PER_CU);
-    c.rows_b = pick_rows(d->H, c.strips_b, d->B, 4, BWD_BLOCKS_PER_CU);
     c.rowblocks_f = ceil_div(d->H, c.rows_f);
-    c.rowblocks_b = ceil_div(d->H, c.rows_b);
-    c.nblk_f = c.strips_f * c.rowblocks_f * d->B;
-    c.nblk_b_img = c.strips_b * c.rowblocks_b;
+    const bool train = !(d->flags & DC_OPT_NO_GRAD);
+    c.strips_p = ceil_div(d->W, 64);
+    c.rows_g = pick_rows(d->H, c.strips_b, d->B, 4, FWDG_BLOCKS_PER_CU);
+    c.rows_p = pick_rows(d->H, c.strips_p, d->B, 0, BWDG_BLOCKS_PER_CU);
+    c.rowblocks_g = ceil_div(d->H, c.rows_g);
+    c.rowblocks_p = ceil_div(d->H, c.rows_p);
+    c.nblk_f = train ? c.strips_b * c.rowblocks_g * d->B : c.strips_f * c.rowblocks_f * d->B;
+    c.nblk_b_img = c.strips_p * c.rowblocks_p;
     c.nchunk = ceil_div(d->H * d->W, SM_CHUNK);
     size_t off = 0;
     c.idl = off; off += align256(N * 2 * 4);
@@ -1107,6 +1355,10 @@ static Carve carve(const dc_photo_desc* d) {
     for (int s = 0; s < DC_MAX_SCALES; ++s) {
         c.gdup[s] = off;
         if (s < d->num_scales) off += align256(N * 4);
+    }
+    for (int s = 0; s < DC_MAX_SCALES; ++s) {
+        c.gw[s] = off;
+        if (s < d->num_scales && train) off += align256(N * 16);
     }
     c.part_dP = off; off += align256((size_t)d->num_scales * 2 * d->B * c.nblk_b_img * 12 * 4);
     c.total = off;
@@ -1147,6 +1399,7 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
         a.depth[s] = d->depth[s]; a.idsel[s] = d->identity_selection[s];
         for (int f = 0; f < 2; ++f) { a.sample[s][f] = d->sample[s][f]; a.color[s][f] = d->color[s][f]; }
         a.gdup[s] = (float*)(ws + c.gdup[s]);
+        a.gw[s] = (float*)(ws + c.gw[s]);
         if (backward) {
             if (!d->d_disp[s]) return DC_EINVAL;
             a.d_disp[s] = d->d_disp[s];
@@ -1166,7 +1419,9 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
     a.stats = (float*)(ws + c.stats);
     a.part_dP = (float*)(ws + c.part_dP);
     a.nblk_f = c.nblk_f; a.nchunk = c.nchunk; a.nblk_b_img = c.nblk_b_img;
-    a.rows_f = c.rows_f; a.rows_b = c.rows_b;
+    a.rows_f = c.rows_f;
+    a.rows_g = c.rows_g; a.rows_p = c.rows_p;
+    if (backward && (d->flags & DC_OPT_NO_GRAD)) return DC_EINVAL;   // the forward emitted no gradient
     return DC_OK;
 }
 
@@ -1261,10 +1516,26 @@ extern "C" int dc_photo_fwd(const dc_photo_desc* d, void* stream) {
     bool logs = false;
     for (int s = 0; s < a.ns; ++s) logs = logs || a.depth[s] || a.sample[s][0] || a.sample[s][1] || a.color[s][0] || a.color[s][1];
     hipEvent_t pe = prof_begin(0, st);
-    if (logs)
-        hipLaunchKernelGGL(photo_fwd_kernel<true>, dim3(c.strips_f, c.rowblocks_f, a.B), dim3(64 * a.ns), 0, st, a);
-    else
-        hipLaunchKernelGGL(photo_fwd_kernel<false>, dim3(c.strips_f, c.rowblocks_f, a.B), dim3(64 * a.ns), 0, st, a);
+    if (a.flags & DC_OPT_NO_GRAD) {
+        if (logs)
+            hipLaunchKernelGGL(photo_fwd_kernel<true>, dim3(c.strips_f, c.rowblocks_f, a.B), dim3(64 * a.ns), 0, st, a);
+        else
+            hipLaunchKernelGGL(photo_fwd_kernel<false>, dim3(c.strips_f, c.rowblocks_f, a.B), dim3(64 * a.ns), 0, st, a);
+    } else {
+        // the default training configuration (SSIM + L1, min over frames, automasking) runs a specialised instantiation
+        const bool dflt = !(a.flags & (DC_OPT_NO_SSIM | DC_OPT_AVG_REPROJ | DC_OPT_NO_AUTOMASK));
+        bool all_ext = true, none_ext = true;
+        for (int s = 0; s < a.ns; ++s) { all_ext = all_ext && a.noise[s]; none_ext = none_ext && !a.noise[s]; }
+        const dim3 grid(c.strips_b, c.rowblocks_g, a.B), blk(64 * a.ns);
+#define DC_FWDG(LOGS_) \
+        do { \
+            if (dflt && none_ext) hipLaunchKernelGGL((photo_fwdg_kernel<LOGS_, 4>), grid, blk, 0, st, a); \
+            else if (dflt && all_ext) hipLaunchKernelGGL((photo_fwdg_kernel<LOGS_, 12>), grid, blk, 0, st, a); \
+            else hipLaunchKernelGGL((photo_fwdg_kernel<LOGS_, -1>), grid, blk, 0, st, a); \
+        } while (0)
+        if (logs) DC_FWDG(true); else DC_FWDG(false);
+#undef DC_FWDG
+    }
     prof_end(pe, st);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, st, a);
@@ -1279,22 +1550,20 @@ extern "C" int dc_photo_bwd(const dc_photo_desc* d, void* stream) {
     int rc = fill_args(d, a, c, true);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)a.ns * BWD_LDS_PER_WAVE * sizeof(float);
     hipEvent_t pc = prof_begin(3, st);
     hipEvent_t pe = prof_begin(1, st);
-    hipLaunchKernelGGL(photo_bwd_kernel, dim3(c.strips_b, c.rowblocks_b, a.B), dim3(64 * a.ns), lds, st, a);
+    hipLaunchKernelGGL(photo_bwdg_kernel, dim3(c.strips_p, c.rowblocks_p, a.B), dim3(64 * a.ns), 0, st, a);
     prof_end(pe, st);
     DC_CHECK_LAUNCH();
     {
-        int gx = 0, gy = 0;   // widest tile grid over the scales (smaller scales exit early)
-        for (int sc = 0; sc < a.ns; ++sc) {
-            gx = std::max(gx, ceil_div(a.ws[sc], DG_W >> sc));
-            gy = std::max(gy, ceil_div(a.hs[sc], DG_H >> sc));
+        DgPlan pl;
+        int nb = 0;
+        for (int sc = 0; sc <= DC_MAX_SCALES; ++sc) {
+            pl.start[sc] = nb;
+            if (sc < a.ns) nb += ceil_div(a.ws[sc], DG_W >> sc) * ceil_div(a.hs[sc], (sc == 0 ? DG_H0 : DG_H >> sc));
         }
-        hipLaunchKernelGGL(disp_grad_kernel, dim3(gx, gy, a.ns * a.B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(disp_grad_kernel, dim3(nb + 2, a.B), dim3(256), 0, st, a, pl);
     }
-    DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pose_grad_kernel, dim3(a.B, 2), dim3(64), 0, st, a);
     prof_end(pc, st);
     DC_CHECK_LAUNCH();
     return DC_OK;

@@ -491,13 +491,23 @@ static inline size_t wino_uhat_bytes(int Ci, int Co) {
 // -- and dc_wino_cache_invalidate when the step's backward is done.  Between the two, wino_launch takes U from the
 // cache; a variant (dgrad, MT) it has not met yet is transformed in place as before and joins the next refresh.
 struct WcVariant { int dgrad, MT, Mp, Kp; float* buf; bool fresh, in_table; };
-struct WcEntry { const float* w; int Ci, Co; std::vector<WcVariant> v; };
+struct WcEntry { const float* w; int Ci, Co, owner; std::vector<WcVariant> v; };
+// One descriptor table PER OWNER (= per model / Trainer).  A refresh transforms -- and a captured hipGraph replays the
+// transform of -- the owner's own weights only, which the owner keeps alive; weights of another owner never enter its
+// table.  (Round 3 had one table for the whole process: a graph captured, or a refresh skipped because the stream was
+// capturing, while the table still named the weights of a model that had since been collected read freed memory -- a GPU
+// page fault, which the HSA runtime turns into abort() of the process.  See DESIGN.md "The r3s abort".)
+struct WcOwner {
+    int id;
+    bool valid = false, dirty = true;
+    WinoWDesc* table = nullptr;
+    int* b2d = nullptr;
+    int table_n = 0, blocks = 0;
+};
 static std::mutex g_wc_mu;
 static std::vector<WcEntry> g_wc;
-static bool g_wc_valid = false, g_wc_dirty = true;
-static WinoWDesc* g_wc_table = nullptr;
-static int* g_wc_b2d = nullptr;
-static int g_wc_table_cap = 0, g_wc_table_n = 0, g_wc_blocks = 0, g_wc_b2d_cap = 0;
+static std::vector<WcOwner> g_wc_owners;
+static int g_wc_next_owner = 1;
 // Device buffers a captured hipGraph may still name in its kernel arguments (descriptor tables that were outgrown, the
 // variant buffers of unregistered weights): parked here, released only by dc_wino_cache_clear().
 static std::vector<void*> g_wc_retired;
@@ -507,6 +517,11 @@ static bool wc_capturing(hipStream_t st) {
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
     return cs != hipStreamCaptureStatusNone;
 }
+static WcOwner* wc_owner(int id) {
+    for (auto& o : g_wc_owners)
+        if (o.id == id) return &o;
+    return nullptr;
+}
 
 // -> cached U for this launch, or nullptr (then the caller transforms into its workspace).  Nothing is allocated while
 // `st` is being captured (hipMalloc is illegal there): an unseen variant is then transformed per launch, as before.
@@ -515,13 +530,15 @@ static const float* wc_lookup(const float* w, int Ci, int Co, bool dgrad, int MT
     for (auto& e : g_wc) {
         if (e.w != w) continue;
         if (e.Ci != Ci || e.Co != Co) return nullptr;
+        WcOwner* o = wc_owner(e.owner);
+        if (!o) return nullptr;
         for (auto& v : e.v)
-            if (v.dgrad == (int)dgrad && v.MT == MT) return (g_wc_valid && v.fresh) ? v.buf : nullptr;
+            if (v.dgrad == (int)dgrad && v.MT == MT) return (o->valid && v.fresh) ? v.buf : nullptr;
         if (wc_capturing(st)) return nullptr;
         WcVariant v{(int)dgrad, MT, Mp, Kp, nullptr, false, false};
         if (hipMalloc((void**)&v.buf, (size_t)Mp * Kp * 16 * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         e.v.push_back(v);
-        g_wc_dirty = true;
+        o->dirty = true;
         return nullptr;
     }
     return nullptr;
@@ -759,73 +776,103 @@ extern "C" int dc_conv_profile_collect(int kind, double* ms, double* algorithmic
     return DC_OK;
 }
 
-extern "C" int dc_wino_cache_register(const float* weight, int Ci, int Co) {
+extern "C" int dc_wino_cache_new_owner(void) {
+    std::lock_guard<std::mutex> lk(g_wc_mu);
+    WcOwner o;
+    o.id = g_wc_next_owner++;
+    g_wc_owners.push_back(o);
+    return o.id;
+}
+
+extern "C" int dc_wino_cache_register(int owner, const float* weight, int Ci, int Co) {
     if (!weight || Ci <= 0 || Co <= 0) return DC_EINVAL;
     std::lock_guard<std::mutex> lk(g_wc_mu);
+    WcOwner* o = wc_owner(owner);
+    if (!o) return DC_EINVAL;
     for (auto& e : g_wc)
-        if (e.w == weight) return (e.Ci == Ci && e.Co == Co) ? DC_OK : DC_EINVAL;
-    g_wc.push_back(WcEntry{weight, Ci, Co, {}});
+        if (e.w == weight) return (e.Ci == Ci && e.Co == Co && e.owner == owner) ? DC_OK : DC_EINVAL;
+    g_wc.push_back(WcEntry{weight, Ci, Co, owner, {}});
+    o->dirty = true;
     return DC_OK;
 }
 
-extern "C" int dc_wino_cache_unregister(const float* weight) {
+// Forget an owner and every weight it registered.  Its tables and variant buffers are parked, not freed: a captured
+// hipGraph of the owner may still name them.
+extern "C" int dc_wino_cache_release_owner(int owner) {
     std::lock_guard<std::mutex> lk(g_wc_mu);
-    for (size_t i = 0; i < g_wc.size(); ++i)
-        if (g_wc[i].w == weight) {
+    for (size_t i = 0; i < g_wc.size();) {
+        if (g_wc[i].owner == owner) {
             for (auto& v : g_wc[i].v)
-                if (v.buf) g_wc_retired.push_back(v.buf);      // a captured graph of the former owner may still write it
+                if (v.buf) g_wc_retired.push_back(v.buf);
             g_wc.erase(g_wc.begin() + i);
-            g_wc_dirty = true;
-            return DC_OK;
+        } else {
+            ++i;
+        }
+    }
+    for (size_t i = 0; i < g_wc_owners.size(); ++i)
+        if (g_wc_owners[i].id == owner) {
+            if (g_wc_owners[i].table) g_wc_retired.push_back(g_wc_owners[i].table);
+            if (g_wc_owners[i].b2d) g_wc_retired.push_back(g_wc_owners[i].b2d);
+            g_wc_owners.erase(g_wc_owners.begin() + i);
+            break;
         }
     return DC_OK;
 }
 
-extern "C" int dc_wino_cache_refresh(void* stream) {
+extern "C" int dc_wino_cache_refresh(int owner, void* stream) {
     std::lock_guard<std::mutex> lk(g_wc_mu);
     hipStream_t st = (hipStream_t)stream;
+    WcOwner* o = wc_owner(owner);
+    if (!o) return DC_EINVAL;
     // The descriptor upload allocates, synchronises and copies: none of it is legal on a capturing stream.  A capture that
-    // meets a dirty registry replays the table as it stands (variants outside it keep transforming per launch).
-    if (g_wc_dirty && !wc_capturing(st)) {
+    // meets a dirty registry replays the owner's table as it stands (variants outside it keep transforming per launch);
+    // every weight the table names belongs to this owner and lives as long as it does.
+    if (o->dirty && !wc_capturing(st)) {
         std::vector<WinoWDesc> host;
         std::vector<int> b2d;
         int blocks = 0;
-        for (auto& e : g_wc)
+        for (auto& e : g_wc) {
+            if (e.owner != owner) continue;
             for (auto& v : e.v) {
                 const int nb = wino_wblocks(v.Mp, v.Kp);
                 b2d.insert(b2d.end(), nb, (int)host.size());
                 host.push_back(WinoWDesc{e.w, v.buf, e.Co, e.Ci, v.MT, v.Mp, v.Kp, v.dgrad, blocks, 0});
                 blocks += nb;
             }
+        }
         // A rebuilt table goes to fresh memory and the old one is retired, not freed or rewritten: a captured graph holds
         // the old address and block count and must keep seeing the old contents.
-        if (g_wc_b2d) g_wc_retired.push_back(g_wc_b2d);
-        if (g_wc_table) g_wc_retired.push_back(g_wc_table);
-        g_wc_b2d = nullptr; g_wc_table = nullptr; g_wc_table_n = g_wc_blocks = 0;
-        g_wc_b2d_cap = blocks; g_wc_table_cap = (int)host.size();
-        if (blocks > 0 && hipMalloc((void**)&g_wc_b2d, sizeof(int) * blocks) != hipSuccess) { g_wc_b2d = nullptr; return DC_ELAUNCH; }
-        if (!host.empty() && hipMalloc((void**)&g_wc_table, sizeof(WinoWDesc) * host.size()) != hipSuccess) { g_wc_table = nullptr; return DC_ELAUNCH; }
+        if (o->b2d) g_wc_retired.push_back(o->b2d);
+        if (o->table) g_wc_retired.push_back(o->table);
+        o->b2d = nullptr; o->table = nullptr; o->table_n = o->blocks = 0;
+        if (blocks > 0 && hipMalloc((void**)&o->b2d, sizeof(int) * blocks) != hipSuccess) { o->b2d = nullptr; return DC_ELAUNCH; }
+        if (!host.empty() && hipMalloc((void**)&o->table, sizeof(WinoWDesc) * host.size()) != hipSuccess) { o->table = nullptr; return DC_ELAUNCH; }
         // synchronous upload (the descriptor list only changes while the variants of a model are still being met)
         if (!host.empty() && hipStreamSynchronize(st) != hipSuccess) return DC_ELAUNCH;
-        if (!host.empty() && hipMemcpy(g_wc_table, host.data(), sizeof(WinoWDesc) * host.size(), hipMemcpyHostToDevice) != hipSuccess) return DC_ELAUNCH;
-        if (!b2d.empty() && hipMemcpy(g_wc_b2d, b2d.data(), sizeof(int) * b2d.size(), hipMemcpyHostToDevice) != hipSuccess) return DC_ELAUNCH;
-        g_wc_table_n = (int)host.size(); g_wc_blocks = blocks; g_wc_dirty = false;
+        if (!host.empty() && hipMemcpy(o->table, host.data(), sizeof(WinoWDesc) * host.size(), hipMemcpyHostToDevice) != hipSuccess) return DC_ELAUNCH;
+        if (!b2d.empty() && hipMemcpy(o->b2d, b2d.data(), sizeof(int) * b2d.size(), hipMemcpyHostToDevice) != hipSuccess) return DC_ELAUNCH;
+        o->table_n = (int)host.size(); o->blocks = blocks; o->dirty = false;
         for (auto& e : g_wc)
-            for (auto& v : e.v) v.in_table = true;
+            if (e.owner == owner)
+                for (auto& v : e.v) v.in_table = true;
     }
-    if (g_wc_table_n > 0 && g_wc_blocks > 0) {
-        hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(g_wc_blocks), dim3(256), 0, st, (const WinoWDesc*)g_wc_table, (const int*)g_wc_b2d, PSK);
+    if (o->table_n > 0 && o->blocks > 0) {
+        hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(o->blocks), dim3(256), 0, st, (const WinoWDesc*)o->table, (const int*)o->b2d, PSK);
         DC_CHECK_LAUNCH();
     }
     for (auto& e : g_wc)
-        for (auto& v : e.v) v.fresh = v.in_table;
-    g_wc_valid = true;
+        if (e.owner == owner)
+            for (auto& v : e.v) v.fresh = v.in_table;
+    o->valid = true;
     return DC_OK;
 }
 
-extern "C" void dc_wino_cache_invalidate(void) {
+extern "C" int dc_wino_cache_invalidate(int owner) {
     std::lock_guard<std::mutex> lk(g_wc_mu);
-    g_wc_valid = false;
+    WcOwner* o = wc_owner(owner);
+    if (!o) return DC_EINVAL;
+    o->valid = false;
+    return DC_OK;
 }
 
 extern "C" int dc_wino_cache_clear(void) {
@@ -839,10 +886,11 @@ extern "C" int dc_wino_cache_clear(void) {
     for (void* q : g_wc_retired)
         if (hipFree(q) != hipSuccess) rc = DC_ELAUNCH;
     g_wc_retired.clear();
-    if (g_wc_table && hipFree(g_wc_table) != hipSuccess) rc = DC_ELAUNCH;
-    if (g_wc_b2d && hipFree(g_wc_b2d) != hipSuccess) rc = DC_ELAUNCH;
-    g_wc_table = nullptr; g_wc_b2d = nullptr; g_wc_table_cap = g_wc_table_n = g_wc_blocks = g_wc_b2d_cap = 0;
-    g_wc_valid = false; g_wc_dirty = true;
+    for (auto& o : g_wc_owners) {
+        if (o.table && hipFree(o.table) != hipSuccess) rc = DC_ELAUNCH;
+        if (o.b2d && hipFree(o.b2d) != hipSuccess) rc = DC_ELAUNCH;
+    }
+    g_wc_owners.clear();
     return rc;
 }
 

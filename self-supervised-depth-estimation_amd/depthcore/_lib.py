@@ -11,13 +11,19 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DEPTHCORE_LIB", os.path.join(_HERE, "libdepthcore.so"))   # env: tuning sweeps only
+PRODUCT_LIB = os.path.join(_HERE, "libdepthcore.so")
+# DEPTHCORE_LIB: a tuning / ablation build (tools/build_variant.sh -> build/variants/<name>/, outside the package) for the
+# sweep scripts under tools/ ONLY.  bench.py, __graft_entry__.smoke() and the tests refuse to run on anything but the
+# product library (IS_VARIANT).
+LIB_PATH = os.environ.get("DEPTHCORE_LIB") or PRODUCT_LIB
+IS_VARIANT = os.path.realpath(LIB_PATH) != os.path.realpath(PRODUCT_LIB)
 MAX_SCALES = 4
 
 OPT_NO_AUTOMASK = 1
 OPT_AVG_REPROJ = 2
 OPT_NO_SSIM = 4
 OPT_ALIGN_CORNERS = 8
+OPT_NO_GRAD = 16
 PREC_F32, PREC_BF16 = 0, 1
 
 _ERR = {-1: "DC_EINVAL (bad shape / null pointer / unsupported option)",
@@ -136,10 +142,12 @@ def _sig(lib):
         "dc_gru_residual_bwd": (i, [p, p, i, z, p]),
         "dc_set_matrix_precision": (i, [i]),
         "dc_get_matrix_precision": (i, []),
-        "dc_wino_cache_register": (i, [p, i, i]),
-        "dc_wino_cache_unregister": (i, [p]),
-        "dc_wino_cache_refresh": (i, [p]),
-        "dc_wino_cache_invalidate": (None, []),
+        "dc_clear_error": (i, []),
+        "dc_wino_cache_new_owner": (i, []),
+        "dc_wino_cache_register": (i, [i, p, i, i]),
+        "dc_wino_cache_release_owner": (i, [i]),
+        "dc_wino_cache_refresh": (i, [i, p]),
+        "dc_wino_cache_invalidate": (i, [i]),
         "dc_wino_cache_clear": (i, []),
         "dc_wino_cache_variants": (i, []),
         "dc_resample_ksize": (i, [i, i]),

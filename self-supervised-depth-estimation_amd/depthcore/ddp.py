@@ -173,6 +173,12 @@ class GradBuckets:
             torch._foreach_mul_(self.flat, 1.0 / self.world)
         for bi, plist in enumerate(self.buckets):
             for p, v in zip(plist, self.views[bi]):
+                if not p.requires_grad:
+                    # frozen after construction (Trainer.freeze_hidden_states): its slice is exchanged as zeros on every
+                    # rank, but `.grad` stays None so that Adam skips it -- step count and moments untouched, exactly as
+                    # at world size 1 (a zero gradient would still move it along its decaying first moment)
+                    p.grad = None
+                    continue
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                     p.grad = v
 

@@ -121,7 +121,7 @@ class PhotoConfig:
         self.extras = {}          # filled by forward: argmin maps + optional log tensors
 
 
-def _fill_desc(cfg, T0, T1, disps):
+def _fill_desc(cfg, T0, T1, disps, no_grad=False):
     B, _, H, W = cfg.target.shape
     ns = len(disps)
     if ns < 1 or ns > _lib.MAX_SCALES:
@@ -130,7 +130,7 @@ def _fill_desc(cfg, T0, T1, disps):
         raise _lib.DepthcoreError("images must be (B,3,H,W)")
     d = PhotoDesc()
     d.B, d.H, d.W, d.num_scales = B, H, W, ns
-    d.flags = cfg.flags
+    d.flags = cfg.flags | (_lib.OPT_NO_GRAD if no_grad else 0)
     d.min_depth, d.max_depth, d.smoothness = cfg.min_depth, cfg.max_depth, cfg.smoothness
     d.target = ptr(cfg.target)
     for f in range(2):
@@ -170,7 +170,9 @@ class _PhotoLoss(torch.autograd.Function):
         dev = cfg.target.device
         B, _, H, W = cfg.target.shape
         ns = len(disps)
-        d = _fill_desc(cfg, T0, T1, disps)
+        # evaluation (nothing requires a gradient): the forward skips the gradient emission and its 24 B/pixel/scale
+        ctx.no_grad = not any(ctx.needs_input_grad)
+        d = _fill_desc(cfg, T0, T1, disps, ctx.no_grad)
         wsz = L.dc_photo_workspace(ctypes.byref(d))
         ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
         d.workspace, d.workspace_bytes = ws.data_ptr(), wsz
@@ -204,7 +206,7 @@ class _PhotoLoss(torch.autograd.Function):
         L = _lib.lib()
         cfg = ctx.cfg
         T0, T1, *disps = ctx.saved_tensors
-        d = _fill_desc(cfg, T0, T1, disps)
+        d = _fill_desc(cfg, T0, T1, disps, ctx.no_grad)
         d.workspace, d.workspace_bytes = ctx.ws.data_ptr(), ctx.ws.numel()
         g = _c(g_losses.to(torch.float32))
         d.g_losses = ptr(g)
@@ -785,43 +787,44 @@ def wino_conv3x3(x, weight, fork=None):
 
 
 # ---- transformed-weight cache of the Winograd kernels (include/depthcore.h: dc_wino_cache_*) ----------------------
-def _wino_unregister(addresses):
+def _wino_release(owner):
     """weakref.finalize target: runs when a WinoWeightCache is closed or collected (never touches the dead object)."""
     try:
-        L = _lib.lib()
-        for a in addresses:
-            L.dc_wino_cache_unregister(a)
+        _lib.lib().dc_wino_cache_release_owner(owner)
     except Exception:
         pass
 
 
 class WinoWeightCache:
-    """A model's registrations in libdepthcore's Winograd weight cache (one per Trainer).
+    """A model's registrations in libdepthcore's Winograd weight cache (one owner per Trainer).
 
     `refresh()` at the start of a training step transforms every registered 3x3 weight in one launch; the step's
     convolutions (forward, data gradient, and every frame of the sequence models) then skip their per-launch transform;
     `invalidate()` once the backward is done, before the optimiser rewrites the weights.
 
-    The registry is shared by all caches of the process: constructing a second one never frees what the first registered,
-    so a hipGraph captured by the first owner keeps replaying on valid buffers; `close()` (also run when the object is
-    collected) unregisters this owner's weights only, and their device buffers are parked until `clear_all()`."""
+    Every cache object is its own OWNER in the library: its refresh launch (and a hipGraph that captured it) reads this
+    object's weights only, which `_keep` holds alive for as long as the owner exists.  Constructing, closing or garbage-
+    collecting another cache can therefore neither free nor rewrite anything a captured graph of this one reads; `close()`
+    (also run when the object is collected) releases this owner only, and its device buffers are parked until `clear_all()`."""
 
     def __init__(self, params):
         L = _lib.lib()
         self._keep = []
+        self._owner = int(L.dc_wino_cache_new_owner())
         for p_ in params:
             if p_.dim() == 4 and tuple(p_.shape[2:]) == (3, 3) and p_.is_cuda and p_.dtype == torch.float32 and p_.is_contiguous():
-                check(L.dc_wino_cache_register(p_.data_ptr(), int(p_.shape[1]), int(p_.shape[0])), "dc_wino_cache_register")
+                check(L.dc_wino_cache_register(self._owner, p_.data_ptr(), int(p_.shape[1]), int(p_.shape[0])),
+                      "dc_wino_cache_register")
                 self._keep.append(p_)           # the registry holds raw addresses: keep the tensors alive with it
-        self._fin = weakref.finalize(self, _wino_unregister, [p_.data_ptr() for p_ in self._keep])
+        self._fin = weakref.finalize(self, _wino_release, self._owner)
 
     def refresh(self):
         if self._fin.alive and self._keep:
-            check(_lib.lib().dc_wino_cache_refresh(stream(self._keep[0])), "dc_wino_cache_refresh")
+            check(_lib.lib().dc_wino_cache_refresh(self._owner, stream(self._keep[0])), "dc_wino_cache_refresh")
 
     def invalidate(self):
         if self._fin.alive:
-            _lib.lib().dc_wino_cache_invalidate()
+            _lib.lib().dc_wino_cache_invalidate(self._owner)
 
     def variants(self):
         """cached (weight, pass, tile layout) variants in the whole registry (0 once every owner is closed)."""

@@ -120,6 +120,25 @@ class Adam(torch.optim.Optimizer):
         return loss
 
     # ---- checkpoints -----------------------------------------------------------------------------------------------------
+    def state_dict(self):
+        """torch's layout, and the flags `torch.optim.Adam(params, lr)` would have written: `capturable` is how THIS class
+        keeps its step counts (device floats), not a property of the checkpoint -- a reference-side `optim.Adam` that loads
+        adam.pth must not inherit it (it would take torch's slower capturable path on the GPU and refuse CPU parameters).
+        The step counts travel as CPU scalars, as torch's non-capturable Adam stores them."""
+        sd = super().state_dict()
+        groups = []
+        for g in sd["param_groups"]:
+            g = dict(g)
+            g["capturable"], g["foreach"], g["fused"] = False, None, None
+            groups.append(g)
+        state = {}
+        for k, st in sd["state"].items():
+            st = dict(st)
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().to("cpu", torch.float32).clone()
+            state[k] = st
+        return {"state": state, "param_groups": groups}
+
     def load_state_dict(self, state_dict):
         """Accepts torch.optim.Adam's files (and its own).  The loaded moments are copied into the flat buffers at the next
         step (the base class replaces the state tensors; _build re-homes them)."""

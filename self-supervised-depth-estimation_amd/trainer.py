@@ -91,12 +91,22 @@ class Trainer:
         self.models = {}
         # weights_init = "pretrained" (the reference's CLI default, also found in every opt.json it writes) means the
         # torchvision ImageNet download there (networks/resnet_encoder.py:53).  No network here: `opt.imagenet_weights`
-        # (path of a torchvision resnet{N}-*.pth) supplies them; with `load_weights_folder` set the initial values are
-        # overwritten by load_model() anyway and a scratch init stands in; otherwise ResnetEncoder refuses.
-        pretrained = self.opt.weights_init == "pretrained"
-        if pretrained:
-            pretrained = getattr(self.opt, "imagenet_weights", None) or (not getattr(self.opt, "load_weights_folder", None))
-        self.models["encoder"] = networks.ResnetEncoder(self.opt.num_layers, pretrained)
+        # (path of a torchvision resnet{N}-*.pth) supplies them.  Without it an encoder may start from a scratch init ONLY
+        # if load_model() is going to overwrite it -- its name is in `models_to_load` AND its .pth exists in
+        # `load_weights_folder`; decided per encoder (a fine-tune run that loads encoder + depth only must still give the
+        # pose encoder its ImageNet weights, as the reference does); otherwise ResnetEncoder refuses (pretrained=True).
+        def _init_for(name):
+            if self.opt.weights_init != "pretrained":
+                return False
+            iw = getattr(self.opt, "imagenet_weights", None)
+            if iw:
+                return iw
+            folder = getattr(self.opt, "load_weights_folder", None)
+            if folder and name in (self.opt.models_to_load or []) and \
+                    os.path.isfile(os.path.join(os.path.expanduser(folder), "{}.pth".format(name))):
+                return False                                     # overwritten by load_model() below
+            return True                                          # -> ResnetEncoder raises: no download, no silent scratch
+        self.models["encoder"] = networks.ResnetEncoder(self.opt.num_layers, _init_for("encoder"))
         self.models["depth"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, self.opt.scales)
         if self.opt.fusion:                                      # trainer_fusion_v3.py:74
             self.models["fusion"] = networks.Fusion_v3(attention=not self.opt.disable_attention)
@@ -104,7 +114,7 @@ class Trainer:
             self.models["gru"] = networks.ConvGRUBlocks_v5(kernel_size=(3, 3), bias=True, device="cpu", height=self.opt.height,
                                                            width=self.opt.width,
                                                            num_ch_enc=tuple(int(c) for c in self.models["encoder"].num_ch_enc))
-        self.models["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, pretrained,
+        self.models["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, _init_for("pose_encoder"),
                                                              num_input_images=self.num_pose_frames)
         self.models["pose"] = networks.PoseDecoder(self.models["pose_encoder"].num_ch_enc, num_input_features=1,
                                                    num_frames_to_predict_for=2)
@@ -170,7 +180,7 @@ class Trainer:
         for cell in self.models["gru"].cells():
             cell.h0_layer1.requires_grad = False
             cell.h0_layer1.grad = None
-        self._graphs, self._graph, self._graph_warm = {}, None, {}
+        self.reset_graphs()
 
     def start_epoch(self, epoch):
         """Per-epoch hooks of the reference's train loops: trainer_gru.py:295 (`(epoch + 1) == h_s_epoch`)."""
@@ -434,6 +444,8 @@ class Trainer:
         adam = os.path.join(folder, "adam.pth")
         if os.path.isfile(adam):
             self.model_optimizer.load_state_dict(torch.load(adam, map_location=self.device))
+        # a captured step names the optimiser's moment buffers and step counts (re-homed by load_state_dict): re-capture
+        self.reset_graphs()
 
     # ------------------------------------------------------------------ trainer.py:233-237
     GRAPH_WARMUP = 3      # eager steps before a capture: lazy allocations, LDS attributes, the weight cache's variants
@@ -443,6 +455,8 @@ class Trainer:
             return self._train_step_eager(inputs)
         shapes = tuple((k, tuple(v.shape)) for k, v in inputs.items())
         key = (shapes, tuple(g["lr"] for g in self.model_optimizer.param_groups))
+        if key in self._graphs and self._graphs[key] is None:      # a capture of this shape failed before: eager
+            return self._eager_on_graph_stream(inputs)
         entry = self._graphs.get(key)
         if entry is None:
             # Everything a capture will see must already have happened on a NON-default stream: autograd binds each
@@ -458,17 +472,36 @@ class Trainer:
             warm = self._graph_warm.get(shapes, 0)
             if warm < self.GRAPH_WARMUP:
                 self._graph_warm[shapes] = warm + 1
-                gs.wait_stream(cur)
-                with torch.cuda.stream(gs):
-                    out = self._train_step_eager(inputs)
-                cur.wait_stream(gs)
-                return out
-            # capture: records the launches of one step (both streams, backward, Adam) without running them
+                return self._eager_on_graph_stream(inputs)
+            # capture: records the launches of one step (both streams, backward, Adam) without running them.
+            # torch.cuda.graph() runs gc.collect() + empty_cache() on entry; a model that died in a reference cycle is
+            # finalised there -- INSIDE the capture, when nothing may allocate, copy or rebuild a table any more.  Collect
+            # first, so that every finaliser (weight-cache owners, workspaces) has run while the stream is still eager.
+            import gc
+            gc.collect()
+            self._evict_graphs(key)
             static_in = {k: v.clone() for k, v in inputs.items()}
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=gs):
-                static_out = self._train_step_eager(static_in)
+            step0 = self.step
+            stream0 = torch.cuda.current_stream(self.device)
+            try:
+                with torch.cuda.graph(g, stream=gs):
+                    static_out = self._train_step_eager(static_in)
+            except Exception as e:       # a launch refused inside the capture, or the capture was invalidated
+                # Nothing of a captured step has run (capture records, it does not execute): host state is rolled back, the
+                # shape is marked eager-only and the step is done eagerly -- a failed capture costs speed, never the process.
+                import warnings
+                from depthcore import _lib
+                self.step = step0
+                self._graphs[key] = None
+                self._graph_failed = getattr(self, "_graph_failed", 0) + 1
+                torch.cuda.set_stream(stream0)          # (torch.cuda.graph.__exit__ does not restore it when capture_end raises)
+                torch.cuda.synchronize(self.device)
+                _lib.lib().dc_clear_error()             # the invalidated capture's error code is not the next launch's
+                warnings.warn("hip_graph: capture of the training step failed (%s: %s); this input shape runs eagerly"
+                              % (type(e).__name__, e))
+                return self._eager_on_graph_stream(inputs)
             entry = self._graphs[key] = (g, static_in, static_out)
             self.step -= 1                      # (the recorded step has not run yet: the replay below is that step)
         else:
@@ -480,9 +513,43 @@ class Trainer:
         self.step += 1
         return entry[2]                       # static tensors: rewritten by every replay of this graph
 
+    def _eager_on_graph_stream(self, inputs):
+        gs, cur = self._graph_stream, torch.cuda.current_stream(self.device)
+        gs.wait_stream(cur)
+        with torch.cuda.stream(gs):
+            out = self._train_step_eager(inputs)
+        cur.wait_stream(gs)
+        return out
+
+    MAX_GRAPHS = 3        # captured steps kept (each holds a private pool of a whole step's activations and gradients)
+
+    def _evict_graphs(self, new_key):
+        """Before a new capture: drop graphs that can never be replayed again (their learning rate is baked into the Adam
+        launch and differs from the optimiser's current one) and keep at most MAX_GRAPHS - 1 others, oldest first."""
+        lr = new_key[1]
+        for k in [k for k in self._graphs if k[1] != lr]:
+            self._drop_graph(k)
+        live = [k for k, v in self._graphs.items() if v is not None]
+        while len(live) >= self.MAX_GRAPHS:
+            self._drop_graph(live.pop(0))
+
+    def _drop_graph(self, key):
+        entry = self._graphs.pop(key, None)
+        if entry is not None:
+            if self._graph is entry[0]:
+                self._graph = None
+            entry[0].reset()
+
+    def reset_graphs(self):
+        """Forget every captured step (their kernel arguments name optimiser state, weights-cache tables and the autograd
+        graph of the moment of capture): after load_model(), a rebuilt optimiser, a change of `requires_grad`."""
+        for k in list(self._graphs):
+            self._drop_graph(k)
+        self._graphs, self._graph, self._graph_warm = {}, None, {}
+
     def close(self):
         """Drop the captured graphs (they name the weight cache's buffers) and this trainer's cache registrations."""
-        self._graphs, self._graph = {}, None
+        self.reset_graphs()
         self.wino_cache.close()
 
     def _train_step_eager(self, inputs):

@@ -15,6 +15,10 @@ def pytest_configure(config):
     # the CPU oracle works on small tensors: a GPU box's 100+ hardware threads only add scheduling overhead
     import torch
     torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    # the tests judge the product library, never a tuning / ablation build (tools/build_variant.sh)
+    from depthcore import _lib
+    if _lib.IS_VARIANT:
+        raise pytest.UsageError("DEPTHCORE_LIB=%s: the tests only run on the product libdepthcore.so" % _lib.LIB_PATH)
 
 
 @pytest.fixture(scope="session")

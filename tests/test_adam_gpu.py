@@ -68,6 +68,7 @@ def test_state_dict_interchanges_with_torch_adam_both_ways():
     a2 = [torch.nn.Parameter(p.detach().clone()) for p in b]
     b2 = [torch.nn.Parameter(p.detach().clone()) for p in a]
     oa2, ob2 = Adam(a2, 1.0), torch.optim.Adam(b2, 1.0)
+    sa_file = copy.deepcopy(sa)          # (torch's load_state_dict adopts CPU `step` tensors without copying them)
     oa2.load_state_dict(sb)
     ob2.load_state_dict(sa)
     assert oa2.param_groups[0]["lr"] == pytest.approx(3e-4) and ob2.param_groups[0]["lr"] == pytest.approx(3e-4)
@@ -82,6 +83,17 @@ def test_state_dict_interchanges_with_torch_adam_both_ways():
         assert _rel(a2[i].detach(), b[i].detach()) <= 2e-6, i       # ours continued from torch's file == torch continued
         assert _rel(b2[i].detach(), a[i].detach()) <= 2e-6, i       # torch continued from our file == ours continued
         assert float(oa2.state[a2[i]]["step"]) == 4.0
+    # the file carries the flags torch.optim.Adam(params, lr) would have written, not this class's internals: a reference-side
+    # optimiser on CPU parameters loads it and steps (capturable=True would make torch refuse CPU parameters)
+    assert sa_file["param_groups"][0]["capturable"] is False and sa_file["param_groups"][0]["fused"] is None
+    assert all(st["step"].device.type == "cpu" for st in sa_file["state"].values())
+    c = [torch.nn.Parameter(p.detach().cpu().clone()) for p in b2]
+    oc = torch.optim.Adam(c, 1.0)
+    oc.load_state_dict(sa_file)
+    for p, g in zip(c, gs):
+        p.grad = g.clone()
+    oc.step()
+    assert all(float(oc.state[p]["step"]) == 4.0 for p in c)
 
 
 def test_trainer_steps_with_depthcore_adam_match_torch_adam():

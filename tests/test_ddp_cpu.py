@@ -82,7 +82,19 @@ def _worker(rank, world, port, q):
         assert m.scale.grad.data_ptr() == m.scale._dc_grad_slot.view.data_ptr()
     assert all(p.grad.data_ptr() == p._dc_grad_slot.view.data_ptr() for b in gb.buckets for p in b)
     assert m.fc.weight.grad is None
-    q.put((rank, [p.grad.numpy().copy() for n, p in m.named_parameters() if not n.startswith("fc.")], list(gb.launch_order)))
+    grads_step1 = [p.grad.numpy().copy() for n, p in m.named_parameters() if not n.startswith("fc.")]
+    # a parameter frozen AFTER the buckets were built (Trainer.freeze_hidden_states at world > 1): its slice still travels
+    # (zeros, same collective sequence on every rank) but `.grad` must stay None, or Adam would keep moving it
+    m.scale.requires_grad = False
+    m.scale.grad = None
+    gb.zero()
+    torch.manual_seed(300 + rank)
+    m(torch.randn(2, 3, 8, 8), use_aux=(rank == 0)).square().mean().backward()
+    gb.finish()
+    assert m.scale.grad is None
+    assert m.c1.weight.grad is not None and m.c1.weight.grad.data_ptr() == m.c1.weight._dc_grad_slot.view.data_ptr()
+    assert float(m.scale._dc_grad_slot.view.abs().max()) == 0.0
+    q.put((rank, grads_step1, list(gb.launch_order)))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -114,3 +114,31 @@ def test_imagenet_weights_are_tiled_and_divided_for_stacked_frames():
     assert torch.equal(depth_enc.encoder.conv1.weight, tv["conv1.weight"])
     with pytest.raises(RuntimeError):
         networks.ResnetEncoder(18, True)
+
+
+def test_pretrained_init_is_decided_per_encoder_when_fine_tuning(tmp_path):
+    """weights_init="pretrained" (the reference's CLI default) without `imagenet_weights`: an encoder may start from a scratch
+    init only if load_model() is going to overwrite it.  A fine-tune run that loads encoder + depth must NOT silently leave the
+    pose encoder at a random init (the reference gives it ImageNet weights, networks/resnet_encoder.py:52-57): it is refused."""
+    import trainer as T
+    a = T.Trainer(T.default_options(batch_size=1, height=64, width=96), device="cpu", seed=1)
+    src, want = _reference_shaped_checkpoint(str(tmp_path / "theirs"), a, 7)
+    kw = dict(batch_size=1, height=64, width=96, load_weights_folder=src, weights_init="pretrained")
+    # every model is in the folder and in models_to_load: scratch stand-ins are fine, load_model() overwrites them
+    b = T.Trainer(T.default_options(**kw), device="cpu", seed=2)
+    assert torch.equal(b.models["pose_encoder"].state_dict()["encoder.conv1.weight"], want["pose_encoder"]["encoder.conv1.weight"])
+    # encoder + depth only: the pose encoder would keep a random init -> refused unless the ImageNet file is given
+    with pytest.raises(RuntimeError):
+        T.Trainer(T.default_options(models_to_load=["encoder", "depth"], **kw), device="cpu", seed=2)
+    # a listed model whose file is missing is not a stand-in either
+    os.remove(os.path.join(src, "pose_encoder.pth"))
+    with pytest.raises(RuntimeError):
+        T.Trainer(T.default_options(**kw), device="cpu", seed=2)
+    from networks.resnet_encoder import ResNetTrunk
+    torch.manual_seed(0)
+    tv = str(tmp_path / "resnet18-stand-in.pth")
+    torch.save(ResNetTrunk(18, 1).state_dict(), tv)
+    c = T.Trainer(T.default_options(models_to_load=["encoder", "depth"], imagenet_weights=tv, **kw), device="cpu", seed=2)
+    w = torch.load(tv)["conv1.weight"]
+    assert torch.equal(c.models["pose_encoder"].encoder.conv1.weight[:, :3], w / 2)      # tiled and divided: ImageNet init
+    assert torch.equal(c.models["encoder"].state_dict()["encoder.conv1.weight"], want["encoder"]["encoder.conv1.weight"])

@@ -53,7 +53,12 @@ def test_workspace_and_bytes_queries_without_gpu():
     d.B, d.H, d.W, d.num_scales = 12, 192, 640, 4
     ws = L.dc_photo_workspace(ctypes.byref(d))
     N = 12 * 192 * 640
-    assert ws > 17 * N * 4 and ws < 20 * N * 4      # idl 2N + three RGBx copies 12N + d(upsampled disp) 4N
+    # training: idl 2N + three RGBx copies 12N + d(upsampled disp) 4N + the forward's d(loss)/d(source coords), 4 floats x 4 scales
+    assert ws > (17 + 16) * N * 4 and ws < (20 + 16) * N * 4
+    d.flags = _lib.OPT_NO_GRAD                        # evaluation: no gradient emission, the smaller workspace
+    ws_eval = L.dc_photo_workspace(ctypes.byref(d))
+    assert ws_eval > 17 * N * 4 and ws_eval < 20 * N * 4
+    d.flags = 0
     fwd = L.dc_photo_algorithmic_bytes(ctypes.byref(d), 0)
     bwd = L.dc_photo_algorithmic_bytes(ctypes.byref(d), 1)
     assert abs(fwd / N - 165.25) < 1e-6 and abs(bwd / N - 170.5625) < 1e-6

@@ -191,3 +191,47 @@ def test_properties_full_size(shape):
     # on-device tie-break RNG: same loss to ~1e-5 (noise only breaks ties)
     l3, _, _, _ = hip_photo(inputs, disps, Ts, None, rng_seed=123)
     close(l3[4], l1[4], rtol=1e-3)
+
+
+@pytest.mark.parametrize("tag,kw", VARIANTS)
+def test_evaluation_forward_equals_training_forward(tag, kw):
+    """Round 4: with gradients required the forward also emits d(loss)/d(source coordinates) for the pointwise backward
+    (photo_fwdg_kernel, 60-lane strips); without (torch.no_grad / nothing requires a gradient) the evaluation kernel runs
+    (photo_fwd_kernel, DC_OPT_NO_GRAD, the smaller workspace).  Same blend, same window sums, same min(): the argmin maps and
+    the log tensors must be IDENTICAL; the five losses are the same per-pixel values summed over a different block partition
+    (60- vs 62-column strips), i.e. equal to summation order."""
+    import ctypes
+    from depthcore import ops, _lib
+    dev = torch.device("cuda:0")
+    inputs = R.synthetic_inputs(3, 64, 160, seed=4)          # ragged: 160 is not a multiple of 60, 62 or 64
+    g = torch.Generator().manual_seed(5)
+    disps = [torch.rand(3, 1, 64 >> s, 160 >> s, generator=g) for s in range(4)]
+    Ts = random_poses(3, 11)
+    noise = R.tiebreak_noise(3, 64, 160)
+    if kw.get("avg_reprojection"):
+        noise = [n[:, :1].contiguous() for n in noise]
+
+    def run(grad):
+        cfg = ops.PhotoConfig(
+            inputs[("color", 0, 0)].to(dev), inputs[("color", -1, 0)].to(dev), inputs[("color", 1, 0)].to(dev),
+            [inputs[("color", 0, s)].to(dev) for s in range(4)], inputs[("K", 0)].to(dev), inputs[("inv_K", 0)].to(dev),
+            noise=[n.to(dev) for n in noise], materialize=True, **kw)
+        d = [x.to(dev).requires_grad_(grad) for x in disps]
+        t = [x.to(dev).requires_grad_(grad) for x in Ts]
+        return ops.photometric_loss(cfg, t[0], t[1], d), cfg.extras
+    (lt, et), (le, ee) = run(True), run(False)
+    assert lt.requires_grad and not le.requires_grad
+    close(lt.detach(), le, rtol=2e-6)
+    for s in range(4):
+        assert torch.equal(et["argmin"][s], ee["argmin"][s])
+        assert torch.equal(et["depth"][s], ee["depth"][s])
+        for f in range(2):
+            assert torch.equal(et["color"][s][f], ee["color"][s][f])
+            assert torch.equal(et["sample"][s][f], ee["sample"][s][f])
+    # C ABI: the evaluation workspace is the smaller one, and dc_photo_bwd refuses an evaluation descriptor
+    L = _lib.lib()
+    d = _lib.PhotoDesc()
+    d.B, d.H, d.W, d.num_scales = 3, 64, 160, 4
+    w_train = L.dc_photo_workspace(ctypes.byref(d))
+    d.flags = _lib.OPT_NO_GRAD
+    assert L.dc_photo_workspace(ctypes.byref(d)) < w_train

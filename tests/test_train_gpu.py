@@ -418,6 +418,77 @@ def test_hip_graph_replays_train_like_eager_steps(gru):
     assert len(set(round(v, 7) for v in lg[3:])) == len(lg[3:])      # every replay is a new step
 
 
+def test_graph_capture_after_an_unclosed_collected_trainer():
+    """The round-3 abort (gpurun_out/r3s): Trainers of FAILED tests were never close()d and sat in reference cycles (exception
+    <-> frame); torch.cuda.graph() runs gc.collect() + empty_cache() when it begins a capture, so their weights were freed --
+    and returned to the driver -- inside the capture, where the weight cache may not rebuild its descriptor table; the
+    captured refresh then named freed memory and the replay page-faulted, which the HSA runtime turns into abort().
+    Now every cache owner has its own table (a refresh only ever reads its owner's live weights) and the Trainer collects
+    garbage BEFORE it starts a capture.  Here: an eager trainer B takes a step, is tied into a cycle and dropped without
+    close(); graph-mode trainer A must capture, replay and follow an eager trainer that never saw a B."""
+    import gc
+    import trainer as T
+    from depthcore.synthetic import synthetic_batch
+    dev = torch.device(DEV)
+    batches = [synthetic_batch(2, 64, 128, dev, seed=s) for s in (2, 3)]
+
+    def opts(graph):
+        return T.default_options(height=64, width=128, batch_size=2, hip_graph=graph)
+
+    ref = T.Trainer(opts(False), device=DEV, seed=5)
+    ref.set_train()
+    want = [float(ref.train_step(dict(batches[i % 2]))[1]["loss"].detach()) for i in range(7)]
+    ref.close()
+
+    gc.collect()
+    gc.disable()                                  # the collection must happen where torch.cuda.graph / the Trainer do it
+    try:
+        b = T.Trainer(opts(False), device=DEV, seed=9)
+        b.set_train()
+        b.train_step(dict(batches[0]))
+        owner_b = b.wino_cache._owner
+        b.cycle = b                               # unreachable but not freed by reference counting, like a failed test's frame
+        del b
+        a = T.Trainer(opts(True), device=DEV, seed=5)
+        a.set_train()
+        got = [float(a.train_step(dict(batches[i % 2]))[1]["loss"].detach()) for i in range(7)]
+        torch.cuda.synchronize()
+    finally:
+        gc.enable()
+    assert a._graph is not None and getattr(a, "_graph_failed", 0) == 0
+    assert a.wino_cache._owner != owner_b
+    assert np.allclose(want, got, rtol=5e-4), (want, got)
+    a.close()
+
+
+def test_failed_capture_falls_back_to_eager_instead_of_killing_the_process(monkeypatch):
+    """A launch that is refused inside the capture (here: a synchronising call injected into the captured step) must surface as
+    a warning + an eager step, with the host-side step counter and the losses of an eager trainer -- never as an abort."""
+    import trainer as T
+    from depthcore.synthetic import synthetic_batch
+    dev = torch.device(DEV)
+    batches = [synthetic_batch(2, 64, 128, dev, seed=s) for s in (2, 3)]
+    ref = T.Trainer(T.default_options(height=64, width=128, batch_size=2), device=DEV, seed=5)
+    ref.set_train()
+    want = [float(ref.train_step(dict(batches[i % 2]))[1]["loss"].detach()) for i in range(6)]
+    ref.close()
+    a = T.Trainer(T.default_options(height=64, width=128, batch_size=2, hip_graph=True), device=DEV, seed=5)
+    a.set_train()
+    orig = a._train_step_eager
+
+    def sabotaged(inputs):
+        out = orig(inputs)
+        if torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()              # illegal during capture: invalidates it
+        return out
+    a._train_step_eager = sabotaged
+    with pytest.warns(UserWarning, match="capture of the training step failed"):
+        got = [float(a.train_step(dict(batches[i % 2]))[1]["loss"].detach()) for i in range(6)]
+    assert a.step == 6 and a._graph is None and a._graph_failed == 1
+    assert np.allclose(want, got, rtol=5e-4), (want, got)
+    a.close()
+
+
 def test_second_trainer_does_not_break_a_captured_graph():
     """The Winograd weight cache is process-wide and a captured hipGraph bakes its buffers into kernel arguments: building
     (and closing) another Trainer must neither free nor rewrite anything the first trainer's graph reads or writes.  Trainer
