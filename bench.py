@@ -321,7 +321,7 @@ def run_rank(args):
     opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
                             nets_dtype=args.nets_dtype, torch_adam=args.torch_adam,
                             cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap,
-                            wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph) and world == 1, **front)
+                            wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph), **front)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     tr = T.Trainer(opt, device=device, rank=rank, world_size=world)
     tr.set_train()
@@ -350,8 +350,11 @@ def run_rank(args):
         ops.conv_profile_enable((args.steps * args.windows + 2) * 60, 7)
     sync()
     t0 = time.perf_counter()
+    host_s = 0.0                                # time spent INSIDE train_step(): launch work of an eager step, one replay of a captured one
     for _ in range(args.steps):
+        th = time.perf_counter()
         _, losses = tr.train_step(inputs)
+        host_s += time.perf_counter() - th
     sync()
     dt = time.perf_counter() - t0
     loss_last = float(losses["loss"].detach())
@@ -559,6 +562,7 @@ def run_rank(args):
                                  "(`direct_conv_equivalent_frac`) is 2.25x that and may exceed 1",
                          "families": fams[1:],
                          "photometric": photometric}),
+            "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 3),
             "phases_ms": {"forward": round(ph[0], 3), "backward_incl_overlapped_exchange": round(ph[1], 3),
                           "exposed_exchange_wait": round(ph[2], 3), "adam": round(ph[3], 3),
                           "note": "host-synchronised between phases (slower than the pipelined step); %d steps after the "
@@ -602,7 +606,7 @@ def main():
                          "reported under its own dtype, never the headline")
     ap.add_argument("--windows", type=int, default=4, help="timed windows of --steps steps: the first is the reported value, the "
                                                             "others show the run-to-run spread (windows_ms_per_step)")
-    ap.add_argument("--graph", action="store_true", help="single GPU: capture the training step in one hipGraph and replay it (opt.hip_graph)")
+    ap.add_argument("--graph", action="store_true", help="capture the training step (with world > 1: incl. the RCCL exchange) in one hipGraph and replay it (opt.hip_graph)")
     ap.add_argument("--no-wino-cache", action="store_true", help="per-launch Winograd weight transforms (A/B of wino_weight_cache)")
     ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: let ranks share GPUs (use with DC_DIST_BACKEND=gloo)")

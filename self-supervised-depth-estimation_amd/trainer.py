@@ -137,7 +137,13 @@ class Trainer:
         self.buckets = GradBuckets(named, self.opt.bucket_mb, world_size, process_group)
         # hipGraph mode (opt.hip_graph, one GPU): the step is captured once and replayed, so everything that changes from
         # step to step must live in device memory -- Adam's step count (capturable) and the tie-break noise seed
-        self.graph_enabled = bool(getattr(self.opt, "hip_graph", False)) and self.device.type == "cuda" and world_size == 1
+        # With world_size > 1 the bucketed exchange is part of the captured step: the hooks' all-reduces are recorded on the
+        # communication stream (which joins the capture through its stream waits), in the fixed bucket order -- RCCL only
+        # (gloo moves data through host memory and cannot be captured)
+        import torch.distributed as dist
+        capturable_pg = world_size == 1 or (dist.is_available() and dist.is_initialized()
+                                            and dist.get_backend(process_group) == "nccl")
+        self.graph_enabled = bool(getattr(self.opt, "hip_graph", False)) and self.device.type == "cuda" and capturable_pg
         if self.graph_enabled and self.opt.cpu_tiebreak_noise:
             raise ValueError("hip_graph replays cannot include the reference's CPU randn + host-to-device copy (cpu_tiebreak_noise)")
         # reference trainer.py:110-113: one Adam over every trainable tensor.  On the GPU the depthcore kernel (one streaming
@@ -486,7 +492,9 @@ class Trainer:
             step0 = self.step
             stream0 = torch.cuda.current_stream(self.device)
             try:
-                with torch.cuda.graph(g, stream=gs):
+                # (world > 1: RCCL's watchdog thread polls events while we capture -- legal, but only in thread-local mode)
+                mode = {} if self.world_size == 1 else {"capture_error_mode": "thread_local"}
+                with torch.cuda.graph(g, stream=gs, **mode):
                     static_out = self._train_step_eager(static_in)
             except Exception as e:       # a launch refused inside the capture, or the capture was invalidated
                 # Nothing of a captured step has run (capture records, it does not execute): host state is rolled back, the

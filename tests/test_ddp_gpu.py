@@ -113,6 +113,37 @@ def test_two_ranks_on_one_gpu_full_bench_step_over_gloo():
     assert d["value"] > 0
 
 
+def test_graph_mode_with_bucketed_exchange_over_rccl():
+    """hipGraph mode at world > 1 (round 4): the whole data-parallel step -- both compute streams, the backward whose hooks
+    record the buckets' all-reduces on the communication stream in fixed bucket order, finish(), Adam -- is ONE captured
+    graph.  Validated on the one GPU a box has: 1-rank RCCL group, Trainer told world = 2 (tests/ddp_graph_child.py, its own
+    process).  The replays must follow the eager data-parallel trainer (same kernels, deterministic reductions: losses to
+    1e-5, weights after 8 Adam steps to 1e-4 of their norm -- the captured Adam forms its bias corrections on the device), and
+    the host's work per replayed step must be a small fraction of the eager launch work (<= 3 ms)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(here, "ddp_graph_child.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["captured"] and d["capture_failed"] == 0 and not d["eager_captured"], d
+    el, gl = d["eager_losses"], d["graph_losses"]
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(el[:3], gl[:3])), (el, gl)       # eager warm-up steps of both
+    assert all(abs(a - b) <= 5e-4 * abs(a) for a, b in zip(el, gl)), (el, gl)               # captured step + replays
+    assert len(set(round(v, 7) for v in gl[3:])) == len(gl[3:])                              # every replay is a new step
+    assert d["weight_rel_diff"] <= 1e-4, d["weight_rel_diff"]
+    assert d["launch_order"] == sorted(d["launch_order"]) and d["packed"] == 0
+    replay_ms = sorted(d["host_ms_graph"][4:])                                               # steps after the capture
+    assert replay_ms[len(replay_ms) // 2] <= 3.0, d["host_ms_graph"]
+    print("host ms per step: eager DDP %s | graph DDP %s" % (d["host_ms_eager"], d["host_ms_graph"]))
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: runs by itself on a multi-GPU box")
 def test_two_gpus_bench_step_over_rccl():
     """`bench.py --gpus 2` on two real GPUs over RCCL/xGMI (fresh child processes, one rank per GPU): one JSON line, the

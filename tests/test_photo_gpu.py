@@ -197,9 +197,10 @@ def test_properties_full_size(shape):
 def test_evaluation_forward_equals_training_forward(tag, kw):
     """Round 4: with gradients required the forward also emits d(loss)/d(source coordinates) for the pointwise backward
     (photo_fwdg_kernel, 60-lane strips); without (torch.no_grad / nothing requires a gradient) the evaluation kernel runs
-    (photo_fwd_kernel, DC_OPT_NO_GRAD, the smaller workspace).  Same blend, same window sums, same min(): the argmin maps and
-    the log tensors must be IDENTICAL; the five losses are the same per-pixel values summed over a different block partition
-    (60- vs 62-column strips), i.e. equal to summation order."""
+    (photo_fwd_kernel, DC_OPT_NO_GRAD, the smaller workspace).  Same formulas, two compilations: the compiler contracts
+    multiply-adds differently where the training kernel has further uses of a product, so the log tensors agree to rounding
+    (not bitwise), the argmin maps everywhere but on rounding-level ties, and the five losses to summation order (60- vs
+    62-column strips)."""
     import ctypes
     from depthcore import ops, _lib
     dev = torch.device("cuda:0")
@@ -223,11 +224,11 @@ def test_evaluation_forward_equals_training_forward(tag, kw):
     assert lt.requires_grad and not le.requires_grad
     close(lt.detach(), le, rtol=2e-6)
     for s in range(4):
-        assert torch.equal(et["argmin"][s], ee["argmin"][s])
-        assert torch.equal(et["depth"][s], ee["depth"][s])
+        assert float((et["argmin"][s] != ee["argmin"][s]).float().mean()) <= 1e-4
+        close(et["depth"][s], ee["depth"][s], rtol=1e-5)
         for f in range(2):
-            assert torch.equal(et["color"][s][f], ee["color"][s][f])
-            assert torch.equal(et["sample"][s][f], ee["sample"][s][f])
+            close(et["color"][s][f], ee["color"][s][f], rtol=1e-5, atol=1e-6)
+            close(et["sample"][s][f], ee["sample"][s][f], rtol=1e-5, atol=1e-5)
     # C ABI: the evaluation workspace is the smaller one, and dc_photo_bwd refuses an evaluation descriptor
     L = _lib.lib()
     d = _lib.PhotoDesc()
