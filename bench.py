@@ -329,9 +329,10 @@ def run_rank(args):
         from depthcore.synthetic import synthetic_sequence_batch
         inputs = synthetic_sequence_batch(args.len_sequence, args.height, args.width, device, seed=100 + rank)
     elif args.front == "fusion":
-        inputs = synthetic_batch(args.batch, args.height, args.width, device, seed=100 + rank, frame_ids=(0, -2, -1, 1))
+        inputs = synthetic_batch(args.batch, args.height, args.width, device, seed=100 + rank, frame_ids=(0, -2, -1, 1),
+                                 packed=not args.no_packed_inputs)
     else:
-        inputs = synthetic_batch(args.batch, args.height, args.width, device, seed=100 + rank)
+        inputs = synthetic_batch(args.batch, args.height, args.width, device, seed=100 + rank, packed=not args.no_packed_inputs)
     imgs_per_step = args.len_sequence if args.front == "gru" else args.batch        # target frames that get a loss per rank and step
 
     def sync():
@@ -550,6 +551,10 @@ def run_rank(args):
                                    % (label, args.num_layers, args.height, args.width, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "tiebreak_noise": "cpu-randn+h2d" if args.cpu_noise else "on-device counter RNG",
+                       "inputs": "resident in HBM before the timed region; " + (
+                           "as the device data step delivers them: planar (\"color\", f, s) / (\"color_aug\", f, s) plus the "
+                           "pixel-interleaved RGBx copy (\"color_packed\", f, 0) of the three loss frames (dc_data_to_rgbx)"
+                           if ("color_packed", 0, 0) in inputs else "planar tensors only (the loss repacks the three frames per step)"),
                        "step_launch": "one hipGraph replay per step" if graphed else "eager (one launch per kernel)"},
             "roofline": dict(dom, **{
                          "traffic": tr_bytes(dom_key) if dom_key else None, "traffic_source": traffic_src if dom_key and tr_bytes(dom_key) else None,
@@ -608,6 +613,9 @@ def main():
                                                             "others show the run-to-run spread (windows_ms_per_step)")
     ap.add_argument("--graph", action="store_true", help="capture the training step (with world > 1: incl. the RCCL exchange) in one hipGraph and replay it (opt.hip_graph)")
     ap.add_argument("--no-wino-cache", action="store_true", help="per-launch Winograd weight transforms (A/B of wino_weight_cache)")
+    ap.add_argument("--no-packed-inputs", action="store_true",
+                    help="inputs without the data step's pixel-interleaved RGBx copies of the three loss frames (a reference data "
+                         "loader's batch): the photometric forward then repacks them at every step")
     ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: let ranks share GPUs (use with DC_DIST_BACKEND=gloo)")
     ap.add_argument("--rehearse", action="store_true", help="rehearsal: CPU stand-in step over gloo (launcher / exchange plumbing only)")

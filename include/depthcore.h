@@ -132,6 +132,9 @@ typedef struct dc_photo_desc {
     const float* target;          /* inputs[("color",0,0)]   (B,3,H,W) */
     const float* source[2];       /* inputs[("color",-1,0)], inputs[("color",+1,0)] */
     const float* color_s[DC_MAX_SCALES]; /* inputs[("color",0,s)]  (B,3,H>>s,W>>s) */
+    const float* packed[3];       /* optional: pixel-interleaved RGBx copies (B,H,W,4) of target / source[0] / source[1]
+                                     (dc_data_to_rgbx / dc_pack_rgbx, 16-byte aligned), all three or none.  The kernels gather
+                                     from this layout; when absent dc_photo_fwd builds it in the workspace at every call */
     const float* K;               /* inputs[("K",0)]      (B,4,4) */
     const float* inv_K;           /* inputs[("inv_K",0)]  (B,4,4) */
     const float* T[2];            /* outputs[("cam_T_cam",0,-1/+1)]  (B,4,4) */
@@ -476,6 +479,13 @@ int dc_data_to_tensor(const uint8_t* img, float* out, int n_img, int npix, void*
  * then everything), nothing written in between; results identical to dc_data_jitter + dc_data_to_tensor. */
 int dc_data_jitter_to_tensor(const uint8_t* img, float* color, float* color_aug, int n_img, int npix, const int* steps,
                              const float* params, unsigned long long* sums, void* stream);
+/* The pixel-interleaved copy the fused photometric kernels gather from (dc_photo_desc.packed), written by the DATA step so that
+ * the training step does not repack its three full-resolution frames every iteration:
+ *   dc_data_to_rgbx: (n, npix, 3) uint8 -> (n, npix, 4) float32 RGBx, value / 255 (the same true division as ToTensor: the three
+ *     colour values are bit-identical to dc_data_to_tensor's), x = 0;   dc_pack_rgbx: (n, 3, npix) float32 -> the same layout, for
+ *     callers whose data loader produced the planar tensors (the reference's).  `out` 16-byte aligned. */
+int dc_data_to_rgbx(const uint8_t* img, float* out, int n_img, int npix, void* stream);
+int dc_pack_rgbx(const float* x, float* out, int n_img, int npix, void* stream);
 
 #ifdef __cplusplus
 }

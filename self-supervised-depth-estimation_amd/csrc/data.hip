@@ -261,6 +261,23 @@ __global__ __launch_bounds__(256) void data_to_tensor_kernel(const uint8_t* __re
     }
 }
 
+// (n, H*W, 3) uint8 -> (n, H*W, 4) float32 / 255, pixel-interleaved RGBx (x = 0): the layout the photometric kernels gather from
+__global__ __launch_bounds__(256) void data_to_rgbx_kernel(const uint8_t* __restrict__ img, float4* __restrict__ out, int npix) {
+    const int im = blockIdx.y;
+    const uint8_t* p = img + (size_t)im * npix * 3;
+    float4* o = out + (size_t)im * npix;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256)
+        o[i] = make_float4((float)p[3 * i] / 255.0f, (float)p[3 * i + 1] / 255.0f, (float)p[3 * i + 2] / 255.0f, 0.f);
+}
+// (n, 3, H*W) float32 -> (n, H*W, 4) float32 RGBx
+__global__ __launch_bounds__(256) void pack_rgbx_kernel(const float* __restrict__ x, float4* __restrict__ out, int npix) {
+    const int im = blockIdx.y;
+    const float* p = x + (size_t)im * npix * 3;
+    float4* o = out + (size_t)im * npix;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256)
+        o[i] = make_float4(p[i], p[(size_t)npix + i], p[(size_t)2 * npix + i], 0.f);
+}
+
 // ---- host: Resample.c precompute_coeffs + normalize_coeffs_8bpc, Lanczos (support 3) over the whole axis ----------------
 static inline double sinc_filter(double x) {
     if (x == 0.0) return 1.0;
@@ -375,6 +392,22 @@ extern "C" int dc_data_to_tensor(const uint8_t* img, float* out, int n_img, int 
     if (!img || !out || n_img <= 0 || n_img > 65535 || npix <= 0 || npix > (1 << 28)) return DC_EINVAL;
     hipLaunchKernelGGL(data_to_tensor_kernel, dim3(std::min((npix + 255) / 256, 1024), n_img), dim3(256), 0, (hipStream_t)stream, img, out,
                        npix);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_data_to_rgbx(const uint8_t* img, float* out, int n_img, int npix, void* stream) {
+    if (!img || !out || ((size_t)out & 15) || n_img <= 0 || n_img > 65535 || npix <= 0 || npix > (1 << 28)) return DC_EINVAL;
+    hipLaunchKernelGGL(data_to_rgbx_kernel, dim3(std::min((npix + 255) / 256, 1024), n_img), dim3(256), 0, (hipStream_t)stream, img,
+                       (float4*)out, npix);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_pack_rgbx(const float* x, float* out, int n_img, int npix, void* stream) {
+    if (!x || !out || ((size_t)out & 15) || n_img <= 0 || n_img > 65535 || npix <= 0 || npix > (1 << 28)) return DC_EINVAL;
+    hipLaunchKernelGGL(pack_rgbx_kernel, dim3(std::min((npix + 255) / 256, 1024), n_img), dim3(256), 0, (hipStream_t)stream, x,
+                       (float4*)out, npix);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }

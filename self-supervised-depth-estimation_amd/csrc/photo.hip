@@ -400,8 +400,9 @@ __device__ __forceinline__ float rng_normal(unsigned long long seed, unsigned id
 // ------------------------------------------------------------------------------------------------
 constexpr int ID_ROWS = 8;
 
-// IDENT = false: only the repack (opt.disable_automasking)
-template <bool IDENT>
+// IDENT = false: only the repack (opt.disable_automasking).  PACKED: the caller supplied the pixel-interleaved copies
+// (dc_photo_desc.packed, written by the data step): they are read instead of the planar frames and nothing is repacked.
+template <bool IDENT, bool PACKED>
 __global__ __launch_bounds__(64) void identity_kernel(PhotoArgs p) {
     const int lane = threadIdx.x;
     const int b = blockIdx.z;
@@ -420,6 +421,12 @@ __global__ __launch_bounds__(64) void identity_kernel(PhotoArgs p) {
     Row rA = {}, rB = {}, nxt;
     auto load_row = [&](int yy) {
         const unsigned o = (unsigned)(reflect_clamp(yy, H) * W + xr) * 4u;
+        if (PACKED) {
+            const f3 t = bload3(c.ptg, o * 4u), a = bload3(c.ps0, o * 4u), bb = bload3(c.ps1, o * 4u);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { nxt.t[ch] = t[ch]; nxt.w[0][ch] = a[ch]; nxt.w[1][ch] = bb[ch]; }
+            return;
+        }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             nxt.t[ch] = bload(c.tg, o, ch * c.plane4);
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(64) void identity_kernel(PhotoArgs p) {
         const Row cur = nxt;
         load_row(yy + 1);   // next row flies during this row's math
         // pixel-interleaved copies of the three images for the gather kernels (rows this wave owns)
-        if (i >= 1 && i <= ID_ROWS && yy < H && lane_ok) {
+        if (!PACKED && i >= 1 && i <= ID_ROWS && yy < H && lane_ok) {
             const unsigned o = (unsigned)(yy * W + x) * 16u;
             bstore4(c.ptg, o, cur.t[0], cur.t[1], cur.t[2], 0.f);
             bstore4(c.ps0, o, cur.w[0][0], cur.w[0][1], cur.w[0][2], 0.f);
@@ -1304,6 +1311,7 @@ struct Carve {
     size_t idl, pk[3], part_photo, part_smooth, stats, gdup[DC_MAX_SCALES], gw[DC_MAX_SCALES], part_dP, total;
     int nblk_f, nchunk, nblk_b_img, strips_f, strips_b, rows_f, rowblocks_f;
     int strips_p, rows_g, rows_p, rowblocks_g, rowblocks_p;   // training forward (60-lane strips) / pointwise backward
+    bool packed_in;                                           // the caller supplied the RGBx copies: none in the workspace
 };
 
 // Rows a wave marches per block.  Taller blocks spend fewer steps on the halo rows (a block costs rows + halo row-steps),
@@ -1348,7 +1356,8 @@ static Carve carve(const dc_photo_desc* d) {
     c.nchunk = ceil_div(d->H * d->W, SM_CHUNK);
     size_t off = 0;
     c.idl = off; off += align256(N * 2 * 4);
-    for (int k = 0; k < 3; ++k) { c.pk[k] = off; off += align256(N * 16); }
+    c.packed_in = d->packed[0] && d->packed[1] && d->packed[2];
+    for (int k = 0; k < 3; ++k) { c.pk[k] = off; if (!c.packed_in) off += align256(N * 16); }
     c.part_photo = off; off += align256((size_t)d->num_scales * c.nblk_f * 4);
     c.part_smooth = off; off += align256((size_t)d->num_scales * d->B * c.nchunk * 3 * 4);
     c.stats = off; off += align256((size_t)d->num_scales * d->B * 3 * 4);
@@ -1372,6 +1381,10 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
         !d->workspace)
         return DC_EINVAL;
     if (!(d->min_depth > 0.f) || !(d->max_depth > d->min_depth)) return DC_EINVAL;
+    const int npk = (d->packed[0] ? 1 : 0) + (d->packed[1] ? 1 : 0) + (d->packed[2] ? 1 : 0);
+    if (npk != 0 && npk != 3) return DC_EINVAL;                      // all three or none
+    for (int k = 0; k < npk; ++k)
+        if ((size_t)d->packed[k] & 15) return DC_EINVAL;
     c = carve(d);
     if (d->workspace_bytes < c.total) return DC_EWORKSPACE;
     a = PhotoArgs{};
@@ -1413,7 +1426,7 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
     }
     a.losses = d->losses;
     a.idl = (float*)(ws + c.idl);
-    for (int k = 0; k < 3; ++k) a.pk[k] = (float*)(ws + c.pk[k]);
+    for (int k = 0; k < 3; ++k) a.pk[k] = c.packed_in ? const_cast<float*>(d->packed[k]) : (float*)(ws + c.pk[k]);
     a.part_photo = (float*)(ws + c.part_photo);
     a.part_smooth = (float*)(ws + c.part_smooth);
     a.stats = (float*)(ws + c.stats);
@@ -1505,11 +1518,12 @@ extern "C" int dc_photo_fwd(const dc_photo_desc* d, void* stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t pc = prof_begin(2, st);
-    // identity losses + the pixel-interleaved image copies the gather kernels read (forward AND backward)
-    if (!(a.flags & DC_OPT_NO_AUTOMASK))
-        hipLaunchKernelGGL(identity_kernel<true>, dim3(c.strips_f, ceil_div(a.H, ID_ROWS), a.B), dim3(64), 0, st, a);
-    else
-        hipLaunchKernelGGL(identity_kernel<false>, dim3(c.strips_f, ceil_div(a.H, ID_ROWS), a.B), dim3(64), 0, st, a);
+    // identity losses + (unless the caller supplied them) the pixel-interleaved image copies the gather kernels read
+    const dim3 idg(c.strips_f, ceil_div(a.H, ID_ROWS), a.B);
+    const bool ident = !(a.flags & DC_OPT_NO_AUTOMASK);
+    if (ident && c.packed_in) hipLaunchKernelGGL((identity_kernel<true, true>), idg, dim3(64), 0, st, a);
+    else if (ident) hipLaunchKernelGGL((identity_kernel<true, false>), idg, dim3(64), 0, st, a);
+    else if (!c.packed_in) hipLaunchKernelGGL((identity_kernel<false, false>), idg, dim3(64), 0, st, a);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3(c.nchunk, a.B, a.ns), dim3(256), 0, st, a);
     DC_CHECK_LAUNCH();

@@ -43,7 +43,7 @@ class PhotoDesc(Structure):
     _fields_ = [
         ("B", c_int32), ("H", c_int32), ("W", c_int32), ("num_scales", c_int32),
         ("flags", c_uint32), ("min_depth", c_float), ("max_depth", c_float), ("smoothness", c_float),
-        ("target", _F), ("source", _F * 2), ("color_s", _F * MAX_SCALES),
+        ("target", _F), ("source", _F * 2), ("color_s", _F * MAX_SCALES), ("packed", _F * 3),
         ("K", _F), ("inv_K", _F), ("T", _F * 2),
         ("disp", _F * MAX_SCALES), ("noise", _F * MAX_SCALES), ("rng_seed", c_uint64), ("rng_seed_dev", _F),
         ("losses", _F), ("argmin", _F * MAX_SCALES),
@@ -156,6 +156,8 @@ def _sig(lib):
         "dc_data_flip": (i, [p, p, i, i, i, p, p]),
         "dc_data_jitter": (i, [p, i, i, p, p, p, p]),
         "dc_data_to_tensor": (i, [p, p, i, i, p]),
+        "dc_data_to_rgbx": (i, [p, p, i, i, p]),
+        "dc_pack_rgbx": (i, [p, p, i, i, p]),
         "dc_data_jitter_to_tensor": (i, [p, p, p, i, i, p, p, p, p]),
         "dc_attnconv_fwd": (i, [POINTER(AttnMap), POINTER(AttnParams), POINTER(AttnMap), p, i, i, i, i, i, i, p]),
         "dc_attnconv_param_count": (i, [i]),

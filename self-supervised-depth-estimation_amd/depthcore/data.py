@@ -145,6 +145,14 @@ class GpuPreprocessor:
             for i, f in enumerate(self.frame_idxs):
                 out[("color", f, s)] = color[i]
                 out[("color_aug", f, s)] = color_aug[i]
+            if s == 0:
+                # the photometric kernels gather from pixel-interleaved RGBx: written here, once per item, from the same uint8
+                # level (same division by 255 -> the same values as ("color", f, 0)) instead of repacked in every training step
+                packed = torch.empty((n, h, w, 4), dtype=torch.float32, device=img.device)
+                check(L.dc_data_to_rgbx(img.data_ptr(), packed.data_ptr(), n, h * w, stream(img)), "dc_data_to_rgbx")
+                packed = packed.view(Fn, B, h, w, 4)
+                for i, f in enumerate(self.frame_idxs):
+                    out[("color_packed", f, 0)] = packed[i]
         return out
 
     def intrinsics(self, K, batch):

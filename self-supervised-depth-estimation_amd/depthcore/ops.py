@@ -100,12 +100,15 @@ class PhotoConfig:
     K / inv_K: inputs[("K"|"inv_K", 0)];  noise[s]: the tie-break randn of trainer.py:594-595
     (None -> on-device counter RNG).  `materialize` asks for the log tensors of
     generate_images_pred (depth / sample / color / identity_selection).
+    packed: optional (target, src_m1, src_p1) as pixel-interleaved RGBx (B,H,W,4) tensors -- `pack_rgbx(x)` or the data step's
+    ("color_packed", f, 0) -- the layout the kernels gather from; without it every forward repacks the three frames.
     """
 
     def __init__(self, target, src_m1, src_p1, color_s, K, inv_K, noise=None, min_depth=0.1, max_depth=100.0,
                  smoothness=1e-3, disable_automasking=False, avg_reprojection=False, no_ssim=False,
-                 align_corners=False, materialize=False, rng_seed=0):
+                 align_corners=False, materialize=False, rng_seed=0, packed=None):
         self.target, self.src = _c(target), (_c(src_m1), _c(src_p1))
+        self.packed = None if packed is None else tuple(_c(t) for t in packed)
         self.color_s = [_c(c) for c in color_s]
         self.K, self.inv_K = _c(K), _c(inv_K)
         self.noise = None if noise is None else [_c(n) for n in noise]
@@ -142,6 +145,11 @@ def _fill_desc(cfg, T0, T1, disps, no_grad=False):
             raise _lib.DepthcoreError("K / inv_K / T must be (B,4,4), got %s" % (tuple(t.shape),))
     d.K, d.inv_K = ptr(cfg.K), ptr(cfg.inv_K)
     d.T[0], d.T[1] = ptr(T0), ptr(T1)
+    if cfg.packed is not None:
+        if len(cfg.packed) != 3 or any(tuple(t.shape) != (B, H, W, 4) for t in cfg.packed):
+            raise _lib.DepthcoreError("packed must be three (B,H,W,4) RGBx tensors (target, source -1, source +1)")
+        for k in range(3):
+            d.packed[k] = ptr(cfg.packed[k])
     nch = 1 if (cfg.flags & _lib.OPT_AVG_REPROJ) else 2
     for s in range(ns):
         shp = (B, 1, H >> s, W >> s)
@@ -218,6 +226,18 @@ class _PhotoLoss(torch.autograd.Function):
         d.d_T[0], d.d_T[1] = ptr(dT[0]), ptr(dT[1])
         check(L.dc_photo_bwd(ctypes.byref(d), stream(cfg.target)), "dc_photo_bwd")
         return (None, dT[0], dT[1], *d_disp)
+
+
+def pack_rgbx(x):
+    """(B,3,H,W) float32 -> (B,H,W,4) pixel-interleaved RGBx: the layout the fused photometric kernels gather from (`PhotoConfig(
+    packed=...)`).  The data step (depthcore.data.GpuPreprocessor) writes it directly as ("color_packed", f, 0)."""
+    xx = _c(x.detach())
+    B, C, H, W = xx.shape
+    if C != 3:
+        raise _lib.DepthcoreError("pack_rgbx takes (B,3,H,W) images")
+    out = torch.empty(B, H, W, 4, dtype=torch.float32, device=xx.device)
+    check(_lib.lib().dc_pack_rgbx(ptr(xx), ptr(out), B, H * W, stream(xx)), "dc_pack_rgbx")
+    return out
 
 
 def photometric_loss(cfg, T_m1, T_p1, disps):

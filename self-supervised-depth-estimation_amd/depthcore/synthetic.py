@@ -7,9 +7,11 @@ import torch.nn.functional as F
 KITTI_K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
 
 
-def synthetic_batch(batch, height, width, device, num_scales=4, frame_ids=(0, -1, 1), seed=0, smooth=True):
+def synthetic_batch(batch, height, width, device, num_scales=4, frame_ids=(0, -1, 1), seed=0, smooth=True, packed=False):
     """U(0,1) images (optionally 5x5 box-smoothed so SSIM is not saturated), pyramid by 2x2 means,
-    KITTI intrinsics scaled per pyramid level, inv_K = pinv(K)."""
+    KITTI intrinsics scaled per pyramid level, inv_K = pinv(K).  `packed`: also what the device data step emits next to
+    ("color", f, 0) -- ("color_packed", f, 0), the pixel-interleaved RGBx copy the photometric kernels gather from
+    (depthcore.data.GpuPreprocessor, dc_data_to_rgbx) -- for the three frames of the loss."""
     g = torch.Generator(device=device).manual_seed(seed)
     inputs = {}
     for f in frame_ids:
@@ -20,6 +22,9 @@ def synthetic_batch(batch, height, width, device, num_scales=4, frame_ids=(0, -1
             img = base if s == 0 else F.avg_pool2d(base, 2 ** s)
             inputs[("color", f, s)] = img.contiguous()
             inputs[("color_aug", f, s)] = inputs[("color", f, s)]
+        if packed and f in (0, -1, 1):
+            from . import ops
+            inputs[("color_packed", f, 0)] = ops.pack_rgbx(inputs[("color", f, 0)])
     for s in range(num_scales):
         K = KITTI_K.copy()
         K[0, :] *= width // (2 ** s)

@@ -303,12 +303,16 @@ class Trainer:
         o = self.opt
         materialize = o.materialize_logs if materialize is None else materialize
         B = inputs[("color", 0, 0)].shape[0]
+        # the data step's pixel-interleaved copies of the three full-resolution frames (depthcore.data / synthetic_batch):
+        # with them the loss does not repack the frames every step; a reference data loader does not provide them
+        packed = tuple(inputs.get(("color_packed", f, 0)) for f in (0, -1, 1))
+        packed = packed if all(t is not None for t in packed) else None
         cfg = ops.PhotoConfig(
             inputs[("color", 0, 0)], inputs[("color", -1, 0)], inputs[("color", 1, 0)],
             [inputs[("color", 0, s)] for s in o.scales], inputs[("K", 0)], inputs[("inv_K", 0)],
             noise=self._noise(B, 1 if o.avg_reprojection else 2), min_depth=o.min_depth, max_depth=o.max_depth,
             smoothness=o.disparity_smoothness, disable_automasking=o.disable_automasking,
-            avg_reprojection=o.avg_reprojection, no_ssim=o.no_ssim, materialize=materialize,
+            avg_reprojection=o.avg_reprojection, no_ssim=o.no_ssim, materialize=materialize, packed=packed,
             rng_seed=self._seed_dev if self._seed_dev is not None else self.step * 1000003 + self.rank)
         lv = ops.photometric_loss(cfg, outputs[("cam_T_cam", 0, -1)], outputs[("cam_T_cam", 0, 1)],
                                   [outputs[("disp", s)] for s in o.scales])

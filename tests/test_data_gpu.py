@@ -42,8 +42,15 @@ def test_kitti_batch_vs_oracle(hw):
     jitters = [((3, 0, 1, 2), (0.83, 1.17, 0.91, 0.093)), None, ((1, 2, 0, 3), (1.2, 0.8, 1.2, -0.1))]
     pre = GpuPreprocessor(h, w, frame_idxs=frames, device=_dev())
     out = pre(torch.from_numpy(native).to(_dev()), flips, jitters)
-    assert len(out) == 2 * 3 * 4
+    assert len(out) == 2 * 3 * 4 + 3                          # + ("color_packed", f, 0) of the three frames
     del rng
+    # the pixel-interleaved RGBx copy the photometric kernels gather from: the same values as ("color", f, 0), x = 0
+    from depthcore import ops
+    for f in frames:
+        pk = out[("color_packed", f, 0)]
+        assert pk.shape == (B, h, w, 4) and pk.is_contiguous() and pk.data_ptr() % 16 == 0
+        assert torch.equal(pk, ops.pack_rgbx(out[("color", f, 0)]))
+        assert torch.equal(pk[..., :3].permute(0, 3, 1, 2), out[("color", f, 0)]) and not pk[..., 3].any()
     for b in range(B):
         for i, f in enumerate(frames):
             want = D.preprocess_item(native[i, b], h, w, 4, flips[b], jitters[b])

@@ -236,3 +236,42 @@ def test_evaluation_forward_equals_training_forward(tag, kw):
     w_train = L.dc_photo_workspace(ctypes.byref(d))
     d.flags = _lib.OPT_NO_GRAD
     assert L.dc_photo_workspace(ctypes.byref(d)) < w_train
+
+
+@pytest.mark.parametrize("tag,kw", VARIANTS[:2])
+def test_packed_inputs_change_nothing(tag, kw):
+    """dc_photo_desc.packed: the pixel-interleaved RGBx copies of the three frames supplied by the caller (the data step writes
+    them, dc_data_to_rgbx / dc_pack_rgbx) instead of rebuilt inside every forward.  Same values in the same layout: losses,
+    argmin maps and every gradient are bit-identical, and the workspace no longer holds the three copies."""
+    import ctypes
+    from depthcore import ops, _lib
+    dev = torch.device("cuda:0")
+    b, h, w = 3, 64, 160
+    inputs = R.synthetic_inputs(b, h, w, seed=4)
+    g = torch.Generator().manual_seed(5)
+    disps = [torch.rand(b, 1, h >> s, w >> s, generator=g) for s in range(4)]
+    Ts = random_poses(b, 11)
+    noise = R.tiebreak_noise(b, h, w)
+    frames = [inputs[("color", f, 0)].to(dev) for f in (0, -1, 1)]
+    packed = [ops.pack_rgbx(x) for x in frames]
+    for x, p in zip(frames, packed):
+        assert p.shape == (b, h, w, 4) and torch.equal(p[..., :3].permute(0, 3, 1, 2), x) and not p[..., 3].any()
+
+    def run(pk):
+        cfg = ops.PhotoConfig(frames[0], frames[1], frames[2], [inputs[("color", 0, s)].to(dev) for s in range(4)],
+                              inputs[("K", 0)].to(dev), inputs[("inv_K", 0)].to(dev), noise=[n.to(dev) for n in noise], packed=pk, **kw)
+        d = [x.to(dev).requires_grad_() for x in disps]
+        t = [x.to(dev).requires_grad_() for x in Ts]
+        losses = ops.photometric_loss(cfg, t[0], t[1], d)
+        grads = torch.autograd.grad(losses[4], d + t)
+        return losses.detach(), cfg.extras["argmin"], grads
+    (l0, a0, g0), (l1, a1, g1) = run(None), run(packed)
+    assert torch.equal(l0, l1)
+    assert all(torch.equal(x, y) for x, y in zip(a0, a1)) and all(torch.equal(x, y) for x, y in zip(g0, g1))
+    L = _lib.lib()
+    d = _lib.PhotoDesc()
+    d.B, d.H, d.W, d.num_scales = b, h, w, 4
+    w_plain = L.dc_photo_workspace(ctypes.byref(d))
+    for k in range(3):
+        d.packed[k] = packed[k].data_ptr()
+    assert w_plain - L.dc_photo_workspace(ctypes.byref(d)) >= 3 * b * h * w * 16
