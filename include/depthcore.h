@@ -48,6 +48,10 @@ const char* dc_arch(void);
  * launch through that code; call this after an error that was NOT theirs (e.g. a hipGraph capture that was invalidated) so
  * that the next launch does not report it as DC_ELAUNCH. */
 int dc_clear_error(void);
+/* Ends whatever hipGraph capture `stream` is in (a capture that was invalidated leaves its origin stream in capture mode, and
+ * every later launch on it fails), discards the graph and clears the error state.  Returns the capture status it found
+ * (0 none, 1 active, 2 invalidated). */
+int dc_abort_capture(void* stream);
 
 /* ------------------------------------------------------------------ a5 */
 /* layers.py:28-103 transformation_from_parameters (+rot_from_axisangle, get_translation_matrix).

@@ -509,11 +509,19 @@ class Trainer:
                 self._graphs[key] = None
                 self._graph_failed = getattr(self, "_graph_failed", 0) + 1
                 torch.cuda.set_stream(stream0)          # (torch.cuda.graph.__exit__ does not restore it when capture_end raises)
-                torch.cuda.synchronize(self.device)
-                _lib.lib().dc_clear_error()             # the invalidated capture's error code is not the next launch's
+                # an invalidated capture leaves its origin stream capturing (every later launch on it would fail): end it
+                _lib.lib().dc_abort_capture(gs.cuda_stream)
+                _lib.lib().dc_clear_error()             # the failed capture's error code is not the next launch's
                 warnings.warn("hip_graph: capture of the training step failed (%s: %s); this input shape runs eagerly"
                               % (type(e).__name__, e))
-                return self._eager_on_graph_stream(inputs)
+                try:
+                    torch.cuda.synchronize(self.device)
+                    return self._eager_on_graph_stream(inputs)
+                except Exception as e2:
+                    # an ILLEGAL call inside the capture (a synchronisation, an allocation by foreign code) can leave the HIP
+                    # runtime's capture state beyond repair for this process: say so instead of failing somewhere else
+                    raise RuntimeError("hip_graph: the capture failed (%s: %s) and the streams could not be recovered (%s: %s); "
+                                       "run without opt.hip_graph" % (type(e).__name__, e, type(e2).__name__, e2)) from e
             entry = self._graphs[key] = (g, static_in, static_out)
             self.step -= 1                      # (the recorded step has not run yet: the replay below is that step)
         else:

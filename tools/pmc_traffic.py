@@ -24,7 +24,7 @@ def main():
     B, H, W, NL = (int(os.environ.get(k, d)) for k, d in (("DC_B", 12), ("DC_H", 192), ("DC_W", 640), ("DC_LAYERS", 18)))
     fusion = os.environ.get("DC_FRONT", "") == "fusion"             # BASELINE configs[4] wiring
     dtype = os.environ.get("DC_DTYPE", "f32")                       # networks' matrix-core precision (f32 | bf16)
-    inp = synthetic_batch(B, H, W, dev, seed=0, frame_ids=(0, -2, -1, 1) if fusion else (0, -1, 1))
+    inp = synthetic_batch(B, H, W, dev, seed=0, frame_ids=(0, -2, -1, 1) if fusion else (0, -1, 1), packed=True)    # as bench.py
     g = torch.Generator(device=dev).manual_seed(0)
     disps = []
     for s in range(4):
@@ -37,7 +37,8 @@ def main():
         t[:, :3, 3] = 0.01 * torch.randn(B, 3, device=dev, generator=g)
         T.append(t.requires_grad_())
     cfg = ops.PhotoConfig(inp[("color", 0, 0)], inp[("color", -1, 0)], inp[("color", 1, 0)],
-                          [inp[("color", 0, s)] for s in range(4)], inp[("K", 0)], inp[("inv_K", 0)])
+                          [inp[("color", 0, s)] for s in range(4)], inp[("K", 0)], inp[("inv_K", 0)],
+                          packed=tuple(inp[("color_packed", f, 0)] for f in (0, -1, 1)))
     for _ in range(5):
         # flush the 256 MiB Infinity Cache between steps so that reads come from HBM, as in a training step
         big.mul_(1.0)

@@ -13,7 +13,7 @@ def load(d):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        n = n.split("<")[0] if ("wino_" in n or "c3b_" in n) else n     # all instantiations of a convolution kernel together
+        n = n.split("<")[0] if any(t in n for t in ("wino_", "c3b_", "photo_", "identity_")) else n     # all instantiations of a kernel together
         agg[n].append(float(r["Counter_Value"]))
         if any(t in n for t in ("g1_fwd_kernel", "g1_dgrad_kernel", "g1_wgrad_kernel")):
             agg["dc::g1_*"].append(float(r["Counter_Value"]))          # the 1x1 GEMM family of bench.py (mean over all its launches)
@@ -24,7 +24,7 @@ known_r, known_w = 256.0 * 2**20, 512.0 * 2**20
 kr, kw = known_r / (fe[cal] * 1024.0), known_w / (wr[cal] * 1024.0)
 out = {"calibration": {"kernel": cal, "FETCH_SIZE_KB": fe[cal], "WRITE_SIZE_KB": wr[cal], "read_factor": kr, "write_factor": kw}}
 for k in fe:
-    if any(t in k for t in ("photo_", "identity", "disp_grad", "wino_", "c3b_", "g1_", "cg_", "bn_", "pw_", "conv_fold", "conv_gprime")):
+    if any(t in k for t in ("photo_", "identity", "disp_grad", "smooth_fwd", "finalize", "wino_", "c3b_", "g1_", "cg_", "bn_", "pw_", "conv_fold", "conv_gprime")):
         out[k] = {"FETCH_SIZE_KB": fe[k], "WRITE_SIZE_KB": wr.get(k, 0.0),
                   "read_bytes_calibrated": fe[k] * 1024 * kr, "write_bytes_calibrated": wr.get(k, 0.0) * 1024 * kw,
                   "hbm_bytes_calibrated": fe[k] * 1024 * kr + wr.get(k, 0.0) * 1024 * kw, "sq_insts_valu": va.get(k)}

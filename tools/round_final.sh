@@ -1,11 +1,11 @@
 #!/bin/bash
-# GPU box: the round's judged artefacts for one configuration -> gpurun_out/r3final/ (tools/make_profile_summary_r3.py copies
-# them into profiles/).  usage: bash tools/r3_final.sh <cfg> [pmc]     cfg: c2 | c3 | c5 | c5bf16 | c1g | c4
+# GPU box: the round's judged artefacts for one configuration -> gpurun_out/r4final/ (tools/make_profile_summary.py copies
+# them into profiles/).  usage: bash tools/round_final.sh <cfg> [pmc]     cfg: c2 | c3 | c5 | c5bf16 | c1g | c4
 #   1. plain bench line        2. rocprofv3 --kernel-trace --stats of the same command (cfg c2 / c3 / c5 / c5bf16)
 #   3. with `pmc`: the three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU; tools/pmc_traffic.sh)
 set -e
 CFG=$1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r3final
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r4final
 mkdir -p $OUT
 case $CFG in
   c2) ARGS=""; ENVS="" ;;
