@@ -55,10 +55,11 @@ FAMILIES = {
 }
 VALU_LANE_OPS_PEAK = 78.6e12   # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: wave-level VALU instructions x 64 lanes per second
 # Issue slots per counted VALU instruction of the photometric kernels' main loops (tools/isa_mix.py on the gfx950 ISA, kept in
-# profiles/round3_photo_isa_mix.txt): SQ_INSTS_VALU counts a packed-fp32 or a transcendental instruction once, the SIMD-32 issues
-# them over twice the cycles (MI355X_MICROARCH.md "vector-instruction ISSUE cost").  backward: 1131 plain + 336 DPP + 16 lane + 2 x
-# (669 packed + 24 transcendental) = 2869 slots per 2176 instructions; forward: 712 + 2 x 60 = 832 per 772.
-VALU_SLOTS_PER_INST = {"bwd": 1.0, "fwd": 1.0}    # refreshed from profiles/round4_photo_isa_mix.txt below
+# profiles/round4_photo_isa_mix.txt): SQ_INSTS_VALU counts a packed-fp32 or a transcendental instruction once, the SIMD-32 issues
+# them over twice the cycles (MI355X_MICROARCH.md "vector-instruction ISSUE cost").  Training forward (photo_fwdg_kernel<false, 4>):
+# 1076 plain + 168 DPP + 21 lane + 2 x (318 packed + 24 transcendental) = 1949 slots per 1607 instructions; pointwise backward
+# (photo_bwdg_kernel): 387 + 4 + 2 x (80 + 12) = 575 per 483.
+VALU_SLOTS_PER_INST = {"bwd": 575.0 / 483.0, "fwd": 1949.0 / 1607.0}
 
 
 # ------------------------------------------------------------------------------------------------ launcher (N > 1)

@@ -46,11 +46,11 @@ for cfg in ("c2", "c3", "c5", "c5bf16"):
     u = json.load(open(os.path.join(SRC, "bench_%s_under_rocprof.json" % cfg)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     steps = u["steps"] + u["warmup"] + 3 + 4
-    L = ["# " + RND + ", %s -- `rocprofv3 --kernel-trace --stats -- python3 bench.py%s --no-cpu-baseline --windows 1` (1x MI355X)\n"
+    L = ["# @R@, %s -- `rocprofv3 --kernel-trace --stats -- python3 bench.py%s --no-cpu-baseline --windows 1` (1x MI355X)\n".replace("@R@", RND)
          % (cfg.upper(), ARGS[cfg]),
          "Workload: %s.\n" % b["config"]["workload"],
-         "Plain run of the same command: **%.3f ms/step = %.1f images/s** (`" + RND + "_%s_bench_n1.json`); under the profiler "
-         "(dispatches serialised, no two-stream overlap): %.3f ms/step = %.1f images/s.\n"
+         ("Plain run of the same command: **%.3f ms/step = %.1f images/s** (`@R@_%s_bench_n1.json`); under the profiler "
+          "(dispatches serialised, no two-stream overlap): %.3f ms/step = %.1f images/s.\n").replace("@R@", RND)
          % (b["ms_per_step"], b["value"], cfg, u["ms_per_step"], u["value"]),
          "Total GPU kernel time in the trace: %.1f ms over ~%d steps.\n" % (tot / 1e6, steps),
          "| kernel family | launches | avg us | total ms | % of GPU time |", "|---|---:|---:|---:|---:|"]
@@ -98,8 +98,8 @@ for cfg in ("c2", "c3", "c5", "c5bf16"):
     tj = os.path.join(SRC, "pmc_%s_traffic.json" % cfg)
     if os.path.exists(tj):
         t = json.load(open(tj))
-        L.append("HBM traffic and VALU instructions per launch (three separate `--pmc` passes: FETCH_SIZE x%.3f calibration, WRITE_SIZE x%.3f, "
-                 "SQ_INSTS_VALU; `" + RND + "_traffic_%s.json`):\n" % (t["calibration"]["read_factor"], t["calibration"]["write_factor"], cfg))
+        L.append(("HBM traffic and VALU instructions per launch (three separate `--pmc` passes: FETCH_SIZE x%.3f calibration, WRITE_SIZE x%.3f, "
+                  "SQ_INSTS_VALU; `@R@_traffic_%s.json`):\n").replace("@R@", RND) % (t["calibration"]["read_factor"], t["calibration"]["write_factor"], cfg))
         L.append("| kernel | HBM MB / launch | read MB | write MB | VALU wave-insts |")
         L.append("|---|---:|---:|---:|---:|")
         for k, v in t.items():
