@@ -38,6 +38,8 @@ extern "C" {
 #define DC_OPT_AVG_REPROJ 2u    /* opt.avg_reprojection */
 #define DC_OPT_NO_SSIM 4u       /* opt.no_ssim */
 #define DC_OPT_ALIGN_CORNERS 8u /* grid_sample(align_corners=True); default False = installed-torch default */
+#define DC_OPT_PRED_MASK 32u    /* opt.predictive_mask (trainer.py:571-584): reprojection losses are multiplied by `pred_mask[s]`; needs
+                                   DC_OPT_NO_AUTOMASK (trainer.py:116-117).  The BCE weighting term of the masks is the caller's */
 #define DC_OPT_NO_GRAD 16u      /* dc_photo_fwd only: evaluation -- the forward does not emit d(loss)/d(warped), the workspace
                                    is smaller and dc_photo_bwd on this descriptor returns DC_EINVAL */
 
@@ -164,6 +166,10 @@ typedef struct dc_photo_desc {
     const float* g_losses;        /* (num_scales+1) upstream gradient of `losses` */
     float* d_disp[DC_MAX_SCALES]; /* (B,1,H>>s,W>>s) */
     float* d_T[2];                /* (B,4,4) */
+    /* DC_OPT_PRED_MASK only */
+    const float* pred_mask[DC_MAX_SCALES]; /* outputs["predictive_mask"][("disp",s)] at FULL resolution (B,2,H,W): the caller
+                                              upsamples (trainer.py:574-577, dc_upsample_bilinear_fwd); channel f = frame -1 / +1 */
+    float* d_pred_mask[DC_MAX_SCALES];     /* backward: (B,2,H,W) */
     /* scratch */
     void* workspace;              /* dc_photo_workspace(desc) bytes, same buffer for fwd and bwd */
     size_t workspace_bytes;

@@ -70,6 +70,9 @@ struct PhotoArgs {
     float* stats;        // [ns][B][3]  (mean disp, Sx, Sy)
     float* gdup[DC_MAX_SCALES];   // full-res d(upsampled disp)
     float* gw[DC_MAX_SCALES];     // d(sum of to_optimise) / d(source coords): (B,H,W,[du-1, dv-1, du+1, dv+1]) written by the forward
+    const float* pmask[DC_MAX_SCALES];   // DC_OPT_PRED_MASK: predictive masks (B,2,H,W), full resolution (trainer.py:571-584)
+    float* gpm[DC_MAX_SCALES];    // d(sum of to_optimise) / d(mask): (B,H,W,2) written by the forward (workspace)
+    float* d_pmask[DC_MAX_SCALES];       // backward output (B,2,H,W)
     int rows_g, rows_p;           // rows per block of the gradient-emitting forward / the pointwise backward
     float* part_dP;      // [ns][2][B][nblk_b_per_image][12]
     int nblk_f, nchunk, nblk_b_img;
@@ -490,7 +493,9 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
     load_geo(g, p, b);
     const unsigned nch4 = (avg ? 1u : 2u) * c.plane4;
     const bool ext_noise = p.noise[s] != nullptr;
-    const rsrc_t nz = make_rsrc(ext_noise ? p.noise[s] + (size_t)b * (avg ? 1 : 2) * plane : p.idl, ext_noise ? nch4 : 0u);
+    const bool pm = p.flags & DC_OPT_PRED_MASK;        // the mask planes ride in the noise load slots (photo_fwdg_kernel)
+    const rsrc_t nz = pm ? make_rsrc(p.pmask[s] + (size_t)b * 2 * plane, 2u * c.plane4)
+                         : make_rsrc(ext_noise ? p.noise[s] + (size_t)b * (avg ? 1 : 2) * plane : p.idl, ext_noise ? nch4 : 0u);
     const rsrc_t idl = make_rsrc(p.idl + (size_t)b * (avg ? 1 : 2) * plane, automask ? nch4 : 0u);   // (B,H,W,2|1)
     const unsigned idl_px = avg ? 4u : 8u;
     uint8_t* am = p.argmin[s] + (size_t)b * plane;
@@ -538,6 +543,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
         }
         float r[2];
         reproj_values(r_old, r_new, cur, no_ssim, r);
+        if (pm) { r[0] *= idn_cur[2]; r[1] *= idn_cur[3]; }
         const int py = yy - 1;
         if (i >= 2 && py < H && lane_ok) {
             // ---- min over [identity(-1), identity(+1), reproj(-1), reproj(+1)]  (trainer.py:592-610)
@@ -733,7 +739,12 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
     load_geo(g, p, b);
     const unsigned nch4 = (avg ? 1u : 2u) * c.plane4;
     const bool ext_noise = SPEC >= 0 ? bool(SPEC & 8) : p.noise[s] != nullptr;
-    const rsrc_t nz = make_rsrc(ext_noise ? p.noise[s] + (size_t)b * (avg ? 1 : 2) * plane : p.idl, ext_noise ? nch4 : 0u);
+    // predictive mask (trainer.py:571-584; automasking is off with it): the two mask planes (B,2,H,W) travel in the load slots
+    // of the tie-break noise, which has the same layout and is not read without automasking -- no extra load, no new load shape
+    const bool pm = SPEC >= 0 ? false : bool(p.flags & DC_OPT_PRED_MASK);
+    const rsrc_t nz = pm ? make_rsrc(p.pmask[s] + (size_t)b * 2 * plane, 2u * c.plane4)
+                         : make_rsrc(ext_noise ? p.noise[s] + (size_t)b * (avg ? 1 : 2) * plane : p.idl, ext_noise ? nch4 : 0u);
+    const rsrc_t gpmb = make_rsrc(pm ? p.gpm[s] + (size_t)b * plane * 2 : p.idl, pm ? plane * 8u : 0u);
     const rsrc_t idl = make_rsrc(p.idl + (size_t)b * (avg ? 1 : 2) * plane, automask ? nch4 : 0u);
     const unsigned idl_px = avg ? 4u : 8u;
     uint8_t* am = p.argmin[s] + (size_t)b * plane;
@@ -749,6 +760,7 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
     Row rA = {}, rB = {};        // rows yy-2 / yy-1 (ping-pong)
     GAcc gA = {}, gB = {};       // pending d/d(warped) of rows yy-2 / yy-1
     int m_prev = -1;             // frame the min() routed pixel row yy-2 to (decided one step ago): -1 none, 0 / 1, 2 = both (avg)
+    float mk_prev[2] = {1.f, 1.f};   // predictive-mask values of that row
     float idnA[4] = {0.f, 0.f, 0.f, 0.f}, idnB[4] = {0.f, 0.f, 0.f, 0.f};
     float acc = 0.f;
     Taps tp;
@@ -833,6 +845,8 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
 #pragma unroll
             for (int f = 0; f < 2; ++f)
                 r[f] = no_ssim ? l1[f] * (1.f / 3.f) : fmaf(0.85f / 3.f, ss[f], (0.15f / 3.f) * l1[f]);
+            float mk[2] = {1.f, 1.f}, ru[2] = {r[0], r[1]};
+            if (pm) { mk[0] = idn_cur[2]; mk[1] = idn_cur[3]; r[0] *= mk[0]; r[1] *= mk[1]; }     // reprojection_losses *= mask
             // ---- min over [identity(-1), identity(+1), reproj(-1), reproj(+1)]  (trainer.py:592-610)
             const unsigned o = (unsigned)(min(max(py, 0), H - 1) * W + xr);
             float best;
@@ -867,6 +881,8 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
                 acc += best;
                 am[o] = (uint8_t)idx;
                 if (isel && automask) isel[o] = (idx > (avg ? 0 : 1)) ? 1.f : 0.f;
+                if (pm)       // d(to_optimise)/d(mask_f) = the unmasked reprojection loss of the frame the min() took (half each under avg)
+                    bstore2(gpmb, o * 8u, (m_p == 0 || m_p == 2) ? sel_val * ru[0] : 0.f, (m_p == 1 || m_p == 2) ? sel_val * ru[1] : 0.f);
             }
             // ---- derivative coefficients of the selected frame, spread (transposed 3x3) onto rows yy-2, yy-1, yy
             if (!no_ssim && __builtin_amdgcn_ballot_w64(m_p >= 0) != 0ull) {
@@ -900,12 +916,12 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
                         for (int f = 0; f < 2; ++f) {
                             const WStat t = warp_from_sums(ts[ch], ws[ch][f].sx, ws[ch][f].sxx, ws[ch][f].sxy);
                             float a, bb, cc;
-                            coeffs(ts[ch], t, gsel, a, bb, cc);
+                            coeffs(ts[ch], t, gsel * mk[f], a, bb, cc);
                             spread(f, ch, a, bb, cc);
                         }
                 } else {
                     const bool s1 = m_p == 1;
-                    const float gsel = (m_p >= 0) ? sel_val * g_ssim : 0.f;
+                    const float gsel = (m_p >= 0) ? sel_val * g_ssim * (s1 ? mk[1] : mk[0]) : 0.f;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         const WStat t = warp_from_sums(ts[ch], s1 ? ws[ch][1].sx : ws[ch][0].sx, s1 ? ws[ch][1].sxx : ws[ch][0].sxx,
@@ -928,7 +944,7 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
                 float duv[2][2];
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
-                    const float gl = (m_prev == f || m_prev == 2) ? g_l1 : 0.f;
+                    const float gl = (m_prev == f || m_prev == 2) ? g_l1 * mk_prev[f] : 0.f;
                     float du = 0.f, dv = 0.f;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
@@ -950,6 +966,7 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
             for (int ch = 0; ch < 3; ++ch) g_old.g[f][ch] = g_tmp[f][ch];
         r_old = cur;
         m_prev = m_p;           // stage C of the next step finishes the row this step decided
+        if (pm) { mk_prev[0] = idn_cur[2]; mk_prev[1] = idn_cur[3]; }
         slot3 = (slot3 == 2) ? 0 : slot3 + 1;
     };
 
@@ -1041,6 +1058,9 @@ __global__ __launch_bounds__(256, BWDG_BLOCKS_PER_CU) void photo_bwdg_kernel(Pho
         for (int k = 0; k < 3; ++k) accA[f][k] = accB[f][k] = accC[f][k] = 0.f;
     const int yend = min(y0 + R_ROWS, H);
     const float xf = (float)xr;
+    const bool pm = p.flags & DC_OPT_PRED_MASK;
+    const rsrc_t gpmb = make_rsrc(pm ? p.gpm[s] + (size_t)b * plane * 2 : p.idl, pm ? plane * 8u : 0u);
+    float* dpm = pm ? p.d_pmask[s] + (size_t)b * 2 * plane : nullptr;
 
 #pragma unroll 1
     for (int qy0 = y0; qy0 < yend; qy0 += BWDG_UNROLL) {
@@ -1052,6 +1072,17 @@ __global__ __launch_bounds__(256, BWDG_BLOCKS_PER_CU) void photo_bwdg_kernel(Pho
             const int qy = min(qy0 + k, H - 1);
             disp_issue(dt[k], c, xr, qy);
             gq[k] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(gwb, (int)((unsigned)(qy * W + xr) * 16u), 0, 0));
+        }
+        if (pm) {       // d(loss)/d(predictive mask) = upstream weight x what the forward left (a separate, rare path)
+#pragma unroll
+            for (int k = 0; k < BWDG_UNROLL; ++k) {
+                const int qy = qy0 + k;
+                const f2 gm = bload2(gpmb, (unsigned)(min(qy, H - 1) * W + xr) * 8u);
+                if (col_ok && qy < yend) {
+                    dpm[(unsigned)(qy * W + x)] = gm.x * wgt;
+                    dpm[plane + (unsigned)(qy * W + x)] = gm.y * wgt;
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < BWDG_UNROLL; ++k) {
@@ -1308,7 +1339,7 @@ __global__ __launch_bounds__(256) void disp_grad_kernel(PhotoArgs p, DgPlan pl) 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Carve {
-    size_t idl, pk[3], part_photo, part_smooth, stats, gdup[DC_MAX_SCALES], gw[DC_MAX_SCALES], part_dP, total;
+    size_t idl, pk[3], part_photo, part_smooth, stats, gdup[DC_MAX_SCALES], gw[DC_MAX_SCALES], gpm[DC_MAX_SCALES], part_dP, total;
     int nblk_f, nchunk, nblk_b_img, strips_f, strips_b, rows_f, rowblocks_f;
     int strips_p, rows_g, rows_p, rowblocks_g, rowblocks_p;   // training forward (60-lane strips) / pointwise backward
     bool packed_in;                                           // the caller supplied the RGBx copies: none in the workspace
@@ -1368,6 +1399,8 @@ static Carve carve(const dc_photo_desc* d) {
     for (int s = 0; s < DC_MAX_SCALES; ++s) {
         c.gw[s] = off;
         if (s < d->num_scales && train) off += align256(N * 16);
+        c.gpm[s] = off;
+        if (s < d->num_scales && train && (d->flags & DC_OPT_PRED_MASK)) off += align256(N * 8);
     }
     c.part_dP = off; off += align256((size_t)d->num_scales * 2 * d->B * c.nblk_b_img * 12 * 4);
     c.total = off;
@@ -1381,6 +1414,7 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
         !d->workspace)
         return DC_EINVAL;
     if (!(d->min_depth > 0.f) || !(d->max_depth > d->min_depth)) return DC_EINVAL;
+    if ((d->flags & DC_OPT_PRED_MASK) && !(d->flags & DC_OPT_NO_AUTOMASK)) return DC_EINVAL;    // trainer.py:116-117
     const int npk = (d->packed[0] ? 1 : 0) + (d->packed[1] ? 1 : 0) + (d->packed[2] ? 1 : 0);
     if (npk != 0 && npk != 3) return DC_EINVAL;                      // all three or none
     for (int k = 0; k < npk; ++k)
@@ -1413,9 +1447,18 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
         for (int f = 0; f < 2; ++f) { a.sample[s][f] = d->sample[s][f]; a.color[s][f] = d->color[s][f]; }
         a.gdup[s] = (float*)(ws + c.gdup[s]);
         a.gw[s] = (float*)(ws + c.gw[s]);
+        a.gpm[s] = (float*)(ws + c.gpm[s]);
+        if (d->flags & DC_OPT_PRED_MASK) {
+            if (!d->pred_mask[s]) return DC_EINVAL;
+            a.pmask[s] = d->pred_mask[s];
+        }
         if (backward) {
             if (!d->d_disp[s]) return DC_EINVAL;
             a.d_disp[s] = d->d_disp[s];
+            if (d->flags & DC_OPT_PRED_MASK) {
+                if (!d->d_pred_mask[s]) return DC_EINVAL;
+                a.d_pmask[s] = d->d_pred_mask[s];
+            }
         }
     }
     if (backward) {
@@ -1537,7 +1580,7 @@ extern "C" int dc_photo_fwd(const dc_photo_desc* d, void* stream) {
             hipLaunchKernelGGL(photo_fwd_kernel<false>, dim3(c.strips_f, c.rowblocks_f, a.B), dim3(64 * a.ns), 0, st, a);
     } else {
         // the default training configuration (SSIM + L1, min over frames, automasking) runs a specialised instantiation
-        const bool dflt = !(a.flags & (DC_OPT_NO_SSIM | DC_OPT_AVG_REPROJ | DC_OPT_NO_AUTOMASK));
+        const bool dflt = !(a.flags & (DC_OPT_NO_SSIM | DC_OPT_AVG_REPROJ | DC_OPT_NO_AUTOMASK | DC_OPT_PRED_MASK));
         bool all_ext = true, none_ext = true;
         for (int s = 0; s < a.ns; ++s) { all_ext = all_ext && a.noise[s]; none_ext = none_ext && !a.noise[s]; }
         const dim3 grid(c.strips_b, c.rowblocks_g, a.B), blk(64 * a.ns);

@@ -24,6 +24,7 @@ OPT_AVG_REPROJ = 2
 OPT_NO_SSIM = 4
 OPT_ALIGN_CORNERS = 8
 OPT_NO_GRAD = 16
+OPT_PRED_MASK = 32
 PREC_F32, PREC_BF16 = 0, 1
 
 _ERR = {-1: "DC_EINVAL (bad shape / null pointer / unsupported option)",
@@ -50,6 +51,7 @@ class PhotoDesc(Structure):
         ("depth", _F * MAX_SCALES), ("sample", (_F * 2) * MAX_SCALES), ("color", (_F * 2) * MAX_SCALES),
         ("identity_selection", _F * MAX_SCALES),
         ("g_losses", _F), ("d_disp", _F * MAX_SCALES), ("d_T", _F * 2),
+        ("pred_mask", _F * MAX_SCALES), ("d_pred_mask", _F * MAX_SCALES),
         ("workspace", _F), ("workspace_bytes", c_size_t),
     ]
 

@@ -122,9 +122,10 @@ class PhotoConfig:
         self.rng_seed_dev = rng_seed if torch.is_tensor(rng_seed) else None
         self.rng_seed = 0 if torch.is_tensor(rng_seed) else int(rng_seed)
         self.extras = {}          # filled by forward: argmin maps + optional log tensors
+        self.n_masks = 0          # set by photometric_loss(pred_masks=...)
 
 
-def _fill_desc(cfg, T0, T1, disps, no_grad=False):
+def _fill_desc(cfg, T0, T1, disps, no_grad=False, masks=()):
     B, _, H, W = cfg.target.shape
     ns = len(disps)
     if ns < 1 or ns > _lib.MAX_SCALES:
@@ -133,7 +134,14 @@ def _fill_desc(cfg, T0, T1, disps, no_grad=False):
         raise _lib.DepthcoreError("images must be (B,3,H,W)")
     d = PhotoDesc()
     d.B, d.H, d.W, d.num_scales = B, H, W, ns
-    d.flags = cfg.flags | (_lib.OPT_NO_GRAD if no_grad else 0)
+    d.flags = cfg.flags | (_lib.OPT_NO_GRAD if no_grad else 0) | (_lib.OPT_PRED_MASK if masks else 0)
+    if masks:
+        if not (cfg.flags & _lib.OPT_NO_AUTOMASK):
+            raise _lib.DepthcoreError("predictive masks need disable_automasking (reference trainer.py:116-117)")
+        if len(masks) != ns or any(tuple(m.shape) != (B, 2, H, W) for m in masks):
+            raise _lib.DepthcoreError("predictive masks: one (B,2,H,W) full-resolution tensor per scale")
+        for s in range(ns):
+            d.pred_mask[s] = ptr(masks[s])
     d.min_depth, d.max_depth, d.smoothness = cfg.min_depth, cfg.max_depth, cfg.smoothness
     d.target = ptr(cfg.target)
     for f in range(2):
@@ -171,16 +179,18 @@ def _fill_desc(cfg, T0, T1, disps, no_grad=False):
 
 class _PhotoLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cfg, T0, T1, *disps):
+    def forward(ctx, cfg, T0, T1, *tensors):
         L = _lib.lib()
         T0, T1 = _c(T0.detach()), _c(T1.detach())
-        disps = [_c(x.detach()) for x in disps]
+        nm = cfg.n_masks                      # the last `nm` tensors are the predictive masks (one per scale), else none
+        disps = [_c(x.detach()) for x in tensors[:len(tensors) - nm]]
+        masks = [_c(x.detach()) for x in tensors[len(tensors) - nm:]] if nm else []
         dev = cfg.target.device
         B, _, H, W = cfg.target.shape
         ns = len(disps)
         # evaluation (nothing requires a gradient): the forward skips the gradient emission and its 24 B/pixel/scale
         ctx.no_grad = not any(ctx.needs_input_grad)
-        d = _fill_desc(cfg, T0, T1, disps, ctx.no_grad)
+        d = _fill_desc(cfg, T0, T1, disps, ctx.no_grad, masks)
         wsz = L.dc_photo_workspace(ctypes.byref(d))
         ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
         d.workspace, d.workspace_bytes = ws.data_ptr(), wsz
@@ -205,16 +215,17 @@ class _PhotoLoss(torch.autograd.Function):
                     d.identity_selection[s] = ptr(ex["identity_selection"][s])
         check(L.dc_photo_fwd(ctypes.byref(d), stream(cfg.target)), "dc_photo_fwd")
         cfg.extras = ex
-        ctx.cfg, ctx.ws, ctx.argmin = cfg, ws, argmin
-        ctx.save_for_backward(T0, T1, *disps)
+        ctx.cfg, ctx.ws, ctx.argmin, ctx.nm = cfg, ws, argmin, nm
+        ctx.save_for_backward(T0, T1, *disps, *masks)
         return losses
 
     @staticmethod
     def backward(ctx, g_losses):
         L = _lib.lib()
         cfg = ctx.cfg
-        T0, T1, *disps = ctx.saved_tensors
-        d = _fill_desc(cfg, T0, T1, disps, ctx.no_grad)
+        T0, T1, *rest = ctx.saved_tensors
+        disps, masks = (rest[:len(rest) - ctx.nm], rest[len(rest) - ctx.nm:]) if ctx.nm else (rest, [])
+        d = _fill_desc(cfg, T0, T1, disps, ctx.no_grad, masks)
         d.workspace, d.workspace_bytes = ctx.ws.data_ptr(), ctx.ws.numel()
         g = _c(g_losses.to(torch.float32))
         d.g_losses = ptr(g)
@@ -224,8 +235,11 @@ class _PhotoLoss(torch.autograd.Function):
             d.argmin[s] = ctx.argmin[s].data_ptr()
             d.d_disp[s] = ptr(d_disp[s])
         d.d_T[0], d.d_T[1] = ptr(dT[0]), ptr(dT[1])
+        d_masks = [torch.empty_like(m) for m in masks]
+        for s in range(len(d_masks)):
+            d.d_pred_mask[s] = ptr(d_masks[s])
         check(L.dc_photo_bwd(ctypes.byref(d), stream(cfg.target)), "dc_photo_bwd")
-        return (None, dT[0], dT[1], *d_disp)
+        return (None, dT[0], dT[1], *d_disp, *d_masks)
 
 
 def pack_rgbx(x):
@@ -240,9 +254,13 @@ def pack_rgbx(x):
     return out
 
 
-def photometric_loss(cfg, T_m1, T_p1, disps):
-    """-> losses tensor (num_scales+1,): [loss/0, ..., loss]  (trainer.py:618-621)."""
-    return _PhotoLoss.apply(cfg, T_m1, T_p1, *disps)
+def photometric_loss(cfg, T_m1, T_p1, disps, pred_masks=None):
+    """-> losses tensor (num_scales+1,): [loss/0, ..., loss]  (trainer.py:618-621).
+    pred_masks: opt.predictive_mask (trainer.py:571-584, needs disable_automasking) -- one FULL-resolution (B,2,H,W) mask per
+    scale (the caller upsamples, trainer.py:574-577); the reprojection losses are multiplied by them inside the kernels and
+    the masks get their gradient.  The BCE weighting term (trainer.py:579-581) is not part of this op."""
+    cfg.n_masks = len(pred_masks) if pred_masks else 0
+    return _PhotoLoss.apply(cfg, T_m1, T_p1, *disps, *(pred_masks or []))
 
 
 def photo_algorithmic_bytes(cfg, T0, T1, disps, backward):

@@ -8,8 +8,10 @@ validation) is out of scope (SURVEY 8, rows a14-a18 only).
 Two equivalent loss paths, both on hand-written gfx950 kernels:
   * fused (default): generate_images_pred + compute_losses are ONE forward op and ONE backward op
     (`depthcore.ops.photometric_loss`); log tensors are produced only when asked for;
-  * layer-by-layer (`opt.fused_loss = False`): the reference's own sequence of `layers.*` calls.  The `v1_multiscale`
-    and `predictive_mask` ablations (trainer.py:471,541,571-590) always take this path.
+  * layer-by-layer (`opt.fused_loss = False`): the reference's own sequence of `layers.*` calls.
+The a15 ablations run on the fused kernels too: `predictive_mask` (trainer.py:571-590: the masks multiply the reprojection
+losses inside the kernels and get their gradient there; the BCE term stays a torch expression) and `v1_multiscale`
+(trainer.py:471,541: one single-scale fused call per scale, `fused_losses_v1`).
 
 `opt.fusion = "v3"` switches the front-end to the reference's trainer_fusion_v3.py:277-330: frames [-2, -1, 0] are stacked
 through the depth encoder + decoder and fused by `networks.Fusion_v3` (BASELINE configs[4]).
@@ -248,8 +250,8 @@ class Trainer:
         else:
             outputs = self._depth_branch(inputs)
             outputs.update(self.predict_poses(inputs, None))
-        if self.opt.fused_loss and not (self.opt.predictive_mask or self.opt.v1_multiscale):
-            losses = self.fused_losses(inputs, outputs)
+        if self.opt.fused_loss:
+            losses = self.fused_losses_v1(inputs, outputs) if self.opt.v1_multiscale else self.fused_losses(inputs, outputs)
         else:
             self.generate_images_pred(inputs, outputs)
             losses = self.compute_losses(inputs, outputs)
@@ -314,10 +316,15 @@ class Trainer:
             smoothness=o.disparity_smoothness, disable_automasking=o.disable_automasking,
             avg_reprojection=o.avg_reprojection, no_ssim=o.no_ssim, materialize=materialize, packed=packed,
             rng_seed=self._seed_dev if self._seed_dev is not None else self.step * 1000003 + self.rank)
+        masks, bce = self._predictive_masks(outputs, full_res=True)
         lv = ops.photometric_loss(cfg, outputs[("cam_T_cam", 0, -1)], outputs[("cam_T_cam", 0, 1)],
-                                  [outputs[("disp", s)] for s in o.scales])
-        losses = {"loss/{}".format(s): lv[i] for i, s in enumerate(o.scales)}
-        losses["loss"] = lv[len(o.scales)]
+                                  [outputs[("disp", s)] for s in o.scales], pred_masks=masks)
+        if masks is None:
+            losses = {"loss/{}".format(s): lv[i] for i, s in enumerate(o.scales)}
+            losses["loss"] = lv[len(o.scales)]
+        else:           # + the masks' BCE weighting term per scale (trainer.py:579-581); total = mean over the scales
+            losses = {"loss/{}".format(s): lv[i] + bce[i] for i, s in enumerate(o.scales)}
+            losses["loss"] = sum(losses["loss/{}".format(s)] for s in o.scales) / self.num_scales
         ex = cfg.extras
         for i, s in enumerate(o.scales):
             outputs[("argmin", s)] = ex["argmin"][i]
@@ -330,6 +337,53 @@ class Trainer:
                         outputs[("color_identity", f, s)] = inputs[("color", f, 0)]
                 if not o.disable_automasking:
                     outputs["identity_selection/{}".format(s)] = ex["identity_selection"][i]
+        return losses
+
+    def _predictive_masks(self, outputs, full_res):
+        """opt.predictive_mask (trainer.py:571-584): the mask decoder's outputs, upsampled to the loss resolution unless every
+        scale works at its own (`v1_multiscale`), and their weighting term 0.2 * BCE(mask, 1) (-log clamped at -100, mean)."""
+        if not self.opt.predictive_mask:
+            return None, None
+        o = self.opt
+        masks = [outputs["predictive_mask"][("disp", s)] for s in o.scales]
+        if full_res:
+            masks = [interpolate_bilinear(m, [o.height, o.width]) for m in masks]
+        return masks, [0.2 * (-torch.clamp(torch.log(m), min=-100.0)).mean() for m in masks]
+
+    def fused_losses_v1(self, inputs, outputs, materialize=None):
+        """`opt.v1_multiscale` (trainer.py:470-472, 541-544) on the fused kernels: every scale warps and compares at its OWN
+        resolution -- its own images, intrinsics, identity losses and tie-break noise -- so the step is one fused call per
+        scale, each a single-scale problem of size (H >> s, W >> s) (the kernels' scale-0 wave: the upsample is the identity),
+        with the smoothness weight divided by 2^s as trainer.py:616 does; total = mean over the scales."""
+        o = self.opt
+        materialize = o.materialize_logs if materialize is None else materialize
+        B = inputs[("color", 0, 0)].shape[0]
+        noise = self._noise(B, 1 if o.avg_reprojection else 2)
+        masks, bce = self._predictive_masks(outputs, full_res=False)
+        losses, total = {}, 0
+        for i, s in enumerate(o.scales):
+            cfg = ops.PhotoConfig(
+                inputs[("color", 0, s)], inputs[("color", -1, s)], inputs[("color", 1, s)], [inputs[("color", 0, s)]],
+                inputs[("K", s)], inputs[("inv_K", s)], noise=None if noise is None else [noise[i]], min_depth=o.min_depth,
+                max_depth=o.max_depth, smoothness=o.disparity_smoothness / (2 ** s), disable_automasking=o.disable_automasking,
+                avg_reprojection=o.avg_reprojection, no_ssim=o.no_ssim, materialize=materialize,
+                rng_seed=(self._seed_dev + i) if self._seed_dev is not None else self.step * 1000003 + self.rank + 7919 * i)
+            lv = ops.photometric_loss(cfg, outputs[("cam_T_cam", 0, -1)], outputs[("cam_T_cam", 0, 1)], [outputs[("disp", s)]],
+                                      pred_masks=None if masks is None else [masks[i]])
+            losses["loss/{}".format(s)] = lv[0] if masks is None else lv[0] + bce[i]
+            total = total + losses["loss/{}".format(s)]
+            ex = cfg.extras
+            outputs[("argmin", s)] = ex["argmin"][0]
+            if materialize:
+                outputs[("depth", 0, s)] = ex["depth"][0]
+                for j, f in enumerate((-1, 1)):
+                    outputs[("sample", f, s)] = ex["sample"][0][j]
+                    outputs[("color", f, s)] = ex["color"][0][j]
+                    if not o.disable_automasking:
+                        outputs[("color_identity", f, s)] = inputs[("color", f, s)]
+                if not o.disable_automasking:
+                    outputs["identity_selection/{}".format(s)] = ex["identity_selection"][0]
+        losses["loss"] = total / self.num_scales
         return losses
 
     # ------------------------------------------------------------------ trainer.py:465-515

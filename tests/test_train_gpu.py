@@ -377,6 +377,114 @@ def test_trainer_ablations_golden(golden, tag):
         vs_fixture(6 + j, "_gtr_%d" % f)
 
 
+def test_v1_multiscale_on_the_fused_kernels_golden(golden):
+    """`v1_multiscale` on the fused kernels (Trainer.fused_losses_v1: one single-scale fused call per scale at that scale's own
+    resolution) against the reference's outputs (tests/golden/trainer_ablations.npz, tag v1ms) and against the layer-by-layer
+    HIP path on the same leaves: losses 1e-3 / 1e-4, disparity gradients 2e-3, pose gradients within the conditioning budget."""
+    import trainer as T
+    import make_golden as MG
+    import make_golden_r2 as MG2
+    from layers import transformation_from_parameters
+    g = golden["trainer_ablations"]
+    B, H, W = MG.B, MG.H, MG.W
+    tr = T.Trainer(T.default_options(batch_size=B, height=H, width=W, cpu_tiebreak_noise=True, v1_multiscale=True), device=DEV, seed=0)
+    inputs = {k: v.to(DEV) for k, v in R.synthetic_inputs(B, H, W, seed=0).items()}
+    disp, aa, tr_, _ = MG2.ablation_inputs("v1ms")
+
+    def run(fused):
+        leaves = [disp[s].to(DEV).requires_grad_() for s in range(4)]
+        pose = [aa[-1].to(DEV).requires_grad_(), aa[1].to(DEV).requires_grad_(), tr_[-1].to(DEV).requires_grad_(),
+                tr_[1].to(DEV).requires_grad_()]
+        outputs = {("disp", s): leaves[s] for s in range(4)}
+        for j, f in enumerate((-1, 1)):
+            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(pose[j], pose[2 + j], invert=(f < 0))
+        torch.manual_seed(1234)
+        if fused:
+            losses = tr.fused_losses_v1(inputs, outputs)
+        else:
+            tr.generate_images_pred(inputs, outputs)
+            losses = tr.compute_losses(inputs, outputs)
+        return losses, torch.autograd.grad(losses["loss"], leaves + pose), outputs
+    lf, gf, of = run(True)
+    ll, gl, ol = run(False)
+    close(lf["loss"], g["v1ms_loss"], rtol=1e-3, atol=0)
+    close(lf["loss"], ll["loss"], rtol=1e-4, atol=0)
+    for s in range(4):
+        close(lf["loss/%d" % s], g["v1ms_loss%d" % s], rtol=1e-3, atol=0)
+        close(lf["loss/%d" % s], ll["loss/%d" % s], rtol=1e-4, atol=0)
+        assert rel_l2(gf[s], gl[s]) <= 2e-3, (s, rel_l2(gf[s], gl[s]))
+        assert of[("argmin", s)].shape == (B, H >> s, W >> s)
+        sel = (of[("argmin", s)] > 1).float()
+        assert float((sel != ol["identity_selection/%d" % s]).float().mean()) <= 1e-3
+    for i in range(4, 8):
+        assert rel_l2(gf[i], gl[i]) <= 3e-2, (i, rel_l2(gf[i], gl[i]))
+    # and a whole training step takes this path by default now
+    _, losses = tr.train_step({k: v.clone() for k, v in inputs.items()})
+    assert torch.isfinite(losses["loss"]) and ("argmin", 3) in _
+
+
+@pytest.mark.parametrize("variant", ["pmask", "pmask+avg", "pmask+v1"])
+def test_predictive_mask_on_the_fused_kernels(golden, variant):
+    """`predictive_mask` (+ disable_automasking, trainer.py:571-590) on the fused kernels: the masks multiply the reprojection
+    losses inside photo_fwdg_kernel (they ride in the load slots of the unused tie-break noise), scale the SSIM / L1 derivative,
+    and get their own gradient (d to_optimise / d mask_f = the unmasked loss of the frame the min() took); the BCE term stays a
+    torch expression.  Against the reference's outputs for the plain variant (tests/golden/trainer_ablations.npz, tag pmask)
+    and against the layer-by-layer HIP path on the same leaves for all three (with avg_reprojection; at each scale's own size)."""
+    import trainer as T
+    import make_golden as MG
+    import make_golden_r2 as MG2
+    from layers import transformation_from_parameters
+    g = golden["trainer_ablations"]
+    B, H, W = MG.B, MG.H, MG.W
+    kw = dict(disable_automasking=True, predictive_mask=True)
+    if variant == "pmask+avg":
+        kw["avg_reprojection"] = True
+    if variant == "pmask+v1":
+        kw["v1_multiscale"] = True
+    tr = T.Trainer(T.default_options(batch_size=B, height=H, width=W, cpu_tiebreak_noise=True, **kw), device=DEV, seed=0)
+    inputs = {k: v.to(DEV) for k, v in R.synthetic_inputs(B, H, W, seed=0).items()}
+    disp, aa, tr_, mask = MG2.ablation_inputs("pmask")
+
+    def run(fused):
+        leaves = [disp[s].to(DEV).requires_grad_() for s in range(4)]
+        pose = [aa[-1].to(DEV).requires_grad_(), aa[1].to(DEV).requires_grad_(), tr_[-1].to(DEV).requires_grad_(),
+                tr_[1].to(DEV).requires_grad_()]
+        masks = [mask[s].to(DEV).requires_grad_() for s in range(4)]
+        outputs = {("disp", s): leaves[s] for s in range(4)}
+        outputs["predictive_mask"] = {("disp", s): masks[s] for s in range(4)}
+        for j, f in enumerate((-1, 1)):
+            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(pose[j], pose[2 + j], invert=(f < 0))
+        torch.manual_seed(1234)
+        if fused:
+            losses = tr.fused_losses_v1(inputs, outputs) if "v1" in variant else tr.fused_losses(inputs, outputs)
+        else:
+            tr.generate_images_pred(inputs, outputs)
+            losses = tr.compute_losses(inputs, outputs)
+        return losses, torch.autograd.grad(losses["loss"], leaves + pose + masks)
+    lf, gf = run(True)
+    ll, gl = run(False)
+    if variant == "pmask":
+        close(lf["loss"], g["pmask_loss"], rtol=1e-3, atol=0)
+        for s in range(4):
+            close(lf["loss/%d" % s], g["pmask_loss%d" % s], rtol=1e-3, atol=0)
+    close(lf["loss"], ll["loss"], rtol=1e-4, atol=0)
+    for s in range(4):
+        close(lf["loss/%d" % s], ll["loss/%d" % s], rtol=1e-4, atol=0)
+        assert rel_l2(gf[s], gl[s]) <= 3e-3, ("disp", s, rel_l2(gf[s], gl[s]))
+        assert rel_l2(gf[8 + s], gl[8 + s]) <= 2e-3, ("mask", s, rel_l2(gf[8 + s], gl[8 + s]))
+    for i in range(4, 8):
+        assert rel_l2(gf[i], gl[i]) <= 3e-2, ("pose", i, rel_l2(gf[i], gl[i]))
+    # a whole training step (mask decoder included) runs on the fused path, and evaluation (no gradient) gives the same loss
+    batch = {k: v.clone() for k, v in inputs.items()}
+    torch.manual_seed(7)
+    with torch.no_grad():
+        _, le = tr.process_batch(dict(batch))
+    torch.manual_seed(7)
+    _, lt = tr.train_step(dict(batch))
+    assert torch.isfinite(lt["loss"])
+    close(le["loss"], lt["loss"], rtol=2e-5, atol=0)
+
+
 def test_fusion_v3_training_steps():
     """BASELINE configs[4] wiring at a small size: frames [-2,-1,0] through encoder + decoder + Fusion_v3, loss finite and
     decreasing over Adam steps, every fusion parameter that the reference trains receives a gradient."""
