@@ -447,6 +447,11 @@ int dc_get_matrix_precision(void);
  * the cache changes launch counts, never results (the transform is the same device function).  Nothing here allocates,
  * synchronises or copies while `stream` is being captured into a hipGraph: a variant first met inside a capture keeps its
  * per-launch transform, and a refresh inside a capture launches the owner's table as it stood before the capture. */
+/* Winograd F(4x4,3x3) for the plain trunk convolutions (dc_wino3x3_fwd / _dgrad / _dgrad_add; the weight gradient and the
+ * decoder's fused blocks keep F(2x2,3x3)): 0.5625 of the matrix-core work at ~5x the rounding error (1.1-1.4e-6 relative L2
+ * against an fp64 direct convolution; F(2x2,3x3): 2-3e-7).  OFF by default; mode 1 uses it where W % 4 == 0 and its tile
+ * groups cover >= 85 % of the map.  Process-global; returns the previous mode, or DC_EINVAL.  Measurements: DESIGN.md 4a. */
+int dc_set_wino_f4(int mode);
 int dc_wino_cache_new_owner(void);
 int dc_wino_cache_register(int owner, const float* weight, int Ci, int Co);
 int dc_wino_cache_release_owner(int owner);

@@ -36,6 +36,7 @@
 #include "dc_common.h"
 #include "conv_bf16.h"
 #include "wino.h"
+#include "wino4.h"
 
 #include <algorithm>
 #include <mutex>
@@ -466,6 +467,13 @@ __global__ __launch_bounds__(256) void wino_ysum_kernel(const float* __restrict_
 
 static inline size_t wino_al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+int wino_ysum_launch(const float* slabs, float* y, size_t n4, int ksplit, const float* addend, hipStream_t st) {
+    hipLaunchKernelGGL(wino_ysum_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, st, slabs, y, n4, n4,
+                       ksplit, (const float*)nullptr, (int)ACT_NONE, 1, 1, addend);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
 // sub-region shapes {RH, RW, RS}: RS makes the 16-lane ds_read_b64 groups of a patch row conflict-free
 static void wino_ps_pick_region(int TH, int TW, int& RH, int& RW, int& RS) {
     const int cand[4][3] = {{4, 8, 24}, {2, 16, 36}, {3, 10, 26}, {8, 4, 12}};
@@ -718,6 +726,8 @@ int wino_conv_full_dgrad(const float* gp, const float* weight, float* dxpad, voi
     return wino_launch(d, st);
 }
 
+static int g_wino_f4 = 0;      // dc_set_wino_f4: 0 = F(2x2,3x3) everywhere (default), 1 = F(4x4,3x3) for the plain trunk convolutions it covers
+
 static int wino_run(const float* x, const float* w, float* y, const float* addend, void* ws, int B, int Ci, int Co, int H, int W,
                     bool dgrad, hipStream_t st) {
     if (!x || !w || !y || !ws || B <= 0 || Ci <= 0 || Co <= 0 || H < 1 || W < 2 || (W & 1)) return DC_EINVAL;
@@ -727,6 +737,12 @@ static int wino_run(const float* x, const float* w, float* y, const float* adden
         const int rc = c3b_conv(x, dgrad ? Co : Ci, 0, nullptr, 0, w, Co, Ci, dgrad ? 1 : 0, 0, nullptr, y, ws, B, H, W, ACT_NONE, PAD_ZERO, 1, st);
         if (rc != DC_OK || !addend) return rc;
         return add_inplace(y, addend, (size_t)B * (dgrad ? Ci : Co) * H * W, st);
+    }
+    // F(4x4,3x3) (wino4.hip): opt-in (dc_set_wino_f4) for maps its tile groups cover well -- measured against this file's
+    // F(2x2,3x3) in tests/test_wino_gpu.py and tools/bench_wino.py; DESIGN 4a has the verdict
+    if (g_wino_f4 && wino4_eligible(B, dgrad ? Co : Ci, dgrad ? Ci : Co, H, W) && wino4_utilisation(H, W) >= 0.85) {
+        float* slabs = (float*)((char*)ws + std::max(wino_uhat_bytes(Ci, Co), wino4_uhat_bytes(Ci, Co)));
+        return wino4_launch(x, w, nullptr, y, addend, ws, slabs, B, Ci, Co, H, W, dgrad, st);
     }
     WinoLaunch d{};
     d.src0 = x; d.C0 = dgrad ? Co : Ci; d.weight = w; d.Co = Co; d.Ci = Ci; d.dgrad = dgrad; d.act = ACT_NONE; d.pad = PAD_ZERO;
@@ -903,7 +919,15 @@ extern "C" int dc_wino_cache_variants(void) {
 
 extern "C" size_t dc_wino3x3_workspace(int B, int Ci, int Co, int H, int W) {
     if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;
-    return std::max(wino_uhat_bytes(Ci, Co), c3b_weights_bytes(Ci, Co)) + wino_al256((size_t)2 * B * std::max(Ci, Co) * H * W * sizeof(float));
+    return std::max({wino_uhat_bytes(Ci, Co), wino4_uhat_bytes(Ci, Co), c3b_weights_bytes(Ci, Co)}) +
+           wino_al256((size_t)2 * B * std::max(Ci, Co) * H * W * sizeof(float));
+}
+
+extern "C" int dc_set_wino_f4(int mode) {
+    if (mode != 0 && mode != 1) return DC_EINVAL;
+    const int prev = g_wino_f4;
+    g_wino_f4 = mode;
+    return prev;
 }
 
 extern "C" int dc_wino3x3_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int H, int W,

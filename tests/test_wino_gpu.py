@@ -115,3 +115,76 @@ def test_two_gib_tensor_takes_the_direct_kernels():
     lhs = float((gy.double() * y.detach().double()).sum())
     rhs = float((gw.double() * w.detach().double()).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
+
+
+F4_CASES = [
+    # B, Ci, Co, H, W          (W % 4 == 0; the dispatch also asks for >= 85 % tile-group coverage)
+    (2, 64, 64, 48, 160),      # layer1: 12 x 40 tiles, 3 x 5 groups
+    (12, 64, 64, 48, 160),     # layer1 at the bench batch
+    (3, 128, 128, 24, 80),     # layer2: 6 x 20 tiles
+    (2, 256, 256, 12, 40),     # layer3: 3 x 10 tiles
+    (2, 64, 128, 80, 256),     # C3 geometry, Ci != Co
+    (1, 20, 40, 12, 20),       # K = 20 (not a multiple of 16), M = 40 straddles 16-channel blocks
+    (2, 6, 18, 8, 16),         # K % 4 != 0: the last step's missing channels read as zero
+    (1, 32, 32, 10, 20),       # H % 4 != 0: the last tile row is half outside the map
+]
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", F4_CASES)
+def test_wino_f4_forward_and_data_gradient(B, Ci, Co, H, W):
+    """dc_set_wino_f4(1): Winograd F(4x4,3x3) (csrc/wino4.hip) for the plain trunk convolutions -- forward, data gradient and
+    the data gradient with a residual-fork addend -- against an fp64 direct convolution.  MEASURED, not assumed:
+    the bound is the same 2e-5 of the output scale the F(2x2,3x3) kernel is held to, and the test prints both kernels' errors
+    (worst element and relative L2) side by side."""
+    from depthcore import _lib
+    from depthcore.ops import ptr
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B * 1000 + Ci + H)
+    x = torch.randn(B, Ci, H, W, generator=g).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5).cuda()
+    gy = torch.randn(B, Co, H, W, generator=g).cuda()
+    add = torch.randn(B, Ci, H, W, generator=g).cuda()
+    yr = F.conv2d(x.double(), w.double(), None, 1, 1)
+    dxr = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), 1, 1)
+    ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for mode in (0, 1):
+        prev = L.dc_set_wino_f4(mode)
+        try:
+            y, dx, dxa = torch.empty(B, Co, H, W, device="cuda"), torch.empty_like(x), torch.empty_like(x)
+            assert L.dc_wino3x3_fwd(ptr(x), ptr(w), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, st) == 0
+            assert L.dc_wino3x3_dgrad(ptr(gy), ptr(w), ptr(dx), ws.data_ptr(), B, Ci, Co, H, W, st) == 0
+            assert L.dc_wino3x3_dgrad_add(ptr(gy), ptr(w), ptr(dxa), ptr(add), ws.data_ptr(), B, Ci, Co, H, W, st) == 0
+            torch.cuda.synchronize()
+        finally:
+            L.dc_set_wino_f4(prev)
+        res[mode] = [(float((got.double() - ref).abs().max() / ref.abs().max()), float((got.double() - ref).norm() / ref.norm()))
+                     for got, ref in ((y, yr), (dx, dxr), (dxa, dxr + add.double()))]
+    print("B=%d %d->%d %dx%d  F(2x2) [max, L2] y / dx / dx+add: %s | F(4x4): %s" % (
+        B, Ci, Co, H, W, ["%.1e %.1e" % e for e in res[0]], ["%.1e %.1e" % e for e in res[1]]))
+    for e_max, e_l2 in res[1]:
+        assert e_max <= 2e-5 and e_l2 <= 5e-6, res[1]
+
+
+def test_wino_f4_is_deterministic_and_off_by_default():
+    from depthcore import _lib
+    from depthcore.ops import ptr
+    L = _lib.lib()
+    assert L.dc_set_wino_f4(0) == 0                     # default: F(2x2,3x3) everywhere
+    B, C, H, W = 4, 64, 48, 160
+    x, w = torch.randn(B, C, H, W).cuda(), (torch.randn(C, C, 3, 3) * 0.05).cuda()
+    ws = torch.empty(L.dc_wino3x3_workspace(B, C, C, H, W), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    L.dc_set_wino_f4(1)
+    try:
+        for _ in range(2):
+            y = torch.empty_like(x)
+            assert L.dc_wino3x3_fwd(ptr(x), ptr(w), ptr(y), ws.data_ptr(), B, C, C, H, W, st) == 0
+            outs.append(y)
+        torch.cuda.synchronize()
+    finally:
+        L.dc_set_wino_f4(0)
+    assert torch.equal(outs[0], outs[1])
+    assert L.dc_set_wino_f4(2) < 0 and L.dc_set_wino_f4(0) == 0       # bad mode refused, state unchanged

@@ -27,6 +27,8 @@ def timed(fn, iters=100):
 
 def main():
     L = _lib.lib()
+    if os.environ.get("DC_WINO_F4"):                 # A/B: F(4x4,3x3) for the plain trunk convolutions (csrc/wino4.hip)
+        L.dc_set_wino_f4(int(os.environ["DC_WINO_F4"]))
     shapes = [(12, 64, 48, 160), (24, 64, 48, 160), (12, 128, 24, 80), (24, 128, 24, 80), (12, 256, 12, 40),
               (24, 256, 12, 40), (12, 512, 6, 20), (24, 512, 6, 20)]
     if len(sys.argv) > 1:
