@@ -188,3 +188,42 @@ def test_wino_f4_is_deterministic_and_off_by_default():
         L.dc_set_wino_f4(0)
     assert torch.equal(outs[0], outs[1])
     assert L.dc_set_wino_f4(2) < 0 and L.dc_set_wino_f4(0) == 0       # bad mode refused, state unchanged
+
+
+def test_wino_f4_full_step_deltas():
+    """"the loss / gradient deltas of a full step".  The same training step (resnet18, 192 x 640, B = 2) with the
+    trunk's forward and data-gradient convolutions on F(4x4,3x3) where it applies (layer1-3 maps) and on F(2x2,3x3): losses and
+    every parameter gradient, relative to the F(2x2) step.  Measured (MI355X): loss delta 1.3e-7; parameter-gradient deltas median
+    5.6e-3, worst 1.2e-2 (pose-encoder BatchNorm biases) -- NOT the kernels' 1e-6: un-forced gradients of a piecewise-smooth
+    network move at the 0.5 % level between ANY two fp32 evaluations (a ReLU / max-pool / min() decision taken the other way on a
+    rounding-level tie re-routes a gradient: DESIGN 2 "ReLU kinks"; the fp32 CPU oracle is as far from the HIP step), and five
+    times the rounding error flips a few more of them.  The loss is the contract's quantity (1e-3); the bounds below are loose
+    recorders, not a claim of gradient parity at that level."""
+    import sys
+    import trainer as T
+    from depthcore import _lib
+    from depthcore.synthetic import synthetic_batch
+    L = _lib.lib()
+    batch = synthetic_batch(2, 192, 640, torch.device("cuda:0"), seed=3)
+    out = {}
+    for mode in (0, 1):
+        prev = L.dc_set_wino_f4(mode)
+        try:
+            tr = T.Trainer(T.default_options(height=192, width=640, batch_size=2, overlap_streams=False), device="cuda:0", seed=6)
+            tr.set_train()
+            _, losses = tr.process_batch(dict(batch))
+            tr.buckets.zero()
+            losses["loss"].backward()
+            torch.cuda.synchronize()
+            out[mode] = (float(losses["loss"].detach()),
+                         {k + "." + n: p.grad.detach().clone() for k, m in tr.models.items() for n, p in m.named_parameters() if p.grad is not None})
+            tr.close()
+        finally:
+            L.dc_set_wino_f4(prev)
+    dl = abs(out[1][0] - out[0][0]) / abs(out[0][0])
+    rel = {n: float((out[1][1][n] - g).norm() / (g.norm() + 1e-30)) for n, g in out[0][1].items()}
+    worst = sorted(rel.items(), key=lambda kv: -kv[1])[:3]
+    print("F(4x4) vs F(2x2) full step: loss delta %.2e; gradient deltas median %.2e, worst %s" % (
+        dl, sorted(rel.values())[len(rel) // 2], ["%s %.1e" % kv for kv in worst]), file=sys.stderr)
+    assert dl <= 1e-5
+    assert sorted(rel.values())[len(rel) // 2] <= 3e-2 and max(rel.values()) <= 0.15
