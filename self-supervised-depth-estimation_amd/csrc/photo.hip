@@ -709,8 +709,15 @@ struct GAcc {
 //   step i (row yy = y0-2+i):  A: blend row yy;  B: pixel row p = yy-1: values, min / argmin, loss sum, derivative
 //   coefficients of the selected frame, spread onto rows yy-2..yy;  C: row q = yy-2 is complete -> store.
 // ------------------------------------------------------------------------------------------------
+// Three blocks per CU (<= 168 VGPRs) with the step's loads issued AFTER stage B, when the window state (the sums and target
+// statistics of three channels x two frames) is dead: 145 VGPRs, no spill.  Issued at the top of the step -- a whole row ahead
+// of their use, as the evaluation forward does -- taps and window state are live together: 185 VGPRs, two blocks per CU.
+// Measured (C2, rocprofv3): 207 us early / 2 per CU, 195 late / 2, 181 late / 3, 205 late / 4 (13 spilled registers).
 #ifndef FWDG_BLOCKS_PER_CU
-#define FWDG_BLOCKS_PER_CU 2
+#define FWDG_BLOCKS_PER_CU 3
+#endif
+#ifndef FWDG_LATE_ISSUE
+#define FWDG_LATE_ISSUE 1
 #endif
 
 // SPEC >= 0: the option flags are compile-time constants (bit 0 no_ssim, 1 avg_reprojection, 2 automasking, 3 external noise
@@ -789,16 +796,21 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
             }
         }
         if (LOGS) lg_cur = lg_nxt;
-        issue_row<true, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), lg_nxt);
-        {   // identity loss + tie-break noise of the pixel row the NEXT step decides (row yy)
-            const unsigned px = (unsigned)(min(max(yy, 0), H - 1) * W + xr);
-            const f2 id2 = bload2(idl, px * idl_px);
-            idn_nxt[0] = id2.x;
-            idn_nxt[1] = id2.y;
-            idn_nxt[2] = bload(nz, px * 4u, 0);
-            idn_nxt[3] = bload(nz, px * 4u, c.plane4);
-        }
-        disp_issue(dt, c, xr, reflect_clamp(yy + 2, H));
+        // every load of the step in ONE phase.  FWDG_LATE_ISSUE = 0: right here, a whole row step ahead of its use (taps and
+        // window state live together: 185 VGPRs, 2 blocks per CU); 1: after stage B, when the window state is dead
+        auto issue_all = [&]() {
+            issue_row<true, LOGS>(tp, g, c, disp_value(dt, c), xr, reflect_clamp(yy + 1, H), lg_nxt);
+            {   // identity loss + tie-break noise of the pixel row the NEXT step decides (row yy)
+                const unsigned px = (unsigned)(min(max(yy, 0), H - 1) * W + xr);
+                const f2 id2 = bload2(idl, px * idl_px);
+                idn_nxt[0] = id2.x;
+                idn_nxt[1] = id2.y;
+                idn_nxt[2] = bload(nz, px * 4u, 0);
+                idn_nxt[3] = bload(nz, px * 4u, c.plane4);
+            }
+            disp_issue(dt, c, xr, reflect_clamp(yy + 2, H));
+        };
+        if (!FWDG_LATE_ISSUE) issue_all();
         if (LOGS && i >= 2 && i <= R_ROWS + 1 && yy < H && q_lane) {
             const unsigned o = (unsigned)(yy * W + x);
 #pragma unroll
@@ -934,6 +946,7 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
                 }
             }
         }
+        if (FWDG_LATE_ISSUE) issue_all();
         // ---------------- stage C: row q = yy-2 has every contribution: add the L1 term, contract with the row's
         // d(warped)/d(coords) from the ring, store (du, dv) of both frames
         if (i >= 4) {
@@ -1378,7 +1391,11 @@ static Carve carve(const dc_photo_desc* d) {
     c.rowblocks_f = ceil_div(d->H, c.rows_f);
     const bool train = !(d->flags & DC_OPT_NO_GRAD);
     c.strips_p = ceil_div(d->W, 64);
+#ifdef FWDG_ROWS
+    c.rows_g = FWDG_ROWS;           // (tuning builds)
+#else
     c.rows_g = pick_rows(d->H, c.strips_b, d->B, 4, FWDG_BLOCKS_PER_CU);
+#endif
     c.rows_p = pick_rows(d->H, c.strips_p, d->B, 0, BWDG_BLOCKS_PER_CU);
     c.rowblocks_g = ceil_div(d->H, c.rows_g);
     c.rowblocks_p = ceil_div(d->H, c.rows_p);

@@ -1,10 +1,8 @@
 #!/bin/bash
-# A/B of the photometric kernel variants under rocprofv3 (GPU box).  usage: bash tools/prof_photo_ab.sh
+# A/B of photometric kernel variants under rocprofv3 (GPU box): the product library, then every build/variants/<name>/ given.
+# usage: bash tools/prof_photo_ab.sh [variant ...]      (variants: tools/build_variant.sh <name> "<flags>" photo.hip)
 R=$GRAFT_REPO_ROOT
-V=$R/build/variants
-run() { tag=$1; shift; ( export "$@" DUMMY=1; bash $R/tools/prof_photo.sh $tag ) 2>&1 | tail -1; }
-run old DC_PHOTO_OLD=1
-run new
-for g in 16 24 32 48; do run g$g DC_PHOTO_ROWS_G=$g; done
-for p in 4 8 12 16 24 32; do run p$p DC_PHOTO_ROWS_P=$p; done
-[ -f $V/fwdg3/libdepthcore.so ] && run fwdg3 DEPTHCORE_LIB=$V/fwdg3/libdepthcore.so
+( bash $R/tools/prof_photo.sh product ) 2>&1 | tail -1
+for v in "$@"; do
+  ( export DEPTHCORE_LIB=$R/build/variants/$v/libdepthcore.so; bash $R/tools/prof_photo.sh $v ) 2>&1 | tail -1
+done
