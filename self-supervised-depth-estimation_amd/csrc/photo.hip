@@ -1041,7 +1041,10 @@ __device__ __forceinline__ void project_q(ProjQ& q, const Geo& g, const Ctx& c, 
     }
 }
 
-constexpr int BWDG_UNROLL = 4;     // rows whose loads are in flight together
+#ifndef BWDG_ROWS_IN_FLIGHT
+#define BWDG_ROWS_IN_FLIGHT 4
+#endif
+constexpr int BWDG_UNROLL = BWDG_ROWS_IN_FLIGHT;     // rows whose loads are in flight together
 
 __global__ __launch_bounds__(256, BWDG_BLOCKS_PER_CU) void photo_bwdg_kernel(PhotoArgs p) {
     const int lane = threadIdx.x & 63;
