@@ -346,7 +346,8 @@ def run_rank(args):
     opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
                             nets_dtype=args.nets_dtype, torch_adam=args.torch_adam,
                             cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap,
-                            wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph), **front)
+                            wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph),
+                            wgrad_lanes=int(args.wgrad_lanes), **front)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     tr = T.Trainer(opt, device=device, rank=rank, world_size=world)
     tr.set_train()
@@ -443,6 +444,7 @@ def run_rank(args):
     SERIAL_STEPS = 3
     if tr.opt.overlap_streams:
         tr.opt.overlap_streams = False
+        lanes, tr.wgrad_lanes = tr.wgrad_lanes, False
         ops.profile_enable(SERIAL_STEPS + 2)
         ops.conv_profile_enable((SERIAL_STEPS + 1) * 400, 1)
         for _ in range(SERIAL_STEPS):
@@ -453,6 +455,7 @@ def run_rank(args):
         ops.profile_enable(0)
         ops.conv_profile_enable(0, 1)
         tr.opt.overlap_streams = True
+        tr.wgrad_lanes = lanes
         roof_src, fam_steps = "%d single-stream steps after the timed region, every launch" % SERIAL_STEPS, SERIAL_STEPS
     else:
         fam = fam_c
@@ -595,7 +598,9 @@ def run_rank(args):
                            "as the device data step delivers them: planar (\"color\", f, s) / (\"color_aug\", f, s) plus the "
                            "pixel-interleaved RGBx copy (\"color_packed\", f, 0) of the three loss frames (dc_data_to_rgbx)"
                            if ("color_packed", 0, 0) in inputs else "planar tensors only (the loss repacks the three frames per step)"),
-                       "step_launch": "one hipGraph replay per step" if graphed else "eager (one launch per kernel)"},
+                       "step_launch": "one hipGraph replay per step" if graphed else "eager (one launch per kernel)",
+                       "streams": ("depth and pose branches on two HIP streams" if tr.opt.overlap_streams else "one HIP stream")
+                                  + ("; weight-gradient kernels on a companion stream of each (opt.wgrad_lanes)" if tr.wgrad_lanes else "")},
             "roofline": dict(dom, **{
                          "traffic": tr_bytes(dom_key) if dom_key else None, "traffic_source": traffic_src if dom_key and tr_bytes(dom_key) else None,
                          "measured_in": roof_src,
@@ -658,6 +663,7 @@ def main():
     ap.add_argument("--no-packed-inputs", action="store_true",
                     help="inputs without the data step's pixel-interleaved RGBx copies of the three loss frames (a reference data "
                          "loader's batch): the photometric forward then repacks them at every step")
+    ap.add_argument("--wgrad-lanes", type=int, default=2, help="weight-gradient kernels on companion streams (opt.wgrad_lanes: 0 off, 1 on, 2 auto)")
     ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: let ranks share GPUs (use with DC_DIST_BACKEND=gloo)")
     ap.add_argument("--rehearse", action="store_true", help="rehearsal: CPU stand-in step over gloo (launcher / exchange plumbing only)")

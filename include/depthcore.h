@@ -356,6 +356,19 @@ size_t dc_convs2_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int ksiz
 int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int ksize,
                     void* stream);
 
+/* Any other nn.Conv2d shape of the trunks (networks/resnet_encoder.py:74-98 via torchvision: square kernel, symmetric stride
+ * and zero padding, no groups / dilation): odd or tiny maps, a 1x1 / 2 on an odd map, a stem whose input needs a gradient.
+ * Plain direct kernels (one thread per output element, fixed-order sums) so that NO shape reaches the framework's
+ * convolution on the GPU; not a fast path, no BASELINE configuration uses it.
+ * x (B,Ci,Hi,Wi); weight (Co,Ci,k,k), 1 <= k <= 11; 1 <= stride <= 4; 0 <= pad < k; y / gy (B,Co,Ho,Wo) with
+ * Ho = (Hi + 2 pad - k) / stride + 1; bias / dbias (Co) or NULL.  DC_EINVAL outside these ranges. */
+int dc_conv2d_direct_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi, int Wi,
+                         int ksize, int stride, int pad, void* stream);
+int dc_conv2d_direct_dgrad(const float* gy, const float* weight, float* dx, int B, int Ci, int Co, int Hi, int Wi, int ksize,
+                           int stride, int pad, void* stream);
+int dc_conv2d_direct_wgrad(const float* x, const float* gy, float* dweight, float* dbias, int B, int Ci, int Co, int Hi, int Wi,
+                           int ksize, int stride, int pad, void* stream);
+
 /* ------------------------------------------------------------------ f1 Fusion_v3 front-end */
 /* AttentionConv of networks/fusion_v2.py:46-98 as instantiated by ResidualAttentionUnit (:101-137): kernel 3, stride 1,
  * padding 1, groups 1, bias=True, C = 2 or 4 channels.  One fused kernel per direction (no q / k / v / unfold / softmax

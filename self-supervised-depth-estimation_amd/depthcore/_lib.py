@@ -136,6 +136,9 @@ def _sig(lib):
         "dc_convs2_dgrad": (i, [p, p, p, p, i, i, i, i, i, i, p]),
         "dc_convs2_wgrad_workspace": (z, [i, i, i, i, i, i]),
         "dc_convs2_wgrad": (i, [p, p, p, p, i, i, i, i, i, i, p]),
+        "dc_conv2d_direct_fwd": (i, [p, p, p, p, i, i, i, i, i, i, i, i, p]),
+        "dc_conv2d_direct_dgrad": (i, [p, p, p, i, i, i, i, i, i, i, i, p]),
+        "dc_conv2d_direct_wgrad": (i, [p, p, p, p, i, i, i, i, i, i, i, i, p]),
         "dc_gru_rh_fwd": (i, [p, p, p, i, i, i, p]),
         "dc_gru_rh_bwd": (i, [p, p, p, p, p, i, i, i, p]),
         "dc_gru_blend_fwd": (i, [p, p, p, p, i, i, i, p]),

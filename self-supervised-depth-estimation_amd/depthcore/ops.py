@@ -3,6 +3,7 @@
 Every op enqueues hand-written gfx950 kernels on the current HIP stream; tensors
 are allocated by PyTorch's caching allocator and passed down as raw pointers.
 """
+import contextlib
 import ctypes
 import threading
 import weakref
@@ -88,6 +89,65 @@ def _grad_dst(slot, like):
     if slot is not None and slot.armed:
         return slot.take()
     return torch.empty_like(like) if like is not None else None
+
+
+# ---- weight gradients off the backward's critical path ----------------------------------------------------------------------
+class WgradLanes:
+    """Only the data gradients feed the next backward op; a weight gradient is not read before the optimiser.  While active
+    (`with WgradLanes.active(): loss.backward()`), the convolutions launch their weight-gradient kernels on a companion
+    HIP stream of the stream their backward runs on ("lane"): the kernels of the data-gradient chain and the weight-gradient
+    kernels then share the chip, one side's blocks filling the other's partial rounds and prologues, instead of queueing
+    behind each other.  Leaving the context joins every lane into the current stream (before the optimiser / the gradient
+    exchange read the gradients).
+
+    A parameter used MORE than once in the graph keeps its weight gradients on the backward's own stream: autograd sums
+    the uses' gradients right away, on a stream that knows nothing about the lane.  Uses are counted by the forwards."""
+    _on = False
+    _lanes = {}          # (device index, raw handle of the backward's stream) -> companion stream
+    _uses = {}           # id(parameter) -> forward uses since the last join
+    _used = set()        # lanes with work enqueued since the last join
+
+    @classmethod
+    @contextlib.contextmanager
+    def active(cls, on=True):
+        prev, cls._on = cls._on, bool(on)
+        try:
+            yield
+        finally:
+            cls._on = prev
+            cls.join()
+
+    @classmethod
+    def join(cls):
+        for lane in cls._used:
+            torch.cuda.current_stream(lane.device).wait_stream(lane)
+        cls._used = set()
+        cls._uses = {}
+
+    @classmethod
+    def count_use(cls, param):
+        cls._uses[id(param)] = cls._uses.get(id(param), 0) + 1
+
+    @classmethod
+    @contextlib.contextmanager
+    def lane(cls, param, *reads):
+        """Inside: the current stream is the lane (or unchanged when the lane cannot be used).  `reads`: tensors of the
+        backward's stream that the weight-gradient kernel reads."""
+        if not (cls._on and param is not None and reads[0].is_cuda and cls._uses.get(id(param), 0) == 1 and param.grad is None):
+            yield
+            return
+        dev = reads[0].device
+        cur = torch.cuda.current_stream(dev)
+        key = (dev.index, cur.cuda_stream)
+        lane = cls._lanes.get(key)
+        if lane is None:
+            lane = cls._lanes[key] = torch.cuda.Stream(dev)
+        lane.wait_stream(cur)
+        with torch.cuda.stream(lane):
+            yield
+        for t in reads:
+            t.record_stream(lane)           # freed on the backward's stream while the lane may still be reading
+        cls._used.add(lane)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -774,6 +834,7 @@ class _WinoConv(torch.autograd.Function):
         check(L.dc_wino3x3_fwd(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, stream(xx)), "dc_wino3x3_fwd")
         ctx.save_for_backward(xx, ww)
         ctx.slot = _slot(weight)
+        ctx.param = _lane_param(ctx, 1, weight)
         ctx.fork = fork if x.requires_grad else None
         return y
 
@@ -793,11 +854,20 @@ class _WinoConv(torch.autograd.Function):
             check(L.dc_wino3x3_dgrad_add(ptr(g_c), ptr(ww), ptr(gx), ptr(add), ws.data_ptr(), B, Ci, Co, H, W, stream(g_c)),
                   "dc_wino3x3_dgrad_add")
         if ctx.needs_input_grad[1]:
-            gw = _grad_dst(ctx.slot, ww)
-            ws = torch.empty(L.dc_wino3x3_wgrad_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
-            check(L.dc_wino3x3_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, H, W, stream(xx)),
-                  "dc_wino3x3_wgrad")
+            with WgradLanes.lane(ctx.param, xx, g_c):
+                gw = _grad_dst(ctx.slot, ww)
+                ws = torch.empty(L.dc_wino3x3_wgrad_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device=xx.device)
+                check(L.dc_wino3x3_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, H, W, stream(xx)),
+                      "dc_wino3x3_wgrad")
         return gx, gw, None
+
+
+def _lane_param(ctx, idx, weight):
+    """forward(): the parameter whose weight gradient may take a lane (WgradLanes), counted as used once more."""
+    if not ctx.needs_input_grad[idx]:
+        return None
+    WgradLanes.count_use(weight)
+    return weight
 
 
 def _fork_addend(ctx, xx):
@@ -901,6 +971,7 @@ class _Conv1x1(torch.autograd.Function):
         ctx.save_for_backward(xx, ww, None if plain else y)
         ctx.cfg = (int(stride), int(act), bias is not None)
         ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
+        ctx.param = _lane_param(ctx, 1, weight)
         ctx.fork = fork if x.requires_grad else None
         return y
 
@@ -934,10 +1005,11 @@ class _Conv1x1(torch.autograd.Function):
         elif first_of_pair:
             raise _lib.DepthcoreError("GradFork: the shared input needs no gradient")
         if ctx.needs_input_grad[1]:
-            gw = _grad_dst(ctx.slots[0], ww)
-            ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
-            check(L.dc_conv1x1_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream(xx)),
-                  "dc_conv1x1_wgrad")
+            with WgradLanes.lane(ctx.param, xx, g_c):
+                gw = _grad_dst(ctx.slots[0], ww)
+                ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
+                check(L.dc_conv1x1_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream(xx)),
+                      "dc_conv1x1_wgrad")
         return gx, gw, gb, None, None, None
 
 
@@ -970,6 +1042,7 @@ class _ConvS2(torch.autograd.Function):
         check(L.dc_convs2_fwd(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, Hi, Wi, ks, stream(xx)), "dc_convs2_fwd")
         ctx.save_for_backward(xx, ww)
         ctx.slot = _slot(weight)
+        ctx.param = _lane_param(ctx, 1, weight)
         return y
 
     @staticmethod
@@ -989,15 +1062,67 @@ class _ConvS2(torch.autograd.Function):
             ws = torch.empty(n, dtype=torch.uint8, device=xx.device)
             check(L.dc_convs2_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), B, Ci, Co, Hi, Wi, ks, stream(xx)), "dc_convs2_dgrad")
         if ctx.needs_input_grad[1]:
-            gw = _grad_dst(ctx.slot, ww)
-            ws = torch.empty(L.dc_convs2_wgrad_workspace(B, Ci, Co, Hi, Wi, ks), dtype=torch.uint8, device=xx.device)
-            check(L.dc_convs2_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, ks, stream(xx)), "dc_convs2_wgrad")
+            with WgradLanes.lane(ctx.param, xx, g_c):
+                gw = _grad_dst(ctx.slot, ww)
+                ws = torch.empty(L.dc_convs2_wgrad_workspace(B, Ci, Co, Hi, Wi, ks), dtype=torch.uint8, device=xx.device)
+                check(L.dc_convs2_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, ks, stream(xx)), "dc_convs2_wgrad")
         return gx, gw
 
 
 def conv_s2(x, weight):
     """F.conv2d(x, weight, None, stride=2, padding=k // 2) for k = 3 or 7."""
     return _ConvS2.apply(x, weight)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1 every other nn.Conv2d shape of the trunk (odd / tiny maps, a stem whose input needs a gradient): plain direct kernels
+# ----------------------------------------------------------------------------------------------
+class _ConvDirect(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        L = _lib.lib()
+        xx, ww = _c(x.detach()), _c(weight.detach())
+        bs = _c(bias.detach()) if bias is not None else None
+        B, Ci, Hi, Wi = xx.shape
+        Co, k = ww.shape[0], ww.shape[-1]
+        if tuple(ww.shape) != (Co, Ci, k, k) or (bs is not None and bs.numel() != Co):
+            raise _lib.DepthcoreError("weight %s / bias do not match an input of %d channels" % (tuple(ww.shape), Ci))
+        Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
+        y = torch.empty(B, Co, max(Ho, 0), max(Wo, 0), dtype=torch.float32, device=xx.device)
+        check(L.dc_conv2d_direct_fwd(ptr(xx), ptr(ww), ptr(bs), ptr(y), B, Ci, Co, Hi, Wi, k, int(stride), int(pad), stream(xx)),
+              "dc_conv2d_direct_fwd")
+        ctx.save_for_backward(xx, ww)
+        ctx.cfg = (int(stride), int(pad), bias is not None)
+        ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        xx, ww = ctx.saved_tensors
+        s_, p_, has_bias = ctx.cfg
+        B, Ci, Hi, Wi = xx.shape
+        Co, k = ww.shape[0], ww.shape[-1]
+        g_c = _c(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(xx)
+            check(L.dc_conv2d_direct_dgrad(ptr(g_c), ptr(ww), ptr(gx), B, Ci, Co, Hi, Wi, k, s_, p_, stream(xx)), "dc_conv2d_direct_dgrad")
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gw = _grad_dst(ctx.slots[0], ww)
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = _grad_dst(ctx.slots[1], None)
+                if gb is None:
+                    gb = torch.empty(Co, dtype=torch.float32, device=xx.device)
+            check(L.dc_conv2d_direct_wgrad(ptr(xx), ptr(g_c), ptr(gw), ptr(gb), B, Ci, Co, Hi, Wi, k, s_, p_, stream(xx)),
+                  "dc_conv2d_direct_wgrad")
+        return gx, gw, gb, None, None
+
+
+def conv2d_direct(x, weight, bias=None, stride=1, padding=0):
+    """F.conv2d(x, weight, bias, stride, padding) for square kernels (k <= 11), stride <= 4, padding < k, no groups / dilation:
+    the shapes outside the tiled kernels (slow, correct, deterministic)."""
+    return _ConvDirect.apply(x, weight, bias, stride, padding)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1031,6 +1156,7 @@ class _StemConv(torch.autograd.Function):
         ctx.save_for_backward(ww, *fr)
         ctx.cfg = (float(mean), float(std))
         ctx.slot = _slot(weight)
+        ctx.param = _lane_param(ctx, 0, weight)
         return y
 
     @staticmethod
@@ -1044,11 +1170,12 @@ class _StemConv(torch.autograd.Function):
         g_c = _c(gy)
         gw = None
         if ctx.needs_input_grad[0]:
-            gw = _grad_dst(ctx.slot, ww)
-            ptrs = (ctypes.c_void_p * nf)(*[ptr(t) for t in fr])
-            ws = torch.empty(L.dc_convs2_wgrad_workspace(B, Ci, Co, Hi, Wi, 7), dtype=torch.uint8, device=ww.device)
-            check(L.dc_stem_wgrad(ptrs, nf, ctx.cfg[0], ctx.cfg[1], ptr(g_c), ptr(gw), ws.data_ptr(), Bf, Hi, Wi, Co, stream(ww)),
-                  "dc_stem_wgrad")
+            with WgradLanes.lane(ctx.param, g_c):
+                gw = _grad_dst(ctx.slot, ww)
+                ptrs = (ctypes.c_void_p * nf)(*[ptr(t) for t in fr])
+                ws = torch.empty(L.dc_convs2_wgrad_workspace(B, Ci, Co, Hi, Wi, 7), dtype=torch.uint8, device=ww.device)
+                check(L.dc_stem_wgrad(ptrs, nf, ctx.cfg[0], ctx.cfg[1], ptr(g_c), ptr(gw), ws.data_ptr(), Bf, Hi, Wi, Co, stream(ww)),
+                      "dc_stem_wgrad")
         return (gw, None, None) + (None,) * nf
 
 

@@ -63,8 +63,8 @@ def _pair_fork_for(block, x):
 
 def _conv(conv, x, fork=None):
     """nn.Conv2d call of the trunk: stride-1 3x3 on dc_wino3x3_* (84 % of a ResNet-18 trunk's multiplies), 1x1 on dc_conv1x1_*,
-    the 7x7 / 2 stem and the 3x3 / 2 convolutions on dc_convs2_*; only shapes outside those kernels' 16-byte staging (odd or
-    tiny maps in tests) reach the framework's convolution."""
+    the 7x7 / 2 stem and the 3x3 / 2 convolutions on dc_convs2_*; shapes outside those kernels' 16-byte staging (odd or
+    tiny maps in tests) take dc_conv2d_direct_*.  On the GPU nothing reaches the framework's convolution."""
     if (WINO_TRUNK and x.is_cuda and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and x.shape[-1] % 2 == 0
             and x.dtype == torch.float32):
@@ -85,7 +85,15 @@ def _conv(conv, x, fork=None):
         return _ops.conv_s2(x, conv.weight)
     if fork is not None:  # (_fork_for mirrors the two conditions above; a fork nobody collects would lose the skip's gradient)
         raise _ops.DepthcoreError("GradFork handed to a convolution that does not run on a kernel with the addend epilogue")
-    return conv(x)      # shapes outside the kernels' 16-byte staging (odd or tiny maps in tests): the framework's convolution
+    if not x.is_cuda:
+        return conv(x)      # CPU: module bookkeeping / export only, not a compute path of this package
+    # shapes outside the tiled kernels' 16-byte staging (odd or tiny maps, a stem whose input needs a gradient): depthcore's
+    # plain direct kernels -- on the GPU no shape reaches the framework's convolution
+    k, s_, p_ = conv.kernel_size, conv.stride, conv.padding
+    if (x.dtype != torch.float32 or conv.groups != 1 or conv.dilation != (1, 1) or k[0] != k[1] or s_[0] != s_[1] or p_[0] != p_[1]
+            or isinstance(p_, str) or conv.padding_mode != "zeros"):
+        raise _ops.DepthcoreError("convolution %r on a %s %s input is outside depthcore's kernels" % (conv, x.dtype, tuple(x.shape)))
+    return _ops.conv2d_direct(x, conv.weight, conv.bias, s_[0], p_[0])
 
 
 class BasicBlock(nn.Module):

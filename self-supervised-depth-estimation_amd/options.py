@@ -89,6 +89,7 @@ _REFERENCE = [
 _BUILD = [
     ("fused_loss", int, 1, [0, 1]),              # 1: fused photometric kernels, 0: layer-by-layer kernels
     ("overlap_streams", int, 1, [0, 1]),         # pose and depth networks on two HIP streams
+    ("wgrad_lanes", int, 2, [0, 1, 2]),          # weight-gradient kernels on companion streams of the backward's streams (ops.WgradLanes): 0 off, 1 on, 2 = on for GPU-bound step sizes (Trainer)
     ("bucket_mb", int, 32, None),                # gradient bucket size for the RCCL exchange
     ("cpu_tiebreak_noise", int, 0, [0, 1]),      # 1: the reference's CPU randn + H2D copy (trainer.py:594-595)
     ("materialize_logs", int, 0, [0, 1]),        # 1: fused path also writes depth / sample / color tensors

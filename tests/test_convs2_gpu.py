@@ -128,3 +128,53 @@ def test_pose_encoder_forward_pairs_equals_stacked_forward():
     for u, v in zip(a, b):
         assert rel(u, v) < 1e-4, rel(u, v)
     assert rel(ga, gb) < 5e-3, rel(ga, gb)          # (a ReLU decision may flip on a last-bit input difference)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,k,s,p,bias", [
+    (2, 3, 8, 17, 23, 7, 2, 3, False),       # a stem on an odd map, input gradient requested
+    (2, 16, 24, 9, 13, 3, 1, 1, False),      # stride-1 3x3 on an odd width
+    (3, 16, 32, 9, 13, 3, 2, 1, False),      # 3x3 / 2 -> 5 x 7
+    (2, 32, 64, 9, 13, 1, 2, 0, False),      # `downsample` 1x1 / 2 on an odd map
+    (1, 5, 7, 6, 10, 3, 1, 1, True),         # channel counts outside every tile, with a bias
+    (2, 4, 4, 3, 3, 3, 1, 0, True),          # one output pixel (no padding)
+    (1, 2, 3, 12, 8, 5, 3, 2, False),        # 5x5 / 3
+])
+def test_conv2d_direct_vs_torch(B, Ci, Co, H, W, k, s, p, bias):
+    """dc_conv2d_direct_*: forward, data gradient, weight and bias gradients against torch's fp64 convolution; bitwise
+    reproducible."""
+    from depthcore import ops
+    g = torch.Generator().manual_seed(B * 100 + Ci + k)
+    x = torch.randn(B, Ci, H, W, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (Ci * k * k)) ** 0.5).cuda().requires_grad_(True)
+    b = torch.randn(Co, generator=g).cuda().requires_grad_(True) if bias else None
+    outs = []
+    for _ in range(2):
+        x.grad = w.grad = None
+        if b is not None:
+            b.grad = None
+        y = ops.conv2d_direct(x, w, b, s, p)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).cuda()
+        y.backward(gy)
+        outs.append([y.detach().clone(), x.grad.clone(), w.grad.clone()] + ([b.grad.clone()] if bias else []))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    br = b.detach().double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, s, p)
+    assert yr.shape == y.shape
+    yr.backward(gy.double())
+    checks = [("y", y, yr), ("dx", x.grad, xr.grad), ("dw", w.grad, wr.grad)] + ([("db", b.grad, br.grad)] if bias else [])
+    for name, got, ref in checks:
+        err = (got.double() - ref).abs().max().item()
+        assert err <= 1e-5 * max(ref.abs().max().item(), 1e-6), "%s: %.3e (scale %.3e)" % (name, err, ref.abs().max().item())
+
+
+def test_conv2d_direct_refuses_what_it_cannot_do():
+    from depthcore import ops, _lib
+    x = torch.randn(1, 2, 4, 4).cuda()
+    with pytest.raises(_lib.DepthcoreError):
+        ops.conv2d_direct(x, torch.randn(3, 2, 13, 13).cuda(), None, 1, 6)      # kernel beyond 11
+    with pytest.raises(_lib.DepthcoreError):
+        ops.conv2d_direct(x, torch.randn(3, 2, 3, 3).cuda(), None, 1, 3)        # padding >= kernel
+    with pytest.raises(_lib.DepthcoreError):
+        ops.conv2d_direct(x, torch.randn(3, 4, 3, 3).cuda(), None, 1, 1)        # channel mismatch

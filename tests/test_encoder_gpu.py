@@ -110,3 +110,15 @@ def _one_input(num_layers, groups, nimg, B, H, W, seed):
     print("resnet%d groups %d seed %d: %d decisions differ from fp64 (worst margin %.1e of rms), worst gradient error %.2e"
           % (num_layers, groups, seed, flips, worst_margin, worst))
     assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
+
+
+@pytest.mark.parametrize("num_layers,H,W", [(18, 70, 102), (50, 66, 90)])
+def test_encoder_odd_maps_run_on_depthcore(num_layers, H, W, monkeypatch):
+    """Maps outside the tiled kernels' staging -- 70 x 102 gives a 35 x 51 stem output, 9 x 13 and 5 x 7 trunk maps, a 1x1 / 2
+    `downsample` on an odd map -- take dc_conv2d_direct_* (and the scalar BatchNorm / max-pool paths): the same decisive
+    comparison as above, and nn.Conv2d.forward is never entered on the GPU."""
+    entered = []
+    real = torch.nn.Conv2d.forward
+    monkeypatch.setattr(torch.nn.Conv2d, "forward", lambda self, x: (entered.append(self), real(self, x))[1])
+    _one_input(num_layers, 1, 1, 2, H, W, 1)
+    assert entered == [], "framework convolution entered for %r" % entered[:3]

@@ -581,6 +581,39 @@ def test_hip_graph_replays_train_like_eager_steps(gru):
     assert len(set(round(v, 7) for v in lg[3:])) == len(lg[3:])      # every replay is a new step
 
 
+@pytest.mark.parametrize("mode", ["eager", "gru"])
+def test_wgrad_lanes_change_nothing(mode):
+    """opt.wgrad_lanes: the convolutions' weight-gradient kernels run on companion streams of the backward's two streams and
+    are joined before Adam.  Same kernels on the same operands, only their streams differ: losses AND every parameter after
+    five steps are bitwise those of the single-lane trainer -- also with the ConvGRU front-end, whose cell weights are used
+    three times per graph and therefore must stay on the backward's own stream (autograd sums their gradients there)."""
+    import trainer as T
+    from depthcore import ops
+    from depthcore.synthetic import synthetic_batch, synthetic_sequence_batch
+    gru = mode == "gru"
+
+    def run(lanes, n=5):
+        kw = dict(gru="v5", len_sequence=3, batch_size=1) if gru else dict(batch_size=2)
+        tr = T.Trainer(T.default_options(height=64, width=128, wgrad_lanes=lanes, **kw), device=DEV, seed=5)
+        assert tr.wgrad_lanes == bool(lanes)
+        tr.set_train()
+        batches = [synthetic_sequence_batch(3, 64, 128, torch.device(DEV), seed=s) if gru else synthetic_batch(2, 64, 128, torch.device(DEV), seed=s)
+                   for s in (2, 3)]
+        losses = [float(tr.train_step(dict(batches[i % 2]))[1]["loss"].detach()) for i in range(n)]
+        torch.cuda.synchronize()
+        params = {"%s.%s" % (m, k): v.detach().clone() for m, net in tr.models.items() for k, v in net.named_parameters()}
+        used = len(ops.WgradLanes._lanes)
+        tr.close()
+        return losses, params, used
+
+    l0, p0, _ = run(0)
+    l1, p1, used = run(1)
+    assert used >= 2                                   # a lane for each of the two branch streams exists
+    assert l0 == l1, (l0, l1)
+    bad = [k for k in p0 if not torch.equal(p0[k], p1[k])]
+    assert not bad, bad[:5]
+
+
 def test_graph_capture_after_an_unclosed_collected_trainer():
     """The round-3 abort (gpurun_out/r3s): Trainers of FAILED tests were never close()d and sat in reference cycles (exception
     <-> frame); torch.cuda.graph() runs gc.collect() + empty_cache() when it begins a capture, so their weights were freed --

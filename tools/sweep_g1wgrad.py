@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""dc_conv1x1_wgrad at the ResNet-50 shapes of BASELINE configs[2] against the split target and tile (DC_G1_WBLOCKS,
-DC_G1_WTILE, read by csrc/gemm1x1.hip): one line per shape, one column per choice."""
+"""dc_conv1x1_wgrad at the ResNet-50 shapes of BASELINE configs[2] against the split target, tile and block order
+(DC_G1_WBLOCKS, DC_G1_WTILE, DC_G1_WXCD, read by csrc/gemm1x1.hip): one line per shape, one column per choice."""
 import os
 import sys
 
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(REPO, "self-supervised-depth-estimation_amd"))
 from depthcore import _lib  # noqa: E402
 from depthcore._lib import ptr  # noqa: E402
 
-CHOICES = [(0, 0), (512, 2), (768, 2), (1024, 2), (1536, 2), (512, 4), (768, 4), (1024, 4)]
+CHOICES = [(0, 0, 0), (0, 0, 1), (256, 0, 1), (384, 0, 1), (768, 0, 1), (512, 2, 1), (1024, 2, 1), (512, 4, 1), (256, 4, 1)]      # (blocks, tile, XCD-local splits)
 
 
 def timed(fn, n=30):
@@ -37,7 +37,7 @@ def main():
                   ("l3.0.down", B, 512, 1024, 40, 128, 2), ("l3.conv1", B, 1024, 256, 20, 64, 1),
                   ("l3.conv3", B, 256, 1024, 20, 64, 1), ("l4.0.down", B, 1024, 2048, 20, 64, 2),
                   ("l4.conv1", B, 2048, 512, 10, 32, 1), ("l4.conv3", B, 512, 2048, 10, 32, 1)]
-    print("shape | " + " | ".join("default" if c == (0, 0) else "%d blocks, %dx%d tile" % (c[0], 32 * c[1], 32 * c[1]) for c in CHOICES))
+    print("shape | " + " | ".join("default" if c == (0, 0, 0) else "%d blocks, %dx%d tile, xcd %d" % (c[0], 32 * c[1], 32 * c[1], c[2]) for c in CHOICES))
     tot = [0.0] * len(CHOICES)
     for name, B, Ci, Co, H, W, s in cases:
         x = torch.randn(B, Ci, H, W, device="cuda")
@@ -45,8 +45,8 @@ def main():
         dw = torch.empty(Co, Ci, 1, 1, device="cuda")
         st = _lib.stream(x)
         out = []
-        for i, (blocks, tile) in enumerate(CHOICES):
-            for k, v in (("DC_G1_WBLOCKS", blocks), ("DC_G1_WTILE", tile)):
+        for i, (blocks, tile, xcd) in enumerate(CHOICES):
+            for k, v in (("DC_G1_WBLOCKS", blocks), ("DC_G1_WTILE", tile), ("DC_G1_WXCD", xcd)):
                 if v:
                     os.environ[k] = str(v)
                 else:
