@@ -998,8 +998,14 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     const int tiles_x = ceil_div(W, CT), tiles_y = ceil_div(H, CT);
     // fast path (v2 kernels): full 16-wide tiles, 16-byte aligned rows, chunks that do not straddle the concat
     const bool fast = (W % 16 == 0) && (C1 == 0 || C0 % CK == 0) && (C1 == 0 || C0 % CW == 0);
+    // the thin single-channel heads have their own plain-FMA gradients (dispconv.hip), which form g' on the fly
+    const bool head_dx = dx0 && wino_enabled() && dispconv_eligible(C0, C1, up0 ? 1 : 0, Co, H, W);
+    const bool head_dw = (dweight || dbias) && wino_enabled() && dispconv_wgrad_eligible(C0, C1, up0 ? 1 : 0, Co, H, W) &&
+                         dispconv_wgrad_scratch(B, C0, H, W) <= al256((size_t)B * Cin * (H + 2) * (W + 5) * 4);
+    const bool gp_unused = (head_dx || !(dx0 || dx1)) && (head_dw || !(dweight || dbias));
     const float* gp = gy;
-    if (fused_db) {
+    if (gp_unused) {
+    } else if (fused_db) {
         hipLaunchKernelGGL(conv_gprime_dbias_kernel, dim3(Co, gpd_split(Co)), dim3(256), 0, ST, gy, y, gpbuf, pbd, B, Co, H * W / 4, act,
                            gpd_split(Co));
         DC_CHECK_LAUNCH();
@@ -1011,7 +1017,7 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
         DC_CHECK_LAUNCH();
         gp = gpbuf;
     }
-    if (dx0 && wino_enabled() && dispconv_eligible(C0, C1, up0 ? 1 : 0, Co, H, W)) {
+    if (head_dx) {
         // thin single-channel head: folded-window data gradient, no padded scratch / fold pass (dispconv.hip)
         const int rc = dispconv_dx(weight, y, gy, dx0, B, C0, H, W, act, pad_mode, ST);
         if (rc != DC_OK) return rc;
@@ -1062,7 +1068,12 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
                            C1, up0 ? 1 : 0, H, W, pad_mode, W + 2);
         DC_CHECK_LAUNCH();
     }
-    if (b16_dw && (dweight || dbias)) {
+    if (head_dw) {
+        // (scratch: the padded-domain buffer -- the head's data gradient does not use it, and any other data-gradient path has
+        // finished with it in stream order)
+        const int rc = dispconv_wgrad(x0, y, gy, dweight, dbias, dxpad, B, C0, H, W, act, pad_mode, ST);
+        if (rc != DC_OK) return rc;
+    } else if (b16_dw && (dweight || dbias)) {
         if (dweight) {
             const int sp = c3b_wgrad_split(B, H, W, Co, Cin, 1);
             int rc = c3b_wgrad(x0, C0, up0 ? 1 : 0, x1, C1, gp, part, sp, B, Co, H, W, pad_mode, 1, ST);

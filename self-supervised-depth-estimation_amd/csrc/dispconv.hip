@@ -6,9 +6,11 @@
 //                              (ReflectionPad2d folds row -1 onto 1 and H onto H-2, same for columns): the 9 folded
 //                              sums are built once per pixel and reused for every channel -- no padded scratch, no fold pass
 // g' = gy * act'(y) is formed on the fly.  No upsampling / concat (the heads never have them).  The weight gradient of
-// the heads stays on the direct split-K kernel (conv3x3.hip).
+// wide low-resolution heads stays on the Winograd / direct split-K kernels (conv3x3.hip); the thin heads (16 / 32 channels) have
+// dispconv_wgrad_kernel below.
 #include "dc_common.h"
 #include "dispconv.h"
+#include "conv_bf16.h"
 
 #include <algorithm>
 
@@ -114,6 +116,94 @@ __global__ __launch_bounds__(256) void dispconv_dx_kernel(const float* __restric
     }
 }
 
+// ---- weight + bias gradient:  dw[c][t] = sum_{b,q} x[b][c][q] * G_t[b][q]  (the SAME folded window as the data gradient: the
+// output pixel q - t reads padded position q),  dbias = sum g'.  A head has ONE output channel: on the split-K matrix-core
+// kernel of conv3x3.hip it ran as a 16-channel tile (15/16 wasted: 89 us for 16 -> 1 at 192 x 640, B = 12, where reading x
+// takes ~17 us).  Here: a block walks DWP pixels of one image in steps of 256 -- thread = pixel builds G (18 L2-resident
+// loads) and parks it in LDS; wave w then owns channels [w CPW, (w+1) CPW) and multiplies their x values of the 256 pixels
+// (coalesced 256-byte rows) into CPW x 9 register accumulators -- one wave tree per accumulator at the end, partials
+// part[block][c*9+t] / pbias[block] summed in fixed order by conv_wreduce_kernel.  Deterministic.
+constexpr int DWP = 2048;              // pixels per block
+template <int CPW>
+__global__ __launch_bounds__(256) void dispconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                             const float* __restrict__ y, float* __restrict__ part,
+                                                             float* __restrict__ pbias, int C, int H, int W, int act, int pad) {
+    __shared__ float Gs[9][256];
+    __shared__ float bs[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = blockIdx.x, b = blockIdx.y, HW = H * W;
+    const float* g = gy + (size_t)b * HW;
+    const float* yy = y + (size_t)b * HW;
+    const float* xb = x + ((size_t)b * C + wave * CPW) * HW;
+    float acc[CPW][9];
+#pragma unroll
+    for (int j = 0; j < CPW; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
+    float bsum = 0.f;
+    for (int it = 0; it < DWP / 256; ++it) {
+        const int q0 = blk * DWP + it * 256;
+        if (q0 >= HW) break;                                   // (block-uniform)
+        // this wave's x values of the 256 pixels: requested first, they fly while G is built
+        float xv[4][CPW];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int qq = min(q0 + s * 64 + lane, HW - 1);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) xv[s][j] = xb[(size_t)j * HW + qq];
+        }
+        const int q = q0 + tid;
+        float G[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) G[t] = 0.f;
+        if (q < HW) {
+            const int qy = q / W, qx = q - qy * W;
+            int ry[2], rx[2], ny = 1, nx = 1;
+            ry[0] = qy; rx[0] = qx;
+            if (pad == PAD_REFLECT) {
+                if (qy == 1) ry[ny++] = -1;
+                if (qy == H - 2) ry[ny++] = H;
+                if (qx == 1) rx[nx++] = -1;
+                if (qx == W - 2) rx[nx++] = W;
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) G[t] = gprime_at(g, yy, H, W, qy + 1 - t / 3, qx + 1 - t % 3, act);
+            bsum += G[4];                                      // the centre tap's own term is g'[q]: every pixel once
+            for (int a = 0; a < ny; ++a)
+                for (int c = (a == 0 ? 1 : 0); c < nx; ++c) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) G[t] += gprime_at(g, yy, H, W, ry[a] + 1 - t / 3, rx[c] + 1 - t % 3, act);
+                }
+        }
+        __syncthreads();                                       // the previous step's readers are done with Gs
+#pragma unroll
+        for (int t = 0; t < 9; ++t) Gs[t][tid] = G[t];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float gg[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) gg[t] = Gs[t][s * 64 + lane];          // (0 for pixels past the image: their x is a clamped re-read)
+#pragma unroll
+            for (int j = 0; j < CPW; ++j)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[j][t] = fmaf(xv[s][j], gg[t], acc[j][t]);
+        }
+    }
+    float* po = part + ((size_t)b * gridDim.x + blk) * (size_t)C * 9 + (size_t)wave * CPW * 9;
+#pragma unroll
+    for (int j = 0; j < CPW; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = wave_sum(acc[j][t]);
+            if (lane == 0) po[j * 9 + t] = v;
+        }
+    bsum = wave_sum(bsum);
+    if (lane == 0) bs[wave] = bsum;
+    __syncthreads();
+    if (tid == 0) pbias[(size_t)b * gridDim.x + blk] = (bs[0] + bs[1]) + (bs[2] + bs[3]);
+}
+
 // measured on the decoder pyramid (tools/bench_convblock.py): these kernels win the forward and the data gradient of the
 // thin high-resolution heads (16 / 32 channels: 61 vs 88 us, 77 vs 174 us at 192x640); the wide low-resolution heads and
 // every weight gradient stay on the Winograd / direct kernels
@@ -135,6 +225,26 @@ int dispconv_dx(const float* w, const float* y, const float* gy, float* dx, int 
                        W, act, pad);
     DC_CHECK_LAUNCH();
     return DC_OK;
+}
+
+bool dispconv_wgrad_eligible(int C0, int C1, int up0, int Co, int H, int W) {
+    return dispconv_eligible(C0, C1, up0, Co, H, W) && (C0 == 16 || C0 == 32);
+}
+size_t dispconv_wgrad_scratch(int B, int C, int H, int W) {
+    return (size_t)B * ceil_div(H * W, DWP) * ((size_t)C * 9 + 1) * sizeof(float);
+}
+
+// dweight (1, C, 3, 3) and dbias (1) from x (B, C, H, W), y / gy (B, 1, H, W); scratch: dispconv_wgrad_scratch bytes
+int dispconv_wgrad(const float* x, const float* y, const float* gy, float* dweight, float* dbias, float* scratch, int B, int C, int H,
+                   int W, int act, int pad, hipStream_t st) {
+    const int nblk = ceil_div(H * W, DWP), split = B * nblk;
+    float* part = scratch;
+    float* pbias = scratch + (size_t)split * C * 9;
+    if (C == 16) hipLaunchKernelGGL(dispconv_wgrad_kernel<4>, dim3(nblk, B), dim3(256), 0, st, x, gy, y, part, pbias, C, H, W, act, pad);
+    else if (C == 32) hipLaunchKernelGGL(dispconv_wgrad_kernel<8>, dim3(nblk, B), dim3(256), 0, st, x, gy, y, part, pbias, C, H, W, act, pad);
+    else return DC_EINVAL;
+    DC_CHECK_LAUNCH();
+    return conv_wreduce(dweight ? part : nullptr, dbias ? pbias : nullptr, dweight, dbias, split, dweight ? C * 9 : 0, dbias ? 1 : 0, st);
 }
 
 }  // namespace dc

@@ -40,6 +40,12 @@ CASES = [
     (1, 40, 0, 36, 48, 80, False, 0, 1),
     (2, 8, 0, 1, 32, 32, False, 2, 0),
     (1, 16, 32, 16, 20, 16, False, 1, 0),
+    # the thin disparity heads (16 / 32 -> 1, reflection pad + sigmoid): plain-FMA forward, data gradient AND weight gradient
+    # (dispconv.hip) -- more than one 2,048-pixel block per image, a ragged last block, a map smaller than one block, zero padding
+    (2, 16, 0, 1, 48, 96, False, 2, 0),
+    (3, 32, 0, 1, 36, 60, False, 2, 0),
+    (2, 16, 0, 1, 9, 13, False, 2, 0),
+    (1, 32, 0, 1, 64, 64, False, 0, 1),
     # pose decoder: zero padding + ReLU (networks/pose_decoder.py), Winograd in all three passes and the direct path
     (4, 256, 0, 256, 6, 20, False, 3, 1),
     (2, 40, 0, 24, 7, 9, False, 3, 1),
