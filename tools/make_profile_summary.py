@@ -46,11 +46,13 @@ for cfg in ("c2", "c3", "c5", "c5bf16"):
     u = json.load(open(os.path.join(SRC, "bench_%s_under_rocprof.json" % cfg)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     steps = u["steps"] + u["warmup"] + 3 + 4
-    L = ["# @R@, %s -- `rocprofv3 --kernel-trace --stats -- python3 bench.py%s --no-cpu-baseline --windows 1` (1x MI355X)\n".replace("@R@", RND)
+    L = ["# @R@, %s -- `rocprofv3 --kernel-trace --stats -- python3 bench.py%s --no-cpu-baseline --windows 1 --wgrad-lanes 0` (1x MI355X)\n".replace("@R@", RND)
          % (cfg.upper(), ARGS[cfg]),
          "Workload: %s.\n" % b["config"]["workload"],
-         ("Plain run of the same command: **%.3f ms/step = %.1f images/s** (`@R@_%s_bench_n1.json`); under the profiler "
-          "(dispatches serialised, no two-stream overlap): %.3f ms/step = %.1f images/s.\n").replace("@R@", RND)
+         ("Plain run (default options: weight-gradient lanes on where the step is GPU-bound): **%.3f ms/step = %.1f images/s** "
+          "(`@R@_%s_bench_n1.json`); under the profiler, lanes off so that the dispatches are serialised (no overlap between "
+          "streams, every duration a kernel's own; with the lanes' four streams the trace shows 3 ms of two-kernel overlap per "
+          "C2 step): %.3f ms/step = %.1f images/s.\n").replace("@R@", RND)
          % (b["ms_per_step"], b["value"], cfg, u["ms_per_step"], u["value"]),
          "Total GPU kernel time in the trace: %.1f ms over ~%d steps.\n" % (tot / 1e6, steps),
          "| kernel family | launches | avg us | total ms | % of GPU time |", "|---|---:|---:|---:|---:|"]

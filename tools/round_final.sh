@@ -1,7 +1,9 @@
 #!/bin/bash
 # GPU box: the round's judged artefacts for one configuration -> gpurun_out/r4final/ (tools/make_profile_summary.py copies
 # them into profiles/).  usage: bash tools/round_final.sh <cfg> [pmc]     cfg: c2 | c3 | c5 | c5bf16 | c1g | c4
-#   1. plain bench line        2. rocprofv3 --kernel-trace --stats of the same command (cfg c2 / c3 / c5 / c5bf16)
+#   1. plain bench line        2. rocprofv3 --kernel-trace --stats of the same command with --wgrad-lanes 0 (cfg c2 / c3 / c5 /
+#      c5bf16): with the weight-gradient lanes the step has four streams and the profiler no longer serialises the dispatches
+#      (3.2 ms of two-kernel overlap per C2 step in its trace), so per-kernel durations would include chip sharing
 #   3. with `pmc`: the three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU; tools/pmc_traffic.sh)
 set -e
 CFG=$1
@@ -22,7 +24,7 @@ python3 bench.py $ARGS $NOCPU > $OUT/bench_$CFG.json 2> $OUT/bench_$CFG.err
 echo "bench $CFG done"; head -c 400 $OUT/bench_$CFG.json; echo
 if [ $CFG = c1g ] || [ $CFG = c4 ]; then exit 0; fi
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_$CFG -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu-baseline --windows 1 > $OUT/bench_${CFG}_under_rocprof.json 2> $OUT/rocprof_$CFG.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rocprof_$CFG -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu-baseline --windows 1 --wgrad-lanes 0 > $OUT/bench_${CFG}_under_rocprof.json 2> $OUT/rocprof_$CFG.err
 echo "rocprof $CFG done"
 if [ "$2" = pmc ]; then
   cd $GRAFT_REPO_ROOT
