@@ -555,6 +555,14 @@ class Trainer:
             self._evict_graphs(key)
             static_in = {k: v.clone() for k, v in inputs.items()}
             torch.cuda.synchronize(self.device)
+            if self.world_size > 1:
+                # The warm-up steps' collectives are finished on the GPU, but the process group's watchdog thread retires
+                # them at its next poll (every 100 ms) by querying their end events -- recorded on the group's internal
+                # stream, which is about to join the capture.  A query that lands inside the capture fails with
+                # hipErrorCapturedEvent, and the watchdog turns that into abort() (seen in 1 of 8 runs of
+                # tests/ddp_graph_child.py).  Let it retire them first: three polls.
+                import time
+                time.sleep(0.35)
             g = torch.cuda.CUDAGraph()
             step0 = self.step
             stream0 = torch.cuda.current_stream(self.device)

@@ -128,7 +128,7 @@ def test_graph_mode_with_bucketed_exchange_over_rccl():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(here, "ddp_graph_child.py")], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    assert r.returncode == 0, (r.returncode, r.stderr[:4000], r.stderr[-2000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
