@@ -465,6 +465,12 @@ int dc_get_matrix_precision(void);
  * against an fp64 direct convolution; F(2x2,3x3): 2-3e-7).  OFF by default; mode 1 uses it where W % 4 == 0 and its tile
  * groups cover >= 85 % of the map.  Process-global; returns the previous mode, or DC_EINVAL.  Measurements: DESIGN.md 4a. */
 int dc_set_wino_f4(int mode);
+/* Persistent form of the plain trunk launches of dc_wino3x3_fwd / _dgrad / _dgrad_add that run in more than one round of
+ * resident blocks (unsplit reduction, an even number >= 4 of 8-channel chunks): one block per slot walks several work items
+ * as ONE software pipeline -- the next item's first loads fly under the current item's row-exchange epilogue.  Same
+ * arithmetic in the same order per output: results are bitwise those of the classic launch.  Process-global; the initial
+ * mode comes from DC_WINO_PERSIST (default 0); returns the previous mode, or DC_EINVAL.  Measurements: DESIGN.md 4a. */
+int dc_set_wino_persist(int mode);
 int dc_wino_cache_new_owner(void);
 int dc_wino_cache_register(int owner, const float* weight, int Ci, int Co);
 int dc_wino_cache_release_owner(int owner);

@@ -137,11 +137,12 @@ struct WinoPsArgs {
     unsigned xbytes;
     size_t slab_stride;               // floats between the K-split slabs
     int mblocks, tblocks, m_fast;
+    int items;                        // work items = tblocks * mblocks; a launch with FEWER blocks than items is persistent (below)
     unsigned mg_mblocks, mg_tblocks, mg_per_img, mg_regs_x, mg_PR, mg_RW;   // fdiv magics of the divisors the kernel divides by
     unsigned long long* diag;         // WINO_DIAG builds only: per block {compute, commit(+load wait), issue, barrier, loop, prologue, epilogue, start time} cycles
 };
 
-template <int MR, int NR, bool FUSED>
+template <int MR, int NR, bool FUSED, bool PERSIST = false>
 __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) void wino_ps_kernel(WinoPsArgs a) {
     constexpr int MT = 16 * MR, G = NR / 2;
     constexpr int UF4 = PSK * 4 * MT;                 // f4 items of one U chunk in global memory
@@ -157,10 +158,21 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     const int CPS = G * SUBS;                         // channel plane stride in the slab
     // block -> (tile block, channel block): the faster index is the one whose operand is the larger stream, so that
     // its other readers find it in L2
+    // Work items.  A launch with as many blocks as items gives every block one (the classic form).  A PERSISTENT launch
+    // (gridDim.x < a.items; gridDim.z == 1, an even number of chunks) gives a block one item per round of gridDim.x items
+    // and runs their chunks as ONE software pipeline: the first two x chunks and the first U chunk of the next item are
+    // requested during the last chunks of the current one, so the next item's first HBM touch flies under this item's
+    // row-exchange epilogue instead of in front of an idle matrix pipe (prologue + epilogue are 12-23 % of a
+    // block and nothing overlaps them inside a lock-step round).
     const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);       // neighbours in this order share an XCD (one L2)
-    const int q_m = fdiv(lbid, a.mg_mblocks), q_t = fdiv(lbid, a.mg_tblocks);
-    const int mblk = a.m_fast ? lbid - q_m * a.mblocks : q_t;
-    const int tblk = a.m_fast ? q_m : lbid - q_t * a.tblocks;
+    int item = lbid;
+    auto item_blocks = [&](int it, int& mb, int& tb) {
+        const int q_m = fdiv(it, a.mg_mblocks), q_t = fdiv(it, a.mg_tblocks);
+        mb = a.m_fast ? it - q_m * a.mblocks : q_t;
+        tb = a.m_fast ? q_m : it - q_t * a.tblocks;
+    };
+    int mblk, tblk;
+    item_blocks(item, mblk, tblk);
     const int per_img = a.regs_x * a.regs_y;
     const int c_begin = blockIdx.z * a.chunks_per_split;
     const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
@@ -168,16 +180,17 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     // index arithmetic: it depends on the block's channel tile only
     f4 ureg[2][PSK / 4][MR];
     const wrsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.uhat) + (size_t)mblk * a.nchunks * UF4 * 4, (short)0, (int)((size_t)a.nchunks * UF4 * 16), 0x00020000);
+        const_cast<float*>(a.uhat), (short)0, (int)((size_t)a.mblocks * a.nchunks * UF4 * 16), 0x00020000);
     const int uoff = ((kk * 4 + wave) * MT + n) * 16;
-    auto load_u = [&](int c, f4 (*dst)[MR]) {
+    auto load_u = [&](int mb, int c, f4 (*dst)[MR]) {
 #pragma unroll
         for (int ks = 0; ks < PSK / 4; ++ks)
 #pragma unroll
             for (int i = 0; i < MR; ++i)
-                dst[ks][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ur, uoff + (ks * 16 * MT + i * 16) * 16, c * (UF4 * 16), 0));
+                dst[ks][i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ur, uoff + (ks * 16 * MT + i * 16) * 16,
+                                                                                          (mb * a.nchunks + c) * (UF4 * 16), 0));
     };
-    if (c_begin < c_end) load_u(c_begin, ureg[0]);
+    if (c_begin < c_end) load_u(mblk, c_begin, ureg[0]);
 
     // ---- staging role: thread -> (sub-region, slab row, column pair) and PK channels of the chunk.  G = 2: the two thread
     // halves take the two sub-regions, all PSK channels each.  G = 1: they take the two channel halves of the one sub-region
@@ -186,11 +199,6 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     const int sg_ = G == 1 ? 0 : tid >> 7, sp = tid & 127;
     const int kh0 = G == 1 ? (wave >> 1) * PK : 0;       // first channel of the chunk this thread stages
     const int PR = RW + 2, SR = 2 * RH + 2;
-    const int ssub = tblk * G + sg_;
-    const bool s_act = sg_ < G && ssub < a.nsub && sp < SR * PR;
-    const int sq = s_act ? ssub : 0;
-    const int sb = fdiv(sq, a.mg_per_img), srq = sq - sb * per_img;
-    const int sry = fdiv(srq, a.mg_regs_x), srx = srq - sry * a.regs_x;
     const int sr = fdiv(sp, a.mg_PR), scp = sp - sr * PR;
     // image position of this thread's column pair (ix even) and the source it is read from:
     //   plain: zero padding, P = 1.  FUSED: ReflectionPad2d(1) folds row -1 -> 1, H -> H-2 and redirects the two border
@@ -198,23 +206,33 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     //   pair (W,W+1) -> (W-2,W-1): .x lands on the column of W); nearest-2x upsampling reads x0[iy>>1][ix>>1] once and
     //   duplicates it; P = 2 shifts the patch origin for the full correlation (slab column 0 = image column X0-2).
     const int P = FUSED ? a.P : 1;
-    const int iy = sry * RH * 2 - P + sr, ix = srx * RW * 2 - 2 + 2 * scp;
-    int sy = iy, sx = ix;
-    if (FUSED && a.pad == PAD_REFLECT) {
-        sy = iy == -1 ? 1 : (iy == H ? H - 2 : iy);
-        sx = ix == -2 ? 0 : (ix == W ? W - 2 : ix);
-    }
-    const bool sok = s_act && sy >= 0 && sy < H && sx >= 0 && sx < W;
     const bool swr = sg_ < G && sp < SR * PR;
     const unsigned plane = (unsigned)(H * W) * 4u;                       // full-resolution plane bytes
     const int up0 = FUSED ? a.up0 : 0;
     const int C0 = FUSED ? a.C0 : a.K;
     const unsigned plane0 = up0 ? (unsigned)((H >> 1) * (W >> 1)) * 4u : plane;
-    // byte offsets inside source 0 (x / x0) and source 1 (x1)
-    const unsigned svoff = sok ? (unsigned)sb * (unsigned)C0 * plane0 +
-                                     (up0 ? (unsigned)((sy >> 1) * (W >> 1) + (sx >> 1)) : (unsigned)(sy * W + sx)) * 4u
-                               : 0x80000000u;
-    const unsigned svoff1 = (FUSED && sok) ? (unsigned)sb * (unsigned)(a.K - C0) * plane + (unsigned)(sy * W + sx) * 4u : 0x80000000u;
+    // byte offsets of this thread's pair inside source 0 (x / x0) and source 1 (x1) for the item with tile block `tb`
+    // (0x80000000: outside the image / the item list -- the buffer load returns 0)
+    auto item_src = [&](int tb, bool valid, unsigned& vo0, unsigned& vo1) {
+        const int ssub = tb * G + sg_;
+        const bool s_act = valid && sg_ < G && ssub < a.nsub && sp < SR * PR;
+        const int sq = s_act ? ssub : 0;
+        const int sb = fdiv(sq, a.mg_per_img), srq = sq - sb * per_img;
+        const int sry = fdiv(srq, a.mg_regs_x), srx = srq - sry * a.regs_x;
+        const int iy = sry * RH * 2 - P + sr, ix = srx * RW * 2 - 2 + 2 * scp;
+        int sy = iy, sx = ix;
+        if (FUSED && a.pad == PAD_REFLECT) {
+            sy = iy == -1 ? 1 : (iy == H ? H - 2 : iy);
+            sx = ix == -2 ? 0 : (ix == W ? W - 2 : ix);
+        }
+        const bool sok = s_act && sy >= 0 && sy < H && sx >= 0 && sx < W;
+        vo0 = sok ? (unsigned)sb * (unsigned)C0 * plane0 +
+                        (up0 ? (unsigned)((sy >> 1) * (W >> 1) + (sx >> 1)) : (unsigned)(sy * W + sx)) * 4u
+                  : 0x80000000u;
+        vo1 = (FUSED && sok) ? (unsigned)sb * (unsigned)(a.K - C0) * plane + (unsigned)(sy * W + sx) * 4u : 0x80000000u;
+    };
+    unsigned svoff, svoff1;
+    item_src(tblk, true, svoff, svoff1);
     const int shift = 2 - P;                          // slab column of the pair's first element = 2 scp - shift
     const int slds0 = sg_ * SUBS + sr * RS + max(2 * scp - shift, 0), slds1 = sg_ * SUBS + sr * RS + 2 * scp + 1 - shift;
     const wrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     // A operands: the four waves need DISJOINT quarters of a U chunk (wave = Winograd row = pq), so U never goes through
     // LDS: each lane loads its own 16 bytes per k-step and 16-channel block straight into the registers the MFMAs read,
     // one chunk ahead (16 lanes x 16 B = 256-byte rows; the other tile blocks of this channel block find them in L2)
-    auto load_x = [&](int c, f2w* dst) {
+    auto load_x = [&](unsigned so0, unsigned so1, int c, f2w* dst) {
         {
             // ONE load shape for every kind of chunk -- eight 8-byte buffer loads, the source picked by scalar selects (chunks
             // never straddle the concat: C0 % PSK == 0, host-checked).  Separate code paths per source (dword loads for the
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
             const int ch0 = c * PSK;
             const bool from1 = FUSED && ch0 >= C0;
             const wrsrc_t rs = from1 ? x1r : xr;
-            const unsigned pl = from1 ? plane : plane0, vbase = from1 ? svoff1 : svoff;
+            const unsigned pl = from1 ? plane : plane0, vbase = from1 ? so1 : so0;
             const int chb = (from1 ? ch0 - C0 : ch0) + kh0, climit = from1 ? a.K - C0 : C0;
 #pragma unroll
             for (int k = 0; k < PK; ++k) {
@@ -316,16 +334,20 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     // The slab is double-buffered in LDS (one barrier per chunk), U lives in registers.  In flight while chunk c is
     // multiplied: U of c+1 (L2-resident) and x of c+1 and c+2 (first touch comes from HBM).
     const int nloc = c_end - c_begin;
+    const int grid = gridDim.x;
+    const bool persist = PERSIST && grid < a.items;  // (host: gridDim.z == 1, nloc even and >= 4; PERSIST instantiations only)
+    int round = 0;
     if (nloc > 0) {
-        load_x(c_begin, px[0]);
-        if (nloc > 1) load_x(c_begin + 1, px[1]);
+        load_x(svoff, svoff1, c_begin, px[0]);
+        if (nloc > 1) load_x(svoff, svoff1, c_begin + 1, px[1]);
         commit_x(0, px[0], c_begin);
-        if (nloc > 2) load_x(c_begin + 2, px[0]);
+        if (nloc > 2) load_x(svoff, svoff1, c_begin + 2, px[0]);
     }
     __syncthreads();
 #ifdef WINO_DIAG
     unsigned long long dg[5] = {0, 0, 0, 0, 0};
     const unsigned long long dg0 = __builtin_amdgcn_s_memtime();
+    unsigned long long dg_loop_end = 0;
 #endif
 #if defined(WINO_DIAG) && WINO_DIAG == 1             // WINO_DIAG=2: only prologue / loop / epilogue (the inner timers cost ~20 % themselves)
 #define DIAG_T(k, stmt) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stmt; dg[k] += __builtin_amdgcn_s_memtime() - t_; }
@@ -334,12 +356,28 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
 #define DIAG_T(k, stmt) { stmt; }
 #define DIAG_WAIT()
 #endif
+  for (;;) {                                          // work items of this block (one, unless the launch is persistent)
+    // the next item's sources: its loads are issued by the last steps of this item's pipeline
+    // (round r hands out the items [r grid, (r+1) grid): the last, partial round goes to the blocks with the LOWEST hardware
+    // ids -- round-robin over the XCDs and breadth-first over their CUs, i.e. spread over the chip -- in XCD-local order)
+    const int n_next = min(grid, a.items - (round + 1) * grid);
+    const bool has_next = PERSIST && persist && (int)blockIdx.x < n_next;
+    const int item_n = has_next ? (round + 1) * grid + xcd_logical_block(blockIdx.x, n_next) : item;
+    int mblk_n = mblk, tblk_n = tblk;
+    if (has_next) item_blocks(item_n, mblk_n, tblk_n);
+    unsigned svoff_n, svoff1_n;
+    item_src(tblk_n, has_next, svoff_n, svoff1_n);
     auto step = [&](int i, f2w* pxn, f4 (*ucur)[MR], f4 (*unxt)[MR]) {   // pxn holds x of chunk i+1
-        if (i + 1 < nloc) load_u(c_begin + i + 1, unxt);
+        const bool more = i + 1 < nloc;
+        if (more || has_next) load_u(more ? mblk : mblk_n, more ? c_begin + i + 1 : c_begin, unxt);
         DIAG_T(0, compute(i & 1, ucur));
-        if (i + 1 < nloc) {
+        if (more) {
             DIAG_T(1, commit_x((i + 1) & 1, pxn, c_begin + i + 1); DIAG_WAIT());
-            DIAG_T(2, if (i + 3 < nloc) load_x(c_begin + i + 3, pxn));
+            // chunk i+3 of this item -- or, at the end of the item, chunk 0 / 1 of the next one (same registers, same parity:
+            // nloc is even), whose commit waits behind the epilogue below
+            const bool in_cur = i + 3 < nloc;
+            DIAG_T(2, if (in_cur || has_next) load_x(in_cur ? svoff : svoff_n, in_cur ? svoff1 : svoff1_n,
+                                                     in_cur ? c_begin + i + 3 : c_begin + i + 3 - nloc, pxn));
         }
         DIAG_T(3, __syncthreads());
     };
@@ -349,8 +387,10 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     }
 
 #ifdef WINO_DIAG
-    const unsigned long long dg_loop_end = __builtin_amdgcn_s_memtime();
-    dg[4] = dg_loop_end - dg0;
+    if (item == lbid) {
+        dg_loop_end = __builtin_amdgcn_s_memtime();
+        dg[4] = dg_loop_end - dg0;
+    }
 #endif
     // ---- combine the four rows: wave a contributes z[a][jj] = sum_b M[a][b] A[b][jj]; Y[0] = z0+z1+z2, Y[1] = z1-z2-z3
     float* ex = &xl[0][0];                                       // [wave][(j*4 + r)*2 + jj][lane]  (the slabs are dead now)
@@ -423,6 +463,22 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
             }
         }
     }
+    if (!has_next) break;
+    // ---- on to the next item: its chunks 0 and 1 are in px[0] / px[1] (requested by the last steps above), its first U chunk
+    // in ureg[0]; the exchange buffer is the slab pair, so chunk 0 is committed only now, then chunk 2 is requested -- the
+    // state a block's prologue leaves
+    __syncthreads();
+    commit_x(0, px[0], c_begin);
+    load_x(svoff_n, svoff1_n, c_begin + 2, px[0]);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][j][q] = f4{0.f, 0.f, 0.f, 0.f};
+    item = item_n; ++round; mblk = mblk_n; tblk = tblk_n; svoff = svoff_n; svoff1 = svoff1_n;
+    __syncthreads();
+  }
 #ifdef WINO_DIAG
     if (a.diag && lane == 0 && wave == 0) {
         unsigned long long* o = a.diag + (size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8;
@@ -603,6 +659,8 @@ static double wino_ps_cost(int v, int ksplit, int nsub, int M, int nchunks, size
     return t;
 }
 
+static int g_wino_persist = [] { const char* f = getenv("DC_WINO_PERSIST"); return f ? atoi(f) : 0; }();      // dc_set_wino_persist
+
 // One convolution launch: reduction over K = C0 + C1 source channels, M output channels.
 struct WinoLaunch {
     const float* src0; int C0; int up0; const float* src1; int C1;     // input = cat(up2?(src0), src1), maps H x W
@@ -672,7 +730,16 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     if ((unsigned long long)a.tblocks * a.mblocks * (unsigned)std::max(a.mblocks, a.tblocks) >= 0xffffffffull ||
         (unsigned long long)(a.nsub + 2 * G) * (unsigned)(a.regs_x * a.regs_y) >= 0xffffffffull) return DC_EINVAL;
     a.m_fast = (size_t)d.B * H * W >= (size_t)M * 16 ? 1 : 0;     // x stream (per reduction channel) vs U stream
-    const dim3 grid(a.tblocks * a.mblocks, 1, ksplit);
+    a.items = a.tblocks * a.mblocks;
+    // Persistent form (wino_ps_kernel: one software pipeline over a block's items): only where a launch runs in more than one
+    // round of resident blocks, on an unsplit reduction with an even number (>= 4) of chunks.
+    int gx = a.items;
+    {
+        const int mode = g_wino_persist;
+        const int bpc = MT == 16 ? 4 : (G == 1 ? 3 : 2), slots = 256 * bpc;
+        if (mode == 1 && !d.fused && ksplit == 1 && a.nchunks >= 4 && (a.nchunks & 1) == 0 && a.items > slots) gx = slots;
+    }
+    const dim3 grid(gx, 1, ksplit);
     // algorithmic = 2 MAC of the direct convolution; executed = the 16 Winograd-domain GEMMs incl. tile padding
     hipEvent_t pe = conv_prof_begin(0, 2.0 * d.B * (double)M * K * 9.0 * H * W,
                                     2.0 * 16.0 * (double)a.nsub * 32.0 * (double)Mp * Kp,
@@ -681,6 +748,10 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
         if (MT == 16) hipLaunchKernelGGL((wino_ps_kernel<1, 2, true>), grid, dim3(256), 0, st, a);
         else if (G == 1) hipLaunchKernelGGL((wino_ps_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wino_ps_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
+    } else if (gx < a.items) {
+        if (MT == 16) hipLaunchKernelGGL((wino_ps_kernel<1, 2, false, true>), grid, dim3(256), 0, st, a);
+        else if (G == 1) hipLaunchKernelGGL((wino_ps_kernel<2, 2, false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wino_ps_kernel<2, 4, false, true>), grid, dim3(256), 0, st, a);
     } else {
         if (MT == 16) hipLaunchKernelGGL((wino_ps_kernel<1, 2, false>), grid, dim3(256), 0, st, a);
         else if (G == 1) hipLaunchKernelGGL((wino_ps_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
@@ -921,6 +992,13 @@ extern "C" size_t dc_wino3x3_workspace(int B, int Ci, int Co, int H, int W) {
     if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;
     return std::max({wino_uhat_bytes(Ci, Co), wino4_uhat_bytes(Ci, Co), c3b_weights_bytes(Ci, Co)}) +
            wino_al256((size_t)2 * B * std::max(Ci, Co) * H * W * sizeof(float));
+}
+
+extern "C" int dc_set_wino_persist(int mode) {
+    if (mode != 0 && mode != 1) return DC_EINVAL;
+    const int prev = g_wino_persist;
+    g_wino_persist = mode;
+    return prev;
 }
 
 extern "C" int dc_set_wino_f4(int mode) {

@@ -150,6 +150,7 @@ def _sig(lib):
         "dc_clear_error": (i, []),
         "dc_abort_capture": (i, [p]),
         "dc_set_wino_f4": (i, [i]),
+        "dc_set_wino_persist": (i, [i]),
         "dc_wino_cache_new_owner": (i, []),
         "dc_wino_cache_register": (i, [i, p, i, i]),
         "dc_wino_cache_release_owner": (i, [i]),

@@ -227,3 +227,47 @@ def test_wino_f4_full_step_deltas():
         dl, sorted(rel.values())[len(rel) // 2], ["%s %.1e" % kv for kv in worst]), file=sys.stderr)
     assert dl <= 1e-5
     assert sorted(rel.values())[len(rel) // 2] <= 3e-2 and max(rel.values()) <= 0.15
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", [
+    (12, 64, 64, 48, 160),        # layer1 at C2, depth batch: 1.4 rounds of the 32 x 64 tile
+    (24, 64, 64, 48, 160),        # pose batch: 2.8 rounds
+    (24, 128, 128, 24, 80),       # layer2
+    (8, 64, 64, 80, 256),         # resnet50 layer1.conv2 at C3
+    (24, 64, 128, 24, 80),        # more output than reduction channels (16 chunks... 8 here), two channel blocks per tile
+    (5, 32, 64, 50, 74),          # ragged: partial sub-regions, an odd number of tile blocks, 4 chunks
+])
+def test_wino_persistent_launch_is_bitwise_the_classic_one(B, Ci, Co, H, W):
+    """dc_set_wino_persist(1): launches that run in more than one round of resident blocks become ONE round of persistent
+    blocks that pipeline their work items' chunks (the next item's first loads fly under the current item's epilogue).  The
+    arithmetic per output is untouched, so forward, data gradient and data gradient + fork addend must be BITWISE the
+    classic launch's -- on shapes with 1.4 to 3 rounds, ragged maps, and a shape (the last) where some blocks get one item
+    and others two."""
+    from depthcore import _lib
+    from depthcore._lib import ptr, stream, check
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B + Ci + H)
+    x = torch.randn(B, Ci, H, W, generator=g).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3.0 * Ci ** 0.5)).cuda()
+    gy = torch.randn(B, Co, H, W, generator=g).cuda()
+    add = torch.randn(B, Ci, H, W, generator=g).cuda()
+    ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, H, W), dtype=torch.uint8, device="cuda")
+    outs = []
+    prev = L.dc_set_wino_persist(0)
+    try:
+        for mode in (0, 1):
+            assert L.dc_set_wino_persist(mode) in (0, 1)
+            y = torch.empty(B, Co, H, W, device="cuda")
+            dx = torch.empty(B, Ci, H, W, device="cuda")
+            dxa = torch.empty(B, Ci, H, W, device="cuda")
+            check(L.dc_wino3x3_fwd(ptr(x), ptr(w), ptr(y), ws.data_ptr(), B, Ci, Co, H, W, stream(x)), "fwd")
+            check(L.dc_wino3x3_dgrad(ptr(gy), ptr(w), ptr(dx), ws.data_ptr(), B, Ci, Co, H, W, stream(x)), "dgrad")
+            check(L.dc_wino3x3_dgrad_add(ptr(gy), ptr(w), ptr(dxa), ptr(add), ws.data_ptr(), B, Ci, Co, H, W, stream(x)), "dgrad_add")
+            torch.cuda.synchronize()
+            outs.append((y, dx, dxa))
+    finally:
+        L.dc_set_wino_persist(prev)
+    for name, u, v in zip(("y", "dx", "dx+addend"), outs[0], outs[1]):
+        assert torch.equal(u, v), (name, float((u - v).abs().max()))
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    assert float((outs[1][0].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
