@@ -99,3 +99,27 @@ def test_facade_names_and_state_dict_layout():
     bp = layers.BackprojectDepth(1, 192, 640)
     pc = bp.pix_coords[0].numpy()
     assert np.array_equal(pc[:, 639:642], np.array([[639, 0, 1], [0, 1, 1], [1, 1, 1]], np.float32))
+
+
+def test_wgrad_lanes_bookkeeping_without_gpu():
+    """ops.WgradLanes host logic: uses are counted per parameter by the forwards, a lane is only taken for a parameter used
+    exactly once whose .grad is still None (autograd sums the gradients of a multiply-used parameter on the backward's own
+    stream), CPU tensors never switch streams, and leaving active() clears the step's bookkeeping."""
+    import torch
+    from depthcore import ops
+    L = ops.WgradLanes
+    p, q = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(3))
+    L.join()
+    assert not L._on and L._uses == {}
+    with L.active():
+        assert L._on
+        L.count_use(p)
+        L.count_use(q)
+        L.count_use(q)
+        assert L._uses[id(p)] == 1 and L._uses[id(q)] == 2
+        with L.lane(p, torch.zeros(2)):          # CPU tensor: no stream switch, nothing recorded
+            pass
+        assert L._used == set()
+    assert not L._on and L._uses == {} and L._used == set()
+    with L.active(False):
+        assert not L._on
