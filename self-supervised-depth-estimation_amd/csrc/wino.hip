@@ -655,9 +655,15 @@ static double wino_ps_cost(int v, int ksplit, int nsub, int M, int nchunks, size
     const long slots = 256L * bpc[v], full = blocks / slots, rem = blocks % slots;
     double t = (double)full * (P[v] + chunks * (A[v] + Bc[v] * bpc[v]));
     if (rem) t += P[v] + chunks * (A[v] + Bc[v] * (double)ceil_div((int)rem, 256));
-    if (ksplit > 1) t += 6.5 + 0.124 * (double)nout * 12.0 * 1e-6;
+    if (ksplit > 1) t += 6.5 + 0.124 * (double)nout * 4.0 * (ksplit + 1) * 1e-6;      // slab sum: reads ksplit slabs, writes one
     return t;
 }
+
+// Largest reduction split a launch may use: 2 in general; 4 or 8 for SMALL outputs (<= 2 MB: the deep, low-resolution layers
+// at batch 1-3 -- 512 channels on a 6 x 20 map is ONE sub-region per image and 64 dependent chunks per block: 44 us for 3.6 us
+// of matrix work; its slabs are a few hundred KB).  Workspace sizes follow the same rule (wino_slab_bytes).
+static int wino_ksplit_cap(size_t nout) { return nout * 4 <= (2u << 20) ? 8 : 2; }
+static size_t wino_slab_bytes(size_t nout) { return (size_t)wino_ksplit_cap(nout) * nout * sizeof(float); }
 
 static int g_wino_persist = [] { const char* f = getenv("DC_WINO_PERSIST"); return f ? atoi(f) : 0; }();      // dc_set_wino_persist
 
@@ -692,9 +698,11 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     const size_t nout = (size_t)d.B * M * Ho * Wo;
     {
         const bool can_split = (Ho * Wo) % 4 == 0 && a.nchunks >= 2;
+        const int ks_cap = can_split ? wino_ksplit_cap(nout) : 1;
         double best = 1e30;
         for (int v = 0; v < 3; ++v)
-            for (int ks = 1; ks <= (can_split ? 2 : 1); ++ks) {
+            for (int ks = 1; ks <= ks_cap; ks *= 2) {
+                if (ks > 1 && a.nchunks < 2 * ks) break;          // at least two chunks per split: something to pipeline
                 const double t = wino_ps_cost(v, ks, a.nsub, M, a.nchunks, nout);
                 if (t < best) { best = t; MT = v == 0 ? 16 : 32; G = v == 2 ? 2 : 1; ksplit = ks; }
             }
@@ -702,7 +710,7 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
             int mr = 0, nr = 0, fks = 0;
             if (sscanf(f, "%d,%d,%d", &mr, &nr, &fks) >= 2 && (mr == 1 || mr == 2) && (nr == 2 || nr == 4) && !(mr == 1 && nr == 4)) {
                 MT = 16 * mr; G = nr / 2;
-                if (fks > 0) ksplit = can_split ? std::min(fks, 2) : 1;
+                if (fks > 0) ksplit = std::max(1, std::min({fks, ks_cap, a.nchunks / 2}));
             }
         }
     }
@@ -772,7 +780,7 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
 size_t wino_conv_ws_bytes(int B, int Ci, int Co, int H, int W) {
     // transformed weights + the reduction-split slabs of the larger of {forward output, full-correlation data gradient}
     const size_t fwd = (size_t)B * Co * H * W, full = (size_t)B * Ci * (H + 2) * (W + 2);
-    return wino_uhat_bytes(Ci, Co) + wino_al256(2 * std::max(fwd, full) * sizeof(float));
+    return wino_uhat_bytes(Ci, Co) + wino_al256(std::max(wino_slab_bytes(fwd), wino_slab_bytes(full)));
 }
 
 bool wino_conv_eligible(int C0, int C1, int H, int W) {
@@ -991,7 +999,7 @@ extern "C" int dc_wino_cache_variants(void) {
 extern "C" size_t dc_wino3x3_workspace(int B, int Ci, int Co, int H, int W) {
     if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;
     return std::max({wino_uhat_bytes(Ci, Co), wino4_uhat_bytes(Ci, Co), c3b_weights_bytes(Ci, Co)}) +
-           wino_al256((size_t)2 * B * std::max(Ci, Co) * H * W * sizeof(float));
+           wino_al256(std::max(wino_slab_bytes((size_t)B * Ci * H * W), wino_slab_bytes((size_t)B * Co * H * W)));
 }
 
 extern "C" int dc_set_wino_persist(int mode) {
