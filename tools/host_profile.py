@@ -15,9 +15,10 @@ from depthcore.synthetic import synthetic_batch  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    tr = T.Trainer(T.default_options(batch_size=12), device=dev)
+    B = int(os.environ.get("DC_B", 12))           # DC_B=1: the host-bound small-batch step
+    tr = T.Trainer(T.default_options(batch_size=B), device=dev)
     tr.set_train()
-    inputs = synthetic_batch(12, 192, 640, dev, seed=1)
+    inputs = synthetic_batch(B, 192, 640, dev, seed=1)
     for _ in range(5):
         tr.train_step(inputs)
     torch.cuda.synchronize()
@@ -28,7 +29,7 @@ def main():
     pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(28)
+    st.sort_stats("tottime").print_stats(int(os.environ.get("DC_TOP", 28)))
 
 
 if __name__ == "__main__":
