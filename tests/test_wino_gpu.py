@@ -19,6 +19,10 @@ CASES = [
     (2, 20, 40, 9, 34),        # K not a multiple of the chunk, M straddles blocks
     (1, 8, 16, 2, 2),          # single tile
     (2, 64, 256, 80, 256),     # bottleneck-style, C3 geometry
+    (1, 512, 512, 6, 20),      # layer4 at batch 1: one sub-region per image, the reduction split 8 ways (small outputs)
+    (1, 256, 256, 12, 40),     # layer3 at batch 1 (split 4 or 8)
+    (3, 512, 512, 6, 20),      # the ConvGRU sequence batch
+    (1, 72, 40, 6, 20),        # 9 chunks: splits whose last slab gets fewer chunks than the others
 ]
 
 
