@@ -575,8 +575,8 @@ def run_rank(args):
             "backward_chain": dict(chain(bytes_bwd, bwd_chain_ms), **kern("dc::photo_bwdg_kernel", bwd_ms, bytes_bwd, VALU_SLOTS_PER_INST["bwd"])),
             "round3": {"forward_chain_ms": 0.17, "backward_chain_ms": 0.2487, "pair_frac": 0.148,
                        "note": "forward without gradient emission + the window backward (profiles/round3_c2_bench_n1.json)"},
-            "limiter": "the training forward is VALU-issue bound (2 waves per SIMD at 203 VGPRs); the pointwise backward and the "
-                       "transposed upsample are latency / HBM bound",
+            "limiter": "the training forward is VALU-issue bound (3 waves per SIMD at 145 VGPRs since its loads are issued behind "
+                       "stage B; 2 at 203 before); the pointwise backward and the transposed upsample are latency / HBM bound",
             "valu_note": "SQ_INSTS_VALU per launch (cited PMC pass) x issue slots per instruction from the ISA mix "
                          "(profiles/round4_photo_isa_mix.txt); 2 cycles per slot per SIMD-32"})
         out = {
