@@ -19,6 +19,7 @@ def main():
     batches = [synthetic_batch(12, 192, 640, dev, seed=s) for s in range(4)]
     losses = []
     mem0 = None
+    trace = []
     for i in range(n):
         _, l = tr.train_step(batches[i % 4])
         if i % 25 == 0 or i == n - 1:
@@ -29,8 +30,11 @@ def main():
         if i == 20:
             torch.cuda.synchronize()
             mem0 = torch.cuda.memory_reserved()
+        if i % 100 == 0:
+            trace.append("%.2f" % (torch.cuda.memory_reserved() / 2**30))
     torch.cuda.synchronize()
     print("steps %d: loss %.5f -> %.5f (every 25th: %s)" % (n, losses[0], losses[-1], " ".join("%.4f" % v for v in losses)))
+    print("reserved GB every 100 steps: " + " ".join(trace) + "  (weight-gradient lanes %s)" % ("on" if tr.wgrad_lanes else "off"))
     print("reserved memory after 20 steps %.2f GB, at the end %.2f GB, peak allocated %.2f GB"
           % (mem0 / 2**30, torch.cuda.memory_reserved() / 2**30, torch.cuda.max_memory_allocated() / 2**30))
 
