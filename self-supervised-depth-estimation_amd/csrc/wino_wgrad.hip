@@ -372,6 +372,55 @@ __global__ __launch_bounds__(64 * WR_GROUPS) void wino_wreduce_kernel(const floa
     }
 }
 
+// The same reduction with one block per (m-block, k-block, i, j, r, COLUMN c of the 3x3) -- three times the blocks, for layers
+// whose tile grid is small (a 64 -> 64 layer: 64 blocks of the kernel above, a quarter of the chip reading 25 MB of slabs;
+// wgrad + reduce 54.9 -> 50.6 us at B = 12, 23.2 -> 19.9 at B = 1; beyond 1,024 base blocks the extra blocks cost more than
+// they bring: 512 channels +2 us).  Same per-output summation order as the kernel above: bitwise the same result.
+// One block per (.., r, c):
+// 64 lanes x 16 split groups; a group sums its contiguous range of splits, the 16 partial sums are then added in order
+// through LDS.  (One block per (.., r) with all three columns was 64 blocks for a 64 -> 64 layer: a quarter of the chip
+// reading 25 MB of slabs.)
+__global__ __launch_bounds__(64 * WR_GROUPS) void wino_wreduce_col_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                      int splits, int nmk, int kblocks, int M, int K, int MR) {
+    constexpr int KR = WG_KR;
+    const size_t WAVE_SLAB = (size_t)MR * KR * 4 * 3 * 64;           // floats one wave (row a) of one block wrote
+    __shared__ float part[WR_GROUPS][4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    int e = blockIdx.x;                                 // (((mk*MR + i)*KR + j)*4 + r)*3 + c
+    const int c = e % 3; e /= 3;
+    const int r = e & 3; e >>= 2;
+    const int j = e % KR; e /= KR;
+    const int i = e % MR; e /= MR;
+    const int mk = e;
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    const int groups = blockDim.x >> 6;                 // <= WR_GROUPS, chosen by the host from the split count
+    const int per = (splits + groups - 1) / groups;
+    const int s1 = min(splits, (grp + 1) * per);
+    for (int s = grp * per; s < s1; ++s) {
+        const float* src = slab + ((size_t)(s * nmk + mk) * 4) * WAVE_SLAB + (size_t)(((i * KR + j) * 4 + r) * 3 + c) * 64 + lane;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) q[w] += src[(size_t)w * WAVE_SLAB];
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) part[grp][w][lane] = q[w];
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        float t = part[0][w][lane];
+        for (int g = 1; g < groups; ++g) t += part[g][w][lane];
+        q[w] = t;
+    }
+    const int mbk = mk / kblocks, kbk = mk - mbk * kblocks;
+    const int m = mbk * (16 * MR) + i * 16 + (lane >> 4) * 4 + r, k = kbk * WG_KT + j * 16 + (lane & 15);
+    if (m >= M || k >= K) return;
+    float* out = dw + ((size_t)m * K + k) * 9;
+    const float h = 0.5f * (q[1] + q[2]);
+    out[0 + c] = q[0] + h;
+    out[3 + c] = 0.5f * (q[1] - q[2]);
+    out[6 + c] = h + q[3];
+}
+
 static inline size_t wg_lds(int mr, int ng) { return (size_t)ng * (2 * 16 * mr * WG_GPS + 2 * WG_KT * WG_XPS) * sizeof(float); }
 template <typename K>
 static bool wg_set_lds(K kernel, size_t bytes) {
@@ -456,8 +505,13 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
     }
     conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wino_wreduce_kernel, dim3(nmk * p.mr * WG_KR * 4), dim3(64 * std::min(WR_GROUPS, std::max(1, p.splits / 2))), 0, st,
-                       (const float*)ws, dweight, p.splits, nmk, p.kblocks, Co, Ci, p.mr);
+    const int rblocks = nmk * p.mr * WG_KR * 4;
+    const dim3 rthreads(64 * std::min(WR_GROUPS, std::max(1, p.splits / 2)));
+    static const int colmode = [] { const char* f = getenv("DC_WREDUCE_COL"); return f ? atoi(f) : -1; }();      // experiments: 0 / 1 force
+    if (colmode < 0 ? rblocks <= 1024 : colmode == 1)
+        hipLaunchKernelGGL(wino_wreduce_col_kernel, dim3(rblocks * 3), rthreads, 0, st, (const float*)ws, dweight, p.splits, nmk, p.kblocks, Co, Ci, p.mr);
+    else
+        hipLaunchKernelGGL(wino_wreduce_kernel, dim3(rblocks), rthreads, 0, st, (const float*)ws, dweight, p.splits, nmk, p.kblocks, Co, Ci, p.mr);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
