@@ -14,9 +14,10 @@ from depthcore.synthetic import synthetic_batch  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     dev = torch.device("cuda:0")
-    tr = T.Trainer(T.default_options(batch_size=12), device=dev)
+    B, H, W, NL = (int(os.environ.get(k, d)) for k, d in (("DC_B", 12), ("DC_H", 192), ("DC_W", 640), ("DC_LAYERS", 18)))
+    tr = T.Trainer(T.default_options(batch_size=B, height=H, width=W, num_layers=NL), device=dev)
     tr.set_train()
-    batches = [synthetic_batch(12, 192, 640, dev, seed=s) for s in range(4)]
+    batches = [synthetic_batch(B, H, W, dev, seed=s) for s in range(4)]
     losses = []
     mem0 = None
     trace = []
