@@ -6,6 +6,7 @@ are allocated by PyTorch's caching allocator and passed down as raw pointers.
 import collections
 import contextlib
 import ctypes
+import os
 import threading
 import weakref
 
@@ -108,6 +109,7 @@ class WgradLanes:
     _uses = {}           # id(parameter) -> forward uses since the last join
     _used = set()        # lanes with work enqueued since the last join
     _held = collections.deque()     # (event recorded behind a lane's kernels, the tensors they read): kept alive until it completes
+    _record_stream = os.environ.get("DC_LANES_RECORD_STREAM", "0") == "1"
 
     @classmethod
     @contextlib.contextmanager
@@ -153,11 +155,15 @@ class WgradLanes:
         # so that their memory goes back to the allocator only when it is really free.  (`record_stream` gives the same
         # safety by deferring the REUSE, but the allocator then grows a whole pool of not-yet-reusable blocks: 16 GB reserved
         # for 3.5 GB allocated at C2, 84 GB for 16.6 GB at C3 in tools/soak.py.)
-        ev = torch.cuda.Event()
-        ev.record(lane)
-        cls._held.append((ev, reads))
-        while cls._held and cls._held[0][0].query():
-            cls._held.popleft()
+        if cls._record_stream:               # (A/B of the first version: DC_LANES_RECORD_STREAM=1)
+            for t in reads:
+                t.record_stream(lane)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(lane)
+            cls._held.append((ev, reads))
+            while cls._held and cls._held[0][0].query():
+                cls._held.popleft()
         cls._used.add(lane)
 
 
