@@ -107,7 +107,7 @@ class WgradLanes:
     _on = False
     _lanes = {}          # (device index, raw handle of the backward's stream) -> companion stream
     _uses = {}           # id(parameter) -> forward uses since the last join
-    _used = set()        # lanes with work enqueued since the last join
+    _used = {}           # lane with work enqueued since the last join -> the stream whose backward it accompanies
     _held = collections.deque()     # (event recorded behind a lane's kernels, the tensors they read): kept alive until it completes
     _record_stream = os.environ.get("DC_LANES_RECORD_STREAM", "0") == "1"
 
@@ -123,9 +123,12 @@ class WgradLanes:
 
     @classmethod
     def join(cls):
-        for lane in cls._used:
+        for lane, parent in cls._used.items():
             torch.cuda.current_stream(lane.device).wait_stream(lane)
-        cls._used = set()
+            # the tensors a lane reads (held below) go back to the pool of the stream that OWNS them -- the backward's stream,
+            # e.g. the pose side stream -- so that stream waits for the lane too before its blocks can be handed out again
+            parent.wait_stream(lane)
+        cls._used = {}
         cls._uses = {}
         cls._held.clear()        # (whatever reuses this memory is enqueued behind the waits above)
 
@@ -164,7 +167,7 @@ class WgradLanes:
             cls._held.append((ev, reads))
             while cls._held and cls._held[0][0].query():
                 cls._held.popleft()
-        cls._used.add(lane)
+        cls._used[lane] = cur
 
 
 # ----------------------------------------------------------------------------------------------
@@ -671,6 +674,8 @@ class _Conv3x3(torch.autograd.Function):
             _record_kink("relu", y)
         ctx.cfg = (int(up0), int(act), int(pad), bias is not None)
         ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
+        if ctx.needs_input_grad[2]:
+            WgradLanes.count_use(weight)     # (no lane of its own; a weight shared with a laned op must not look single-use)
         return y
 
     @staticmethod
@@ -1111,6 +1116,8 @@ class _ConvDirect(torch.autograd.Function):
         ctx.save_for_backward(xx, ww)
         ctx.cfg = (int(stride), int(pad), bias is not None)
         ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
+        if ctx.needs_input_grad[1]:
+            WgradLanes.count_use(weight)     # (see _Conv3x3)
         return y
 
     @staticmethod

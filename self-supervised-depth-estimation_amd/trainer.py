@@ -167,6 +167,7 @@ class Trainer:
                                               fused=self.device.type == "cuda", capturable=self.graph_enabled)
         self._seed_dev = torch.full((1,), rank, dtype=torch.int64, device=self.device) if self.graph_enabled else None
         self._graphs, self._graph, self._graph_warm, self._graph_stream = {}, None, {}, None
+        self._capture_pg = None           # world > 1: the process group whose collectives are CAPTURED (never used eagerly)
         self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
 
         self.ssim = SSIM()
@@ -555,22 +556,32 @@ class Trainer:
             self._evict_graphs(key)
             static_in = {k: v.clone() for k, v in inputs.items()}
             torch.cuda.synchronize(self.device)
+            cap_pg = None
             if self.world_size > 1:
-                # The warm-up steps' collectives are finished on the GPU, but the process group's watchdog thread retires
-                # them at its next poll (every 100 ms) by querying their end events -- recorded on the group's internal
-                # stream, which is about to join the capture.  A query that lands inside the capture fails with
-                # hipErrorCapturedEvent, and the watchdog turns that into abort() (seen in 1 of 8 runs of
-                # tests/ddp_graph_child.py).  Let it retire them first: three polls.
-                import time
-                time.sleep(0.35)
+                # The captured collectives run on a process group of their own that has never executed anything eagerly.
+                # (Cause of the round-4 abort: RCCL's watchdog thread retires finished eager collectives by querying their end
+                # events, recorded on the group's internal stream; once that stream has joined a capture the query fails with
+                # hipErrorCapturedEvent and the watchdog abort()s.  The warm-up steps' group is never part of a capture now, so
+                # its watchdog only ever queries events of an eager stream; the capture group's watchdog has nothing to query,
+                # since torch does not enqueue collectives issued during a capture.  A condition, not a sleep.)
+                cap_pg = self._capture_group()
+                if cap_pg is None:           # no communicator without a collective on this stack: this trainer stays eager
+                    self.graph_enabled = False
+                    return self._eager_on_graph_stream(inputs)
             g = torch.cuda.CUDAGraph()
             step0 = self.step
             stream0 = torch.cuda.current_stream(self.device)
             try:
                 # (world > 1: RCCL's watchdog thread polls events while we capture -- legal, but only in thread-local mode)
                 mode = {} if self.world_size == 1 else {"capture_error_mode": "thread_local"}
-                with torch.cuda.graph(g, stream=gs, **mode):
-                    static_out = self._train_step_eager(static_in)
+                pg0 = self.buckets.pg
+                try:
+                    if cap_pg is not None:
+                        self.buckets.pg = cap_pg
+                    with torch.cuda.graph(g, stream=gs, **mode):
+                        static_out = self._train_step_eager(static_in)
+                finally:
+                    self.buckets.pg = pg0
             except Exception as e:       # a launch refused inside the capture, or the capture was invalidated
                 # Nothing of a captured step has run (capture records, it does not execute): host state is rolled back, the
                 # shape is marked eager-only and the step is done eagerly -- a failed capture costs speed, never the process.
@@ -583,6 +594,14 @@ class Trainer:
                 # an invalidated capture leaves its origin stream capturing (every later launch on it would fail): end it
                 _lib.lib().dc_abort_capture(gs.cuda_stream)
                 _lib.lib().dc_clear_error()             # the failed capture's error code is not the next launch's
+                # CUDAGraph.capture_end ends the stream capture BEFORE it tells the caching allocator that the capture is over:
+                # when the former throws, the allocator would keep routing this stream to the graph's pool and never process
+                # its deferred frees (record_stream blocks) again -- a slow leak in the eager fallback.  Close it here.
+                try:
+                    torch._C._cuda_endAllocateToPool(self.device.index or 0, g.pool())
+                    torch._C._cuda_releasePool(self.device.index or 0, g.pool())
+                except Exception:
+                    pass
                 warnings.warn("hip_graph: capture of the training step failed (%s: %s); this input shape runs eagerly"
                               % (type(e).__name__, e))
                 try:
@@ -603,6 +622,24 @@ class Trainer:
         entry[0].replay()
         self.step += 1
         return entry[2]                       # static tensors: rewritten by every replay of this graph
+
+    def _capture_group(self):
+        """The process group of the captured steps' collectives: same ranks as the gradient exchange's group, RCCL, its
+        communicator connected eagerly (no collective, hence no work item its watchdog would ever poll).  Collective over the
+        ranks -- every rank reaches its first capture at the same step.  None if the communicator cannot be had that way."""
+        if self._capture_pg is None:
+            import torch.distributed as dist
+            base = self.buckets.pg if self.buckets.pg is not None else dist.group.WORLD
+            pg = dist.new_group(ranks=dist.get_process_group_ranks(base), backend="nccl", device_id=self.device)
+            be = pg._get_backend(self.device)
+            try:
+                if not be._is_initialized():
+                    be.eager_connect_single_device(self.device)
+                ok = bool(be._is_initialized())
+            except Exception:
+                ok = False
+            self._capture_pg = pg if ok else False
+        return self._capture_pg or None
 
     def _eager_on_graph_stream(self, inputs):
         gs, cur = self._graph_stream, torch.cuda.current_stream(self.device)
@@ -629,6 +666,9 @@ class Trainer:
         if entry is not None:
             if self._graph is entry[0]:
                 self._graph = None
+            # the host runs ahead of the GPU: the last replay of this graph may still be executing, and reset() destroys the
+            # hipGraphExec and hands its private pool back while kernels read their arguments and static buffers
+            torch.cuda.synchronize(self.device)
             entry[0].reset()
 
     def reset_graphs(self):
