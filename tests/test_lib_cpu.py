@@ -119,7 +119,7 @@ def test_wgrad_lanes_bookkeeping_without_gpu():
         assert L._uses[id(p)] == 1 and L._uses[id(q)] == 2
         with L.lane(p, torch.zeros(2)):          # CPU tensor: no stream switch, nothing recorded
             pass
-        assert L._used == set()
-    assert not L._on and L._uses == {} and L._used == set()
+        assert not L._used
+    assert not L._on and L._uses == {} and not L._used
     with L.active(False):
         assert not L._on
