@@ -235,6 +235,53 @@ int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, const float*
                    const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, void* ws,
                    const void* relu_mask, int N, int C, int HW, int relu, int groups, void* stream);
 
+/* ------------------------------------------------------------------ a1 BatchNorm folded into the neighbouring convolutions
+ * The same training-mode BatchNorm2d (+ReLU, +residual) of torchvision's BasicBlock / Bottleneck (networks/resnet_encoder.py:87-98),
+ * without its stand-alone passes over HBM wherever a neighbouring convolution already holds the tensor:
+ *   forward   conv A (statistics epilogue: per-channel partial {sum, sum of squares} of its raw output x)
+ *             -> dc_bn_finalize (partials -> mean, invstd, running statistics, scale = gamma*invstd, shift = beta - mean*scale)
+ *             -> conv B reads relu(scale*x + shift) in its loader            (a BatchNorm + ReLU with ONE consumer), or
+ *                dc_bn_apply writes y = relu?(scale*x + shift [+ res])       (block outputs: several consumers);
+ *   backward  conv B's data gradient masks its result with the ReLU decision in the store epilogue (g') and emits partial
+ *             {sum g', sum g'*(x - mean)} -> dc_bn_bwd_finalize (coefficients, dgamma, dbeta)
+ *             -> dc_bn_bwd_apply: dx = a*g' + b*(x - mean) + c0;   conv B's weight gradient re-forms relu(scale*x + shift)
+ *             in its loader.
+ * Partials: float2 part[channel][p], p < nparts; partial p covers pixels of one BatchNorm group, group(p) = min(p / ppg,
+ * groups - 1) (the *_parts queries return nparts and ppg, 0 = this shape has no epilogue: use dc_bn_stats / dc_bn_relu_bwd).
+ * Everything is summed in a fixed order: deterministic.  Arithmetic = dc_bn_relu_fwd / _bwd up to the order of the sums. */
+typedef struct dc_bn_fold {
+    int groups;                 /* BatchNorm groups of the batch (dc_bn_relu_fwd); image b belongs to group b / (B / groups) */
+    /* input side (forward, weight gradient): the convolution's input is relu(in_scale[g,c]*x + in_shift[g,c]); NULL = plain x.
+     * In the data gradient the same pair re-derives the ReLU decision when bn_mask is NULL. */
+    const float* in_scale;      /* (groups, Ci) */
+    const float* in_shift;      /* (groups, Ci) */
+    /* output side, forward: statistics epilogue.  (Co, nparts, 2) floats, nparts = dc_*_stat_parts(); NULL = none */
+    float* stat_part;
+    /* input side, data gradient: BatchNorm-backward epilogue.  bn_x = the raw input of the BatchNorm whose ReLU-ed output this
+     * convolution read (same shape as dx), bn_mean (groups, Ci), bn_mask = that BatchNorm's ReLU bit mask (dc_bn_apply; for
+     * decisions that involved a residual) or NULL, bwd_part (Ci, nparts, 2) floats, nparts = dc_*_bwd_parts(); NULL = none */
+    const float* bn_x;
+    const float* bn_mean;
+    const void* bn_mask;
+    float* bwd_part;
+} dc_bn_fold;
+/* stand-alone statistics pass in the partial layout, for producers without the epilogue: x (N,C,HW), HW % 4 == 0 */
+int dc_bn_stat_parts(int N, int C, int HW, int groups, int* ppg);
+int dc_bn_stats(const float* x, float* part, int N, int C, int HW, int groups, void* stream);
+/* count = elements per (group, channel).  mean, invstd, scale, shift: (groups, C); running_* nullable, updated group by group */
+int dc_bn_finalize(const float* part, int nparts, int ppg, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                   int C, int groups, float eps, float momentum, void* stream);
+/* y = relu?(scale*x + shift [+ res]); relu_mask (nullable) as in dc_bn_relu_fwd.  HW % 4 == 0 */
+int dc_bn_apply(const float* x, const float* res, const float* scale, const float* shift, float* y, void* relu_mask,
+                int N, int C, int HW, int relu, int groups, void* stream);
+/* coef: (groups, C, 4) floats; dgamma, dbeta (C) nullable */
+int dc_bn_bwd_finalize(const float* part, int nparts, int ppg, double count, const float* gamma, const float* mean,
+                       const float* invstd, float* coef, float* dgamma, float* dbeta, int C, int groups, void* stream);
+/* dx = a*gp + b*(x - mean) + c0 with gp the MASKED upstream gradient (which is also the residual input's gradient) */
+int dc_bn_bwd_apply(const float* x, const float* gp, const float* coef, float* dx, int N, int C, int HW, int groups,
+                    void* stream);
+
 /* nn.MaxPool2d(3, 2, 1) of the ResNet stem (networks/resnet_encoder.py:93).  x (NC planes of HxW) ->
  * y (NC planes of Ho x Wo, Ho = (H-1)/2+1) and `code` (one byte per output: window position of the first
  * maximum, ATen's tie-break).  NC <= 65535.  Backward: gather, no atomics. */
@@ -295,6 +342,19 @@ int dc_conv1x1_dgrad_add(const float* gy, const float* weight, float* dx, const 
 size_t dc_conv1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride);
 int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
                      void* stream);
+
+/* The 1x1 convolution with a BatchNorm folded in (dc_bn_fold above; `bn` nullable = the plain calls).  Tiled-kernel shapes
+ * only: dc_conv1x1_bn_ok() tells whether all three passes of a stride-1 shape take the fold, the *_parts queries size the
+ * partial buffers of the two epilogues (0 = not on this shape / group layout). */
+int dc_conv1x1_bn_ok(int B, int Ci, int Co, int Hi, int Wi);
+int dc_conv1x1_stat_parts(int B, int Ci, int Co, int Hi, int Wi, int stride, int groups, int* ppg);
+int dc_conv1x1_bwd_parts(int B, int Ci, int Co, int Hi, int Wi, int groups, int* ppg);
+int dc_conv1x1_fwd_bn(const float* x, const float* weight, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                      const dc_bn_fold* bn, void* stream);
+int dc_conv1x1_dgrad_bn(const float* gy, const float* weight, float* dx, const float* addend, int B, int Ci, int Co, int Hi, int Wi,
+                        int stride, const dc_bn_fold* bn, void* stream);
+int dc_conv1x1_wgrad_bn(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                        const dc_bn_fold* bn, void* stream);
 
 /* The same convolution with bias and activation fused into the epilogue: y = act(conv1x1(x) + bias), act as in
  * dc_conv3x3_fwd (0 none, 1 ELU, 2 sigmoid, 3 ReLU, 4 tanh); bias may be NULL.  This is `relu(squeeze(f))` and the final

@@ -408,6 +408,225 @@ extern "C" int dc_bn_relu_bwd(const float* x, const float* y, const float* gy, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// BatchNorm folded into the neighbouring convolutions (round 5).  The statistics pass is gone -- the PRODUCING
+// convolution's store epilogue emits per-channel partial {sum, sum of squares} of its output -- and, where a BatchNorm + ReLU
+// has ONE consumer, so is the apply pass: the consuming convolution reads relu(scale * x + shift) in its loader.  What is
+// left of the layer in HBM terms is a finalize launch over the partials (a few KB per channel) and, for the block outputs
+// (BatchNorm + residual + ReLU, several consumers), one apply pass.  Backward: the consuming convolution's data-gradient
+// epilogue masks its result with the ReLU decision and emits partial {sum g, sum g (x - mean)}; a finalize turns them into
+// per-channel coefficients and ONE pass forms dx = a g + b (x - mean) + c.
+//
+// Partials: float2 part[c][p], p < nparts; partial p covers pixels of ONE BatchNorm group, group(p) = min(p / ppg, groups-1).
+// Fixed summation order everywhere (thread-strided sums + the block tree): deterministic, every rank the same.
+// ------------------------------------------------------------------------------------------------
+namespace dc {
+
+__device__ __forceinline__ void block_sum256x2_all(float& a, float& b, float* sm8) {
+    __syncthreads();
+    block_sum256x2(a, b, sm8);
+}
+
+// grid (C), block 256.  mean / invstd / scale / shift: (groups, C).  Running statistics updated group after group, as
+// separate module calls would.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float2* __restrict__ part, int nparts, int ppg, float count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ scale, float* __restrict__ shift, int C, int groups,
+                                                          float eps, float momentum) {
+    __shared__ float sm[8];
+    const int c = blockIdx.x;
+    const float2* p = part + (size_t)c * nparts;
+    float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 0.f;
+    const float ga = gamma[c], be = beta[c];
+    for (int g = 0; g < groups; ++g) {
+        const int lo = g * ppg, hi = g == groups - 1 ? nparts : (g + 1) * ppg;
+        float s = 0.f, q = 0.f;
+        for (int i = lo + threadIdx.x; i < hi; i += 256) { const float2 v = p[i]; s += v.x; q += v.y; }
+        block_sum256x2_all(s, q, sm);
+        const float m = s / count;
+        const float var = fmaxf(q / count - m * m, 0.f);
+        const float is = rsqrtf(var + eps);
+        if (threadIdx.x == 0) {
+            mean[g * C + c] = m; invstd[g * C + c] = is;
+            const float a = is * ga;
+            scale[g * C + c] = a; shift[g * C + c] = be - m * a;
+        }
+        rm = (1.f - momentum) * rm + momentum * m;
+        rv = (1.f - momentum) * rv + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+    }
+    if (threadIdx.x == 0 && run_mean) { run_mean[c] = rm; run_var[c] = rv; }
+}
+
+// y = relu?(scale * x + shift [+ res]) from finished per-(group, channel) scale / shift; same item walk, same ReLU bit mask
+// as bn_apply_kernel.  grid (chunks, C, N / ns).
+__global__ __launch_bounds__(256) void bn_apply2_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        float* __restrict__ y, int C, int HW, int relu, int n_per_group,
+                                                        unsigned long long* __restrict__ mask, int ns) {
+    const int c = blockIdx.y, n0 = blockIdx.z * ns;
+    const int gc = (n0 / n_per_group) * C + c;
+    const float a = scale[gc], b = shift[gc];
+    const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
+    const BnItems it(ns, HW, lo, hi);
+    const float* rsrc = res ? res : x;
+    for (int k0 = 0; k0 < it.nitems; k0 += BN_U) {
+        float4 v[BN_U], r[BN_U];
+        size_t off[BN_U];
+        bool ok[BN_U];
+        int iu[BN_U], nu[BN_U];
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            ok[u] = it.at(k0 + u, nu[u], iu[u]);
+            off[u] = ((size_t)(n0 + nu[u]) * C + c) * HW + iu[u];
+            v[u] = *reinterpret_cast<const float4*>(x + off[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) r[u] = *reinterpret_cast<const float4*>(rsrc + off[u]);
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            float4 w = v[u];
+            w.x = fmaf(w.x, a, b); w.y = fmaf(w.y, a, b); w.z = fmaf(w.z, a, b); w.w = fmaf(w.w, a, b);
+            if (res) { w.x += r[u].x; w.y += r[u].y; w.z += r[u].z; w.w += r[u].w; }
+            if (relu) {
+                if (mask) {
+                    const unsigned long long b0 = __ballot(ok[u] && w.x > 0.f), b1 = __ballot(ok[u] && w.y > 0.f),
+                                             b2 = __ballot(ok[u] && w.z > 0.f), b3 = __ballot(ok[u] && w.w > 0.f);
+                    const bool any = __ballot(ok[u]) != 0ull;
+                    if (any && (threadIdx.x & 63) == 0) {
+                        unsigned long long* mw = mask + (((size_t)(n0 + nu[u]) * C + c) * ((HW + 255) >> 8) + (iu[u] >> 8)) * 4;
+                        mw[0] = b0; mw[1] = b1; mw[2] = b2; mw[3] = b3;
+                    }
+                }
+                w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
+            }
+            if (ok[u]) *reinterpret_cast<float4*>(y + off[u]) = w;
+        }
+    }
+}
+
+// Backward partials {sum g', sum g' (x - mean)} -> coef[(g, c)] = {a, b, c0, mean} with dx = a g' + b (x - mean) + c0,
+// a = gamma invstd, b = -a invstd^2 mean(g' (x - mean)), c0 = -a mean(g'); dgamma = sum_g invstd sum g' (x - mean), dbeta = sum g'.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float2* __restrict__ part, int nparts, int ppg, float count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float4* __restrict__ coef,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int groups) {
+    __shared__ float sm[8];
+    const int c = blockIdx.x;
+    const float2* p = part + (size_t)c * nparts;
+    const float ga = gamma[c];
+    float tg = 0.f, tb = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const int lo = g * ppg, hi = g == groups - 1 ? nparts : (g + 1) * ppg;
+        float s = 0.f, q = 0.f;
+        for (int i = lo + threadIdx.x; i < hi; i += 256) { const float2 v = p[i]; s += v.x; q += v.y; }
+        block_sum256x2_all(s, q, sm);
+        const float m = mean[g * C + c], is = invstd[g * C + c];
+        q *= is;                                             // sum g' x_hat
+        const float k = ga * is;
+        if (threadIdx.x == 0) coef[g * C + c] = make_float4(k, -k * is * (q / count), -k * (s / count), m);
+        tg += q; tb += s;
+    }
+    if (threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = tg;
+        if (dbeta) dbeta[c] = tb;
+    }
+}
+
+// dx = a g' + b (x - mean) + c0.  g' is the ALREADY MASKED upstream gradient (the producing data-gradient kernel's epilogue
+// applied the ReLU decision), which is also the gradient of the residual input: no dres store.  grid (chunks, C, N / ns).
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const float* __restrict__ x, const float* __restrict__ gp,
+                                                            const float4* __restrict__ coef, float* __restrict__ dx, int C, int HW,
+                                                            int n_per_group, int ns) {
+    const int c = blockIdx.y, n0 = blockIdx.z * ns;
+    const float4 k = coef[(n0 / n_per_group) * C + c];
+    const int lo = blockIdx.x * BN_CHUNK, hi = min(lo + BN_CHUNK, HW);
+    const BnItems it(ns, HW, lo, hi);
+    for (int k0 = 0; k0 < it.nitems; k0 += BN_U) {
+        float4 xv[BN_U], g[BN_U];
+        size_t off[BN_U];
+        bool ok[BN_U];
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            int nn, i;
+            ok[u] = it.at(k0 + u, nn, i);
+            off[u] = ((size_t)(n0 + nn) * C + c) * HW + i;
+            xv[u] = *reinterpret_cast<const float4*>(x + off[u]);
+            g[u] = *reinterpret_cast<const float4*>(gp + off[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            float4 d;
+            d.x = fmaf(k.x, g[u].x, fmaf(k.y, xv[u].x - k.w, k.z)); d.y = fmaf(k.x, g[u].y, fmaf(k.y, xv[u].y - k.w, k.z));
+            d.z = fmaf(k.x, g[u].z, fmaf(k.y, xv[u].z - k.w, k.z)); d.w = fmaf(k.x, g[u].w, fmaf(k.y, xv[u].w - k.w, k.z));
+            if (ok[u]) *reinterpret_cast<float4*>(dx + off[u]) = d;
+        }
+    }
+}
+
+}  // namespace dc
+
+// stand-alone statistics pass in the partial layout (for producers without a statistics epilogue): the partials of
+// bn_stats_kernel, (N / ns) * chunks per channel, equal shares per group
+extern "C" int dc_bn_stat_parts(int N, int C, int HW, int groups, int* ppg) {
+    if (N <= 0 || C <= 0 || HW <= 0 || groups < 1 || N % groups || (HW & 3)) return 0;
+    const int chunks = ceil_div(HW, BN_CHUNK), ns = bn_ns(N / groups, HW);
+    if (ppg) *ppg = (N / groups / ns) * chunks;
+    return (N / ns) * chunks;
+}
+
+extern "C" int dc_bn_stats(const float* x, float* part, int N, int C, int HW, int groups, void* stream) {
+    if (!x || !part || !dc_bn_stat_parts(N, C, HW, groups, nullptr)) return DC_EINVAL;
+    const int chunks = ceil_div(HW, BN_CHUNK), ns = bn_ns(N / groups, HW);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(chunks, C, N / ns), dim3(256), 0, ST, x, part, C, HW, ns);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_bn_finalize(const float* part, int nparts, int ppg, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                              int C, int groups, float eps, float momentum, void* stream) {
+    if (!part || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || groups < 1 || nparts < groups || ppg < 1 ||
+        (groups - 1) * ppg >= nparts || count < 1.0)
+        return DC_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, ST, (const float2*)part, nparts, ppg, (float)count, gamma, beta,
+                       running_mean, running_var, mean, invstd, scale, shift, C, groups, eps, momentum);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_bn_apply(const float* x, const float* res, const float* scale, const float* shift, float* y, void* relu_mask,
+                           int N, int C, int HW, int relu, int groups, void* stream) {
+    if (!x || !scale || !shift || !y || N <= 0 || C <= 0 || HW <= 0 || (HW & 3) || groups < 1 || N % groups) return DC_EINVAL;
+    const int chunks = ceil_div(HW, BN_CHUNK), ns = bn_ns(N / groups, HW);
+    hipLaunchKernelGGL(bn_apply2_kernel, dim3(chunks, C, N / ns), dim3(256), 0, ST, x, res, scale, shift, y, C, HW, relu, N / groups,
+                       relu ? (unsigned long long*)relu_mask : (unsigned long long*)nullptr, ns);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_bn_bwd_finalize(const float* part, int nparts, int ppg, double count, const float* gamma, const float* mean,
+                                  const float* invstd, float* coef, float* dgamma, float* dbeta, int C, int groups, void* stream) {
+    if (!part || !gamma || !mean || !invstd || !coef || C <= 0 || groups < 1 || nparts < groups || ppg < 1 ||
+        (groups - 1) * ppg >= nparts || count < 1.0)
+        return DC_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, ST, (const float2*)part, nparts, ppg, (float)count, gamma, mean,
+                       invstd, (float4*)coef, dgamma, dbeta, C, groups);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_bn_bwd_apply(const float* x, const float* gp, const float* coef, float* dx, int N, int C, int HW, int groups,
+                               void* stream) {
+    if (!x || !gp || !coef || !dx || N <= 0 || C <= 0 || HW <= 0 || (HW & 3) || groups < 1 || N % groups) return DC_EINVAL;
+    const int chunks = ceil_div(HW, BN_CHUNK), ns = bn_ns(N / groups, HW);
+    hipLaunchKernelGGL(bn_bwd_apply2_kernel, dim3(chunks, C, N / ns), dim3(256), 0, ST, x, gp, (const float4*)coef, dx, C, HW,
+                       N / groups, ns);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // MaxPool2d(kernel 3, stride 2, padding 1) of the ResNet stem (torchvision ResNet.maxpool, reached from
 // networks/resnet_encoder.py:93).  Forward stores the window position of the maximum (first maximum in
 // row-major scan order, like ATen) as one byte per output; backward is a gather over the <= 4 windows that

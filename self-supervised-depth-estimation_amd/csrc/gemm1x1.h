@@ -2,16 +2,21 @@
 #pragma once
 #include <stddef.h>
 
+#include "depthcore.h"
+
 extern "C" {
 /* per pass: 16-byte staging possible and the reduction extent a multiple of the 32-wide chunk */
 int dc_gemm1x1_fwd_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);
 int dc_gemm1x1_dgrad_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);
 int dc_gemm1x1_wgrad_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);
+/* bn (nullable): BatchNorm folded into the pass, see dc_bn_fold in depthcore.h */
+int dc_gemm1x1_stat_parts(int B, int Ci, int Co, int Hi, int Wi, int stride, int groups, int* ppg);
+int dc_gemm1x1_bwd_parts(int B, int Ci, int Co, int Hi, int Wi, int stride, int groups, int* ppg);
 int dc_gemm1x1_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride,
-                   int act, void* stream);
+                   int act, const dc_bn_fold* bn, void* stream);
 int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx, const float* addend, int B, int Ci, int Co, int Hi, int Wi, int stride,
-                     void* stream);      /* addend (stride 1 only, may be NULL): added to dx in the store epilogue */
+                     const dc_bn_fold* bn, void* stream);      /* addend (stride 1 only, may be NULL): added to dx in the store epilogue */
 size_t dc_gemm1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride);
 int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
-                     void* stream);
+                     const dc_bn_fold* bn, void* stream);
 }

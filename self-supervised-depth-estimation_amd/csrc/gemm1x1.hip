@@ -52,7 +52,30 @@ struct G1Args {
     int mtiles, ntiles;   // tile grid
     int splits, chunks;   // weight gradient: reduction chunks in total, blocks along the reduction
     int xcd;              // weight gradient: tiles of one split on one XCD (see g1_wgrad_kernel)
+    // ---- BatchNorm folded into the convolution (include/depthcore.h: dc_bn_fold) ----
+    const float* in_scale;   // (groups, Ci): the B operand is relu(scale x + shift), applied on the way into LDS (forward, weight
+    const float* in_shift;   //  gradient); in the data gradient the same pair re-derives the ReLU decision of the epilogue
+    int npg;                 // images per BatchNorm group
+    float* stat_part;        // forward epilogue: (Co, stat_nparts) x {sum, sum of squares} of the output, one partial per wave column
+    int stat_nparts;
+    const float* bn_x;       // data-gradient epilogue: the raw input of the BatchNorm whose (ReLU-ed) output this convolution read,
+    const float* bn_mean;    //  its batch mean (groups, Ci), its ReLU decisions as bits (or null: scale x + shift > 0), and the
+    const unsigned long long* bn_mask;   // partials (Ci, bwd_nparts) x {sum g', sum g' (x - mean)} of the MASKED result g'
+    float* bwd_part;
+    int bwd_nparts;
 };
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane of the row: four row_ror steps
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ gf4 bn_relu4(gf4 v, float sc, float sh) {
+    return gf4{fmaxf(fmaf(v.x, sc, sh), 0.f), fmaxf(fmaf(v.y, sc, sh), 0.f), fmaxf(fmaf(v.z, sc, sh), 0.f), fmaxf(fmaf(v.w, sc, sh), 0.f)};
+}
 
 // ---- pixel addressing: element offset of (b, channel 0, first pixel) of a 4-pixel group of the flattened (b, p) dimension.
 // n is clamped to the last valid group (P % 4 == 0; stride 2: Wo % 4 == 0, so a group lies in one row).
@@ -79,7 +102,7 @@ __device__ __forceinline__ gf4 load_pix4(const float* plane_ptr) {
 // =====================================================================================================================
 // forward.  A = w [co][ci] (reduction-contiguous), B = x [ci][n] (index-contiguous).  Ci % KC == 0.
 // =====================================================================================================================
-template <int MT, int NT, bool EPI, int S>
+template <int MT, int NT, bool EPI, int S, bool BNIN = false>
 __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
     constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SB = IdxStride<NT, BN>::v;
     constexpr int NA = BM * KC / 1024, NB = KC * BN / 1024;          // float4 per thread per chunk
@@ -109,18 +132,36 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
         bsrc[j] = a.x + pix_group_off(n0 + c4 * 4, N, P, a.Wo, a.Ci, a.Hi, a.Wi, S) + (size_t)k * plane;
         bdst[j] = k * SB + c4 * 4;
     }
+    // BNIN: the input is relu(scale[g, ci] x + shift[g, ci]) -- the BatchNorm + ReLU in front of this convolution, applied to
+    // the 16-byte pieces between their global load and their LDS store; (group, channel) table offset of each piece:
+    int btab[BNIN ? NB : 1];
+    float bsc[BNIN ? NB : 1], bsh[BNIN ? NB : 1];
+    if constexpr (BNIN) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = tid + j * 256, k = idx / (BN / 4), c4 = idx % (BN / 4);
+            btab[j] = (min(n0 + c4 * 4, N - 4) / P / a.npg) * a.Ci + k;
+        }
+    }
     gf4 ra[NA], rb[NB];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const gf4*>(asrc[j] + k0);
 #pragma unroll
         for (int j = 0; j < NB; ++j) rb[j] = load_pix4<S>(bsrc[j] + (size_t)k0 * plane);
+        if constexpr (BNIN) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { bsc[j] = a.in_scale[btab[j] + k0]; bsh[j] = a.in_shift[btab[j] + k0]; }
+        }
     };
     auto commit = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) store_red4(As + buf * ASZ + adst[j], ra[j]);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) *reinterpret_cast<gf4*>(Bs + buf * BSZ + bdst[j]) = rb[j];
+        for (int j = 0; j < NB; ++j) {
+            if constexpr (BNIN) rb[j] = bn_relu4(rb[j], bsc[j], bsh[j]);
+            *reinterpret_cast<gf4*>(Bs + buf * BSZ + bdst[j]) = rb[j];
+        }
     };
 
     gf4 acc[MT][NT];
@@ -144,34 +185,48 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
     // D: row r' = (lane >> 4) * 4 + r of tile mt <-> m = m0 + wm*16MT + mt*16 + r';  col j = lane & 15 of tile nt <-> n = .. + j*NT + nt
     const int j = lane & 15;
     const int n = n0 + wn * 16 * NT + j * NT;
-    if (n < N) {
-        const int b = n / P, p = n - b * P;
+    const bool nok = n < N;
+    const int nn = nok ? n : 0;
+    const int b = nn / P, p = nn - b * P;
+    // statistics epilogue (a.stat_part, wave-uniform): {sum, sum of squares} of this wave column's 16 NT pixels per output
+    // channel -- the 16 lanes of a DPP row hold one channel's pixels -- as partial number (pixel tile, wn)
+    const bool stats = a.stat_part != nullptr;
+    const int slot = (lb / a.mtiles) * 2 + wn;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
-                if (m >= a.Co) continue;
-                float v[4];
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 16 * MT + mt * 16 + (lane >> 4) * 4 + r;
+            const bool mok = m < a.Co;
+            float v[4];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt][r];
-                if constexpr (EPI) {
-                    const float bsv = a.bias ? a.bias[m] : 0.f;
+            for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt][r];
+            if constexpr (EPI) {
+                const float bsv = (a.bias && mok) ? a.bias[m] : 0.f;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) v[nt] = act_fwd(v[nt] + bsv, a.act);
-                }
+                for (int nt = 0; nt < NT; ++nt) v[nt] = act_fwd(v[nt] + bsv, a.act);
+            }
+            if (nok && mok) {
                 float* dst = a.out + ((size_t)b * a.Co + m) * P + p;
                 if constexpr (NT == 4) *reinterpret_cast<gf4*>(dst) = gf4{v[0], v[1], v[2], v[3]};
                 else *reinterpret_cast<gf2*>(dst) = gf2{v[0], v[1]};
             }
-    }
+            if (stats) {
+                float sv = 0.f, qv = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { sv += v[nt]; qv = fmaf(v[nt], v[nt], qv); }
+                if (!nok) { sv = 0.f; qv = 0.f; }
+                sv = row16_sum(sv); qv = row16_sum(qv);
+                if (j == 0 && mok) *reinterpret_cast<gf2*>(a.stat_part + ((size_t)m * a.stat_nparts + slot) * 2) = gf2{sv, qv};
+            }
+        }
 }
 
 // =====================================================================================================================
 // data gradient.  rows = input channels ci, reduction = co.  A = w [co][ci] (index-contiguous), B = gy [co][n] (index-cont.)
 // Co % KC == 0.
 // =====================================================================================================================
-template <int MT, int NT>
+template <int MT, int NT, int BNE = 0>
 __global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
     constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SA = IdxStride<MT, BM>::v, SB = IdxStride<NT, BN>::v;
     constexpr int NA = KC * BM / 1024, NB = KC * BN / 1024;
@@ -231,6 +286,88 @@ __global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
     // row r' of tile mt <-> ci = m0 + wm*16MT + r'*MT + mt;  col j of tile nt <-> n = .. + j*NT + nt
     const int j = lane & 15;
     const int n = n0 + wn * 16 * NT + j * NT;
+    if constexpr (BNE != 0) {
+        // BatchNorm-backward epilogue (stride 1).  This convolution read a = relu(bn(x) [+ res]); its data gradient
+        // dL/da [+ the skip's gradient] is masked with the ReLU decision HERE -- BNE 1: scale x + shift > 0 re-derived from the
+        // BatchNorm's raw input x; BNE 2: the forward's bit mask (decisions that involved a residual) -- stored as g', and the
+        // wave column's partial {sum g', sum g' (x - mean)} per channel goes to a.bwd_part.  What used to be a streaming
+        // statistics pass over g and x reads x once, in tiles that are still warm in this XCD's L2 from the forward's order.
+        const bool nok = n < N;
+        const int nn = nok ? n : 0;
+        const int b = nn / P, p = nn - b * P;
+        const size_t plane = (size_t)a.Hi * a.Wi;
+        const int grp = b / a.npg;
+        const int slot = (lb / a.mtiles) * 2 + wn;
+        const int pblk = (P + 255) >> 8;
+        constexpr bool ADD = BNE == 2;      // (BNE 1 = a folded BatchNorm + ReLU: single consumer, never a residual fork's conv1)
+        gf4 xv[2][4], ad[ADD ? 2 : 1][4];
+        float rmean[2][4], rsc[2][4], rsh[2][4];
+        unsigned bits[2][4];
+        auto eload = [&](int mt, int h) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = min(m0 + wm * 16 * MT + ((lane >> 4) * 4 + r) * MT + mt, a.Ci - 1);
+                const size_t o = ((size_t)b * a.Ci + ci) * plane + p;
+                const int tab = grp * a.Ci + ci;
+                rmean[h][r] = a.bn_mean[tab];
+                if constexpr (BNE == 1) { rsc[h][r] = a.in_scale[tab]; rsh[h][r] = a.in_shift[tab]; }
+                if constexpr (NT == 4) {
+                    xv[h][r] = *reinterpret_cast<const gf4*>(a.bn_x + o);
+                    if constexpr (ADD) ad[h][r] = a.addend ? *reinterpret_cast<const gf4*>(a.addend + o) : gf4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    const gf2 t = *reinterpret_cast<const gf2*>(a.bn_x + o);
+                    xv[h][r] = gf4{t.x, t.y, 0.f, 0.f};
+                    if constexpr (ADD) {
+                        const gf2 u = a.addend ? *reinterpret_cast<const gf2*>(a.addend + o) : gf2{0.f, 0.f};
+                        ad[h][r] = gf4{u.x, u.y, 0.f, 0.f};
+                    }
+                }
+                if constexpr (BNE == 2) {
+                    // bit l of word w of a 256-element block <-> element 4 l + w (bn_apply_kernel's wave ballots)
+                    // (only the 32-bit half that holds bit l of each word is fetched)
+                    const int l = (p & 255) >> 2, w0 = p & 3;
+                    const unsigned* mw = reinterpret_cast<const unsigned*>(a.bn_mask + (((size_t)b * a.Ci + ci) * pblk + (p >> 8)) * 4) + (l >> 5);
+                    unsigned bt = 0;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bt |= ((mw[2 * (w0 + nt)] >> (l & 31)) & 1u) << nt;
+                    bits[h][r] = bt;
+                }
+            }
+        };
+        eload(0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int h = mt & 1;
+            if (mt + 1 < MT) eload(mt + 1, h ^ 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = m0 + wm * 16 * MT + ((lane >> 4) * 4 + r) * MT + mt;
+                float g[4], sv = 0.f, qv = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float x = xv[h][r][nt];
+                    bool keep;
+                    if constexpr (BNE == 1) keep = fmaf(x, rsc[h][r], rsh[h][r]) > 0.f;
+                    else keep = (bits[h][r] >> nt) & 1u;
+                    float gv = acc[mt][nt][r];
+                    if constexpr (ADD) gv += ad[h][r][nt];
+                    g[nt] = keep ? gv : 0.f;
+                    sv += g[nt]; qv = fmaf(g[nt], x - rmean[h][r], qv);
+                }
+                if (!nok) { sv = 0.f; qv = 0.f; }
+                sv = row16_sum(sv); qv = row16_sum(qv);
+                if (ci < a.Ci) {
+                    if (j == 0) *reinterpret_cast<gf2*>(a.bwd_part + ((size_t)ci * a.bwd_nparts + slot) * 2) = gf2{sv, qv};
+                    if (nok) {
+                        float* dst = a.out + ((size_t)b * a.Ci + ci) * plane + p;
+                        if constexpr (NT == 4) *reinterpret_cast<gf4*>(dst) = gf4{g[0], g[1], g[2], g[3]};
+                        else *reinterpret_cast<gf2*>(dst) = gf2{g[0], g[1]};
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (n >= N) return;
     const int b = n / P, p = n - b * P;
     const size_t plane = (size_t)a.Hi * a.Wi;
@@ -293,7 +430,7 @@ __global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
 // reduction-contiguous.  blockIdx.y = split: a contiguous range of chunks (its successive 128-byte row segments stay in one
 // L2); writes slab[split][co][ci] (or dw itself when there is one split).
 // =====================================================================================================================
-template <int MT, int NT, int S>
+template <int MT, int NT, int S, bool BNIN = false>
 __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
     constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC;
     constexpr int NA = BM * KC / 1024, NB = BN * KC / 1024;
@@ -318,10 +455,21 @@ __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
     for (int j = 0; j < NA; ++j) arow[j] = (size_t)min(m0 + row0 + j * (1024 / KC), a.Co - 1) * P;
 #pragma unroll
     for (int j = 0; j < NB; ++j) brow[j] = (size_t)min(c0 + row0 + j * (1024 / KC), a.Ci - 1) * plane;
+    // BNIN: x is the raw input of a BatchNorm + ReLU that was folded into this convolution's loader in the forward; the
+    // weight gradient needs the same relu(scale x + shift), re-formed between the global load and the LDS store
+    float bsc[BNIN ? NB : 1], bsh[BNIN ? NB : 1];
     gf4 ra[NA], rb[NB];
     auto gload = [&](int ch) {           // chunk ch = KC consecutive flattened pixels; a 4-pixel group lies in one image row
         const int n = ch * KC + kq * 4;
         const int b = n / P, p = n - b * P;
+        if constexpr (BNIN) {
+            const int tab = (b / a.npg) * a.Ci;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int cch = min(c0 + row0 + j * (1024 / KC), a.Ci - 1);
+                bsc[j] = a.in_scale[tab + cch]; bsh[j] = a.in_shift[tab + cch];
+            }
+        }
         size_t pix;
         if constexpr (S == 1) {
             pix = p;
@@ -341,8 +489,10 @@ __global__ __launch_bounds__(256) void g1_wgrad_kernel(G1Args a) {
         for (int j = 0; j < NA; ++j)
             store_red4(g1_smem + buf * ASZ + (row0 + j * (1024 / KC)) * (KC + RP) + kq * 4, ra[j]);
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
+        for (int j = 0; j < NB; ++j) {
+            if constexpr (BNIN) rb[j] = bn_relu4(rb[j], bsc[j], bsh[j]);
             store_red4(g1_smem + 2 * ASZ + buf * BSZ + (row0 + j * (1024 / KC)) * (KC + RP) + kq * 4, rb[j]);
+        }
     };
     gf4 acc[MT][NT];
 #pragma unroll
@@ -485,14 +635,46 @@ static void g1_fill(G1Args& a, int B, int Ci, int Co, int Hi, int Wi, int stride
     a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;
 }
 
+// partials per channel of the forward's statistics epilogue / the data gradient's BatchNorm epilogue (0: not on this shape):
+// one per wave column of 16 NT pixels; a group boundary must not fall inside one
+static int g1_parts(int rows, int B, int P, int groups, size_t (*lds)(G1Tile), int* ppg) {
+    if (groups < 1 || B % groups) return 0;
+    const int N = B * P;
+    const G1Tile t = g1_pick(rows, N, lds);
+    const int cover = 16 * t.nt;
+    if (groups > 1 && (N / groups) % cover) return 0;
+    if (ppg) *ppg = (N / groups) / cover;
+    return ceil_div(N, 32 * t.nt) * 2;
+}
+extern "C" int dc_gemm1x1_stat_parts(int B, int Ci, int Co, int Hi, int Wi, int stride, int groups, int* ppg) {
+    if (!dc_gemm1x1_fwd_ok(B, Ci, Co, Hi, Wi, stride)) return 0;
+    return g1_parts(Co, B, (Hi / stride) * (Wi / stride), groups, g1_lds_fwd, ppg);
+}
+extern "C" int dc_gemm1x1_bwd_parts(int B, int Ci, int Co, int Hi, int Wi, int stride, int groups, int* ppg) {
+    if (stride != 1 || !dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) return 0;
+    return g1_parts(Ci, B, Hi * Wi, groups, g1_lds_dgrad, ppg);
+}
+
 extern "C" int dc_gemm1x1_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi, int Wi,
-                              int stride, int act, void* stream) {
+                              int stride, int act, const dc_bn_fold* bn, void* stream) {
     if (!x || !weight || !y || !dc_gemm1x1_fwd_ok(B, Ci, Co, Hi, Wi, stride) || act < 0 || act > ACT_LAST) return DC_EINVAL;
     G1Args a{};
     g1_fill(a, B, Ci, Co, Hi, Wi, stride);
     a.w = weight; a.x = x; a.bias = bias; a.out = y; a.act = act;
     const int N = B * a.Ho * a.Wo;
     const G1Tile t = g1_pick(Co, N, g1_lds_fwd);
+    const bool bnin = bn && bn->in_scale;
+    if (bn) {
+        if (bn->groups < 1 || B % bn->groups) return DC_EINVAL;
+        a.npg = B / bn->groups;
+        if (bnin && (!bn->in_shift || stride != 1 || bias || act != ACT_NONE)) return DC_EINVAL;
+        a.in_scale = bn->in_scale; a.in_shift = bn->in_shift;
+        if (bn->stat_part) {
+            a.stat_nparts = dc_gemm1x1_stat_parts(B, Ci, Co, Hi, Wi, stride, bn->groups, nullptr);
+            if (!a.stat_nparts) return DC_EINVAL;
+            a.stat_part = bn->stat_part;
+        }
+    }
     a.mtiles = ceil_div(Co, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
     const dim3 grid(a.mtiles * a.ntiles);
     hipStream_t st = (hipStream_t)stream;
@@ -501,12 +683,15 @@ extern "C" int dc_gemm1x1_fwd(const float* x, const float* weight, const float* 
     static const bool attr = g1_set_lds(g1_fwd_kernel<4, 4, false, 1>, g1_lds_fwd({4, 4})) &&
                              g1_set_lds(g1_fwd_kernel<4, 4, true, 1>, g1_lds_fwd({4, 4})) &&
                              g1_set_lds(g1_fwd_kernel<4, 4, false, 2>, g1_lds_fwd({4, 4})) &&
-                             g1_set_lds(g1_fwd_kernel<4, 4, true, 2>, g1_lds_fwd({4, 4}));
+                             g1_set_lds(g1_fwd_kernel<4, 4, true, 2>, g1_lds_fwd({4, 4})) &&
+                             g1_set_lds(g1_fwd_kernel<4, 4, false, 1, true>, g1_lds_fwd({4, 4}));
     if (!attr) return DC_ELAUNCH;
     hipEvent_t pe = conv_prof_begin(4, 2.0 * (double)B * Co * Ci * a.Ho * a.Wo, 2.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * Ci, 4.0 * ((double)B * Ci * a.Ho * a.Wo + (double)B * Co * a.Ho * a.Wo + (double)Co * Ci), st);
 #define G1_FWD(MT, NT)                                                                            \
     do {                                                                                          \
-        if (stride == 1) {                                                                            \
+        if (bnin) {                                                                                   \
+            hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, false, 1, true>), grid, dim3(256), lds, st, a);     \
+        } else if (stride == 1) {                                                                     \
             if (epi) hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, true, 1>), grid, dim3(256), lds, st, a);   \
             else hipLaunchKernelGGL((g1_fwd_kernel<MT, NT, false, 1>), grid, dim3(256), lds, st, a);      \
         } else {                                                                                      \
@@ -524,23 +709,41 @@ extern "C" int dc_gemm1x1_fwd(const float* x, const float* weight, const float* 
 }
 
 extern "C" int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx, const float* addend, int B, int Ci, int Co, int Hi,
-                                int Wi, int stride, void* stream) {
+                                int Wi, int stride, const dc_bn_fold* bn, void* stream) {
     if (!gy || !weight || !dx || !dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride) || (addend && stride != 1)) return DC_EINVAL;
     G1Args a{};
     g1_fill(a, B, Ci, Co, Hi, Wi, stride);
     a.w = weight; a.gy = gy; a.out = dx; a.addend = addend;
+    int bne = 0;
+    if (bn && bn->bwd_part) {
+        a.bwd_nparts = dc_gemm1x1_bwd_parts(B, Ci, Co, Hi, Wi, stride, bn->groups, nullptr);
+        if (!a.bwd_nparts || !bn->bn_x || !bn->bn_mean || (!bn->bn_mask && (!bn->in_scale || !bn->in_shift || addend))) return DC_EINVAL;
+        if (bn->bn_mask && ((Hi * Wi) & 3)) return DC_EINVAL;
+        a.npg = B / bn->groups;
+        a.bn_x = bn->bn_x; a.bn_mean = bn->bn_mean; a.bn_mask = (const unsigned long long*)bn->bn_mask; a.bwd_part = bn->bwd_part;
+        a.in_scale = bn->in_scale; a.in_shift = bn->in_shift;
+        bne = bn->bn_mask ? 2 : 1;
+    }
     const int N = B * a.Ho * a.Wo;
     const G1Tile t = g1_pick(Ci, N, g1_lds_dgrad);
     a.mtiles = ceil_div(Ci, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
     const dim3 grid(a.mtiles * a.ntiles);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = g1_lds_dgrad(t);
-    static const bool attr = g1_set_lds(g1_dgrad_kernel<4, 4>, g1_lds_dgrad({4, 4}));
+    static const bool attr = g1_set_lds(g1_dgrad_kernel<4, 4>, g1_lds_dgrad({4, 4})) && g1_set_lds(g1_dgrad_kernel<4, 4, 1>, g1_lds_dgrad({4, 4})) &&
+                             g1_set_lds(g1_dgrad_kernel<4, 4, 2>, g1_lds_dgrad({4, 4}));
     if (!attr) return DC_ELAUNCH;
     hipEvent_t pe = conv_prof_begin(4, 2.0 * (double)B * Co * Ci * a.Ho * a.Wo, 2.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * Co, 4.0 * ((double)B * Ci * a.Ho * a.Wo + (double)B * Co * a.Ho * a.Wo + (double)Co * Ci), st);
-    if (t.mt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<4, 4>), grid, dim3(256), lds, st, a);
-    else if (t.nt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<2, 4>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((g1_dgrad_kernel<2, 2>), grid, dim3(256), lds, st, a);
+#define G1_DGRAD(BNE)                                                                                  \
+    do {                                                                                               \
+        if (t.mt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<4, 4, BNE>), grid, dim3(256), lds, st, a);      \
+        else if (t.nt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<2, 4, BNE>), grid, dim3(256), lds, st, a); \
+        else hipLaunchKernelGGL((g1_dgrad_kernel<2, 2, BNE>), grid, dim3(256), lds, st, a);                \
+    } while (0)
+    if (bne == 0) G1_DGRAD(0);
+    else if (bne == 1) G1_DGRAD(1);
+    else G1_DGRAD(2);
+#undef G1_DGRAD
     conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     return DC_OK;
@@ -555,11 +758,16 @@ extern "C" size_t dc_gemm1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int 
 }
 
 extern "C" int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,
-                                int stride, void* stream) {
+                                int stride, const dc_bn_fold* bn, void* stream) {
     if (!x || !gy || !dweight || !ws || !dc_gemm1x1_wgrad_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
     G1Args a{};
     g1_fill(a, B, Ci, Co, Hi, Wi, stride);
     a.x = x; a.gy = gy;
+    const bool bnin = bn && bn->in_scale;
+    if (bnin) {
+        if (!bn->in_shift || stride != 1 || bn->groups < 1 || B % bn->groups) return DC_EINVAL;
+        a.npg = B / bn->groups; a.in_scale = bn->in_scale; a.in_shift = bn->in_shift;
+    }
     a.chunks = B * a.Ho * a.Wo / GKC;
     const G1Tile t = g1_wpick(Co, Ci);
     a.splits = g1_wsplits(Co, Ci, a.chunks, t);
@@ -570,10 +778,14 @@ extern "C" int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight,
     const dim3 grid(a.mtiles * a.ntiles, a.splits);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = g1_lds_wgrad(t);
-    static const bool attr = g1_set_lds(g1_wgrad_kernel<4, 4, 1>, g1_lds_wgrad({4, 4})) && g1_set_lds(g1_wgrad_kernel<4, 4, 2>, g1_lds_wgrad({4, 4}));
+    static const bool attr = g1_set_lds(g1_wgrad_kernel<4, 4, 1>, g1_lds_wgrad({4, 4})) && g1_set_lds(g1_wgrad_kernel<4, 4, 2>, g1_lds_wgrad({4, 4})) &&
+                             g1_set_lds(g1_wgrad_kernel<4, 4, 1, true>, g1_lds_wgrad({4, 4}));
     if (!attr) return DC_ELAUNCH;
     hipEvent_t pe = conv_prof_begin(4, 2.0 * (double)B * Co * Ci * a.Ho * a.Wo, 2.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * (double)a.chunks * GKC, 4.0 * ((double)B * Ci * a.Ho * a.Wo + (double)B * Co * a.Ho * a.Wo + (double)Co * Ci), st);
-    if (stride == 1) {
+    if (bnin) {
+        if (t.mt == 4) hipLaunchKernelGGL((g1_wgrad_kernel<4, 4, 1, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((g1_wgrad_kernel<2, 2, 1, true>), grid, dim3(256), lds, st, a);
+    } else if (stride == 1) {
         if (t.mt == 4) hipLaunchKernelGGL((g1_wgrad_kernel<4, 4, 1>), grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL((g1_wgrad_kernel<2, 2, 1>), grid, dim3(256), lds, st, a);
     } else {

@@ -236,7 +236,7 @@ extern "C" int dc_conv1x1_bias_act_fwd(const float* x, const float* weight, cons
                                        int Wi, int stride, int act, void* stream) {
     if (!x || !weight || !y || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride) || act < 0 || act > ACT_LAST) return DC_EINVAL;
     if (dc_gemm1x1_fwd_ok(B, Ci, Co, Hi, Wi, stride))
-        return dc_gemm1x1_fwd(x, weight, bias, y, B, Ci, Co, Hi, Wi, stride, act, stream);
+        return dc_gemm1x1_fwd(x, weight, bias, y, B, Ci, Co, Hi, Wi, stride, act, nullptr, stream);
     PwArgs a{};
     a.bias = bias; a.act = act;
     a.a = weight; a.b = x; a.out = y; a.B = B; a.M = Co; a.K = Ci; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;
@@ -274,7 +274,7 @@ extern "C" int dc_conv1x1_dgrad_add(const float* gy, const float* weight, float*
     if (!gy || !weight || !dx || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
     if (dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) {
         // the tiled GEMM adds it in its store epilogue (stride 1: dx is written once, densely)
-        const int rc = dc_gemm1x1_dgrad(gy, weight, dx, stride == 1 ? addend : nullptr, B, Ci, Co, Hi, Wi, stride, stream);
+        const int rc = dc_gemm1x1_dgrad(gy, weight, dx, stride == 1 ? addend : nullptr, B, Ci, Co, Hi, Wi, stride, nullptr, stream);
         if (rc != DC_OK || stride == 1 || !addend) return rc;
         return add_inplace(dx, addend, (size_t)B * Ci * Hi * Wi, (hipStream_t)stream);
     }
@@ -294,7 +294,7 @@ extern "C" int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight,
                                 int stride, void* stream) {
     if (!x || !gy || !dweight || !ws || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
     if (dc_gemm1x1_wgrad_ok(B, Ci, Co, Hi, Wi, stride))
-        return dc_gemm1x1_wgrad(x, gy, dweight, ws, B, Ci, Co, Hi, Wi, stride, stream);
+        return dc_gemm1x1_wgrad(x, gy, dweight, ws, B, Ci, Co, Hi, Wi, stride, nullptr, stream);
     PwArgs a{};
     a.a = gy; a.b = x; a.out = (float*)ws; a.B = B; a.M = Co; a.K = Ci; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;
     a.splits = pw_splits(B, a.Ho, a.Wo, Co, Ci);
@@ -304,4 +304,34 @@ extern "C" int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight,
                        a.splits, Co * Ci);
     DC_CHECK_LAUNCH();
     return DC_OK;
+}
+
+// ---- the 1x1 convolutions with a BatchNorm folded in (dc_bn_fold): tiled kernels only ----------------------------------------
+static bool bn_active(const dc_bn_fold* bn) { return bn && (bn->in_scale || bn->stat_part || bn->bwd_part); }
+extern "C" int dc_conv1x1_bn_ok(int B, int Ci, int Co, int Hi, int Wi) {
+    return dc_gemm1x1_fwd_ok(B, Ci, Co, Hi, Wi, 1) && dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, 1) && dc_gemm1x1_wgrad_ok(B, Ci, Co, Hi, Wi, 1);
+}
+extern "C" int dc_conv1x1_stat_parts(int B, int Ci, int Co, int Hi, int Wi, int stride, int groups, int* ppg) {
+    return dc_gemm1x1_stat_parts(B, Ci, Co, Hi, Wi, stride, groups, ppg);
+}
+extern "C" int dc_conv1x1_bwd_parts(int B, int Ci, int Co, int Hi, int Wi, int groups, int* ppg) {
+    return dc_gemm1x1_bwd_parts(B, Ci, Co, Hi, Wi, 1, groups, ppg);
+}
+extern "C" int dc_conv1x1_fwd_bn(const float* x, const float* weight, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                                 const dc_bn_fold* bn, void* stream) {
+    if (!bn_active(bn)) return dc_conv1x1_fwd(x, weight, y, B, Ci, Co, Hi, Wi, stride, stream);
+    if (!dc_gemm1x1_fwd_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    return dc_gemm1x1_fwd(x, weight, nullptr, y, B, Ci, Co, Hi, Wi, stride, ACT_NONE, bn, stream);
+}
+extern "C" int dc_conv1x1_dgrad_bn(const float* gy, const float* weight, float* dx, const float* addend, int B, int Ci, int Co, int Hi,
+                                   int Wi, int stride, const dc_bn_fold* bn, void* stream) {
+    if (!bn || !bn->bwd_part) return dc_conv1x1_dgrad_add(gy, weight, dx, addend, B, Ci, Co, Hi, Wi, stride, stream);
+    if (stride != 1 || !dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    return dc_gemm1x1_dgrad(gy, weight, dx, addend, B, Ci, Co, Hi, Wi, stride, bn, stream);
+}
+extern "C" int dc_conv1x1_wgrad_bn(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,
+                                   int stride, const dc_bn_fold* bn, void* stream) {
+    if (!bn || !bn->in_scale) return dc_conv1x1_wgrad(x, gy, dweight, ws, B, Ci, Co, Hi, Wi, stride, stream);
+    if (!dc_gemm1x1_wgrad_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    return dc_gemm1x1_wgrad(x, gy, dweight, ws, B, Ci, Co, Hi, Wi, stride, bn, stream);
 }

@@ -68,6 +68,12 @@ class AttnParams(Structure):
 
 ATTN_PLAIN, ATTN_PIXEL_SHUFFLE2 = 0, 1
 
+
+class BnFold(Structure):
+    """Mirror of `dc_bn_fold`: a BatchNorm folded into the passes of a neighbouring convolution (include/depthcore.h)."""
+    _fields_ = [("groups", c_int32), ("in_scale", _F), ("in_shift", _F), ("stat_part", _F),
+                ("bn_x", _F), ("bn_mean", _F), ("bn_mask", _F), ("bwd_part", _F)]
+
 _lib = None
 
 
@@ -107,6 +113,18 @@ def _sig(lib):
         "dc_bn_mask_bytes": (z, [i, i, i]),
         "dc_bn_relu_fwd": (i, [p, p, p, p, p, p, p, p, p, p, p, i, i, i, f, f, i, i, p]),
         "dc_bn_relu_bwd": (i, [p, p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, i, p]),
+        "dc_bn_stat_parts": (i, [i, i, i, i, POINTER(c_int)]),
+        "dc_bn_stats": (i, [p, p, i, i, i, i, p]),
+        "dc_bn_finalize": (i, [p, i, i, c_double, p, p, p, p, p, p, p, p, i, i, f, f, p]),
+        "dc_bn_apply": (i, [p, p, p, p, p, p, i, i, i, i, i, p]),
+        "dc_bn_bwd_finalize": (i, [p, i, i, c_double, p, p, p, p, p, p, i, i, p]),
+        "dc_bn_bwd_apply": (i, [p, p, p, p, i, i, i, i, p]),
+        "dc_conv1x1_bn_ok": (i, [i, i, i, i, i]),
+        "dc_conv1x1_stat_parts": (i, [i, i, i, i, i, i, i, POINTER(c_int)]),
+        "dc_conv1x1_bwd_parts": (i, [i, i, i, i, i, i, POINTER(c_int)]),
+        "dc_conv1x1_fwd_bn": (i, [p, p, p, i, i, i, i, i, i, POINTER(BnFold), p]),
+        "dc_conv1x1_dgrad_bn": (i, [p, p, p, p, i, i, i, i, i, i, POINTER(BnFold), p]),
+        "dc_conv1x1_wgrad_bn": (i, [p, p, p, p, i, i, i, i, i, i, POINTER(BnFold), p]),
         "dc_maxpool3x3s2_fwd": (i, [p, p, p, i, i, i, p]),
         "dc_maxpool3x3s2_bwd": (i, [p, p, p, i, i, i, p]),
         "dc_wino3x3_workspace": (z, [i, i, i, i, i]),

@@ -76,8 +76,9 @@ def _use_precision(prec):
 
 
 def _record_kink(kind, t):
+    """`t`: the tensor that carries the decision, or a thunk that forms it (folded ReLUs never materialise theirs)."""
     if KinkTape._active:
-        KinkTape._active[-1].entries.append((kind, t))
+        KinkTape._active[-1].entries.append((kind, t() if callable(t) else t))
 
 
 def _slot(param):

@@ -7,11 +7,14 @@ state_dict keys: `encoder.conv1.weight`, `encoder.layer1.0.bn1.running_mean`, ..
 Convolutions go through `conv_impl` so that the MFMA implicit-GEMM kernels can be swapped in
 without touching the module tree.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from depthcore import bnfold as _bnf
 from depthcore import ops as _ops
 
 
@@ -32,6 +35,11 @@ CONV_S2 = True        # 7x7 / 2 stem and 3x3 / 2 convolutions on depthcore's imp
 GEMM_1X1 = True       # 1x1 stride-2 `downsample` convolutions on depthcore's NCHW MFMA GEMM (GPU)
 WINO_TRUNK = True     # stride-1 3x3 trunk convolutions on depthcore's fused Winograd kernel (GPU, even widths)
 STEM_FUSED = True     # input normalisation (and the pose pairs' concat) inside the stem kernels' loader (dc_stem_*)
+
+
+# BatchNorm passes folded into the neighbouring convolutions (depthcore.bnfold; training mode on the GPU).  DC_BN_FOLD=0: the
+# stand-alone BatchNorm kernels (same-box A/Bs)
+BN_FOLD = os.environ.get("DC_BN_FOLD", "1") != "0"
 
 
 GRAD_FORK = True      # residual blocks without a downsample branch: the skip's gradient is added inside conv1's data-gradient kernel
@@ -131,9 +139,43 @@ class Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
+        self.link_out = False      # set by ResNetTrunk: the NEXT block of the stage is this block output's only consumer
+
+    def _fold_ok(self, x, g):
+        """The folded chain applies: training step on the GPU, every 1x1 of the block on the tiled GEMM kernels with both
+        epilogues, fp32 matrix precision."""
+        if not (BN_FOLD and GEMM_1X1 and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and _ops._precision[0] == _ops.PRECISIONS["f32"] and x.numel() * 4 < 0x7fffffff):
+            return False
+        B, _, H, W = x.shape
+        s = self.conv2.stride[0]
+        if self.conv2.stride not in ((1, 1), (2, 2)) or H % s or W % s or (H * W) % 4 or ((H // s) * (W // s)) % 4 or B % g:
+            return False
+        return _bnf.conv1x1_ok(self.conv3, (B, self.conv2.out_channels, H // s, W // s), g)
+
+    def _forward_fold(self, x, g):
+        """conv1 (statistics epilogue; the previous block's BatchNorm backward in its data-gradient epilogue) -> bn1 + ReLU ->
+        conv2 (3x3) -> [bn2 + ReLU inside conv3's loader] conv3 (statistics epilogue) -> relu(bn3 + skip), one apply pass."""
+        if self.downsample is None:
+            fork = _fork_for(self, x)
+            prev = _bnf.take_link(x, self.conv1, g) if fork is not None else None
+        else:
+            fork, prev = _pair_fork_for(self, x), None
+        y1, s1 = _bnf.conv1x1(x, self.conv1.weight, 1, g, fork=fork, prev=prev)
+        a1 = _bnf.bn_apply(y1, self.bn1, s1, groups=g)
+        y2 = _conv(self.conv2, a1)
+        y3, s3 = _bnf.conv1x1(y2, self.conv3.weight, 1, g, in_bn=self.bn2)
+        if self.downsample is None:
+            return _bnf.bn_apply(y3, self.bn3, s3, res=x, groups=g, fork=fork, leave_link=self.link_out)
+        d = self.downsample[0]
+        yd, sd = _bnf.conv1x1(x, d.weight, d.stride[0], g, fork=fork)
+        idt = _bnf.bn_apply(yd, self.downsample[1], sd, relu=False, groups=g)
+        return _bnf.bn_apply(y3, self.bn3, s3, res=idt, groups=g, leave_link=self.link_out)
 
     def forward(self, x):
         g = self._g[0]
+        if self._fold_ok(x, g):
+            return self._forward_fold(x, g)
         fork = _fork_for(self, x)
         if self.downsample is None:
             out = _bn_act(_conv(self.conv1, x, fork), self.bn1, groups=g)
@@ -188,6 +230,8 @@ class ResNetTrunk(nn.Module):
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
             layers.append(block(self.inplanes, planes, groups_ref=self._g))
+        for b in layers[:-1]:
+            b.link_out = True       # (a stage's last output is a feature map with several consumers: no link)
         return nn.Sequential(*layers)
 
 

@@ -1,0 +1,108 @@
+"""BatchNorm folded into the neighbouring convolutions (depthcore.bnfold, dc_bn_fold) against plain torch on the CPU and
+against the unfolded depthcore chain (networks.resnet_encoder.BN_FOLD = False) on the same inputs.
+Reference arithmetic: torchvision Bottleneck / BasicBlock behind networks/resnet_encoder.py:87-98."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from helpers import close, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bn(C, g, dev="cpu"):
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    return bn.to(dev)
+
+
+@pytest.mark.parametrize("B,Ci,Cm,Co,H,W,groups", [(4, 64, 64, 256, 16, 32, 1), (4, 64, 32, 128, 8, 16, 2), (2, 128, 128, 512, 24, 40, 1),
+                                                   (6, 256, 64, 64, 10, 32, 2)])
+def test_conv_bn_relu_conv_chain_vs_torch(B, Ci, Cm, Co, H, W, groups):
+    """x -> conv A (statistics epilogue) -> [bn + relu folded into conv B's loader] -> conv B (statistics epilogue) -> bn + relu
+    (apply pass) vs the same chain in plain torch, per BatchNorm group: outputs, running statistics, every gradient."""
+    from depthcore import bnfold
+    g = torch.Generator().manual_seed(B * 1000 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    wa = torch.randn(Cm, Ci, 1, 1, generator=g) / Ci ** 0.5
+    wb = torch.randn(Co, Cm, 1, 1, generator=g) / Cm ** 0.5
+    cot = torch.randn(B, Co, H, W, generator=g)
+    bn1r, bn2r = _bn(Cm, g), _bn(Co, g)
+    bn1h, bn2h = nn.BatchNorm2d(Cm).to(DEV), nn.BatchNorm2d(Co).to(DEV)
+    bn1h.load_state_dict(bn1r.state_dict()); bn2h.load_state_dict(bn2r.state_dict())
+    # reference, group by group (separate module calls, in order)
+    xr, war, wbr = x.clone().requires_grad_(), wa.clone().requires_grad_(), wb.clone().requires_grad_()
+    outs = []
+    n = B // groups
+    for k in range(groups):
+        a = F.relu(bn1r(F.conv2d(xr[k * n:(k + 1) * n], war)))
+        outs.append(F.relu(bn2r(F.conv2d(a, wbr))))
+    yr = torch.cat(outs, 0)
+    gr = torch.autograd.grad((yr * cot).sum(), [xr, war, wbr, bn1r.weight, bn1r.bias, bn2r.weight, bn2r.bias])
+    # folded
+    xh = x.to(DEV).requires_grad_()
+    wah, wbh = wa.to(DEV).requires_grad_(), wb.to(DEV).requires_grad_()
+    ya, sa = bnfold.conv1x1(xh, wah, 1, groups)
+    assert sa is not None, "no statistics epilogue on a tiled shape"
+    yb, sb = bnfold.conv1x1(ya, wbh, 1, groups, in_bn=bn1h, in_stats=sa)
+    assert sb is not None
+    yh = bnfold.bn_apply(yb, bn2h, sb, groups=groups)
+    gh = torch.autograd.grad((yh * cot.to(DEV)).sum(), [xh, wah, wbh, bn1h.weight, bn1h.bias, bn2h.weight, bn2h.bias])
+    close(yh, yr, rtol=2e-4, atol=2e-5)
+    for bh, br in ((bn1h, bn1r), (bn2h, bn2r)):
+        close(bh.running_mean, br.running_mean, rtol=1e-5, atol=1e-6)
+        close(bh.running_var, br.running_var, rtol=1e-4, atol=1e-6)
+    for a, b, name in zip(gh, gr, ["dx", "dwa", "dwb", "dg1", "db1", "dg2", "db2"]):
+        assert rel_l2(a, b) < 3e-4, (name, rel_l2(a, b))
+
+
+def test_stats_epilogue_is_deterministic_and_matches_the_stats_pass():
+    from depthcore import bnfold, _lib
+    import ctypes
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 64, 20, 64, generator=g).to(DEV)
+    w = (torch.randn(256, 64, 1, 1, generator=g) / 8).to(DEV)
+    y1, s1 = bnfold.conv1x1(x, w, 1, 1)
+    y2, s2 = bnfold.conv1x1(x, w, 1, 1)
+    assert torch.equal(y1, y2) and torch.equal(s1.part, s2.part)
+    p = s1.part.view(256, s1.nparts, 2).double().sum(1).cpu()
+    yd = y1.double().cpu()
+    close(p[:, 0].float(), yd.sum((0, 2, 3)).float(), rtol=1e-4, atol=1e-3)
+    close(p[:, 1].float(), (yd * yd).sum((0, 2, 3)).float(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("num_layers,groups", [(50, 1), (50, 2)])
+def test_encoder_fold_vs_unfolded_chain(num_layers, groups):
+    """The whole trunk with the fold against the same trunk on the stand-alone BatchNorm kernels: features, running
+    statistics, every parameter gradient (the two differ by summation order only)."""
+    import networks
+    from networks import resnet_encoder as RE
+    torch.manual_seed(3)
+    B, H, W = 4, 64, 128
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1)).to(DEV)
+    runs = {}
+    for fold in (True, False):
+        torch.manual_seed(7)
+        enc = networks.ResnetEncoder(num_layers, False).to(DEV)
+        enc.train()
+        RE.BN_FOLD = fold
+        try:
+            feats = enc(x, bn_groups=groups)
+            cots = [torch.randn(f.shape, generator=torch.Generator().manual_seed(i)).to(DEV) for i, f in enumerate(feats)]
+            loss = sum((f * c).sum() for f, c in zip(feats, cots))
+            params = [p for n, p in enc.named_parameters() if ".fc." not in n]
+            grads = torch.autograd.grad(loss, params)
+        finally:
+            RE.BN_FOLD = True
+        runs[fold] = ([f.detach() for f in feats], grads, {k: v.clone() for k, v in enc.state_dict().items() if "running" in k},
+                      [n for n, _ in enc.named_parameters() if ".fc." not in n])
+    for a, b in zip(runs[True][0], runs[False][0]):
+        assert rel_l2(a, b) < 1e-4, rel_l2(a, b)
+    for k in runs[True][2]:
+        close(runs[True][2][k], runs[False][2][k], rtol=1e-4, atol=1e-6)
+    worst = max((rel_l2(a, b), n) for a, b, n in zip(runs[True][1], runs[False][1], runs[True][3]))
+    assert worst[0] < 2e-3, worst
