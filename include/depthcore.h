@@ -306,6 +306,20 @@ int dc_wino3x3_dgrad(const float* gy, const float* weight, float* gx, void* ws, 
 int dc_wino3x3_dgrad_add(const float* gy, const float* weight, float* gx, const float* addend, void* ws, int B, int Ci, int Co,
                          int H, int W, void* stream);
 
+/* The trunk's 3x3 convolution with a BatchNorm folded in (dc_bn_fold; `bn` nullable = the plain calls): forward with the
+ * BatchNorm + ReLU of its input in the loader and / or the statistics epilogue, data gradient with the BatchNorm-backward
+ * epilogue.  dc_wino3x3_bn_ok(): both passes of this shape take the fold (fp32 policy, <= 2 groups, unsplit reduction);
+ * the *_parts queries size the partial buffers (0 = no epilogue: split reduction on a small map, bf16 policy). */
+int dc_wino3x3_bn_ok(int B, int Ci, int Co, int H, int W, int groups);
+int dc_wino3x3_stat_parts(int B, int Ci, int Co, int H, int W, int groups, int* ppg);
+int dc_wino3x3_bwd_parts(int B, int Ci, int Co, int H, int W, int groups, int* ppg);
+int dc_wino3x3_fwd_bn(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int H, int W,
+                      const dc_bn_fold* bn, void* stream);
+int dc_wino3x3_dgrad_bn(const float* gy, const float* weight, float* gx, const float* addend, void* ws, int B, int Ci, int Co,
+                        int H, int W, const dc_bn_fold* bn, void* stream);
+int dc_wino3x3_wgrad_bn(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int H, int W,
+                        const dc_bn_fold* bn, void* stream);
+
 /* Measurement hook for the convolution kernels (bench.py `roofline`): when enabled, every Winograd launch brackets its
  * main kernel with hipEvents on the launch stream.  kind 0 = wino_ps_kernel (forward / data gradient of the trunk and
  * decoder convolutions), 1 = wino_wgrad_kernel.  collect returns the summed kernel milliseconds, the summed

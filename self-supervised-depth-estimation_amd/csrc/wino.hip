@@ -140,10 +140,33 @@ struct WinoPsArgs {
     int items;                        // work items = tblocks * mblocks; a launch with FEWER blocks than items is persistent (below)
     unsigned mg_mblocks, mg_tblocks, mg_per_img, mg_regs_x, mg_PR, mg_RW;   // fdiv magics of the divisors the kernel divides by
     unsigned long long* diag;         // WINO_DIAG builds only: per block {compute, commit(+load wait), issue, barrier, loop, prologue, epilogue, start time} cycles
+    // ---- BatchNorm folded into the launch (plain launches; include/depthcore.h: dc_bn_fold) ----
+    const float* in_scale;            // MODE 1: the input is relu(scale[g, k] x + shift[g, k]) (zero padding stays zero), applied between
+    const float* in_shift;            //   the global load and the LDS store; MODE 2: the same pair re-derives the ReLU decision
+    int npg;                          // images per BatchNorm group
+    float* stat_part;                 // MODE 0 / 1, nullable: (M, stat_nparts) x {sum, sum of squares} of the output, partial 2 sub + half
+    int stat_nparts;
+    const float* bn_x;                // MODE 2 / 3 (data gradient): raw input of the BatchNorm whose ReLU-ed output the forward read,
+    const float* bn_mean;             //   its mean (groups, M), its ReLU bit mask (MODE 3) and the partials (M, bwd_nparts) x
+    const unsigned long long* bn_mask;   // {sum g', sum g' (x - mean)} of the masked result g'
+    float* bwd_part;
+    int bwd_nparts;
 };
 
-template <int MR, int NR, bool FUSED, bool PERSIST = false>
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane of the row
+__device__ __forceinline__ float wrow16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+// MODE (plain, non-persistent launches only): 0 none (+ optional statistics epilogue), 1 BatchNorm + ReLU folded into the loader
+// (+ optional statistics epilogue), 2 / 3 BatchNorm-backward epilogue of a data gradient (ReLU decision re-derived / from bits)
+template <int MR, int NR, bool FUSED, bool PERSIST = false, int MODE = 0>
 __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) void wino_ps_kernel(WinoPsArgs a) {
+    static_assert(MODE == 0 || (!FUSED && !PERSIST), "the BatchNorm fold exists for the plain trunk launches");
     constexpr int MT = 16 * MR, G = NR / 2;
     constexpr int UF4 = PSK * 4 * MT;                 // f4 items of one U chunk in global memory
     static_assert(NR % 2 == 0 && NR * 2048 <= 2 * PSK * G * PSUB, "the row exchange aliases the slab double buffer");
@@ -233,6 +256,13 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     };
     unsigned svoff, svoff1;
     item_src(tblk, true, svoff, svoff1);
+    // MODE 1: (BatchNorm group of this wave's sub-region) * K -- the thread halves / channel halves that stage are whole waves, so
+    // the scale / shift reads below are scalar loads
+    int bn_gofs = 0;
+    if constexpr (MODE == 1) {
+        const int ssub = min(tblk * G + (G == 1 ? 0 : (wave >> 1)), a.nsub - 1);
+        bn_gofs = __builtin_amdgcn_readfirstlane((fdiv(ssub, a.mg_per_img) / a.npg) * a.K);
+    }
     const int shift = 2 - P;                          // slab column of the pair's first element = 2 scp - shift
     const int slds0 = sg_ * SUBS + sr * RS + max(2 * scp - shift, 0), slds1 = sg_ * SUBS + sr * RS + 2 * scp + 1 - shift;
     const wrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
@@ -289,10 +319,22 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
         if (swr) {
             float* xw = xl[buf];
             const bool dup = FUSED && up0 && c * PSK < C0;        // chunk of the nearest-x2 upsampled source: one value, two columns
+            if constexpr (MODE == 1) {
+                const bool inside = svoff != 0x80000000u;        // (zero padding and the lanes outside the item list stay 0)
 #pragma unroll
-            for (int k = 0; k < PK; ++k) {
-                xw[(kh0 + k) * CPS + slds0] = src[k].x;
-                xw[(kh0 + k) * CPS + slds1] = dup ? src[k].x : src[k].y;
+                for (int k = 0; k < PK; ++k) {
+                    const int ch = c * PSK + kh0 + k, chc = min(ch, a.K - 1);
+                    const float sc = a.in_scale[bn_gofs + chc], sh = a.in_shift[bn_gofs + chc];
+                    const bool ok = inside && ch < a.K;
+                    xw[(kh0 + k) * CPS + slds0] = ok ? fmaxf(fmaf(src[k].x, sc, sh), 0.f) : 0.f;
+                    xw[(kh0 + k) * CPS + slds1] = ok ? fmaxf(fmaf(src[k].y, sc, sh), 0.f) : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PK; ++k) {
+                    xw[(kh0 + k) * CPS + slds0] = src[k].x;
+                    xw[(kh0 + k) * CPS + slds1] = dup ? src[k].x : src[k].y;
+                }
             }
         }
     };
@@ -435,8 +477,83 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
                 ad[rr][1] = *reinterpret_cast<const f2w*>(a.addend + o + (oy + 1 < Ho ? Wo : 0));
             }
         }
+        // BatchNorm epilogues: the lane's 2 x 2 block of the BatchNorm's raw input and the row constants, requested before the barrier too
+        constexpr bool BNE = MODE >= 2;
+        const bool stats = MODE <= 1 && a.stat_part != nullptr && gridDim.z == 1;
+        f2w bx[BNE ? RPW : 1][2];
+        float bmean[BNE ? RPW : 1], bsc[BNE ? RPW : 1], bsh[BNE ? RPW : 1];
+        unsigned bbits[BNE ? RPW : 1];
+        if constexpr (BNE) {
+            const int gtab = (ob / a.npg) * a.M;
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int m = min(mblk * MT + i * 16 + kk * 4 + r0 + rr, a.M - 1);
+                const int e0 = min(oy, Ho - 1) * Wo + min(ox, Wo - 2), e1 = e0 + (oy + 1 < Ho ? Wo : 0);
+                const size_t pl = (size_t)ob * a.M + m;
+                bx[rr][0] = *reinterpret_cast<const f2w*>(a.bn_x + pl * Ho * Wo + e0);
+                bx[rr][1] = *reinterpret_cast<const f2w*>(a.bn_x + pl * Ho * Wo + e1);
+                bmean[rr] = a.bn_mean[gtab + m];
+                if constexpr (MODE == 2) { bsc[rr] = a.in_scale[gtab + m]; bsh[rr] = a.in_shift[gtab + m]; }
+                if constexpr (MODE == 3) {
+                    // bit l of word w of a 256-element block <-> element 4 l + w (bn_apply_kernel's ballots); e0, e1 are even
+                    const unsigned* mw = reinterpret_cast<const unsigned*>(a.bn_mask + pl * ((Ho * Wo + 255) >> 8) * 4);
+                    const int l0 = (e0 & 255) >> 2, l1 = (e1 & 255) >> 2;
+                    const unsigned* w0 = mw + ((e0 >> 8) * 4 + (e0 & 3)) * 2 + (l0 >> 5);
+                    const unsigned* w1 = mw + ((e1 >> 8) * 4 + (e1 & 3)) * 2 + (l1 >> 5);
+                    bbits[rr] = ((w0[0] >> (l0 & 31)) & 1u) | (((w0[2] >> (l0 & 31)) & 1u) << 1) |
+                                (((w1[0] >> (l1 & 31)) & 1u) << 2) | (((w1[2] >> (l1 & 31)) & 1u) << 3);
+                }
+            }
+        }
         __syncthreads();
-        if (o_ok) {
+        if (BNE || stats) {
+            // every lane runs this form (the 16 lanes of a DPP row hold 16 tiles of ONE output channel and are summed across)
+            const bool row1 = oy + 1 < Ho;
+            const int slot = tblk * NR + oj;
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int r = r0 + rr;
+                const int m = mblk * MT + i * 16 + kk * 4 + r;
+                const bool mok = m < a.M;
+                float z[4][2];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    z[w][0] = ex[((w * NR * 4 + oj * 4 + r) * 2 + 0) * 64 + lane];
+                    z[w][1] = ex[((w * NR * 4 + oj * 4 + r) * 2 + 1) * 64 + lane];
+                }
+                float y00 = z[0][0] + z[1][0] + z[2][0], y01 = z[0][1] + z[1][1] + z[2][1];
+                float y10 = z[1][0] - z[2][0] - z[3][0], y11 = z[1][1] - z[2][1] - z[3][1];
+                if (has_add) { y00 += ad[rr][0].x; y01 += ad[rr][0].y; y10 += ad[rr][1].x; y11 += ad[rr][1].y; }
+                float sv, qv;
+                if constexpr (BNE) {
+                    bool k00, k01, k10, k11;
+                    if constexpr (MODE == 2) {
+                        k00 = fmaf(bx[rr][0].x, bsc[rr], bsh[rr]) > 0.f; k01 = fmaf(bx[rr][0].y, bsc[rr], bsh[rr]) > 0.f;
+                        k10 = fmaf(bx[rr][1].x, bsc[rr], bsh[rr]) > 0.f; k11 = fmaf(bx[rr][1].y, bsc[rr], bsh[rr]) > 0.f;
+                    } else {
+                        k00 = bbits[rr] & 1u; k01 = bbits[rr] & 2u; k10 = bbits[rr] & 4u; k11 = bbits[rr] & 8u;
+                    }
+                    y00 = k00 ? y00 : 0.f; y01 = k01 ? y01 : 0.f; y10 = k10 ? y10 : 0.f; y11 = k11 ? y11 : 0.f;
+                    const float mu = bmean[rr];
+                    sv = (y00 + y01) + (row1 ? y10 + y11 : 0.f);
+                    qv = fmaf(y00, bx[rr][0].x - mu, y01 * (bx[rr][0].y - mu)) + (row1 ? fmaf(y10, bx[rr][1].x - mu, y11 * (bx[rr][1].y - mu)) : 0.f);
+                } else {
+                    sv = (y00 + y01) + (row1 ? y10 + y11 : 0.f);
+                    qv = fmaf(y00, y00, y01 * y01) + (row1 ? fmaf(y10, y10, y11 * y11) : 0.f);
+                }
+                if (!o_ok) { sv = 0.f; qv = 0.f; }
+                sv = wrow16_sum(sv); qv = wrow16_sum(qv);
+                if (n == 0 && mok) {
+                    float* pp = BNE ? a.bwd_part + ((size_t)m * a.bwd_nparts + slot) * 2 : a.stat_part + ((size_t)m * a.stat_nparts + slot) * 2;
+                    *reinterpret_cast<f2w*>(pp) = f2w{sv, qv};
+                }
+                if (o_ok && mok) {
+                    float* dst = yout + (((size_t)ob * a.M + m) * Ho + oy) * Wo + ox;
+                    *reinterpret_cast<f2w*>(dst) = f2w{y00, y01};
+                    if (row1) *reinterpret_cast<f2w*>(dst + Wo) = f2w{y10, y11};
+                }
+            }
+        } else if (o_ok) {
 #pragma unroll
             for (int rr = 0; rr < RPW; ++rr) {
                 const int r = r0 + rr;
@@ -676,7 +793,38 @@ struct WinoLaunch {
     float* out; void* ws;
     int B, H, W, M;
     bool fused;
+    const dc_bn_fold* bn;                                                // plain launches: BatchNorm folded in (may be null)
 };
+
+// sub-region shape, tile variant and reduction split of a launch: deterministic in the shape (wino_ps_cost below)
+struct WinoPlan { int RH, RW, RS, regs_x, regs_y, nsub, nchunks, MT, G, ksplit; };
+static WinoPlan wino_plan(int B, int K, int M, int Ho, int Wo) {
+    WinoPlan p{};
+    const int TH = ceil_div(Ho, 2), TW = Wo / 2;
+    wino_ps_pick_region(TH, TW, p.RH, p.RW, p.RS);
+    p.regs_x = ceil_div(TW, p.RW); p.regs_y = ceil_div(TH, p.RH); p.nsub = p.regs_x * p.regs_y * B;
+    p.nchunks = ceil_div(K, PSK);
+    // Tile variant and reduction split: the cheapest of {16x32, 32x32, 32x64} x {1, 2 slabs} under wino_ps_cost
+    p.MT = 32; p.G = 2; p.ksplit = 1;
+    const size_t nout = (size_t)B * M * Ho * Wo;
+    const bool can_split = (Ho * Wo) % 4 == 0 && p.nchunks >= 2;
+    const int ks_cap = can_split ? wino_ksplit_cap(nout) : 1;
+    double best = 1e30;
+    for (int v = 0; v < 3; ++v)
+        for (int ks = 1; ks <= ks_cap; ks *= 2) {
+            if (ks > 1 && p.nchunks < 2 * ks) break;          // at least two chunks per split: something to pipeline
+            const double t = wino_ps_cost(v, ks, p.nsub, M, p.nchunks, nout);
+            if (t < best) { best = t; p.MT = v == 0 ? 16 : 32; p.G = v == 2 ? 2 : 1; p.ksplit = ks; }
+        }
+    if (const char* f = getenv("DC_WINO_FORCE")) {       // experiments: "MR,NR,ksplit" (tools/sweep_wino.py)
+        int mr = 0, nr = 0, fks = 0;
+        if (sscanf(f, "%d,%d,%d", &mr, &nr, &fks) >= 2 && (mr == 1 || mr == 2) && (nr == 2 || nr == 4) && !(mr == 1 && nr == 4)) {
+            p.MT = 16 * mr; p.G = nr / 2;
+            if (fks > 0) p.ksplit = std::max(1, std::min({fks, ks_cap, p.nchunks / 2}));
+        }
+    }
+    return p;
+}
 
 static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     const int K = d.C0 + d.C1, M = d.M, H = d.H, W = d.W;
@@ -688,30 +836,33 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     a.B = d.B; a.K = K; a.M = M; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
     a.C0 = d.C0; a.up0 = d.up0; a.pad = d.pad; a.P = d.P; a.act = d.act;
     a.xbytes = (unsigned)b0; a.x1bytes = (unsigned)b1;
-    const int TH = ceil_div(Ho, 2), TW = Wo / 2;
-    wino_ps_pick_region(TH, TW, a.RH, a.RW, a.RS);
+    const WinoPlan pl = wino_plan(d.B, K, M, Ho, Wo);
+    a.RH = pl.RH; a.RW = pl.RW; a.RS = pl.RS;
     a.SUBS = (2 * a.RH + 2) * a.RS;
-    a.regs_x = ceil_div(TW, a.RW); a.regs_y = ceil_div(TH, a.RH); a.nsub = a.regs_x * a.regs_y * d.B;
-    a.nchunks = ceil_div(K, PSK);
-    // Tile variant and reduction split: the cheapest of {16x32, 32x32, 32x64} x {1, 2 slabs} under wino_ps_cost (below)
-    int MT = 32, G = 2, ksplit = 1;
+    a.regs_x = pl.regs_x; a.regs_y = pl.regs_y; a.nsub = pl.nsub;
+    a.nchunks = pl.nchunks;
+    const int MT = pl.MT, G = pl.G, ksplit = pl.ksplit;
     const size_t nout = (size_t)d.B * M * Ho * Wo;
-    {
-        const bool can_split = (Ho * Wo) % 4 == 0 && a.nchunks >= 2;
-        const int ks_cap = can_split ? wino_ksplit_cap(nout) : 1;
-        double best = 1e30;
-        for (int v = 0; v < 3; ++v)
-            for (int ks = 1; ks <= ks_cap; ks *= 2) {
-                if (ks > 1 && a.nchunks < 2 * ks) break;          // at least two chunks per split: something to pipeline
-                const double t = wino_ps_cost(v, ks, a.nsub, M, a.nchunks, nout);
-                if (t < best) { best = t; MT = v == 0 ? 16 : 32; G = v == 2 ? 2 : 1; ksplit = ks; }
-            }
-        if (const char* f = getenv("DC_WINO_FORCE")) {       // experiments: "MR,NR,ksplit" (tools/sweep_wino.py)
-            int mr = 0, nr = 0, fks = 0;
-            if (sscanf(f, "%d,%d,%d", &mr, &nr, &fks) >= 2 && (mr == 1 || mr == 2) && (nr == 2 || nr == 4) && !(mr == 1 && nr == 4)) {
-                MT = 16 * mr; G = nr / 2;
-                if (fks > 0) ksplit = std::max(1, std::min({fks, ks_cap, a.nchunks / 2}));
-            }
+    // BatchNorm fold (plain launches): 1 loader, 2 / 3 data-gradient epilogue; the statistics epilogue rides on mode 0 / 1
+    int mode = 0;
+    if (d.bn && !d.fused) {
+        const dc_bn_fold* bn = d.bn;
+        if (bn->groups < 1 || bn->groups > 2 || d.B % bn->groups) return DC_EINVAL;
+        a.npg = d.B / bn->groups;
+        a.in_scale = bn->in_scale; a.in_shift = bn->in_shift;
+        if (bn->bwd_part) {
+            if (ksplit > 1 || !bn->bn_x || !bn->bn_mean || (!bn->bn_mask && (!bn->in_scale || !bn->in_shift)) || (bn->bn_mask && ((H * W) & 3)))
+                return DC_EINVAL;
+            a.bn_x = bn->bn_x; a.bn_mean = bn->bn_mean; a.bn_mask = (const unsigned long long*)bn->bn_mask; a.bwd_part = bn->bwd_part;
+            a.bwd_nparts = 2 * ceil_div(pl.nsub, G) * G;
+            mode = bn->bn_mask ? 3 : 2;
+        } else if (bn->in_scale) {
+            if (!bn->in_shift) return DC_EINVAL;
+            mode = 1;
+        }
+        if (bn->stat_part) {
+            if (ksplit > 1 || mode >= 2) return DC_EINVAL;
+            a.stat_part = bn->stat_part; a.stat_nparts = 2 * ceil_div(pl.nsub, G) * G;
         }
     }
     const int Mp = ceil_div(M, MT) * MT, Kp = a.nchunks * PSK;
@@ -743,10 +894,11 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     // round of resident blocks, on an unsplit reduction with an even number (>= 4) of chunks.
     int gx = a.items;
     {
-        const int mode = g_wino_persist;
+        const int pmode = g_wino_persist;
         const int bpc = MT == 16 ? 4 : (G == 1 ? 3 : 2), slots = 256 * bpc;
-        if (mode == 1 && !d.fused && ksplit == 1 && a.nchunks >= 4 && (a.nchunks & 1) == 0 && a.items > slots) gx = slots;
+        if (pmode == 1 && !d.fused && ksplit == 1 && a.nchunks >= 4 && (a.nchunks & 1) == 0 && a.items > slots) gx = slots;
     }
+    if (mode != 0 || a.stat_part) gx = a.items;           // (the fold lives in the one-item-per-block form)
     const dim3 grid(gx, 1, ksplit);
     // algorithmic = 2 MAC of the direct convolution; executed = the 16 Winograd-domain GEMMs incl. tile padding
     hipEvent_t pe = conv_prof_begin(0, 2.0 * d.B * (double)M * K * 9.0 * H * W,
@@ -761,9 +913,17 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
         else if (G == 1) hipLaunchKernelGGL((wino_ps_kernel<2, 2, false, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wino_ps_kernel<2, 4, false, true>), grid, dim3(256), 0, st, a);
     } else {
-        if (MT == 16) hipLaunchKernelGGL((wino_ps_kernel<1, 2, false>), grid, dim3(256), 0, st, a);
-        else if (G == 1) hipLaunchKernelGGL((wino_ps_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((wino_ps_kernel<2, 4, false>), grid, dim3(256), 0, st, a);
+#define WINO_PLAIN(MODE)                                                                                            \
+        do {                                                                                                        \
+            if (MT == 16) hipLaunchKernelGGL((wino_ps_kernel<1, 2, false, false, MODE>), grid, dim3(256), 0, st, a);    \
+            else if (G == 1) hipLaunchKernelGGL((wino_ps_kernel<2, 2, false, false, MODE>), grid, dim3(256), 0, st, a); \
+            else hipLaunchKernelGGL((wino_ps_kernel<2, 4, false, false, MODE>), grid, dim3(256), 0, st, a);             \
+        } while (0)
+        if (mode == 0) WINO_PLAIN(0);
+        else if (mode == 1) WINO_PLAIN(1);
+        else if (mode == 2) WINO_PLAIN(2);
+        else WINO_PLAIN(3);
+#undef WINO_PLAIN
     }
     conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
@@ -807,9 +967,24 @@ int wino_conv_full_dgrad(const float* gp, const float* weight, float* dxpad, voi
 
 static int g_wino_f4 = 0;      // dc_set_wino_f4: 0 = F(2x2,3x3) everywhere (default), 1 = F(4x4,3x3) for the plain trunk convolutions it covers
 
+static bool wino_bn_active(const dc_bn_fold* bn) { return bn && (bn->in_scale || bn->stat_part || bn->bwd_part); }
+// the plain F(2x2,3x3) fp32 launch is the one that carries the fold
+static bool wino_bn_path(int B, int Ci, int Co, int H, int W, bool dgrad) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || H < 1 || W < 2 || (W & 1)) return false;
+    if (matrix_precision() == DC_PREC_BF16 && c3b_eligible(dgrad ? Co : Ci, 0, 0, H, W, 1)) return false;
+    return true;
+}
+
 static int wino_run(const float* x, const float* w, float* y, const float* addend, void* ws, int B, int Ci, int Co, int H, int W,
-                    bool dgrad, hipStream_t st) {
+                    bool dgrad, hipStream_t st, const dc_bn_fold* bn = nullptr) {
     if (!x || !w || !y || !ws || B <= 0 || Ci <= 0 || Co <= 0 || H < 1 || W < 2 || (W & 1)) return DC_EINVAL;
+    if (wino_bn_active(bn)) {
+        if (!wino_bn_path(B, Ci, Co, H, W, dgrad)) return DC_EINVAL;
+        WinoLaunch d{};
+        d.src0 = x; d.C0 = dgrad ? Co : Ci; d.weight = w; d.Co = Co; d.Ci = Ci; d.dgrad = dgrad; d.act = ACT_NONE; d.pad = PAD_ZERO;
+        d.P = 1; d.out = y; d.ws = ws; d.B = B; d.H = H; d.W = W; d.M = dgrad ? Ci : Co; d.fused = false; d.addend = addend; d.bn = bn;
+        return wino_launch(d, st);
+    }
     // reduced-precision policy: direct implicit GEMM on the bf16 matrix cores (conv_bf16.hip; the data gradient of a
     // zero-padded convolution is the convolution with the rotated, transposed filter)
     if (matrix_precision() == DC_PREC_BF16 && c3b_eligible(dgrad ? Co : Ci, 0, 0, H, W, 1)) {
@@ -1030,4 +1205,35 @@ extern "C" int dc_wino3x3_dgrad_add(const float* gy, const float* weight, float*
                                     int Co, int H, int W, void* stream) {
     if (addend && (((size_t)addend | (size_t)gx) & 15)) return DC_EINVAL;
     return wino_run(gy, weight, gx, addend, ws, B, Ci, Co, H, W, true, (hipStream_t)stream);
+}
+
+// ---- the same launches with a BatchNorm folded in (dc_bn_fold) ----------------------------------------------------------------
+// partials per channel of the statistics epilogue (forward, rows = Co) / the BatchNorm-backward epilogue (data gradient, rows =
+// Ci): two per sub-region (its 16-tile halves), sub-regions image after image; 0 = this launch has no epilogue (a split
+// reduction, more than two groups, the bf16 policy)
+static int wino_parts(int B, int K, int M, int H, int W, int groups, bool dgrad, int Ci, int Co, int* ppg) {
+    if (groups < 1 || groups > 2 || B % groups || !wino_bn_path(B, Ci, Co, H, W, dgrad)) return 0;
+    const WinoPlan p = wino_plan(B, K, M, H, W);
+    if (p.ksplit > 1) return 0;
+    if (ppg) *ppg = 2 * p.regs_x * p.regs_y * (B / groups);
+    return 2 * ceil_div(p.nsub, p.G) * p.G;
+}
+extern "C" int dc_wino3x3_stat_parts(int B, int Ci, int Co, int H, int W, int groups, int* ppg) {
+    return wino_parts(B, Ci, Co, H, W, groups, false, Ci, Co, ppg);
+}
+extern "C" int dc_wino3x3_bwd_parts(int B, int Ci, int Co, int H, int W, int groups, int* ppg) {
+    return wino_parts(B, Co, Ci, H, W, groups, true, Ci, Co, ppg);
+}
+extern "C" int dc_wino3x3_bn_ok(int B, int Ci, int Co, int H, int W, int groups) {
+    return groups >= 1 && groups <= 2 && B % groups == 0 && wino_bn_path(B, Ci, Co, H, W, false) && wino_bn_path(B, Ci, Co, H, W, true) &&
+           dc_wino3x3_bwd_parts(B, Ci, Co, H, W, groups, nullptr) > 0;
+}
+extern "C" int dc_wino3x3_fwd_bn(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int H, int W,
+                                 const dc_bn_fold* bn, void* stream) {
+    return wino_run(x, weight, y, nullptr, ws, B, Ci, Co, H, W, false, (hipStream_t)stream, bn);
+}
+extern "C" int dc_wino3x3_dgrad_bn(const float* gy, const float* weight, float* gx, const float* addend, void* ws, int B, int Ci,
+                                   int Co, int H, int W, const dc_bn_fold* bn, void* stream) {
+    if (addend && (((size_t)addend | (size_t)gx) & 15)) return DC_EINVAL;
+    return wino_run(gy, weight, gx, addend, ws, B, Ci, Co, H, W, true, (hipStream_t)stream, bn);
 }

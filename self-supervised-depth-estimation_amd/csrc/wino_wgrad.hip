@@ -53,6 +53,10 @@ struct WinoWgArgs {
     unsigned xbytes, gbytes;
     unsigned mg_nmk, mg_kblocks, mg_RW, mg_XPR, mg_per_img, mg_regs_x;      // fdiv magics (dc_common.h)
     unsigned long long* diag;         // -DWINO_DIAG builds: per block {end, hw id, xcc, -, loop, prologue, epilogue, start} (tools/diag_wino.py)
+    // BNIN (plain launches): x is the RAW input of a BatchNorm + ReLU folded into the forward's loader; the same
+    // relu(scale[g, k] x + shift[g, k]) is re-formed between the global load and the LDS store (dc_bn_fold)
+    const float* in_scale; const float* in_shift;
+    int npg;
 };
 unsigned long long* wino_diag_ptr();
 
@@ -60,8 +64,9 @@ unsigned long long* wino_diag_ptr();
 // of the block's split with their own LDS slabs, and at the end group 1 hands its q values to group 0 through LDS (the
 // staging slabs are dead by then): one slab write per CU instead of two -- the slabs were 50 MB written and 50 MB read
 // back per launch whatever the layer (512 blocks x 96 KB), ~13 % of the kernel + reduce time -- at the same 8 waves per CU.
-template <bool FUSED, int MR, int NG>
+template <bool FUSED, int MR, int NG, bool BNIN = false>
 __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
+    static_assert(!(FUSED && BNIN), "the BatchNorm fold exists for the plain trunk launches");
     constexpr int KR = WG_KR, MT = 16 * MR, NGQ = MT / 8;       // NGQ: gy channels staged per thread
     constexpr int GL = MT * WG_GPS, XL = WG_KT * WG_XPS, GROUP_LDS = 2 * GL + 2 * XL;
     static_assert(NG == 1 || NG * GROUP_LDS >= 4 * MR * KR * 4 * 3 * 64, "the q exchange aliases the staging slabs");
@@ -106,8 +111,11 @@ __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     const int xlds0 = xcg * WG_XPS + xrow * XRS + max(2 * xcp - 1, 0), xlds1 = xcg * WG_XPS + xrow * XRS + 2 * xcp;
 
     f2w pg[NGQ], px[8];
+    bool px_ok = false;          // BNIN: the pair requested last lies inside the image (zero padding stays zero)
+    int px_gofs = 0;             //       and (BatchNorm group of its image) * K -- wave-uniform, like the channels: scalar loads
     auto prefetch = [&](int sub) {
         const int b = fdiv(sub, a.mg_per_img), rq = sub - b * per_img;
+        if constexpr (BNIN) px_gofs = __builtin_amdgcn_readfirstlane((b / a.npg) * a.K);
         const int ry = fdiv(rq, a.mg_regs_x), rx = rq - ry * a.regs_x;
         const int Y0 = ry * RH * 2, X0 = rx * RW * 2;
         {
@@ -128,6 +136,7 @@ __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
                 sx = xx == -2 ? 0 : (xx == W ? W - 2 : xx);
             }
             const bool ok = x_in && sy >= 0 && sy < H && sx >= 0 && sx < W;
+            if constexpr (BNIN) px_ok = ok;
             const unsigned pix0 = (up0 ? (unsigned)((sy >> 1) * (W >> 1) + (sx >> 1)) : (unsigned)(sy * W + sx)) * 4u;
             const unsigned pix1 = (unsigned)(sy * W + sx) * 4u;
             const int chb = kb * WG_KT + xcg;               // wave-uniform: xcg = wave
@@ -151,11 +160,22 @@ __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
             for (int q = 0; q < NGQ; ++q) *reinterpret_cast<f2w*>(gl(buf) + glds + 8 * q * WG_GPS) = pg[q];
         }
         if (x_in) {
+            if constexpr (BNIN) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const bool dup = FUSED && up0 && (kb * WG_KT + xcg + 4 * q) < C0;      // nearest-x2 source: one value, two columns
-                xl(buf)[xlds0 + 4 * q * WG_XPS] = px[q].x;      // (pair 0: the discarded column lands on, and is overwritten by, .y)
-                xl(buf)[xlds1 + 4 * q * WG_XPS] = dup ? px[q].x : px[q].y;
+                for (int q = 0; q < 8; ++q) {
+                    const int ch = kb * WG_KT + wave + 4 * q, chc = min(ch, a.K - 1);        // (xcg == wave)
+                    const float sc = a.in_scale[px_gofs + chc], sh = a.in_shift[px_gofs + chc];
+                    const bool ok = px_ok && ch < a.K;
+                    xl(buf)[xlds0 + 4 * q * WG_XPS] = ok ? fmaxf(fmaf(px[q].x, sc, sh), 0.f) : 0.f;
+                    xl(buf)[xlds1 + 4 * q * WG_XPS] = ok ? fmaxf(fmaf(px[q].y, sc, sh), 0.f) : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool dup = FUSED && up0 && (kb * WG_KT + xcg + 4 * q) < C0;      // nearest-x2 source: one value, two columns
+                    xl(buf)[xlds0 + 4 * q * WG_XPS] = px[q].x;      // (pair 0: the discarded column lands on, and is overwritten by, .y)
+                    xl(buf)[xlds1 + 4 * q * WG_XPS] = dup ? px[q].x : px[q].y;
+                }
             }
         }
     };
@@ -461,7 +481,7 @@ static WgPlan wg_plan(int B, int Ci, int Co, int H, int W) {
 }
 
 static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, int pad, bool fused, const float* gy, float* dweight,
-                     void* ws, int B, int Co, int H, int W, hipStream_t st) {
+                     void* ws, int B, int Co, int H, int W, hipStream_t st, const dc_bn_fold* bn = nullptr) {
     const int Ci = C0 + C1;
     const size_t b0 = (size_t)B * C0 * (H >> up0) * (W >> up0) * 4, b1 = (size_t)B * C1 * H * W * 4, gb = (size_t)B * Co * H * W * 4;
     if (b0 >= 0x7fffffffull || b1 >= 0x7fffffffull || gb >= 0x7fffffffull) return DC_EINVAL;      // 32-bit buffer offsets
@@ -483,17 +503,28 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
 #ifdef WINO_DIAG
     a.diag = wino_diag_ptr();
 #endif
+    const bool bnin = bn && bn->in_scale;
+    if (bnin) {
+        if (fused || !bn->in_shift || bn->groups < 1 || B % bn->groups) return DC_EINVAL;
+        a.in_scale = bn->in_scale; a.in_shift = bn->in_shift; a.npg = B / bn->groups;
+    }
     const int nmk = p.mblocks * p.kblocks;
     hipEvent_t pe = conv_prof_begin(1, 2.0 * B * (double)Co * Ci * 9.0 * H * W,
                                     2.0 * 16.0 * (double)p.nsub * 16.0 * (double)(p.mblocks * 16 * p.mr) * (p.kblocks * WG_KT),
                                     (double)b0 + (double)b1 + (double)gb + 36.0 * Co * Ci, st);
     static const bool attr = wg_set_lds(wino_wgrad_kernel<true, 4, 1>, wg_lds(4, 1)) && wg_set_lds(wino_wgrad_kernel<false, 4, 1>, wg_lds(4, 1)) &&
                              wg_set_lds(wino_wgrad_kernel<true, 4, 2>, wg_lds(4, 2)) && wg_set_lds(wino_wgrad_kernel<false, 4, 2>, wg_lds(4, 2)) &&
-                             wg_set_lds(wino_wgrad_kernel<true, 2, 1>, wg_lds(2, 1)) && wg_set_lds(wino_wgrad_kernel<false, 2, 1>, wg_lds(2, 1));
+                             wg_set_lds(wino_wgrad_kernel<true, 2, 1>, wg_lds(2, 1)) && wg_set_lds(wino_wgrad_kernel<false, 2, 1>, wg_lds(2, 1)) &&
+                             wg_set_lds(wino_wgrad_kernel<false, 4, 1, true>, wg_lds(4, 1)) && wg_set_lds(wino_wgrad_kernel<false, 4, 2, true>, wg_lds(4, 2)) &&
+                             wg_set_lds(wino_wgrad_kernel<false, 2, 1, true>, wg_lds(2, 1));
     if (!attr) return DC_ELAUNCH;
     const dim3 grid(p.splits * nmk);
     const size_t lds = wg_lds(p.mr, p.ng);
-    if (p.mr == 4 && p.ng == 2) {
+    if (bnin) {
+        if (p.mr == 4 && p.ng == 2) hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 2, true>), grid, dim3(512), lds, st, a);
+        else if (p.mr == 4) hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 1, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 2, 1, true>), grid, dim3(256), lds, st, a);
+    } else if (p.mr == 4 && p.ng == 2) {
         if (fused) hipLaunchKernelGGL((wino_wgrad_kernel<true, 4, 2>), grid, dim3(512), lds, st, a);
         else hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 2>), grid, dim3(512), lds, st, a);
     } else if (p.mr == 4) {
@@ -545,4 +576,13 @@ extern "C" int dc_wino3x3_wgrad(const float* x, const float* gy, float* dweight,
         return rc != DC_OK ? rc : conv_wreduce((const float*)ws, nullptr, dweight, nullptr, sp, Co * Ci * 9, 0, (hipStream_t)stream);
     }
     return wg_launch(x, Ci, 0, nullptr, 0, PAD_ZERO, false, gy, dweight, ws, B, Co, H, W, (hipStream_t)stream);
+}
+
+/* the weight gradient with the input's BatchNorm + ReLU re-formed in the loader (dc_bn_fold.in_scale / in_shift; fp32 policy) */
+extern "C" int dc_wino3x3_wgrad_bn(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int H, int W,
+                                   const dc_bn_fold* bn, void* stream) {
+    if (!bn || !bn->in_scale) return dc_wino3x3_wgrad(x, gy, dweight, ws, B, Ci, Co, H, W, stream);
+    if (!x || !gy || !dweight || !ws || B <= 0 || Ci <= 0 || Co <= 0 || H < 1 || W < 2 || (W & 1)) return DC_EINVAL;
+    if (matrix_precision() == DC_PREC_BF16 && c3b_eligible(Ci, 0, 0, H, W, 1)) return DC_EINVAL;
+    return wg_launch(x, Ci, 0, nullptr, 0, PAD_ZERO, false, gy, dweight, ws, B, Co, H, W, (hipStream_t)stream, bn);
 }

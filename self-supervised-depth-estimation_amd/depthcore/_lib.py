@@ -125,6 +125,12 @@ def _sig(lib):
         "dc_conv1x1_fwd_bn": (i, [p, p, p, i, i, i, i, i, i, POINTER(BnFold), p]),
         "dc_conv1x1_dgrad_bn": (i, [p, p, p, p, i, i, i, i, i, i, POINTER(BnFold), p]),
         "dc_conv1x1_wgrad_bn": (i, [p, p, p, p, i, i, i, i, i, i, POINTER(BnFold), p]),
+        "dc_wino3x3_bn_ok": (i, [i, i, i, i, i, i]),
+        "dc_wino3x3_stat_parts": (i, [i, i, i, i, i, i, POINTER(c_int)]),
+        "dc_wino3x3_bwd_parts": (i, [i, i, i, i, i, i, POINTER(c_int)]),
+        "dc_wino3x3_fwd_bn": (i, [p, p, p, p, i, i, i, i, i, POINTER(BnFold), p]),
+        "dc_wino3x3_dgrad_bn": (i, [p, p, p, p, p, i, i, i, i, i, POINTER(BnFold), p]),
+        "dc_wino3x3_wgrad_bn": (i, [p, p, p, p, i, i, i, i, i, POINTER(BnFold), p]),
         "dc_maxpool3x3s2_fwd": (i, [p, p, p, i, i, i, p]),
         "dc_maxpool3x3s2_bwd": (i, [p, p, p, i, i, i, p]),
         "dc_wino3x3_workspace": (z, [i, i, i, i, i]),

@@ -85,7 +85,7 @@ def _bwd_finish(L, xx, gp, bwd, gamma, tab, groups, slots):
 
 class _Cfg:
     """non-tensor arguments of the folded ops (one object, so that the autograd signatures stay short)"""
-    __slots__ = ("stride", "groups", "fork", "in_stats", "bn", "prev", "want_stats", "relu", "res_fork", "leave_link",
+    __slots__ = ("kind", "stride", "groups", "fork", "in_stats", "bn", "prev", "want_stats", "relu", "res_fork", "leave_link",
                  "out_stats", "out_link")      # the last two are written by the forward (read by the wrapper right after apply)
 
     def __init__(self, **kw):
@@ -99,17 +99,86 @@ def _bn_buffers(bn):
 
 
 # ----------------------------------------------------------------------------------------------
-# 1x1 convolution with the fold: [relu(bn(x)) in the loader] -> conv -> [statistics epilogue]
+# convolution with the fold: [relu(bn(x)) in the loader] -> conv -> [statistics epilogue]; the backward's data gradient carries
+# the BatchNorm-backward epilogue.  kind "g1": 1x1 on the tiled GEMMs (dc_conv1x1_*_bn); "wino": stride-1 3x3 (dc_wino3x3_*_bn)
 # ----------------------------------------------------------------------------------------------
-class _Conv1x1F(torch.autograd.Function):
+class _K1:
+    """1x1 (stride 1 / 2) on the tiled GEMM kernels"""
+    @staticmethod
+    def out_hw(Hi, Wi, s_):
+        return Hi // s_, Wi // s_
+
+    @staticmethod
+    def stat_parts(L, B, Ci, Co, Hi, Wi, s_, groups, ppg):
+        return L.dc_conv1x1_stat_parts(B, Ci, Co, Hi, Wi, s_, groups, ppg)
+
+    @staticmethod
+    def bwd_parts(L, B, Ci, Co, Hi, Wi, s_, groups, ppg):
+        return L.dc_conv1x1_bwd_parts(B, Ci, Co, Hi, Wi, groups, ppg) if s_ == 1 else 0
+
+    @staticmethod
+    def fwd(L, xx, ww, y, B, Ci, Co, Hi, Wi, s_, f):
+        check(L.dc_conv1x1_fwd_bn(ptr(xx), ptr(ww), ptr(y), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(xx)), "dc_conv1x1_fwd_bn")
+
+    @staticmethod
+    def dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f):
+        check(L.dc_conv1x1_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ptr(add), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(gx)),
+              "dc_conv1x1_dgrad_bn")
+
+    @staticmethod
+    def wgrad(L, xx, g_c, gw, B, Ci, Co, Hi, Wi, s_, f):
+        ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
+        check(L.dc_conv1x1_wgrad_bn(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(xx)),
+              "dc_conv1x1_wgrad_bn")
+
+
+class _KW:
+    """stride-1 3x3, zero padding 1: fused Winograd on the fp32 matrix cores"""
+    @staticmethod
+    def out_hw(Hi, Wi, s_):
+        return Hi, Wi
+
+    @staticmethod
+    def stat_parts(L, B, Ci, Co, Hi, Wi, s_, groups, ppg):
+        return L.dc_wino3x3_stat_parts(B, Ci, Co, Hi, Wi, groups, ppg)
+
+    @staticmethod
+    def bwd_parts(L, B, Ci, Co, Hi, Wi, s_, groups, ppg):
+        return L.dc_wino3x3_bwd_parts(B, Ci, Co, Hi, Wi, groups, ppg)
+
+    @staticmethod
+    def fwd(L, xx, ww, y, B, Ci, Co, Hi, Wi, s_, f):
+        ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, Hi, Wi), dtype=torch.uint8, device=xx.device)
+        check(L.dc_wino3x3_fwd_bn(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, Hi, Wi, ctypes.byref(f), stream(xx)), "dc_wino3x3_fwd_bn")
+
+    @staticmethod
+    def dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f):
+        ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, Hi, Wi), dtype=torch.uint8, device=gx.device)
+        check(L.dc_wino3x3_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ptr(add), ws.data_ptr(), B, Ci, Co, Hi, Wi, ctypes.byref(f), stream(gx)),
+              "dc_wino3x3_dgrad_bn")
+
+    @staticmethod
+    def wgrad(L, xx, g_c, gw, B, Ci, Co, Hi, Wi, s_, f):
+        ws = torch.empty(L.dc_wino3x3_wgrad_workspace(B, Ci, Co, Hi, Wi), dtype=torch.uint8, device=xx.device)
+        check(L.dc_wino3x3_wgrad_bn(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, ctypes.byref(f), stream(xx)),
+              "dc_wino3x3_wgrad_bn")
+
+
+_KINDS = {"g1": _K1, "wino": _KW}
+
+
+class _ConvF(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, cfg):
         L = _lib.lib()
+        K = _KINDS[cfg.kind]
         xx, ww = _c(x.detach()), _c(weight.detach())
         B, Ci, Hi, Wi = xx.shape
         Co, s_, groups = ww.shape[0], cfg.stride, cfg.groups
-        if ww.numel() != Co * Ci:
-            raise _lib.DepthcoreError("1x1 weight %s does not match %d input channels" % (tuple(ww.shape), Ci))
+        if ww.shape[1] != Ci:
+            raise _lib.DepthcoreError("weight %s does not match %d input channels" % (tuple(ww.shape), Ci))
+        if cfg.kind == "wino":
+            _ops._use_precision(_lib.PREC_F32)       # (the fold is an fp32-policy path; the callers check the policy)
         fold_in = gamma is not None
         f = BnFold()
         f.groups = groups
@@ -119,22 +188,22 @@ class _Conv1x1F(torch.autograd.Function):
             tab = _finalize(L, xx, cfg.in_stats, g, _c(beta.detach()), *_bn_buffers(cfg.bn), groups)
             f.in_scale, f.in_shift = tab[2].data_ptr(), tab[3].data_ptr()
             _ops._record_kink("relu", lambda: _materialize(xx, tab, groups))
-        y = torch.empty(B, Co, Hi // s_, Wi // s_, dtype=torch.float32, device=xx.device)
-        part = None
+        Ho, Wo = K.out_hw(Hi, Wi, s_)
+        y = torch.empty(B, Co, Ho, Wo, dtype=torch.float32, device=xx.device)
         if cfg.want_stats:
             ppg = _ival()
-            nparts = L.dc_conv1x1_stat_parts(B, Ci, Co, Hi, Wi, s_, groups, ctypes.byref(ppg))
+            nparts = K.stat_parts(L, B, Ci, Co, Hi, Wi, s_, groups, ctypes.byref(ppg))
             if nparts:
                 part = torch.empty(Co * nparts * 2, dtype=torch.float32, device=xx.device)
                 f.stat_part = part.data_ptr()
                 cfg.out_stats = BNStats(part, nparts, ppg.value, groups)
-        check(L.dc_conv1x1_fwd_bn(ptr(xx), ptr(ww), ptr(y), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(xx)), "dc_conv1x1_fwd_bn")
+        K.fwd(L, xx, ww, y, B, Ci, Co, Hi, Wi, s_, f)
         prev = cfg.prev if (cfg.prev is not None and x.requires_grad and cfg.fork is not None and not cfg.fork.pair) else None
         if prev is not None:
             prev.armed = True
         ctx.save_for_backward(xx, ww, g, tab, prev.x if prev is not None else None, prev.mean if prev is not None else None,
                               prev.mask if prev is not None else None)
-        ctx.cfg = (s_, groups, fold_in)
+        ctx.cfg = (s_, groups, fold_in, cfg.kind)
         ctx.prev = prev
         ctx.slots = (_ops._slot(weight), _ops._slot(gamma) if fold_in else None, _ops._slot(beta) if fold_in else None)
         ctx.param = _ops._lane_param(ctx, 1, weight)
@@ -146,9 +215,12 @@ class _Conv1x1F(torch.autograd.Function):
         L = _lib.lib()
         xx, ww, g, tab, px, pmean, pmask = ctx.saved_tensors
         B, Ci, Hi, Wi = xx.shape
-        s_, groups, fold_in = ctx.cfg
+        s_, groups, fold_in, kind = ctx.cfg
+        K = _KINDS[kind]
         Co = ww.shape[0]
         g_c = _c(gy)
+        if kind == "wino":
+            _ops._use_precision(_lib.PREC_F32)
         gx = gw = dgamma = dbeta = None
         fork = ctx.fork
         first_of_pair = fork is not None and fork.pair and fork.arrive() == 0
@@ -163,7 +235,7 @@ class _Conv1x1F(torch.autograd.Function):
             gx = torch.empty_like(xx)
             if fold_in or ctx.prev is not None:
                 ppg = _ival()
-                nparts = L.dc_conv1x1_bwd_parts(B, Ci, Co, Hi, Wi, groups, ctypes.byref(ppg))
+                nparts = K.bwd_parts(L, B, Ci, Co, Hi, Wi, s_, groups, ctypes.byref(ppg))
                 if not nparts:
                     raise _lib.DepthcoreError("BatchNorm fold: no backward epilogue for %s" % (tuple(xx.shape),))
                 bpart = torch.empty(Ci * nparts * 2, dtype=torch.float32, device=xx.device)
@@ -174,8 +246,7 @@ class _Conv1x1F(torch.autograd.Function):
                     f.in_scale, f.in_shift = tab[2].data_ptr(), tab[3].data_ptr()
                 else:
                     f.bn_x, f.bn_mean, f.bn_mask = px.data_ptr(), pmean.data_ptr(), pmask.data_ptr()
-            check(L.dc_conv1x1_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ptr(add), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(xx)),
-                  "dc_conv1x1_dgrad_bn")
+            K.dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f)
             if first_of_pair:
                 fork.park(gx)
                 gx = None
@@ -192,9 +263,7 @@ class _Conv1x1F(torch.autograd.Function):
                 reads.append(tab)
             with _ops.WgradLanes.lane(ctx.param, *reads):
                 gw = _ops._grad_dst(ctx.slots[0], ww)
-                ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
-                check(L.dc_conv1x1_wgrad_bn(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, ctypes.byref(fw), stream(xx)),
-                      "dc_conv1x1_wgrad_bn")
+                K.wgrad(L, xx, g_c, gw, B, Ci, Co, Hi, Wi, s_, fw)
         if fold_in and gx is not None:
             gx, dgamma, dbeta = _bwd_finish(L, xx, gx, bwd, g, tab, groups, ctx.slots[1:])
         return gx, gw, dgamma, dbeta, None
@@ -219,13 +288,32 @@ def conv1x1_ok(conv, xshape, groups):
             and L.dc_conv1x1_bwd_parts(B, Ci, conv.out_channels, Hi, Wi, groups, None) > 0)
 
 
+def wino_ok(conv, xshape, groups):
+    """Forward and data gradient of this stride-1 3x3 convolution take the fold with a BatchNorm on its input."""
+    B, Ci, Hi, Wi = xshape
+    _ops._use_precision(_lib.PREC_F32)      # (the query below looks at the calling thread's policy; the callers run the fp32 one)
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is None and conv.in_channels == Ci and Wi % 2 == 0 and (Hi * Wi) % 4 == 0
+            and max(B * Ci * Hi * Wi, B * conv.out_channels * Hi * Wi) * 4 < 0x7fffffff
+            and bool(_lib.lib().dc_wino3x3_bn_ok(B, Ci, conv.out_channels, Hi, Wi, groups)))
+
+
+def _conv(kind, x, weight, stride, groups, fork, in_bn, in_stats, prev, want_stats):
+    cfg = _Cfg(kind=kind, stride=int(stride), groups=int(groups), fork=fork, in_stats=in_stats, bn=in_bn, prev=prev, want_stats=want_stats)
+    y = _ConvF.apply(x, weight, in_bn.weight if in_bn is not None else None, in_bn.bias if in_bn is not None else None, cfg)
+    return y, cfg.out_stats
+
+
 def conv1x1(x, weight, stride=1, groups=1, fork=None, in_bn=None, in_stats=None, prev=None, want_stats=True):
     """y_raw, BNStats-or-None = conv1x1([relu(in_bn(x))]).  `in_bn`: the nn.BatchNorm2d (training mode) in front of this convolution
     whose ReLU-ed output has no other consumer -- x is then that BatchNorm's RAW input and `in_stats` its statistics partials
     (None: a stand-alone statistics pass).  `prev`: BNLink of the block output x.  `fork`: GradFork."""
-    cfg = _Cfg(stride=int(stride), groups=int(groups), fork=fork, in_stats=in_stats, bn=in_bn, prev=prev, want_stats=want_stats)
-    y = _Conv1x1F.apply(x, weight, in_bn.weight if in_bn is not None else None, in_bn.bias if in_bn is not None else None, cfg)
-    return y, cfg.out_stats
+    return _conv("g1", x, weight, stride, groups, fork, in_bn, in_stats, prev, want_stats)
+
+
+def conv3x3(x, weight, groups=1, fork=None, in_bn=None, in_stats=None, prev=None, want_stats=True):
+    """The same for F.conv2d(x, weight, None, 1, 1) on the Winograd kernels (even width)."""
+    return _conv("wino", x, weight, 1, groups, fork, in_bn, in_stats, prev, want_stats)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -305,8 +393,13 @@ def take_link(x, conv, groups):
     if link is None or link.groups != groups:
         return None
     B, Ci, Hi, Wi = x.shape
-    if conv.kernel_size == (1, 1):
+    if (Hi * Wi) % 4:
+        ok = False
+    elif conv.kernel_size == (1, 1):
         ok = conv.stride == (1, 1) and _lib.lib().dc_conv1x1_bwd_parts(B, Ci, conv.out_channels, Hi, Wi, groups, None) > 0
+    elif conv.kernel_size == (3, 3):
+        ok = (conv.stride == (1, 1) and conv.padding == (1, 1) and Wi % 2 == 0
+              and _lib.lib().dc_wino3x3_bwd_parts(B, Ci, conv.out_channels, Hi, Wi, groups, None) > 0)
     else:
         ok = False
     return link if ok else None

@@ -116,9 +116,45 @@ class BasicBlock(nn.Module):
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
+        self.link_out = False      # set by ResNetTrunk: the NEXT block of the stage is this block output's only consumer
+
+    def _fold_ok(self, x, g):
+        """The folded chain applies: fp32 training step on the GPU, conv2 on the Winograd kernels with both epilogues."""
+        if not (BN_FOLD and WINO_TRUNK and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and _ops._precision[0] == _ops.PRECISIONS["f32"]):
+            return False
+        B, _, H, W = x.shape
+        s = self.conv1.stride[0]
+        if self.conv1.stride not in ((1, 1), (2, 2)) or H % s or W % s or B % g:
+            return False
+        return _bnf.wino_ok(self.conv2, (B, self.conv2.in_channels, H // s, W // s), g)
+
+    def _forward_fold(self, x, g):
+        """conv1 (statistics epilogue; the previous block's BatchNorm backward in its data-gradient epilogue) -> [bn1 + ReLU
+        inside conv2's loader] conv2 (statistics epilogue) -> relu(bn2 + skip), one apply pass."""
+        fork = _fork_for(self, x)
+        if fork is not None and _bnf.wino_ok(self.conv1, tuple(x.shape), g):
+            y1, s1 = _bnf.conv3x3(x, self.conv1.weight, g, fork=fork, prev=_bnf.take_link(x, self.conv1, g))
+        elif fork is None and self.conv1.stride == (1, 1) and _bnf.wino_ok(self.conv1, tuple(x.shape), g):
+            y1, s1 = _bnf.conv3x3(x, self.conv1.weight, g)
+        else:
+            y1, s1 = _conv(self.conv1, x, fork), None           # (3x3 / 2: no statistics epilogue yet -- a stand-alone pass)
+        y2, s2 = _bnf.conv3x3(y1, self.conv2.weight, g, in_bn=self.bn1, in_stats=s1)
+        if self.downsample is None:
+            return _bnf.bn_apply(y2, self.bn2, s2, res=x, groups=g, fork=fork, leave_link=self.link_out)
+        d = self.downsample[0]
+        if (GEMM_1X1 and d.kernel_size == (1, 1) and d.padding == (0, 0) and d.groups == 1 and d.bias is None and d.stride in ((1, 1), (2, 2))
+                and (d.stride == (1, 1) or (x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0))):
+            yd, sd = _bnf.conv1x1(x, d.weight, d.stride[0], g)            # statistics epilogue on the tiled shapes
+        else:
+            yd, sd = _conv(d, x), None
+        idt = _bnf.bn_apply(yd, self.downsample[1], sd, relu=False, groups=g)
+        return _bnf.bn_apply(y2, self.bn2, s2, res=idt, groups=g, leave_link=self.link_out)
 
     def forward(self, x):
         g = self._g[0]
+        if self._fold_ok(x, g):
+            return self._forward_fold(x, g)
         idt = x if self.downsample is None else _bn_act(_conv(self.downsample[0], x), self.downsample[1], relu=False, groups=g)
         fork = _fork_for(self, x)
         out = _bn_act(_conv(self.conv1, x, fork), self.bn1, groups=g)
@@ -162,9 +198,11 @@ class Bottleneck(nn.Module):
         else:
             fork, prev = _pair_fork_for(self, x), None
         y1, s1 = _bnf.conv1x1(x, self.conv1.weight, 1, g, fork=fork, prev=prev)
-        a1 = _bnf.bn_apply(y1, self.bn1, s1, groups=g)
-        y2 = _conv(self.conv2, a1)
-        y3, s3 = _bnf.conv1x1(y2, self.conv3.weight, 1, g, in_bn=self.bn2)
+        if WINO_TRUNK and _bnf.wino_ok(self.conv2, tuple(y1.shape), g):
+            y2, s2 = _bnf.conv3x3(y1, self.conv2.weight, g, in_bn=self.bn1, in_stats=s1)     # bn1 + ReLU inside conv2's loader
+        else:
+            y2, s2 = _conv(self.conv2, _bnf.bn_apply(y1, self.bn1, s1, groups=g)), None      # (3x3 / 2: apply pass, stand-alone statistics)
+        y3, s3 = _bnf.conv1x1(y2, self.conv3.weight, 1, g, in_bn=self.bn2, in_stats=s2)
         if self.downsample is None:
             return _bnf.bn_apply(y3, self.bn3, s3, res=x, groups=g, fork=fork, leave_link=self.link_out)
         d = self.downsample[0]

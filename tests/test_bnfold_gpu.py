@@ -106,3 +106,80 @@ def test_encoder_fold_vs_unfolded_chain(num_layers, groups):
         close(runs[True][2][k], runs[False][2][k], rtol=1e-4, atol=1e-6)
     worst = max((rel_l2(a, b), n) for a, b, n in zip(runs[True][1], runs[False][1], runs[True][3]))
     assert worst[0] < 2e-3, worst
+
+
+@pytest.mark.parametrize("B,Ci,Cm,Co,H,W,groups", [(4, 64, 64, 64, 16, 32, 1), (4, 64, 32, 64, 12, 20, 2), (2, 128, 128, 128, 24, 40, 1),
+                                                   (12, 64, 64, 64, 48, 160, 1)])
+def test_conv3x3_bn_relu_conv3x3_chain_vs_torch(B, Ci, Cm, Co, H, W, groups):
+    """The Winograd flavour of the chain: conv A 3x3 (statistics epilogue) -> [bn + relu in conv B's loader, zero padding kept
+    zero] -> conv B 3x3 (statistics epilogue) -> bn + relu; every gradient incl. the one-pass BatchNorm backward."""
+    from depthcore import bnfold
+    g = torch.Generator().manual_seed(B * 1000 + Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    wa = torch.randn(Cm, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    wb = torch.randn(Co, Cm, 3, 3, generator=g) / (9 * Cm) ** 0.5
+    cot = torch.randn(B, Co, H, W, generator=g)
+    bn1r, bn2r = _bn(Cm, g), _bn(Co, g)
+    bn1h, bn2h = nn.BatchNorm2d(Cm).to(DEV), nn.BatchNorm2d(Co).to(DEV)
+    bn1h.load_state_dict(bn1r.state_dict()); bn2h.load_state_dict(bn2r.state_dict())
+    xr, war, wbr = x.clone().requires_grad_(), wa.clone().requires_grad_(), wb.clone().requires_grad_()
+    outs = []
+    n = B // groups
+    for k in range(groups):
+        a = F.relu(bn1r(F.conv2d(xr[k * n:(k + 1) * n], war, padding=1)))
+        outs.append(F.relu(bn2r(F.conv2d(a, wbr, padding=1))))
+    yr = torch.cat(outs, 0)
+    gr = torch.autograd.grad((yr * cot).sum(), [xr, war, wbr, bn1r.weight, bn1r.bias, bn2r.weight, bn2r.bias])
+    xh = x.to(DEV).requires_grad_()
+    wah, wbh = wa.to(DEV).requires_grad_(), wb.to(DEV).requires_grad_()
+    ya, sa = bnfold.conv3x3(xh, wah, groups)
+    yb, sb = bnfold.conv3x3(ya, wbh, groups, in_bn=bn1h, in_stats=sa)
+    yh = bnfold.bn_apply(yb, bn2h, sb, groups=groups)
+    gh = torch.autograd.grad((yh * cot.to(DEV)).sum(), [xh, wah, wbh, bn1h.weight, bn1h.bias, bn2h.weight, bn2h.bias])
+    close(yh, yr, rtol=3e-4, atol=3e-5)
+    for bh, br in ((bn1h, bn1r), (bn2h, bn2r)):
+        close(bh.running_mean, br.running_mean, rtol=1e-5, atol=1e-6)
+        close(bh.running_var, br.running_var, rtol=1e-4, atol=1e-6)
+    for a, b, name in zip(gh, gr, ["dx", "dwa", "dwb", "dg1", "db1", "dg2", "db2"]):
+        assert rel_l2(a, b) < 5e-4, (name, rel_l2(a, b))
+
+
+@pytest.mark.parametrize("kind", ["g1", "wino"])
+def test_block_output_link_moves_the_backward_statistics_into_the_consumer(kind):
+    """y = relu(bn(x) + skip) with ONE consumer (conv + the skip, joined by a GradFork): the consumer's data-gradient epilogue
+    masks with the bit mask and takes the backward partials; gradients equal the unlinked chain's."""
+    from depthcore import bnfold, ops
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = 4, 64, 16, 32
+    x0 = torch.randn(B, C, H, W, generator=g).to(DEV)
+    skip0 = torch.randn(B, C, H, W, generator=g).to(DEV)
+    k = 1 if kind == "g1" else 3
+    w0 = (torch.randn(C, C, k, k, generator=g) / (C * k * k) ** 0.5).to(DEV)
+    cot = torch.randn(B, C, H, W, generator=g).to(DEV)
+    res = {}
+    for linked in (True, False):
+        torch.manual_seed(0)
+        bn_a, bn_b = nn.BatchNorm2d(C).to(DEV), nn.BatchNorm2d(C).to(DEV)
+        with torch.no_grad():
+            bn_a.weight.uniform_(0.5, 1.5); bn_a.bias.normal_(0, 0.3)
+        x, skip, w = x0.clone().requires_grad_(), skip0.clone().requires_grad_(), w0.clone().requires_grad_()
+        y = bnfold.bn_apply(x, bn_a, None, res=skip, leave_link=linked)          # block k output
+        fork = ops.GradFork()
+        conv = nn.Conv2d(C, C, k, 1, k // 2, bias=False)
+        link = bnfold.take_link(y, conv, 1)
+        assert (link is not None) == linked
+        if kind == "g1":
+            z, sz = bnfold.conv1x1(y, w, 1, 1, fork=fork, prev=link)
+        else:
+            z, sz = bnfold.conv3x3(y, w, 1, fork=fork, prev=link)
+        out = bnfold.bn_apply(z, bn_b, sz, res=y, fork=fork)                     # block k+1: relu(bn(conv(y)) + y)
+        grads = torch.autograd.grad((out * cot).sum(), [x, skip, w, bn_a.weight, bn_a.bias])
+        res[linked] = (out.detach(), grads)
+    close(res[True][0], res[False][0], rtol=0, atol=0)
+    for a, b, name in zip(res[True][1], res[False][1], ["dx", "dskip", "dw", "dgamma", "dbeta"]):
+        assert rel_l2(a, b) < 2e-5, (name, rel_l2(a, b))
+
+
+@pytest.mark.parametrize("num_layers,groups", [(18, 1), (18, 2), (34, 1)])
+def test_basicblock_encoder_fold_vs_unfolded_chain(num_layers, groups):
+    test_encoder_fold_vs_unfolded_chain(num_layers, groups)
