@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
         const int ssub = min(tblk * G + (G == 1 ? 0 : (wave >> 1)), a.nsub - 1);
         bn_gofs = __builtin_amdgcn_readfirstlane((fdiv(ssub, a.mg_per_img) / a.npg) * a.K);
     }
+    const bool bn_inside = svoff != 0x80000000u;
     const int shift = 2 - P;                          // slab column of the pair's first element = 2 scp - shift
     const int slds0 = sg_ * SUBS + sr * RS + max(2 * scp - shift, 0), slds1 = sg_ * SUBS + sr * RS + 2 * scp + 1 - shift;
     const wrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
@@ -315,19 +316,30 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
             }
         }
     };
+    // MODE 1: scale / shift of the chunk that is committed next (wave-uniform addresses: scalar loads), requested one compute
+    // phase ahead of their use
+    float bnsc[MODE == 1 ? PK : 1], bnsh[MODE == 1 ? PK : 1];
+    auto load_bn = [&](int c) {
+        if constexpr (MODE == 1) {
+            const int ch0 = min(c * PSK + kh0, a.K - PK);
+#pragma unroll
+            for (int k = 0; k < PK; ++k) { bnsc[k] = a.in_scale[bn_gofs + ch0 + k]; bnsh[k] = a.in_shift[bn_gofs + ch0 + k]; }
+        }
+    };
     auto commit_x = [&](int buf, const f2w* src, int c) {
         if (swr) {
             float* xw = xl[buf];
             const bool dup = FUSED && up0 && c * PSK < C0;        // chunk of the nearest-x2 upsampled source: one value, two columns
             if constexpr (MODE == 1) {
-                const bool inside = svoff != 0x80000000u;        // (zero padding and the lanes outside the item list stay 0)
+                // (threads whose pair lies outside the image -- zero padding, lanes past the item list -- zeroed their slab
+                // positions once, in the prologue, and store nothing here; K % PSK == 0, host-checked)
+                if (bn_inside) {
 #pragma unroll
-                for (int k = 0; k < PK; ++k) {
-                    const int ch = c * PSK + kh0 + k, chc = min(ch, a.K - 1);
-                    const float sc = a.in_scale[bn_gofs + chc], sh = a.in_shift[bn_gofs + chc];
-                    const bool ok = inside && ch < a.K;
-                    xw[(kh0 + k) * CPS + slds0] = ok ? fmaxf(fmaf(src[k].x, sc, sh), 0.f) : 0.f;
-                    xw[(kh0 + k) * CPS + slds1] = ok ? fmaxf(fmaf(src[k].y, sc, sh), 0.f) : 0.f;
+                    for (int k = 0; k < PK; ++k) {
+                        const f2w v = src[k] * f2w{bnsc[k], bnsc[k]} + f2w{bnsh[k], bnsh[k]};
+                        xw[(kh0 + k) * CPS + slds0] = fmaxf(v.x, 0.f);
+                        xw[(kh0 + k) * CPS + slds1] = fmaxf(v.y, 0.f);
+                    }
                 }
             } else {
 #pragma unroll
@@ -379,6 +391,16 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     const int grid = gridDim.x;
     const bool persist = PERSIST && grid < a.items;  // (host: gridDim.z == 1, nloc even and >= 4; PERSIST instantiations only)
     int round = 0;
+    if constexpr (MODE == 1) {
+        if (swr && !bn_inside) {
+#pragma unroll
+            for (int k = 0; k < PK; ++k) {
+                xl[0][(kh0 + k) * CPS + slds0] = 0.f; xl[0][(kh0 + k) * CPS + slds1] = 0.f;
+                xl[1][(kh0 + k) * CPS + slds0] = 0.f; xl[1][(kh0 + k) * CPS + slds1] = 0.f;
+            }
+        }
+        load_bn(c_begin);
+    }
     if (nloc > 0) {
         load_x(svoff, svoff1, c_begin, px[0]);
         if (nloc > 1) load_x(svoff, svoff1, c_begin + 1, px[1]);
@@ -412,6 +434,7 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
     auto step = [&](int i, f2w* pxn, f4 (*ucur)[MR], f4 (*unxt)[MR]) {   // pxn holds x of chunk i+1
         const bool more = i + 1 < nloc;
         if (more || has_next) load_u(more ? mblk : mblk_n, more ? c_begin + i + 1 : c_begin, unxt);
+        if (more) load_bn(c_begin + i + 1);
         DIAG_T(0, compute(i & 1, ucur));
         if (more) {
             DIAG_T(1, commit_x((i + 1) & 1, pxn, c_begin + i + 1); DIAG_WAIT());
@@ -857,7 +880,7 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
             a.bwd_nparts = 2 * ceil_div(pl.nsub, G) * G;
             mode = bn->bn_mask ? 3 : 2;
         } else if (bn->in_scale) {
-            if (!bn->in_shift) return DC_EINVAL;
+            if (!bn->in_shift || K % PSK) return DC_EINVAL;
             mode = 1;
         }
         if (bn->stat_part) {
@@ -1225,7 +1248,7 @@ extern "C" int dc_wino3x3_bwd_parts(int B, int Ci, int Co, int H, int W, int gro
     return wino_parts(B, Co, Ci, H, W, groups, true, Ci, Co, ppg);
 }
 extern "C" int dc_wino3x3_bn_ok(int B, int Ci, int Co, int H, int W, int groups) {
-    return groups >= 1 && groups <= 2 && B % groups == 0 && wino_bn_path(B, Ci, Co, H, W, false) && wino_bn_path(B, Ci, Co, H, W, true) &&
+    return groups >= 1 && groups <= 2 && B % groups == 0 && Ci % PSK == 0 && wino_bn_path(B, Ci, Co, H, W, false) && wino_bn_path(B, Ci, Co, H, W, true) &&
            dc_wino3x3_bwd_parts(B, Ci, Co, H, W, groups, nullptr) > 0;
 }
 extern "C" int dc_wino3x3_fwd_bn(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int H, int W,

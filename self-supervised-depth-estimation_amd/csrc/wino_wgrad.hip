@@ -64,7 +64,8 @@ unsigned long long* wino_diag_ptr();
 // of the block's split with their own LDS slabs, and at the end group 1 hands its q values to group 0 through LDS (the
 // staging slabs are dead by then): one slab write per CU instead of two -- the slabs were 50 MB written and 50 MB read
 // back per launch whatever the layer (512 blocks x 96 KB), ~13 % of the kernel + reduce time -- at the same 8 waves per CU.
-template <bool FUSED, int MR, int NG, bool BNIN = false>
+// BNIN: 0 plain input, 1 BatchNorm + ReLU folded into the loader with one BatchNorm group, 2 with two groups
+template <bool FUSED, int MR, int NG, int BNIN = 0>
 __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
     static_assert(!(FUSED && BNIN), "the BatchNorm fold exists for the plain trunk launches");
     constexpr int KR = WG_KR, MT = 16 * MR, NGQ = MT / 8;       // NGQ: gy channels staged per thread
@@ -112,10 +113,20 @@ __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
 
     f2w pg[NGQ], px[8];
     bool px_ok = false;          // BNIN: the pair requested last lies inside the image (zero padding stays zero)
-    int px_gofs = 0;             //       and (BatchNorm group of its image) * K -- wave-uniform, like the channels: scalar loads
+    int px_grp = 0;              //       and the BatchNorm group of its image (wave-uniform)
+    // BNIN: this wave stages the same 8 channels for the whole kernel: their scale / shift for both groups, read once
+    float bsc[BNIN == 2 ? 2 : 1][BNIN ? 8 : 1], bsh[BNIN == 2 ? 2 : 1][BNIN ? 8 : 1];
+    if constexpr (BNIN != 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int chc = min(kb * WG_KT + wave + 4 * q, a.K - 1);
+            bsc[0][q] = a.in_scale[chc]; bsh[0][q] = a.in_shift[chc];
+            if constexpr (BNIN == 2) { bsc[1][q] = a.in_scale[a.K + chc]; bsh[1][q] = a.in_shift[a.K + chc]; }
+        }
+    }
     auto prefetch = [&](int sub) {
         const int b = fdiv(sub, a.mg_per_img), rq = sub - b * per_img;
-        if constexpr (BNIN) px_gofs = __builtin_amdgcn_readfirstlane((b / a.npg) * a.K);
+        if constexpr (BNIN == 2) px_grp = __builtin_amdgcn_readfirstlane(b / a.npg);
         const int ry = fdiv(rq, a.mg_regs_x), rx = rq - ry * a.regs_x;
         const int Y0 = ry * RH * 2, X0 = rx * RW * 2;
         {
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
                 sx = xx == -2 ? 0 : (xx == W ? W - 2 : xx);
             }
             const bool ok = x_in && sy >= 0 && sy < H && sx >= 0 && sx < W;
-            if constexpr (BNIN) px_ok = ok;
+            if constexpr (BNIN != 0) px_ok = ok;
             const unsigned pix0 = (up0 ? (unsigned)((sy >> 1) * (W >> 1) + (sx >> 1)) : (unsigned)(sy * W + sx)) * 4u;
             const unsigned pix1 = (unsigned)(sy * W + sx) * 4u;
             const int chb = kb * WG_KT + xcg;               // wave-uniform: xcg = wave
@@ -160,14 +171,16 @@ __global__ __launch_bounds__(256 * NG, 2) void wino_wgrad_kernel(WinoWgArgs a) {
             for (int q = 0; q < NGQ; ++q) *reinterpret_cast<f2w*>(gl(buf) + glds + 8 * q * WG_GPS) = pg[q];
         }
         if (x_in) {
-            if constexpr (BNIN) {
+            if constexpr (BNIN != 0) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const int ch = kb * WG_KT + wave + 4 * q, chc = min(ch, a.K - 1);        // (xcg == wave)
-                    const float sc = a.in_scale[px_gofs + chc], sh = a.in_shift[px_gofs + chc];
+                    const int ch = kb * WG_KT + wave + 4 * q;        // (xcg == wave)
+                    float sc = bsc[0][q], sh = bsh[0][q];
+                    if constexpr (BNIN == 2) { sc = px_grp ? bsc[1][q] : sc; sh = px_grp ? bsh[1][q] : sh; }
                     const bool ok = px_ok && ch < a.K;
-                    xl(buf)[xlds0 + 4 * q * WG_XPS] = ok ? fmaxf(fmaf(px[q].x, sc, sh), 0.f) : 0.f;
-                    xl(buf)[xlds1 + 4 * q * WG_XPS] = ok ? fmaxf(fmaf(px[q].y, sc, sh), 0.f) : 0.f;
+                    const f2w v = px[q] * f2w{sc, sc} + f2w{sh, sh};
+                    xl(buf)[xlds0 + 4 * q * WG_XPS] = ok ? fmaxf(v.x, 0.f) : 0.f;
+                    xl(buf)[xlds1 + 4 * q * WG_XPS] = ok ? fmaxf(v.y, 0.f) : 0.f;
                 }
             } else {
 #pragma unroll
@@ -505,7 +518,7 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
 #endif
     const bool bnin = bn && bn->in_scale;
     if (bnin) {
-        if (fused || !bn->in_shift || bn->groups < 1 || B % bn->groups) return DC_EINVAL;
+        if (fused || !bn->in_shift || bn->groups < 1 || bn->groups > 2 || B % bn->groups) return DC_EINVAL;
         a.in_scale = bn->in_scale; a.in_shift = bn->in_shift; a.npg = B / bn->groups;
     }
     const int nmk = p.mblocks * p.kblocks;
@@ -515,15 +528,21 @@ static int wg_launch(const float* x0, int C0, int up0, const float* x1, int C1, 
     static const bool attr = wg_set_lds(wino_wgrad_kernel<true, 4, 1>, wg_lds(4, 1)) && wg_set_lds(wino_wgrad_kernel<false, 4, 1>, wg_lds(4, 1)) &&
                              wg_set_lds(wino_wgrad_kernel<true, 4, 2>, wg_lds(4, 2)) && wg_set_lds(wino_wgrad_kernel<false, 4, 2>, wg_lds(4, 2)) &&
                              wg_set_lds(wino_wgrad_kernel<true, 2, 1>, wg_lds(2, 1)) && wg_set_lds(wino_wgrad_kernel<false, 2, 1>, wg_lds(2, 1)) &&
-                             wg_set_lds(wino_wgrad_kernel<false, 4, 1, true>, wg_lds(4, 1)) && wg_set_lds(wino_wgrad_kernel<false, 4, 2, true>, wg_lds(4, 2)) &&
-                             wg_set_lds(wino_wgrad_kernel<false, 2, 1, true>, wg_lds(2, 1));
+                             wg_set_lds(wino_wgrad_kernel<false, 4, 1, 1>, wg_lds(4, 1)) && wg_set_lds(wino_wgrad_kernel<false, 4, 2, 1>, wg_lds(4, 2)) &&
+                             wg_set_lds(wino_wgrad_kernel<false, 2, 1, 1>, wg_lds(2, 1)) &&
+                             wg_set_lds(wino_wgrad_kernel<false, 4, 1, 2>, wg_lds(4, 1)) && wg_set_lds(wino_wgrad_kernel<false, 4, 2, 2>, wg_lds(4, 2)) &&
+                             wg_set_lds(wino_wgrad_kernel<false, 2, 1, 2>, wg_lds(2, 1));
     if (!attr) return DC_ELAUNCH;
     const dim3 grid(p.splits * nmk);
     const size_t lds = wg_lds(p.mr, p.ng);
-    if (bnin) {
-        if (p.mr == 4 && p.ng == 2) hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 2, true>), grid, dim3(512), lds, st, a);
-        else if (p.mr == 4) hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 1, true>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 2, 1, true>), grid, dim3(256), lds, st, a);
+    if (bnin && bn->groups == 1) {
+        if (p.mr == 4 && p.ng == 2) hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 2, 1>), grid, dim3(512), lds, st, a);
+        else if (p.mr == 4) hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 1, 1>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 2, 1, 1>), grid, dim3(256), lds, st, a);
+    } else if (bnin) {
+        if (p.mr == 4 && p.ng == 2) hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 2, 2>), grid, dim3(512), lds, st, a);
+        else if (p.mr == 4) hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 1, 2>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((wino_wgrad_kernel<false, 2, 1, 2>), grid, dim3(256), lds, st, a);
     } else if (p.mr == 4 && p.ng == 2) {
         if (fused) hipLaunchKernelGGL((wino_wgrad_kernel<true, 4, 2>), grid, dim3(512), lds, st, a);
         else hipLaunchKernelGGL((wino_wgrad_kernel<false, 4, 2>), grid, dim3(512), lds, st, a);

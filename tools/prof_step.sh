@@ -10,16 +10,16 @@ import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "photo_bwd_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "photo_bwdg_kernel" in r["Kernel_Name"]]
 a, b = marks[-2], marks[-1]
 wall = (int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e6
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[a:b]) / 1e6
 print("step wall %.2f ms, kernel busy %.2f ms, %d kernels" % (wall, busy, b - a))
 agg, cnt = collections.Counter(), collections.Counter()
 for r in rows[a:b]:
-    k = r["Kernel_Name"][:64]
+    k = r["Kernel_Name"].replace("void dc::", "").replace("dc::", "")[:64]
     agg[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     cnt[k] += 1
-for k, v in agg.most_common(34):
+for k, v in agg.most_common(48):
     print("%-66s n=%3d %8.1f us" % (k, cnt[k], v))
 PY
