@@ -37,9 +37,17 @@ WINO_TRUNK = True     # stride-1 3x3 trunk convolutions on depthcore's fused Win
 STEM_FUSED = True     # input normalisation (and the pose pairs' concat) inside the stem kernels' loader (dc_stem_*)
 
 
-# BatchNorm passes folded into the neighbouring convolutions (depthcore.bnfold; training mode on the GPU).  DC_BN_FOLD=0: the
-# stand-alone BatchNorm kernels (same-box A/Bs)
-BN_FOLD = os.environ.get("DC_BN_FOLD", "1") != "0"
+# BatchNorm passes folded into the neighbouring convolutions (depthcore.bnfold; training mode on the GPU).  DC_BN_FOLD (same-box
+# A/Bs): 0 = the stand-alone BatchNorm kernels; 1 = statistics from the producing convolution's epilogue only; 2 = + the block
+# outputs' backward statistics in the next block's data-gradient epilogue (BNLink); 3 = + BatchNorm + ReLU with one consumer
+# folded into that convolution's loader.  Unset = "auto" (-1): level 3 for the Bottleneck trunks (resnet50+: -3.0 % of a C3 step,
+# 49.28 -> 47.81 ms same box), level 0 for the BasicBlock trunks (resnet18 at C2: 11.63 / 11.64 ms without, 11.60-11.69 ms at
+# levels 1-3 -- the BatchNorm passes there are 6-11 us each and hide behind the other stream's convolutions)
+BN_FOLD = int(os.environ.get("DC_BN_FOLD", "-1"))
+
+
+def _fold_level(bottleneck):
+    return BN_FOLD if BN_FOLD >= 0 else (3 if bottleneck else 0)
 
 
 GRAD_FORK = True      # residual blocks without a downsample branch: the skip's gradient is added inside conv1's data-gradient kernel
@@ -120,7 +128,7 @@ class BasicBlock(nn.Module):
 
     def _fold_ok(self, x, g):
         """The folded chain applies: fp32 training step on the GPU, conv2 on the Winograd kernels with both epilogues."""
-        if not (BN_FOLD and WINO_TRUNK and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+        if not (_fold_level(False) and WINO_TRUNK and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and _ops._precision[0] == _ops.PRECISIONS["f32"]):
             return False
         B, _, H, W = x.shape
@@ -139,9 +147,14 @@ class BasicBlock(nn.Module):
             y1, s1 = _bnf.conv3x3(x, self.conv1.weight, g)
         else:
             y1, s1 = _conv(self.conv1, x, fork), None           # (3x3 / 2: no statistics epilogue yet -- a stand-alone pass)
-        y2, s2 = _bnf.conv3x3(y1, self.conv2.weight, g, in_bn=self.bn1, in_stats=s1)
+        lvl = _fold_level(False)
+        if lvl >= 3:
+            y2, s2 = _bnf.conv3x3(y1, self.conv2.weight, g, in_bn=self.bn1, in_stats=s1)
+        else:
+            y2, s2 = _bnf.conv3x3(_bnf.bn_apply(y1, self.bn1, s1, groups=g), self.conv2.weight, g)
+        link = self.link_out and lvl >= 2
         if self.downsample is None:
-            return _bnf.bn_apply(y2, self.bn2, s2, res=x, groups=g, fork=fork, leave_link=self.link_out)
+            return _bnf.bn_apply(y2, self.bn2, s2, res=x, groups=g, fork=fork, leave_link=link)
         d = self.downsample[0]
         if (GEMM_1X1 and d.kernel_size == (1, 1) and d.padding == (0, 0) and d.groups == 1 and d.bias is None and d.stride in ((1, 1), (2, 2))
                 and (d.stride == (1, 1) or (x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0))):
@@ -149,7 +162,7 @@ class BasicBlock(nn.Module):
         else:
             yd, sd = _conv(d, x), None
         idt = _bnf.bn_apply(yd, self.downsample[1], sd, relu=False, groups=g)
-        return _bnf.bn_apply(y2, self.bn2, s2, res=idt, groups=g, leave_link=self.link_out)
+        return _bnf.bn_apply(y2, self.bn2, s2, res=idt, groups=g, leave_link=link)
 
     def forward(self, x):
         g = self._g[0]
@@ -180,7 +193,7 @@ class Bottleneck(nn.Module):
     def _fold_ok(self, x, g):
         """The folded chain applies: training step on the GPU, every 1x1 of the block on the tiled GEMM kernels with both
         epilogues, fp32 matrix precision."""
-        if not (BN_FOLD and GEMM_1X1 and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+        if not (_fold_level(True) and GEMM_1X1 and self.training and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and _ops._precision[0] == _ops.PRECISIONS["f32"] and x.numel() * 4 < 0x7fffffff):
             return False
         B, _, H, W = x.shape
@@ -198,17 +211,25 @@ class Bottleneck(nn.Module):
         else:
             fork, prev = _pair_fork_for(self, x), None
         y1, s1 = _bnf.conv1x1(x, self.conv1.weight, 1, g, fork=fork, prev=prev)
-        if WINO_TRUNK and _bnf.wino_ok(self.conv2, tuple(y1.shape), g):
+        lvl = _fold_level(True)
+        wino2 = WINO_TRUNK and _bnf.wino_ok(self.conv2, tuple(y1.shape), g)
+        if wino2 and lvl >= 3:
             y2, s2 = _bnf.conv3x3(y1, self.conv2.weight, g, in_bn=self.bn1, in_stats=s1)     # bn1 + ReLU inside conv2's loader
+        elif wino2:
+            y2, s2 = _bnf.conv3x3(_bnf.bn_apply(y1, self.bn1, s1, groups=g), self.conv2.weight, g)
         else:
             y2, s2 = _conv(self.conv2, _bnf.bn_apply(y1, self.bn1, s1, groups=g)), None      # (3x3 / 2: apply pass, stand-alone statistics)
-        y3, s3 = _bnf.conv1x1(y2, self.conv3.weight, 1, g, in_bn=self.bn2, in_stats=s2)
+        if lvl >= 3:
+            y3, s3 = _bnf.conv1x1(y2, self.conv3.weight, 1, g, in_bn=self.bn2, in_stats=s2)
+        else:
+            y3, s3 = _bnf.conv1x1(_bnf.bn_apply(y2, self.bn2, s2, groups=g), self.conv3.weight, 1, g)
+        link = self.link_out and lvl >= 2
         if self.downsample is None:
-            return _bnf.bn_apply(y3, self.bn3, s3, res=x, groups=g, fork=fork, leave_link=self.link_out)
+            return _bnf.bn_apply(y3, self.bn3, s3, res=x, groups=g, fork=fork, leave_link=link)
         d = self.downsample[0]
         yd, sd = _bnf.conv1x1(x, d.weight, d.stride[0], g, fork=fork)
         idt = _bnf.bn_apply(yd, self.downsample[1], sd, relu=False, groups=g)
-        return _bnf.bn_apply(y3, self.bn3, s3, res=idt, groups=g, leave_link=self.link_out)
+        return _bnf.bn_apply(y3, self.bn3, s3, res=idt, groups=g, leave_link=link)
 
     def forward(self, x):
         g = self._g[0]
