@@ -436,6 +436,20 @@ def run_rank(args):
             ph[i] += (ts[i + 1] - ts[i]) * 1e3 / PH
         del outputs, losses
     packed = tr.buckets.packed
+    # what the step would pay if the data loader did NOT deliver the pixel-interleaved copies: three dc_pack_rgbx launches
+    rgbx_pack_ms = None
+    if ("color_packed", 0, 0) in inputs:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        frames = [inputs[("color", f, 0)] for f in (0, -1, 1)]
+        for _ in range(3):
+            keep = [ops.pack_rgbx(fr) for fr in frames]
+        e0.record()
+        for _ in range(20):
+            keep = [ops.pack_rgbx(fr) for fr in frames]
+        e1.record()
+        torch.cuda.synchronize()
+        rgbx_pack_ms = e0.elapsed_time(e1) / 20.0
+        del keep
 
     # In the timed region the pose and the depth network run on two HIP streams, so a launch's event pair also spans
     # the time it shares the GPU with a kernel of the other stream.  The kernel's own duration (what rocprofv3, which
@@ -571,8 +585,13 @@ def run_rank(args):
                        if tr_bytes("dc::photo_fwdg_kernel") else None,
             "traffic_source": traffic_src, "launches": prof["bwd_launches"],
             "bytes_definition": "SURVEY 8d: forward sum_s 36 N + 16 n_s, backward sum_s 36 N + 20 n_s (fp32, N = B H W)",
-            "forward_chain": dict(chain(bytes_fwd, fwd_chain_ms), **kern("dc::photo_fwdg_kernel", fwd_ms, bytes_fwd, VALU_SLOTS_PER_INST["fwd"])),
-            "backward_chain": dict(chain(bytes_bwd, bwd_chain_ms), **kern("dc::photo_bwdg_kernel", bwd_ms, bytes_bwd, VALU_SLOTS_PER_INST["bwd"])),
+            # (only the PAIR is priced against SURVEY 8d's bytes: since round 4 the backward's window work runs in the forward, so a
+            # per-chain fraction would credit the backward with bytes it no longer moves)
+            "forward_chain": dict({"avg_chain_ms": round(fwd_chain_ms, 4)}, **kern("dc::photo_fwdg_kernel", fwd_ms, bytes_fwd + bytes_bwd, VALU_SLOTS_PER_INST["fwd"])),
+            "backward_chain": dict({"avg_chain_ms": round(bwd_chain_ms, 4)}, **kern("dc::photo_bwdg_kernel", bwd_ms, bytes_fwd + bytes_bwd, VALU_SLOTS_PER_INST["bwd"])),
+            "valu_wave_insts_per_step": (sum(valu(k) or 0 for k in ("dc::identity_kernel", "dc::smooth_fwd_kernel", "dc::photo_fwdg_kernel",
+                                                                     "dc::finalize_kernel", "dc::photo_bwdg_kernel", "dc::disp_grad_kernel"))
+                                         if valu("dc::photo_fwdg_kernel") else None),
             "round3": {"forward_chain_ms": 0.17, "backward_chain_ms": 0.2487, "pair_frac": 0.148,
                        "note": "forward without gradient emission + the window backward (profiles/round3_c2_bench_n1.json)"},
             "limiter": "the training forward is VALU-issue bound (3 waves per SIMD at 145 VGPRs since its loads are issued behind "
@@ -598,6 +617,7 @@ def run_rank(args):
                            "as the device data step delivers them: planar (\"color\", f, s) / (\"color_aug\", f, s) plus the "
                            "pixel-interleaved RGBx copy (\"color_packed\", f, 0) of the three loss frames (dc_data_to_rgbx)"
                            if ("color_packed", 0, 0) in inputs else "planar tensors only (the loss repacks the three frames per step)"),
+                       "rgbx_pack_ms_if_done_inside_the_step": round(rgbx_pack_ms, 4) if rgbx_pack_ms is not None else None,
                        "step_launch": "one hipGraph replay per step" if graphed else "eager (one launch per kernel)",
                        "streams": ("depth and pose branches on two HIP streams" if tr.opt.overlap_streams else "one HIP stream")
                                   + ("; weight-gradient kernels on a companion stream of each (opt.wgrad_lanes)" if tr.wgrad_lanes else "")},

@@ -112,6 +112,12 @@ class GradBuckets:
             self.comm.wait_stream(cur)
             for st in self.streams:
                 self.comm.wait_stream(st)
+            # weight gradients produced on the companion streams of ops.WgradLanes (their kernels write straight into this
+            # bucket's slices): every lane with work enqueued so far -- this runs from the hook of the bucket's LAST gradient,
+            # whose lane was registered when its backward returned
+            from .ops import WgradLanes
+            for lane in WgradLanes._used:
+                self.comm.wait_stream(lane)
             ctx = torch.cuda.stream(self.comm)
         else:
             ctx = contextlib.nullcontext()

@@ -146,15 +146,15 @@ class Trainer:
         capturable_pg = world_size == 1 or (dist.is_available() and dist.is_initialized()
                                             and dist.get_backend(process_group) == "nccl")
         self.graph_enabled = bool(getattr(self.opt, "hip_graph", False)) and self.device.type == "cuda" and capturable_pg
-        # weight-gradient kernels on companion streams (ops.WgradLanes): eager single-GPU steps.  Not under hip_graph (as forks
-        # of a captured step the lanes measured +10 % at C2 where they give -0.7 % eagerly) and not with the bucketed
-        # exchange (its collectives are ordered against the backward's own streams).  2 = "auto": only where the step is
-        # GPU-bound -- a lane costs ~15 us of host work per convolution (stream switches, record_stream), which a batch-1 step
-        # that waits for the host pays in full (C1 7.5 -> 8.4 ms) and a 12 x 192 x 640 step hides (C2 -0.7 %, C3 -1.9 %)
+        # weight-gradient kernels on companion streams (ops.WgradLanes): eager steps, with or without the bucketed exchange (its
+        # communication stream waits for the lanes that wrote a bucket's slices, depthcore/ddp.py).  Not under hip_graph (as
+        # forks of a captured step the lanes measured +10 % at C2 where they give -0.7 % eagerly).  2 = "auto": only where the
+        # step is GPU-bound -- a lane costs ~15 us of host work per convolution (stream switches, an event), which a batch-1
+        # step that waits for the host pays in full (C1 7.5 -> 8.4 ms) and a 12 x 192 x 640 step hides (C2 -0.7 %, C3 -1.9 %)
         lanes = int(getattr(self.opt, "wgrad_lanes", 0))
         if lanes == 2:
             lanes = int(self.opt.batch_size * self.opt.height * self.opt.width >= 4 * 192 * 640 and not self.opt.gru)
-        self.wgrad_lanes = bool(lanes) and self.device.type == "cuda" and world_size == 1 and not self.graph_enabled
+        self.wgrad_lanes = bool(lanes) and self.device.type == "cuda" and not self.graph_enabled
         if self.graph_enabled and self.opt.cpu_tiebreak_noise:
             raise ValueError("hip_graph replays cannot include the reference's CPU randn + host-to-device copy (cpu_tiebreak_noise)")
         # reference trainer.py:110-113: one Adam over every trainable tensor.  On the GPU the depthcore kernel (one streaming

@@ -166,3 +166,34 @@ def test_two_gpus_bench_step_over_rccl():
     assert d["config"]["global_batch"] == 24 and d["config"]["parallelism"] == "dp2"
     assert d["grad_bytes_allreduced_per_step"] > 100e6          # 26.8 M fp32 parameters
     assert d["value"] > 0
+
+
+def test_wgrad_lanes_with_the_bucketed_exchange_change_nothing():
+    """Weight-gradient lanes together with the bucketed exchange (1-rank RCCL group, Trainer told world = 2): the lanes' kernels
+    write into the bucket slices, the communication stream waits for them, and three training steps end in bitwise the same
+    weights as with the lanes off."""
+    import trainer as T
+    from depthcore.synthetic import synthetic_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        B, H, W = 2, 64, 128
+        batches = [synthetic_batch(B, H, W, torch.device(DEV), seed=s) for s in (5, 6)]
+        out = {}
+        for lanes in (0, 1):
+            tr = T.Trainer(T.default_options(batch_size=B, height=H, width=W, wgrad_lanes=lanes), device=DEV, rank=0, world_size=2, seed=11)
+            assert tr.wgrad_lanes == bool(lanes) and tr.buckets.world == 2
+            tr.set_train()
+            losses = []
+            for i in range(3):
+                _, l = tr.train_step(dict(batches[i % 2]))
+                losses.append(float(l["loss"].detach()))
+            torch.cuda.synchronize()
+            assert tr.buckets.packed == 0
+            out[lanes] = (losses, torch.cat([p.detach().flatten() for p in tr.parameters_to_train]).clone())
+            tr.close()
+        assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+        assert torch.equal(out[0][1], out[1][1])
+    finally:
+        dist.destroy_process_group()
