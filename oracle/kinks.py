@@ -3,7 +3,7 @@
 A ReLU / max-pool network is only piecewise smooth: a pre-activation within rounding of zero (or two window entries within
 rounding of each other) is routed differently by an fp32 and an fp64 evaluation, and on small maps one such element moves
 every upstream gradient by a fraction of a percent -- which says nothing about the kernels under test.  The HIP path
-records the decisions it took (depthcore.ops.KinkTape: the output of every fused ReLU, the argmax code of the max-pool);
+records the decisions it took (tests/kink_tape.py: the output of every fused ReLU, the argmax code of the max-pool);
 `ForcedKinks` replays those decisions inside the oracle, so both sides evaluate the SAME smooth function and every
 feature map and gradient can be held to the rounding-level bound with no exception list.  Where the oracle's own decision
 differs from the imposed one, the size of the pre-activation (or of the gap between the two window entries) is recorded:

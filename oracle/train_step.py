@@ -32,7 +32,7 @@ class CpuTrainer:
         self.num_ch_enc = [64, 64, 128, 256, 512] if num_layers <= 34 else [64, 256, 512, 1024, 2048]
 
     def process_batch(self, inputs, noise, kinks=None, nets_autocast=None):
-        """`kinks`: {"encoder" | "pose_encoder" | "pose": tape entries recorded by the HIP path (depthcore.ops.KinkTape)} --
+        """`kinks`: {"encoder" | "pose_encoder" | "pose": tape entries recorded by the HIP path (tests/kink_tape.py)} --
         the ReLU / max-pool decisions of those networks are then imposed (oracle/kinks.py); the imposed-vs-own disagreements
         are left in `self.kink_report`.  The HIP path stacks both pose pairs along the batch: pair i = rows [i*B, (i+1)*B).
         `nets_autocast`: a torch dtype -- the networks are evaluated under torch's own CPU autocast of that type and their

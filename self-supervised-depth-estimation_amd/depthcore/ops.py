@@ -20,22 +20,21 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-class KinkTape:
-    """Test hook: while active, every fused ReLU records its output (`("relu", y)`: the decision taken is y > 0) and the
-    max-pool its argmax codes (`("maxpool", code)`), in call order.  The parity tests replay these decisions inside the fp64
-    oracle (oracle/kinks.py) so that both sides evaluate the same smooth function.  Records references, copies nothing."""
-    _active = []
+# ---- decision observers -------------------------------------------------------------------------------------------------
+# Instrumentation hook (no test logic lives here): a callable registered with `add_decision_observer` is told every discrete
+# decision the forward takes -- `("relu", y)` with the fused op's output (the decision is y > 0), `("maxpool", code)` with the
+# argmax codes -- in call order.  ReLUs that are folded into a convolution's loader never materialise their output: they hand
+# over a thunk, which is only evaluated while an observer is registered.  The parity tests build their tape on this
+# (tests/kink_tape.py); nothing in the training path registers one.
+_decision_observers = []
 
-    def __init__(self):
-        self.entries = []
 
-    def __enter__(self):
-        KinkTape._active.append(self)
-        return self
+def add_decision_observer(fn):
+    _decision_observers.append(fn)
 
-    def __exit__(self, *exc):
-        KinkTape._active.remove(self)
-        return False
+
+def remove_decision_observer(fn):
+    _decision_observers.remove(fn)
 
 
 # ---- matrix-core precision of the convolutions (include/depthcore.h: dc_set_matrix_precision) ----------------------------
@@ -77,8 +76,10 @@ def _use_precision(prec):
 
 def _record_kink(kind, t):
     """`t`: the tensor that carries the decision, or a thunk that forms it (folded ReLUs never materialise theirs)."""
-    if KinkTape._active:
-        KinkTape._active[-1].entries.append((kind, t() if callable(t) else t))
+    if _decision_observers:
+        t = t() if callable(t) else t
+        for fn in _decision_observers:
+            fn(kind, t)
 
 
 def _slot(param):

@@ -83,3 +83,17 @@ def data_case_image(h, w, seed):
     grey = rng.rand(h, w) < 0.05
     img = np.where(grey[..., None], img[..., :1], img)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def pass_rate_1e3(a, b, rel=1e-3):
+    """Fraction of elements that meet the PLAIN pointwise tolerance of BASELINE.json's north_star -- |a - b| <= 1e-3 |b|, with
+    1e-3 of the tensor's rms as the absolute floor for elements near zero.  Reported next to the calibrated / normwise gates so
+    that the distance to that tolerance is a number."""
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    if isinstance(b, torch.Tensor):
+        b = b.detach().cpu().numpy()
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    rms = float(np.sqrt((b * b).mean())) if b.size else 0.0
+    ok = np.abs(a - b) <= rel * (np.abs(b) + rel * rms + 1e-30)
+    return float(ok.mean()) if ok.size else 1.0

@@ -5,7 +5,7 @@ no exception list.
 A ReLU / max-pool network is only piecewise smooth: a pre-activation within fp32 rounding of zero is routed differently by
 an fp32 and an fp64 evaluation, and on these small maps ONE such element moves every upstream gradient by ~0.5 %.  That is a
 property of comparing across precisions, not of the kernels -- so the comparison removes it instead of tolerating it: the
-HIP forward records every decision it takes (depthcore.ops.KinkTape: the output of each fused BatchNorm+ReLU, the max-pool's
+HIP forward records every decision it takes (tests/kink_tape.py: KinkTape: the output of each fused BatchNorm+ReLU, the max-pool's
 argmax codes) and the fp64 oracle is evaluated with THOSE decisions imposed (oracle/kinks.py: `x * [y_hip > 0]`, gather at
 the recorded window position).  Both sides then evaluate the same smooth function and
 
@@ -23,6 +23,7 @@ The input image itself never needs a gradient on this path (the stem's kernels h
 import pytest
 import torch
 
+from kink_tape import KinkTape
 from helpers import rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -72,7 +73,7 @@ def _one_input(num_layers, groups, nimg, B, H, W, seed):
     g = torch.Generator().manual_seed(seed)
     x = torch.rand(B, 3 * nimg, H, W, generator=g)
     xh = x.to(DEV)
-    with ops.KinkTape() as tape:
+    with KinkTape() as tape:
         got = enc(xh, bn_groups=groups)
     cots = [torch.randn(f.shape, generator=g) / f[0].numel() ** 0.5 for f in got]
     loss = sum((f * c.to(DEV)).sum() for f, c in zip(got, cots))

@@ -10,7 +10,7 @@ from oracle.resnet_ref import resnet_encoder_forward
 
 
 class Recorder(Kinks):
-    """What depthcore.ops.KinkTape records on the GPU, restated on the CPU: post-ReLU outputs and dc_maxpool codes."""
+    """What tests/kink_tape.py records on the GPU, restated on the CPU: post-ReLU outputs and dc_maxpool codes."""
 
     def __init__(self):
         self.entries = []

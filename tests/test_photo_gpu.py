@@ -6,7 +6,7 @@ import torch
 
 from oracle import ref_cpu as R
 import make_golden as MG
-from helpers import T, close, close_frac, rel_l2, oracle_photo, random_poses
+from helpers import T, close, close_frac, rel_l2, oracle_photo, random_poses, pass_rate_1e3
 
 pytestmark = pytest.mark.gpu
 B, H, W = MG.B, MG.H, MG.W
@@ -59,6 +59,9 @@ def test_golden_trainer_level(golden, tag, kw):
             sel = (ex["argmin"][s] >= first_reproj).cpu().numpy().astype(np.uint8)
             want = np.unpackbits(g[p + "idsel%d" % s])[:sel.size].reshape(sel.shape)
             assert (sel != want).mean() < 2e-3
+    # the distance to north_star's PLAIN tolerance, as a number (the gates above are the calibrated ones)
+    print("%s: fraction of d(disp) elements within 1e-3 pointwise of the reference's fixture, scales 0-3:" % tag,
+          [round(pass_rate_1e3(gd[s], g[p + "gdisp%d" % s]), 4) for s in range(4)])
     # dT against the oracle's autograd (the golden file pins d axisangle / d translation instead)
     opt = R.Opt(height=H, width=W, **kw)
     _, _, _, ogT = oracle_photo(inputs, disps, Ts, opt, noise)
@@ -117,6 +120,9 @@ def test_full_size_c2_vs_oracle():
         assert rel_l2(gd[s], ogd[s]) < 2e-2
     for f in range(2):
         assert rel_l2(gT[f][:, :3, :], ogT[f][:, :3, :]) < 2e-2
+    print("C2 full size: fraction of gradient elements within 1e-3 pointwise of the fp32 oracle -- d(disp) scales 0-3:",
+          [round(pass_rate_1e3(gd[s], ogd[s]), 4) for s in range(4)], "d(T) frames -1, +1:",
+          [round(pass_rate_1e3(gT[f][:, :3, :], ogT[f][:, :3, :]), 4) for f in range(2)])
 
 
 @pytest.mark.parametrize("shape", [(1, 192, 640), (2, 160, 512), (1, 320, 1024)])
