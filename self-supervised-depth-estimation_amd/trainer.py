@@ -633,9 +633,12 @@ class Trainer:
             pg = dist.new_group(ranks=dist.get_process_group_ranks(base), backend="nccl", device_id=self.device)
             be = pg._get_backend(self.device)
             try:
-                if not be._is_initialized():
-                    be.eager_connect_single_device(self.device)
-                ok = bool(be._is_initialized())
+                # (new_group(device_id=...) connects eagerly where the backend supports it; asking again is a no-op then.
+                # `_is_initialized()` is not a usable signal on this stack -- it stays False for a connected communicator -- so
+                # the evidence is that the connect call returns; a communicator that is still missing would be created by
+                # the first captured collective, fail the capture, and the step falls back to eager: train_step's except path)
+                be.eager_connect_single_device(self.device)
+                ok = True
             except Exception:
                 ok = False
             self._capture_pg = pg if ok else False
