@@ -211,6 +211,11 @@ size_t dc_conv3x3_bwd_workspace(int C0, int C1, int B, int Co, int H, int W);
 int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
                    const float* y, const float* gy, float* dx0, float* dx1, float* dweight, float* dbias,
                    void* ws, int B, int Co, int H, int W, int act, int pad_mode, void* stream);
+/* dx0 += addend0, dx1 += addend1 (nullable, shapes of dx0 / dx1) inside the pass that writes them: the gradient of another
+ * consumer of the same input (the decoder's x feeds dispconv AND the next upconv, networks/depth_decoder.py:55-66). */
+int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
+                       const float* y, const float* gy, float* dx0, float* dx1, const float* addend0, const float* addend1,
+                       float* dweight, float* dbias, void* ws, int B, int Co, int H, int W, int act, int pad_mode, void* stream);
 
 /* ------------------------------------------------------------------ a1 BatchNorm + residual + ReLU */
 /* Training-mode nn.BatchNorm2d fused with the residual add and ReLU of torchvision's BasicBlock / Bottleneck
@@ -287,6 +292,11 @@ int dc_bn_bwd_apply(const float* x, const float* gp, const float* coef, float* d
  * maximum, ATen's tie-break).  NC <= 65535.  Backward: gather, no atomics. */
 int dc_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* code, int NC, int H, int W, void* stream);
 int dc_maxpool3x3s2_bwd(const float* gy, const uint8_t* code, float* dx, int NC, int H, int W, void* stream);
+/* dx = max-pool backward + addend (same shape as dx, nullable): the pooled tensor's other consumer's gradient -- the stem's
+ * output feeds the pool AND the depth decoder's skip connection (networks/depth_decoder.py:57-59) -- added on the way out
+ * instead of by an elementwise pass of autograd. */
+int dc_maxpool3x3s2_bwd_add(const float* gy, const uint8_t* code, float* dx, const float* addend, int NC, int H, int W,
+                            void* stream);
 
 /* Stride-1 3x3 convolution with zero padding 1 and no bias -- the conv3x3 of the ResNet trunks (reference
  * networks/resnet_encoder.py:74-98 -> torchvision BasicBlock/Bottleneck) -- as a fused Winograd F(2x2,3x3) on the
@@ -353,6 +363,11 @@ int dc_conv1x1_dgrad(const float* gy, const float* weight, float* dx, int B, int
  * in-place pass otherwise. */
 int dc_conv1x1_dgrad_add(const float* gy, const float* weight, float* dx, const float* addend, int B, int Ci, int Co, int Hi, int Wi,
                          int stride, void* stream);
+/* ... + addend + addend2: an input with three consumers (a stage's first block: the 3x3 / 2 convolution, the 1x1 / 2 `downsample`
+ * and the decoder's skip connection).  At stride 2 the tiled kernel writes every cell of dx -- values and the skipped zeros --
+ * once, so the addends ride in that store. */
+int dc_conv1x1_dgrad_add2(const float* gy, const float* weight, float* dx, const float* addend, const float* addend2, int B, int Ci,
+                          int Co, int Hi, int Wi, int stride, void* stream);
 size_t dc_conv1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride);
 int dc_conv1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
                      void* stream);

@@ -758,7 +758,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* gy, const
 // eight consecutive input pixels per thread (x0 % 8 == 0, W % 8 == 0): the five windows ox = x0/2 .. x0/2+4 of a window row
 // are one aligned 32-bit code load + one byte and one 16-byte gy load + one dword, routed to two float4 stores
 __global__ __launch_bounds__(256) void maxpool_bwd8_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ code,
-                                                           float* __restrict__ dx, int H, int W, int Ho, int Wo) {
+                                                           float* __restrict__ dx, int H, int W, int Ho, int Wo,
+                                                           const float* __restrict__ addend) {
     const size_t plane = blockIdx.y;
     const float* g = gy + plane * Ho * Wo;
     const uint8_t* cd = code + plane * Ho * Wo;
@@ -767,6 +768,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd8_kernel(const float* __restri
     if (i >= H * W8) return;
     const int yy = i / W8, x0 = (i - yy * W8) * 8;
     float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (addend) {       // the pooled tensor's OTHER consumer's gradient (the decoder's skip connection), added on the way out
+        const float* ap = addend + plane * H * W + (size_t)yy * W + x0;
+        const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+        out[0] = a0.x; out[1] = a0.y; out[2] = a0.z; out[3] = a0.w; out[4] = a1.x; out[5] = a1.y; out[6] = a1.z; out[7] = a1.w;
+    }
     const int oy0 = yy >> 1, oy1 = min((yy + 1) >> 1, Ho - 1);
     const int oxb = x0 >> 1;                                  // multiple of 4
     for (int oy = oy0; oy <= oy1; ++oy) {
@@ -809,11 +815,20 @@ extern "C" int dc_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* code, int 
 }
 
 extern "C" int dc_maxpool3x3s2_bwd(const float* gy, const uint8_t* code, float* dx, int NC, int H, int W, void* stream) {
+    return dc_maxpool3x3s2_bwd_add(gy, code, dx, nullptr, NC, H, W, stream);
+}
+
+extern "C" int dc_maxpool3x3s2_bwd_add(const float* gy, const uint8_t* code, float* dx, const float* addend, int NC, int H, int W,
+                                       void* stream) {
     if (!gy || !code || !dx || NC <= 0 || H < 2 || W < 2 || NC > 65535) return DC_EINVAL;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    if (addend && (W & 7)) {          // (the vectorised kernel adds on the way out; the others in a pass of their own)
+        const int rc = dc_maxpool3x3s2_bwd_add(gy, code, dx, nullptr, NC, H, W, stream);
+        return rc != DC_OK ? rc : dc::add_inplace(dx, addend, (size_t)NC * H * W, (hipStream_t)stream);
+    }
     if ((W & 7) == 0)
         hipLaunchKernelGGL(dc::maxpool_bwd8_kernel, dim3(dc::ceil_div(H * (W >> 3), 256), NC), dim3(256), 0, (hipStream_t)stream, gy, code,
-                           dx, H, W, Ho, Wo);
+                           dx, H, W, Ho, Wo, addend);
     else if ((W & 3) == 0)
         hipLaunchKernelGGL(dc::maxpool_bwd_kernel<true>, dim3(dc::ceil_div(H * (W >> 2), 256), NC), dim3(256), 0,
                            (hipStream_t)stream, gy, code, dx, H, W, Ho, Wo);

@@ -456,8 +456,11 @@ __device__ __forceinline__ float fold_at(const float* p, int r, int c, int H, in
 // padding: every thread issues its own 1 (4: upsampled source) loads per pixel for all its pixels first, and the few
 // threads that touch a mirrored row or column redo that pixel through fold_at afterwards.
 constexpr int FOLD_PPT = 1;      // (4 pixels per thread measured slower: 352 vs 307 us per decoder step -- it is not the block count)
+// add0 / add1 (nullable, shapes of dx0 / dx1): another consumer's gradient of the same input, added on the way out (the sum
+// autograd would otherwise form in a pass of its own)
 __global__ __launch_bounds__(256) void conv_fold_kernel(const float* __restrict__ dxpad, float* __restrict__ dx0, float* __restrict__ dx1,
-                                                        int B, int C0, int C1, int up0, int H, int W, int pad, int pitch) {
+                                                        int B, int C0, int C1, int up0, int H, int W, int pad, int pitch,
+                                                        const float* __restrict__ add0, const float* __restrict__ add1) {
     const int Cin = C0 + C1;
     const int b = blockIdx.z, ch = blockIdx.y;
     const float* p = dxpad + ((size_t)b * Cin + ch) * (H + 2) * pitch;
@@ -468,7 +471,10 @@ __global__ __launch_bounds__(256) void conv_fold_kernel(const float* __restrict_
     if (!dst) return;
     const int upx = first ? up0 : 0;
     const int h0 = H >> upx, w0 = W >> upx, np = h0 * w0;
-    dst += ((size_t)b * (first ? C0 : C1) + (first ? ch : ch - C0)) * np;
+    const size_t plane_off = ((size_t)b * (first ? C0 : C1) + (first ? ch : ch - C0)) * np;
+    dst += plane_off;
+    const float* add = first ? add0 : add1;
+    float av[FOLD_PPT];
     float v[FOLD_PPT];
     int yy[FOLD_PPT], xx[FOLD_PPT];
     bool in[FOLD_PPT];
@@ -478,6 +484,7 @@ __global__ __launch_bounds__(256) void conv_fold_kernel(const float* __restrict_
         in[k] = i < np;
         const int ii = in[k] ? i : 0;
         yy[k] = ii / w0; xx[k] = ii - yy[k] * w0;
+        av[k] = add ? add[plane_off + ii] : 0.f;
         if (upx) {
             const float* r0 = p + (size_t)(2 * yy[k] + 1) * pitch + 1 + 2 * xx[k];
             v[k] = (r0[0] + r0[1]) + (r0[pitch] + r0[pitch + 1]);
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(256) void conv_fold_kernel(const float* __restrict_
         } else if (generic || (refl && (y == 1 || y == H - 2 || x == 1 || x == W - 2))) {
             v[k] = fold_at(p, y, x, H, W, pad, pitch);
         }
-        if (in[k]) dst[(blockIdx.x * FOLD_PPT + k) * 256 + threadIdx.x] = v[k];
+        if (in[k]) dst[(blockIdx.x * FOLD_PPT + k) * 256 + threadIdx.x] = v[k] + av[k];
     }
 }
 
@@ -992,6 +999,15 @@ extern "C" size_t dc_conv3x3_bwd_workspace(int C0, int C1, int B, int Co, int H,
 extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
                               const float* y, const float* gy, float* dx0, float* dx1, float* dweight, float* dbias,
                               void* ws, int B, int Co, int H, int W, int act, int pad_mode, void* stream) {
+    return dc_conv3x3_bwd_add(x0, C0, up0, x1, C1, weight, y, gy, dx0, dx1, nullptr, nullptr, dweight, dbias, ws, B, Co, H, W, act, pad_mode,
+                              stream);
+}
+
+extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight,
+                                  const float* y, const float* gy, float* dx0, float* dx1, const float* addend0, const float* addend1,
+                                  float* dweight, float* dbias, void* ws, int B, int Co, int H, int W, int act, int pad_mode,
+                                  void* stream) {
+    if ((addend0 && !dx0) || (addend1 && !dx1)) return DC_EINVAL;
     if (!x0 || C0 <= 0 || (C1 > 0 && !x1) || C1 < 0 || !weight || !y || !gy || !ws || B <= 0 || Co <= 0 || H < 2 || W < 2)
         return DC_EINVAL;
     if (up0 && ((H | W) & 1)) return DC_EINVAL;
@@ -1041,20 +1057,21 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
     }
     if (head_dx) {
         // thin single-channel head: folded-window data gradient, no padded scratch / fold pass (dispconv.hip)
-        const int rc = dispconv_dx(weight, y, gy, dx0, B, C0, H, W, act, pad_mode, ST);
+        const int rc = dispconv_dx(weight, y, gy, dx0, addend0, B, C0, H, W, act, pad_mode, ST);
         if (rc != DC_OK) return rc;
     } else if (b16 && (dx0 || dx1)) {
         // bf16 matrix cores: a zero-padded single-source block gets its data gradient directly (convolution of g' with the
         // rotated, transposed filter); reflection / upsample / concat go through the padded domain and the fold below
         if (pad_mode == PAD_ZERO && !up0 && C1 == 0) {
-            const int rc = c3b_conv(gp, Co, 0, nullptr, 0, weight, Co, Cin, 1, 0, nullptr, dx0, wd, B, H, W, ACT_NONE, PAD_ZERO, 1, ST);
+            int rc = c3b_conv(gp, Co, 0, nullptr, 0, weight, Co, Cin, 1, 0, nullptr, dx0, wd, B, H, W, ACT_NONE, PAD_ZERO, 1, ST);
+            if (rc == DC_OK && addend0) rc = add_inplace(dx0, addend0, (size_t)B * C0 * H * W, ST);
             if (rc != DC_OK) return rc;
         } else {
             const int rc = c3b_conv(gp, Co, 0, nullptr, 0, weight, Co, Cin, 1, 1, nullptr, dxpad, wd, B, H, W, ACT_NONE, PAD_ZERO, 1, ST);
             if (rc != DC_OK) return rc;
             const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
             hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256 * FOLD_PPT), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0, C1,
-                               up0 ? 1 : 0, H, W, pad_mode, c3b_dpad_pitch(W));
+                               up0 ? 1 : 0, H, W, pad_mode, c3b_dpad_pitch(W), addend0, addend1);
             DC_CHECK_LAUNCH();
         }
     } else if (w_dx) {
@@ -1063,7 +1080,7 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
         if (rc != DC_OK) return rc;
         const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
         hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256 * FOLD_PPT), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0, C1,
-                           up0 ? 1 : 0, H, W, pad_mode, W + 2);
+                           up0 ? 1 : 0, H, W, pad_mode, W + 2, addend0, addend1);
         DC_CHECK_LAUNCH();
     } else if (dx0 || dx1) {
         hipLaunchKernelGGL(conv_wprep_kernel, dim3(ceil_div((int)nW, 256)), dim3(256), 0, ST, weight, (float*)nullptr, wd,
@@ -1087,7 +1104,7 @@ extern "C" int dc_conv3x3_bwd(const float* x0, int C0, int up0, const float* x1,
         DC_CHECK_LAUNCH();
         const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
         hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256 * FOLD_PPT), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0,
-                           C1, up0 ? 1 : 0, H, W, pad_mode, W + 2);
+                           C1, up0 ? 1 : 0, H, W, pad_mode, W + 2, addend0, addend1);
         DC_CHECK_LAUNCH();
     }
     if (head_dw) {

@@ -12,7 +12,7 @@ bool dispconv_wgrad_eligible(int C0, int C1, int up0, int Co, int H, int W);    
 size_t dispconv_wgrad_scratch(int B, int C, int H, int W);
 int dispconv_wgrad(const float* x, const float* y, const float* gy, float* dweight, float* dbias, float* scratch, int B, int C, int H,
                    int W, int act, int pad, hipStream_t st);
-int dispconv_dx(const float* w, const float* y, const float* gy, float* dx, int B, int C, int H, int W, int act, int pad,
-                hipStream_t st);
+int dispconv_dx(const float* w, const float* y, const float* gy, float* dx, const float* addend, int B, int C, int H, int W, int act,
+                int pad, hipStream_t st);      /* addend (nullable): added to dx */
 
 }  // namespace dc

@@ -81,7 +81,7 @@ __device__ __forceinline__ float gprime_at(const float* gy, const float* y, int 
 // grid (ceil(H*W / 256), B): one thread per pixel, loops over the channels (coalesced plane writes)
 __global__ __launch_bounds__(256) void dispconv_dx_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                           const float* __restrict__ w, float* __restrict__ dx, int C, int H, int W,
-                                                          int act, int pad) {
+                                                          int act, int pad, const float* __restrict__ addend) {
     extern __shared__ float wsm[];                       // C * 9 weights
     for (int e = threadIdx.x; e < C * 9; e += 256) wsm[e] = w[e];
     __syncthreads();
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void dispconv_dx_kernel(const float* __restric
         float v = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t) v = fmaf(wsm[c * 9 + t], G[t], v);
-        dx[((size_t)b * C + c) * H * W + q] = v;
+        const size_t o = ((size_t)b * C + c) * H * W + q;
+        dx[o] = addend ? v + addend[o] : v;      // (the other consumer's gradient of the head's input, see conv_fold_kernel)
     }
 }
 
@@ -219,10 +220,10 @@ int dispconv_fwd(const float* x, const float* w, const float* bias, float* y, in
     return DC_OK;
 }
 
-int dispconv_dx(const float* w, const float* y, const float* gy, float* dx, int B, int C, int H, int W, int act, int pad,
-                hipStream_t st) {
+int dispconv_dx(const float* w, const float* y, const float* gy, float* dx, const float* addend, int B, int C, int H, int W, int act,
+                int pad, hipStream_t st) {
     hipLaunchKernelGGL(dispconv_dx_kernel, dim3(ceil_div(H * W, 256), B), dim3(256), (size_t)C * 9 * sizeof(float), st, gy, y, w, dx, C, H,
-                       W, act, pad);
+                       W, act, pad, addend);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }

@@ -14,8 +14,8 @@ int dc_gemm1x1_stat_parts(int B, int Ci, int Co, int Hi, int Wi, int stride, int
 int dc_gemm1x1_bwd_parts(int B, int Ci, int Co, int Hi, int Wi, int stride, int groups, int* ppg);
 int dc_gemm1x1_fwd(const float* x, const float* weight, const float* bias, float* y, int B, int Ci, int Co, int Hi, int Wi, int stride,
                    int act, const dc_bn_fold* bn, void* stream);
-int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx, const float* addend, int B, int Ci, int Co, int Hi, int Wi, int stride,
-                     const dc_bn_fold* bn, void* stream);      /* addend (stride 1 only, may be NULL): added to dx in the store epilogue */
+int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx, const float* addend, const float* addend2, int B, int Ci, int Co,
+                     int Hi, int Wi, int stride, const dc_bn_fold* bn, void* stream);      /* addends (nullable): added to dx in the store epilogue */
 size_t dc_gemm1x1_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride);
 int dc_gemm1x1_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
                      const dc_bn_fold* bn, void* stream);

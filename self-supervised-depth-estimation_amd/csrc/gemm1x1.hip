@@ -46,6 +46,7 @@ struct G1Args {
     const float* gy;      // (B, Co, Ho, Wo)           (backward)
     const float* bias;    // (Co) or null               (forward)
     const float* addend;  // (B, Ci, Hi, Wi) or null: added to dx in the epilogue (stride 1; the other gradient of a residual fork)
+    const float* addend2; // a second one (a feature map's third consumer: the decoder's skip connection), or null
     float* out;           // y / dx / slab-or-dw
     int B, Co, Ci, Hi, Wi, Ho, Wo, s;
     int act;              // forward epilogue
@@ -226,8 +227,10 @@ __global__ __launch_bounds__(256) void g1_fwd_kernel(G1Args a) {
 // data gradient.  rows = input channels ci, reduction = co.  A = w [co][ci] (index-contiguous), B = gy [co][n] (index-cont.)
 // Co % KC == 0.
 // =====================================================================================================================
-template <int MT, int NT, int BNE = 0>
+// SD: 1 = stride 1; 2 = stride 2; 3 = stride 2 with addends (its cell-block staging costs registers: its own instantiation)
+template <int MT, int NT, int BNE = 0, int SD = 1>
 __global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
+    static_assert(BNE == 0 || SD == 1, "the BatchNorm epilogues exist at stride 1");
     constexpr int BM = 32 * MT, BN = 32 * NT, KC = GKC, SA = IdxStride<MT, BM>::v, SB = IdxStride<NT, BN>::v;
     constexpr int NA = KC * BM / 1024, NB = KC * BN / 1024;
     constexpr int ASZ = KC * SA, BSZ = KC * SB;
@@ -378,51 +381,95 @@ __global__ __launch_bounds__(256) void g1_dgrad_kernel(G1Args a) {
         const int py = p / a.Wo, px = p - py * a.Wo;
         pix = (size_t)(py * 2) * a.Wi + px * 2;
     }
-    if (a.addend) {
-        // the other gradient of a residual fork (stride 1): ALL of this lane's addend values are loaded before the first
-        // store -- a load next to its store in the loop below waited for itself 4 MT times over (121 -> 167 us at 128 x 128)
-        gf4 ad[MT][4];
+    if constexpr (SD == 1) {
+        // the other gradient(s) of a residual fork: ALL of this lane's addend values are loaded before the first store -- a load
+        // next to its store in the loop below waited for itself 4 MT times over (121 -> 167 us at 128 x 128)
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            const float* addp = which == 0 ? a.addend : a.addend2;
+            if (!addp) continue;
+            gf4 ad[MT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = min(m0 + wm * 16 * MT + ((lane >> 4) * 4 + r) * MT + mt, a.Ci - 1);
+                    const float* src = addp + ((size_t)b * a.Ci + ci) * plane + pix;
+                    if constexpr (NT == 4) ad[mt][r] = *reinterpret_cast<const gf4*>(src);
+                    else { const gf2 t = *reinterpret_cast<const gf2*>(src); ad[mt][r] = gf4{t.x, t.y, 0.f, 0.f}; }
+                }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[mt][0][r] += ad[mt][r].x; acc[mt][1][r] += ad[mt][r].y;
+                    if constexpr (NT == 4) { acc[mt][2][r] += ad[mt][r].z; acc[mt][3][r] += ad[mt][r].w; }
+                }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ci = min(m0 + wm * 16 * MT + ((lane >> 4) * 4 + r) * MT + mt, a.Ci - 1);
-                const float* src = a.addend + ((size_t)b * a.Ci + ci) * plane + pix;
-                if constexpr (NT == 4) ad[mt][r] = *reinterpret_cast<const gf4*>(src);
-                else { const gf2 t = *reinterpret_cast<const gf2*>(src); ad[mt][r] = gf4{t.x, t.y, 0.f, 0.f}; }
+                const int ci = m0 + wm * 16 * MT + ((lane >> 4) * 4 + r) * MT + mt;
+                if (ci >= a.Ci) continue;
+                float* dst = a.out + ((size_t)b * a.Ci + ci) * plane + pix;
+                if constexpr (NT == 4)
+                    *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                else
+                    *reinterpret_cast<gf2*>(dst) = gf2{acc[mt][0][r], acc[mt][1][r]};
             }
+        return;
+    } else {
+    // stride 2: the 2 x (2 NT) cell block of these NT output pixels -- the values and the zeros the stride skips -- plus, where the
+    // input has other consumers (the 3x3 / 2 convolution next to a `downsample` branch, the decoder's skip connection), their
+    // gradients: every cell of the block is written exactly once, so the sum autograd would form in passes of its own rides here.
+    // One 16-channel tile (four rows per lane) at a time: its addend cells are all requested before the first store.
+    constexpr int CV = NT / 2;                // 16-byte vectors per cell row
+    constexpr bool has_add = SD == 3;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        gf4 c0[4][CV], c1[4][CV];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[mt][0][r] += ad[mt][r].x; acc[mt][1][r] += ad[mt][r].y;
-                if constexpr (NT == 4) { acc[mt][2][r] += ad[mt][r].z; acc[mt][3][r] += ad[mt][r].w; }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int v = 0; v < CV; ++v) { c0[r][v] = gf4{0, 0, 0, 0}; c1[r][v] = gf4{0, 0, 0, 0}; }
+        if constexpr (has_add) {
+#pragma unroll 1
+            for (int which = 0; which < 2; ++which) {
+                const float* addp = which == 0 ? a.addend : a.addend2;
+                if (!addp) continue;
+                gf4 t0[4][CV], t1[4][CV];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = min(m0 + wm * 16 * MT + ((lane >> 4) * 4 + r) * MT + mt, a.Ci - 1);
+                    const float* src = addp + ((size_t)b * a.Ci + ci) * plane + pix;
+#pragma unroll
+                    for (int v = 0; v < CV; ++v) {
+                        t0[r][v] = *reinterpret_cast<const gf4*>(src + 4 * v);
+                        t1[r][v] = *reinterpret_cast<const gf4*>(src + a.Wi + 4 * v);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int v = 0; v < CV; ++v) { c0[r][v] += t0[r][v]; c1[r][v] += t1[r][v]; }
             }
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = m0 + wm * 16 * MT + ((lane >> 4) * 4 + r) * MT + mt;
             if (ci >= a.Ci) continue;
             float* dst = a.out + ((size_t)b * a.Ci + ci) * plane + pix;
-            if (a.s == 1) {
-                if constexpr (NT == 4)
-                    *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-                else
-                    *reinterpret_cast<gf2*>(dst) = gf2{acc[mt][0][r], acc[mt][1][r]};
-            } else {                         // the 2 x (2 NT) cell block of these NT output pixels: values and the zeros
-                if constexpr (NT == 4) {
-                    *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], 0.f, acc[mt][1][r], 0.f};
-                    *reinterpret_cast<gf4*>(dst + 4) = gf4{acc[mt][2][r], 0.f, acc[mt][3][r], 0.f};
-                    *reinterpret_cast<gf4*>(dst + a.Wi) = gf4{0, 0, 0, 0};
-                    *reinterpret_cast<gf4*>(dst + a.Wi + 4) = gf4{0, 0, 0, 0};
-                } else {
-                    *reinterpret_cast<gf4*>(dst) = gf4{acc[mt][0][r], 0.f, acc[mt][1][r], 0.f};
-                    *reinterpret_cast<gf4*>(dst + a.Wi) = gf4{0, 0, 0, 0};
-                }
+#pragma unroll
+            for (int v = 0; v < CV; ++v) {
+                gf4 o = c0[r][v];
+                o.x += acc[mt][2 * v][r]; o.z += acc[mt][2 * v + 1][r];
+                *reinterpret_cast<gf4*>(dst + 4 * v) = o;
+                *reinterpret_cast<gf4*>(dst + a.Wi + 4 * v) = c1[r][v];
             }
         }
+    }
+    }
 }
 
 // =====================================================================================================================
@@ -708,12 +755,13 @@ extern "C" int dc_gemm1x1_fwd(const float* x, const float* weight, const float* 
     return DC_OK;
 }
 
-extern "C" int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx, const float* addend, int B, int Ci, int Co, int Hi,
-                                int Wi, int stride, const dc_bn_fold* bn, void* stream) {
-    if (!gy || !weight || !dx || !dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride) || (addend && stride != 1)) return DC_EINVAL;
+extern "C" int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx, const float* addend, const float* addend2, int B, int Ci,
+                                int Co, int Hi, int Wi, int stride, const dc_bn_fold* bn, void* stream) {
+    if (!gy || !weight || !dx || !dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    if (addend2 && bn && bn->bwd_part) return DC_EINVAL;          // (the BatchNorm epilogues take one addend)
     G1Args a{};
     g1_fill(a, B, Ci, Co, Hi, Wi, stride);
-    a.w = weight; a.gy = gy; a.out = dx; a.addend = addend;
+    a.w = weight; a.gy = gy; a.out = dx; a.addend = addend; a.addend2 = addend2;
     int bne = 0;
     if (bn && bn->bwd_part) {
         a.bwd_nparts = dc_gemm1x1_bwd_parts(B, Ci, Co, Hi, Wi, stride, bn->groups, nullptr);
@@ -731,18 +779,21 @@ extern "C" int dc_gemm1x1_dgrad(const float* gy, const float* weight, float* dx,
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = g1_lds_dgrad(t);
     static const bool attr = g1_set_lds(g1_dgrad_kernel<4, 4>, g1_lds_dgrad({4, 4})) && g1_set_lds(g1_dgrad_kernel<4, 4, 1>, g1_lds_dgrad({4, 4})) &&
-                             g1_set_lds(g1_dgrad_kernel<4, 4, 2>, g1_lds_dgrad({4, 4}));
+                             g1_set_lds(g1_dgrad_kernel<4, 4, 2>, g1_lds_dgrad({4, 4})) && g1_set_lds(g1_dgrad_kernel<4, 4, 0, 2>, g1_lds_dgrad({4, 4})) &&
+                             g1_set_lds(g1_dgrad_kernel<4, 4, 0, 3>, g1_lds_dgrad({4, 4}));
     if (!attr) return DC_ELAUNCH;
     hipEvent_t pe = conv_prof_begin(4, 2.0 * (double)B * Co * Ci * a.Ho * a.Wo, 2.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * Co, 4.0 * ((double)B * Ci * a.Ho * a.Wo + (double)B * Co * a.Ho * a.Wo + (double)Co * Ci), st);
-#define G1_DGRAD(BNE)                                                                                  \
-    do {                                                                                               \
-        if (t.mt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<4, 4, BNE>), grid, dim3(256), lds, st, a);      \
-        else if (t.nt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<2, 4, BNE>), grid, dim3(256), lds, st, a); \
-        else hipLaunchKernelGGL((g1_dgrad_kernel<2, 2, BNE>), grid, dim3(256), lds, st, a);                \
+#define G1_DGRAD(BNE, SD)                                                                                  \
+    do {                                                                                                   \
+        if (t.mt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<4, 4, BNE, SD>), grid, dim3(256), lds, st, a);      \
+        else if (t.nt == 4) hipLaunchKernelGGL((g1_dgrad_kernel<2, 4, BNE, SD>), grid, dim3(256), lds, st, a); \
+        else hipLaunchKernelGGL((g1_dgrad_kernel<2, 2, BNE, SD>), grid, dim3(256), lds, st, a);                \
     } while (0)
-    if (bne == 0) G1_DGRAD(0);
-    else if (bne == 1) G1_DGRAD(1);
-    else G1_DGRAD(2);
+    if (stride == 2 && (addend || addend2)) G1_DGRAD(0, 3);
+    else if (stride == 2) G1_DGRAD(0, 2);
+    else if (bne == 0) G1_DGRAD(0, 1);
+    else if (bne == 1) G1_DGRAD(1, 1);
+    else G1_DGRAD(2, 1);
 #undef G1_DGRAD
     conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();

@@ -273,10 +273,8 @@ extern "C" int dc_conv1x1_dgrad_add(const float* gy, const float* weight, float*
                                     int Wi, int stride, void* stream) {
     if (!gy || !weight || !dx || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
     if (dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) {
-        // the tiled GEMM adds it in its store epilogue (stride 1: dx is written once, densely)
-        const int rc = dc_gemm1x1_dgrad(gy, weight, dx, stride == 1 ? addend : nullptr, B, Ci, Co, Hi, Wi, stride, nullptr, stream);
-        if (rc != DC_OK || stride == 1 || !addend) return rc;
-        return add_inplace(dx, addend, (size_t)B * Ci * Hi * Wi, (hipStream_t)stream);
+        // the tiled GEMM adds it in its store epilogue (every element of dx is written once, densely, at either stride)
+        return dc_gemm1x1_dgrad(gy, weight, dx, addend, nullptr, B, Ci, Co, Hi, Wi, stride, nullptr, stream);
     }
     PwArgs a{};
     a.a = weight; a.b = gy; a.out = dx; a.B = B; a.M = Co; a.K = Ci; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride; a.s = stride;
@@ -327,7 +325,18 @@ extern "C" int dc_conv1x1_dgrad_bn(const float* gy, const float* weight, float* 
                                    int Wi, int stride, const dc_bn_fold* bn, void* stream) {
     if (!bn || !bn->bwd_part) return dc_conv1x1_dgrad_add(gy, weight, dx, addend, B, Ci, Co, Hi, Wi, stride, stream);
     if (stride != 1 || !dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
-    return dc_gemm1x1_dgrad(gy, weight, dx, addend, B, Ci, Co, Hi, Wi, stride, bn, stream);
+    return dc_gemm1x1_dgrad(gy, weight, dx, addend, nullptr, B, Ci, Co, Hi, Wi, stride, bn, stream);
+}
+
+// dx = data gradient + addend + addend2 (both nullable): an input with up to three consumers, summed in one store epilogue
+extern "C" int dc_conv1x1_dgrad_add2(const float* gy, const float* weight, float* dx, const float* addend, const float* addend2, int B,
+                                     int Ci, int Co, int Hi, int Wi, int stride, void* stream) {
+    if (!addend2) return dc_conv1x1_dgrad_add(gy, weight, dx, addend, B, Ci, Co, Hi, Wi, stride, stream);
+    if (!gy || !weight || !dx || !pw_shape_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    if (dc_gemm1x1_dgrad_ok(B, Ci, Co, Hi, Wi, stride))
+        return dc_gemm1x1_dgrad(gy, weight, dx, addend, addend2, B, Ci, Co, Hi, Wi, stride, nullptr, stream);
+    const int rc = dc_conv1x1_dgrad_add(gy, weight, dx, addend, B, Ci, Co, Hi, Wi, stride, stream);
+    return rc != DC_OK ? rc : add_inplace(dx, addend2, (size_t)B * Ci * Hi * Wi, (hipStream_t)stream);
 }
 extern "C" int dc_conv1x1_wgrad_bn(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,
                                    int stride, const dc_bn_fold* bn, void* stream) {

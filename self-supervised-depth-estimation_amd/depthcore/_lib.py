@@ -133,6 +133,9 @@ def _sig(lib):
         "dc_wino3x3_wgrad_bn": (i, [p, p, p, p, i, i, i, i, i, POINTER(BnFold), p]),
         "dc_maxpool3x3s2_fwd": (i, [p, p, p, i, i, i, p]),
         "dc_maxpool3x3s2_bwd": (i, [p, p, p, i, i, i, p]),
+        "dc_maxpool3x3s2_bwd_add": (i, [p, p, p, p, i, i, i, p]),
+        "dc_conv1x1_dgrad_add2": (i, [p, p, p, p, p, i, i, i, i, i, i, p]),
+        "dc_conv3x3_bwd_add": (i, [p, i, i, p, i, p, p, p, p, p, p, p, p, p, p, i, i, i, i, i, i, p]),
         "dc_wino3x3_workspace": (z, [i, i, i, i, i]),
         "dc_wino3x3_fwd": (i, [p, p, p, p, i, i, i, i, i, p]),
         "dc_wino3x3_dgrad": (i, [p, p, p, p, i, i, i, i, i, p]),

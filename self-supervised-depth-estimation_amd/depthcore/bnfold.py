@@ -85,7 +85,7 @@ def _bwd_finish(L, xx, gp, bwd, gamma, tab, groups, slots):
 
 class _Cfg:
     """non-tensor arguments of the folded ops (one object, so that the autograd signatures stay short)"""
-    __slots__ = ("kind", "stride", "groups", "fork", "in_stats", "bn", "prev", "want_stats", "relu", "res_fork", "leave_link",
+    __slots__ = ("kind", "stride", "groups", "fork", "skip", "in_stats", "bn", "prev", "want_stats", "relu", "res_fork", "leave_link",
                  "out_stats", "out_link")      # the last two are written by the forward (read by the wrapper right after apply)
 
     def __init__(self, **kw):
@@ -121,7 +121,11 @@ class _K1:
         check(L.dc_conv1x1_fwd_bn(ptr(xx), ptr(ww), ptr(y), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(xx)), "dc_conv1x1_fwd_bn")
 
     @staticmethod
-    def dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f):
+    def dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f, add2=None):
+        if add2 is not None:      # (a stage's first block: no BatchNorm epilogue on this launch, two addends)
+            check(L.dc_conv1x1_dgrad_add2(ptr(g_c), ptr(ww), ptr(gx), ptr(add), ptr(add2), B, Ci, Co, Hi, Wi, s_, stream(gx)),
+                  "dc_conv1x1_dgrad_add2")
+            return
         check(L.dc_conv1x1_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ptr(add), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(gx)),
               "dc_conv1x1_dgrad_bn")
 
@@ -152,7 +156,9 @@ class _KW:
         check(L.dc_wino3x3_fwd_bn(ptr(xx), ptr(ww), ptr(y), ws.data_ptr(), B, Ci, Co, Hi, Wi, ctypes.byref(f), stream(xx)), "dc_wino3x3_fwd_bn")
 
     @staticmethod
-    def dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f):
+    def dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f, add2=None):
+        if add2 is not None:
+            raise _lib.DepthcoreError("SkipSum on a 3x3 convolution")
         ws = torch.empty(L.dc_wino3x3_workspace(B, Ci, Co, Hi, Wi), dtype=torch.uint8, device=gx.device)
         check(L.dc_wino3x3_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ptr(add), ws.data_ptr(), B, Ci, Co, Hi, Wi, ctypes.byref(f), stream(gx)),
               "dc_wino3x3_dgrad_bn")
@@ -208,6 +214,10 @@ class _ConvF(torch.autograd.Function):
         ctx.slots = (_ops._slot(weight), _ops._slot(gamma) if fold_in else None, _ops._slot(beta) if fold_in else None)
         ctx.param = _ops._lane_param(ctx, 1, weight)
         ctx.fork = cfg.fork if x.requires_grad else None
+        # x's SkipSum (ops.SkipSum): the member of a pair fork that runs second collects the secondary consumers' gradients
+        ctx.skip = cfg.skip if (cfg.skip is not None and cfg.kind == "g1" and ctx.fork is not None and ctx.fork.pair and not fold_in) else None
+        if ctx.skip is not None:
+            ctx.skip.arm()
         return y
 
     @staticmethod
@@ -246,7 +256,10 @@ class _ConvF(torch.autograd.Function):
                     f.in_scale, f.in_shift = tab[2].data_ptr(), tab[3].data_ptr()
                 else:
                     f.bn_x, f.bn_mean, f.bn_mask = px.data_ptr(), pmean.data_ptr(), pmask.data_ptr()
-            K.dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f)
+            add2 = ctx.skip.take() if (ctx.skip is not None and not first_of_pair) else None
+            if add2 is not None and (add2.shape != xx.shape or not add2.is_contiguous()):
+                raise _lib.DepthcoreError("SkipSum: gradient %s does not match the input %s" % (tuple(add2.shape), tuple(xx.shape)))
+            K.dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f, add2)
             if first_of_pair:
                 fork.park(gx)
                 gx = None
@@ -298,17 +311,18 @@ def wino_ok(conv, xshape, groups):
             and bool(_lib.lib().dc_wino3x3_bn_ok(B, Ci, conv.out_channels, Hi, Wi, groups)))
 
 
-def _conv(kind, x, weight, stride, groups, fork, in_bn, in_stats, prev, want_stats):
-    cfg = _Cfg(kind=kind, stride=int(stride), groups=int(groups), fork=fork, in_stats=in_stats, bn=in_bn, prev=prev, want_stats=want_stats)
+def _conv(kind, x, weight, stride, groups, fork, in_bn, in_stats, prev, want_stats, skip=None):
+    cfg = _Cfg(kind=kind, stride=int(stride), groups=int(groups), fork=fork, skip=skip, in_stats=in_stats, bn=in_bn, prev=prev,
+               want_stats=want_stats)
     y = _ConvF.apply(x, weight, in_bn.weight if in_bn is not None else None, in_bn.bias if in_bn is not None else None, cfg)
     return y, cfg.out_stats
 
 
-def conv1x1(x, weight, stride=1, groups=1, fork=None, in_bn=None, in_stats=None, prev=None, want_stats=True):
+def conv1x1(x, weight, stride=1, groups=1, fork=None, in_bn=None, in_stats=None, prev=None, want_stats=True, skip=None):
     """y_raw, BNStats-or-None = conv1x1([relu(in_bn(x))]).  `in_bn`: the nn.BatchNorm2d (training mode) in front of this convolution
     whose ReLU-ed output has no other consumer -- x is then that BatchNorm's RAW input and `in_stats` its statistics partials
     (None: a stand-alone statistics pass).  `prev`: BNLink of the block output x.  `fork`: GradFork."""
-    return _conv("g1", x, weight, stride, groups, fork, in_bn, in_stats, prev, want_stats)
+    return _conv("g1", x, weight, stride, groups, fork, in_bn, in_stats, prev, want_stats, skip)
 
 
 def conv3x3(x, weight, groups=1, fork=None, in_bn=None, in_stats=None, prev=None, want_stats=True):

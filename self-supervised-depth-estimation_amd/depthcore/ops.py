@@ -652,7 +652,7 @@ PAD_REFLECT, PAD_ZERO = 0, 1
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, up0, act, pad):
+    def forward(ctx, x0, x1, weight, bias, up0, act, pad, fork0=None):
         L = _lib.lib()
         a0 = _c(x0.detach())
         a1 = _c(x1.detach()) if x1 is not None else None
@@ -678,6 +678,11 @@ class _Conv3x3(torch.autograd.Function):
         ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
         if ctx.needs_input_grad[2]:
             WgradLanes.count_use(weight)     # (no lane of its own; a weight shared with a laned op must not look single-use)
+        # x0 shared with another fused block (the decoder's x feeds dispconv AND the next upconv): a pair GradFork -- whichever
+        # backward runs first parks its dx0, the second adds it in the pass that writes its own.  x1 an encoder feature map
+        # with a SkipSum: dx1 is offered to the feature's primary consumer (SkipSum)
+        ctx.fork0 = fork0 if (fork0 is not None and x0.requires_grad) else None
+        ctx.skip1 = skip_of(x1) if (x1 is not None and x1.requires_grad) else None
         return y
 
     @staticmethod
@@ -700,13 +705,23 @@ class _Conv3x3(torch.autograd.Function):
         _use_precision(ctx.prec)
         ws = torch.empty(L.dc_conv3x3_bwd_workspace(C0, C1, B, Co, H, W), dtype=torch.uint8, device=y.device)
         g_c = _c(gy)      # named: stays alive until the launch is enqueued
-        check(L.dc_conv3x3_bwd(ptr(a0), C0, up0, ptr(a1), C1, ptr(w), ptr(y), ptr(g_c), ptr(dx0), ptr(dx1), ptr(dw),
-                               ptr(db), ws.data_ptr(), B, Co, H, W, act, pad, stream(a0)), "dc_conv3x3_bwd")
-        return dx0, dx1, dw, db, None, None, None
+        fork0 = ctx.fork0 if dx0 is not None else None
+        first = fork0 is not None and fork0.arrive() == 0
+        add0 = fork0.take() if (fork0 is not None and not first) else None
+        if add0 is not None and (add0.shape != a0.shape or not add0.is_contiguous()):
+            raise _lib.DepthcoreError("GradFork: parked gradient %s does not match the shared input %s" % (tuple(add0.shape), tuple(a0.shape)))
+        check(L.dc_conv3x3_bwd_add(ptr(a0), C0, up0, ptr(a1), C1, ptr(w), ptr(y), ptr(g_c), ptr(dx0), ptr(dx1), ptr(add0), None, ptr(dw),
+                                   ptr(db), ws.data_ptr(), B, Co, H, W, act, pad, stream(a0)), "dc_conv3x3_bwd_add")
+        if first:
+            fork0.park(dx0)            # the other block adds it and returns the sum
+            dx0 = None
+        if ctx.skip1 is not None:
+            dx1 = ctx.skip1.offer(dx1)
+        return dx0, dx1, dw, db, None, None, None, None
 
 
-def conv3x3_block(x0, x1, weight, bias, up0=False, act=ACT_NONE, pad=PAD_REFLECT):
-    return _Conv3x3.apply(x0, x1, weight, bias, up0, act, pad)
+def conv3x3_block(x0, x1, weight, bias, up0=False, act=ACT_NONE, pad=PAD_REFLECT, fork0=None):
+    return _Conv3x3.apply(x0, x1, weight, bias, up0, act, pad, fork0)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -750,6 +765,51 @@ class GradFork:
         if self.pair and a is None:
             raise _lib.DepthcoreError("GradFork: the first convolution's data gradient was never parked")
         return a
+
+
+class SkipSum:
+    """A tensor with a PRIMARY consumer whose data-gradient kernel can add another gradient on its way out (the stem output's
+    max-pool, a stage's first block) and SECONDARY consumers that run their backward earlier (the depth decoder's skip
+    connections, networks/depth_decoder.py:57-59).  The producer tags the tensor (`t._dc_skip = SkipSum()`); the primary
+    `arm()`s it in its forward when its backward is certain to run; a secondary `offer()`s its gradient in its backward --
+    taken and reported as None while the sum is armed and empty, handed back (autograd then sums as usual) otherwise; the
+    primary `take()`s whatever was offered and adds it in its store epilogue.  The elementwise sums autograd would launch
+    (16 per C2 step, 41 us for the stem's output alone) become one more read in kernels that write the gradient anyway.
+    An offered gradient that nobody took is a lost gradient: `assert_no_dangling_sums()` (Trainer, after every backward)."""
+    __slots__ = ("addend", "armed", "__weakref__")
+    _pending = weakref.WeakSet()
+
+    def __init__(self):
+        self.addend, self.armed = None, False
+
+    def arm(self):
+        self.armed = True
+
+    def offer(self, g):
+        if g is None or not self.armed or self.addend is not None:
+            return g
+        self.addend = g
+        SkipSum._pending.add(self)
+        return None
+
+    def take(self):
+        self.armed = False
+        a, self.addend = self.addend, None
+        SkipSum._pending.discard(self)
+        return a
+
+
+def skip_of(t):
+    """The SkipSum a producer attached to tensor `t`, or None."""
+    return getattr(t, "_dc_skip", None) if t is not None else None
+
+
+def assert_no_dangling_sums():
+    left = [s for s in SkipSum._pending if s.addend is not None]
+    for s in left:
+        s.take()
+    if left:
+        raise _lib.DepthcoreError("%d gradient(s) were handed to a SkipSum whose primary consumer never collected them" % len(left))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -814,7 +874,7 @@ def bn_relu(x, bn, res=None, relu=True, groups=1, fork=None):
 # ----------------------------------------------------------------------------------------------
 class _MaxPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, skip=None):
         L = _lib.lib()
         xx = _c(x.detach())
         N, C, H, W = xx.shape
@@ -825,6 +885,9 @@ class _MaxPool(torch.autograd.Function):
         ctx.save_for_backward(code)
         _record_kink("maxpool", code)
         ctx.dims = (N, C, H, W)
+        ctx.skip = skip if (skip is not None and x.requires_grad) else None
+        if ctx.skip is not None:
+            ctx.skip.arm()
         return y
 
     @staticmethod
@@ -834,12 +897,16 @@ class _MaxPool(torch.autograd.Function):
         N, C, H, W = ctx.dims
         g_c = _c(gy)
         dx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
-        check(L.dc_maxpool3x3s2_bwd(ptr(g_c), code.data_ptr(), ptr(dx), N * C, H, W, stream(g_c)), "dc_maxpool3x3s2_bwd")
-        return dx
+        add = ctx.skip.take() if ctx.skip is not None else None
+        if add is not None and (tuple(add.shape) != (N, C, H, W) or not add.is_contiguous()):
+            raise _lib.DepthcoreError("SkipSum: gradient %s does not match the pooled tensor %s" % (tuple(add.shape), (N, C, H, W)))
+        check(L.dc_maxpool3x3s2_bwd_add(ptr(g_c), code.data_ptr(), ptr(dx), ptr(add), N * C, H, W, stream(g_c)), "dc_maxpool3x3s2_bwd_add")
+        return dx, None
 
 
-def maxpool3x3s2(x):
-    return _MaxPool.apply(x)
+def maxpool3x3s2(x, skip=None):
+    """nn.MaxPool2d(3, 2, 1).  `skip`: the SkipSum of x (its other consumers' gradients are added in the backward kernel)."""
+    return _MaxPool.apply(x, skip)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -978,7 +1045,7 @@ class WinoWeightCache:
 # ----------------------------------------------------------------------------------------------
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, act, fork=None):
+    def forward(ctx, x, weight, bias, stride, act, fork=None, skip=None):
         L = _lib.lib()
         xx, ww = _c(x.detach()), _c(weight.detach())
         bs = _c(bias.detach()) if bias is not None else None
@@ -997,6 +1064,11 @@ class _Conv1x1(torch.autograd.Function):
         ctx.slots = (_slot(weight), _slot(bias) if bias is not None else None)
         ctx.param = _lane_param(ctx, 1, weight)
         ctx.fork = fork if x.requires_grad else None
+        # x's SkipSum: this convolution is (one of) the primary consumer(s) -- the member of the pair fork that runs second
+        # returns the complete gradient of x and collects the secondary consumers' gradients with it
+        ctx.skip = skip if (skip is not None and ctx.fork is not None and ctx.fork.pair) else None
+        if ctx.skip is not None:
+            ctx.skip.arm()
         return y
 
     @staticmethod
@@ -1022,7 +1094,11 @@ class _Conv1x1(torch.autograd.Function):
         add = None if first_of_pair else _fork_addend(ctx, xx)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xx)
-            check(L.dc_conv1x1_dgrad_add(ptr(g_c), ptr(ww), ptr(gx), ptr(add), B, Ci, Co, Hi, Wi, s_, stream(xx)), "dc_conv1x1_dgrad_add")
+            add2 = ctx.skip.take() if (ctx.skip is not None and not first_of_pair) else None
+            if add2 is not None and (add2.shape != xx.shape or not add2.is_contiguous()):
+                raise _lib.DepthcoreError("SkipSum: gradient %s does not match the input %s" % (tuple(add2.shape), tuple(xx.shape)))
+            check(L.dc_conv1x1_dgrad_add2(ptr(g_c), ptr(ww), ptr(gx), ptr(add), ptr(add2), B, Ci, Co, Hi, Wi, s_, stream(xx)),
+                  "dc_conv1x1_dgrad_add2")
             if first_of_pair:
                 ctx.fork.park(gx)          # the other convolution of the pair adds it and returns the sum
                 gx = None
@@ -1034,12 +1110,13 @@ class _Conv1x1(torch.autograd.Function):
                 ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
                 check(L.dc_conv1x1_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream(xx)),
                       "dc_conv1x1_wgrad")
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def conv1x1(x, weight, stride=1, bias=None, act=ACT_NONE, fork=None):
-    """act(F.conv2d(x, weight, bias, stride)) for (Co,Ci,1,1) weights; stride 2 needs even H, W.  `fork`: GradFork."""
-    return _Conv1x1.apply(x, weight, bias, stride, act, fork)
+def conv1x1(x, weight, stride=1, bias=None, act=ACT_NONE, fork=None, skip=None):
+    """act(F.conv2d(x, weight, bias, stride)) for (Co,Ci,1,1) weights; stride 2 needs even H, W.  `fork`: GradFork; `skip`:
+    the SkipSum of x (used when `fork` is a pair fork)."""
+    return _Conv1x1.apply(x, weight, bias, stride, act, fork, skip)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1052,7 +1129,7 @@ def conv_s2_supported(x, weight):
 
 class _ConvS2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, fork=None):
         L = _lib.lib()
         xx, ww = _c(x.detach()), _c(weight.detach())
         B, Ci, Hi, Wi = xx.shape
@@ -1067,6 +1144,7 @@ class _ConvS2(torch.autograd.Function):
         ctx.save_for_backward(xx, ww)
         ctx.slot = _slot(weight)
         ctx.param = _lane_param(ctx, 1, weight)
+        ctx.fork = fork if (fork is not None and x.requires_grad) else None     # pair GradFork with the block's `downsample`
         return y
 
     @staticmethod
@@ -1078,6 +1156,7 @@ class _ConvS2(torch.autograd.Function):
         g_c = _c(gy)
         gx = gw = None
         _use_precision(ctx.prec)
+        first = ctx.fork is not None and ctx.fork.arrive() == 0
         if ctx.needs_input_grad[0]:
             n = L.dc_convs2_dgrad_workspace(B, Ci, Co, Hi, Wi, ks)
             if not n:
@@ -1085,17 +1164,25 @@ class _ConvS2(torch.autograd.Function):
             gx = torch.empty_like(xx)
             ws = torch.empty(n, dtype=torch.uint8, device=xx.device)
             check(L.dc_convs2_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), B, Ci, Co, Hi, Wi, ks, stream(xx)), "dc_convs2_dgrad")
+            if first:
+                ctx.fork.park(gx)          # the 1x1 `downsample` adds it in its store epilogue and returns the sum
+                gx = None
+            elif ctx.fork is not None:     # (this kernel has no addend epilogue: arriving second, it adds in a pass of its own)
+                gx = gx + ctx.fork.take()
+        elif ctx.fork is not None:
+            raise _lib.DepthcoreError("GradFork: the shared input needs no gradient")
         if ctx.needs_input_grad[1]:
             with WgradLanes.lane(ctx.param, xx, g_c):
                 gw = _grad_dst(ctx.slot, ww)
                 ws = torch.empty(L.dc_convs2_wgrad_workspace(B, Ci, Co, Hi, Wi, ks), dtype=torch.uint8, device=xx.device)
                 check(L.dc_convs2_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, ks, stream(xx)), "dc_convs2_wgrad")
-        return gx, gw
+        return gx, gw, None
 
 
-def conv_s2(x, weight):
-    """F.conv2d(x, weight, None, stride=2, padding=k // 2) for k = 3 or 7."""
-    return _ConvS2.apply(x, weight)
+def conv_s2(x, weight, fork=None):
+    """F.conv2d(x, weight, None, stride=2, padding=k // 2) for k = 3 or 7.  `fork`: pair GradFork shared with the block's
+    1x1 `downsample` (the other consumer of x)."""
+    return _ConvS2.apply(x, weight, fork)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -48,10 +48,13 @@ class Conv3x3(nn.Module):
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
         self._pad_mode = _ops.PAD_REFLECT if use_refl else _ops.PAD_ZERO
 
-    def forward(self, x, skip=None, up=False, act=_ops.ACT_NONE):
+    def forward(self, x, skip=None, up=False, act=_ops.ACT_NONE, fork=None):
+        """`fork`: a pair ops.GradFork shared with the other fused block that reads x (DepthDecoder)."""
         H, W = (x.shape[2] * 2, x.shape[3] * 2) if up else (x.shape[2], x.shape[3])
         if H * W >= FUSED_CONV_MIN_PIXELS:
-            return _ops.conv3x3_block(x, skip, self.conv.weight, self.conv.bias, up, act, self._pad_mode)
+            return _ops.conv3x3_block(x, skip, self.conv.weight, self.conv.bias, up, act, self._pad_mode, fork)
+        if fork is not None:
+            raise _ops.DepthcoreError("GradFork handed to the library comparison path")
         # comparison path for tools/time_decoder.py (DC_MIN_PIXELS): the same arithmetic as separate library launches
         if up:
             x = F.interpolate(x, scale_factor=2, mode="nearest")
@@ -70,8 +73,8 @@ class ConvBlock(nn.Module):
         self.conv = Conv3x3(in_channels, out_channels)
         self.nonlin = nn.ELU(inplace=True)
 
-    def forward(self, x, skip=None, up=False):
-        return self.conv(x, skip, up, _ops.ACT_ELU)
+    def forward(self, x, skip=None, up=False, fork=None):
+        return self.conv(x, skip, up, _ops.ACT_ELU, fork)
 
 
 class BackprojectDepth(nn.Module):

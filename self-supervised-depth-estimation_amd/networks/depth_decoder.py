@@ -1,6 +1,7 @@
 """DepthDecoder with the reference's constructor / forward / state_dict layout
 (reference networks/depth_decoder.py:17-67): state_dict keys `decoder.{0..9}.conv.conv.*` for the
 ten ConvBlocks (upconv(4,0), (4,1), (3,0) ... (0,1)) and `decoder.{10..}.conv.*` for the dispconvs."""
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -8,7 +9,11 @@ import torch
 import torch.nn as nn
 
 from layers import ConvBlock, Conv3x3
+from depthcore import ops as _ops
 from depthcore.ops import ACT_SIGMOID as _ACT_SIGMOID
+
+
+X_FORK = os.environ.get("DC_GRAD_SUMS", "1") != "0"     # level i's x feeds dispconv(i) and upconv(i-1, 0): their two gradients are summed inside the second one's backward pass
 
 
 class DepthDecoder(nn.Module):
@@ -37,10 +42,19 @@ class DepthDecoder(nn.Module):
         upconv(i,1) fused; the dispconv + sigmoid is a third."""
         self.outputs = {}
         x = input_features[-1]
+        fork = None
         for i in range(4, -1, -1):
-            x = self.convs[("upconv", i, 0)](x)
+            x = self.convs[("upconv", i, 0)](x, fork=fork)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
             x = self.convs[("upconv", i, 1)](x, skip, up=True)
+            fork = None
             if i in self.scales:
-                self.outputs[("disp", i)] = x if pre_disp else self.convs[("dispconv", i)](x, act=_ACT_SIGMOID)
+                if pre_disp:
+                    self.outputs[("disp", i)] = x
+                else:
+                    # level i's x feeds dispconv(i) AND upconv(i-1, 0): a pair GradFork -- upconv's backward runs first and
+                    # parks its gradient of x, dispconv's data-gradient pass adds it (no elementwise sum by autograd)
+                    if X_FORK and i > 0 and self.training and x.is_cuda and x.requires_grad and torch.is_grad_enabled():
+                        fork = _ops.GradFork(pair=True)
+                    self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act=_ACT_SIGMOID, fork=fork)
         return self.outputs

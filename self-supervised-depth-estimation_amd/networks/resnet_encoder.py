@@ -51,6 +51,7 @@ def _fold_level(bottleneck):
 
 
 GRAD_FORK = True      # residual blocks without a downsample branch: the skip's gradient is added inside conv1's data-gradient kernel
+SKIP_SUMS = os.environ.get("DC_GRAD_SUMS", "1") != "0"   # (DC_GRAD_SUMS=0: autograd's elementwise sums, same-box A/Bs) feature maps carry an ops.SkipSum: the decoder's skip-connection gradient is added by the map's primary consumer
 
 
 def _fork_for(block, x):
@@ -77,7 +78,20 @@ def _pair_fork_for(block, x):
     return _ops.GradFork(pair=True) if ok else None
 
 
-def _conv(conv, x, fork=None):
+def _basic_pair_fork(block, x):
+    """A pair GradFork for a BasicBlock with a downsample branch (3x3 / 2 conv1 on dc_convs2_*, 1x1 / 2 `downsample` on the tiled
+    GEMM whose data gradient takes addends), or None."""
+    c, d = block.conv1, block.downsample[0]
+    B, Ci, H, W = x.shape
+    ok = (GRAD_FORK and GEMM_1X1 and CONV_S2 and block.training and x.is_cuda and x.requires_grad and x.dtype == torch.float32
+          and torch.is_grad_enabled() and x.numel() * 4 < 0x7fffffff and _ops._precision[0] == _ops.PRECISIONS["f32"]
+          and c.kernel_size == (3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.groups == 1 and c.bias is None
+          and d.kernel_size == (1, 1) and d.stride == (2, 2) and d.padding == (0, 0) and d.groups == 1 and d.bias is None
+          and H % 2 == 0 and W % 2 == 0 and c.in_channels % 4 == 0 and c.out_channels % 32 == 0 and _ops.conv_s2_supported(x, c.weight))
+    return _ops.GradFork(pair=True) if ok else None
+
+
+def _conv(conv, x, fork=None, skip=None):
     """nn.Conv2d call of the trunk: stride-1 3x3 on dc_wino3x3_* (84 % of a ResNet-18 trunk's multiplies), 1x1 on dc_conv1x1_*,
     the 7x7 / 2 stem and the 3x3 / 2 convolutions on dc_convs2_*; shapes outside those kernels' 16-byte staging (odd or
     tiny maps in tests) take dc_conv2d_direct_*.  On the GPU nothing reaches the framework's convolution."""
@@ -89,16 +103,16 @@ def _conv(conv, x, fork=None):
             and conv.bias is None and conv.stride in ((1, 1), (2, 2)) and x.dtype == torch.float32
             and (conv.stride == (1, 1) or (x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0))):
         # Bottleneck conv1 / conv3 and every `downsample` branch: NCHW fp32-MFMA GEMMs (dc_conv1x1_*), no layout transposes
-        return _ops.conv1x1(x, conv.weight, conv.stride[0], fork=fork)
+        return _ops.conv1x1(x, conv.weight, conv.stride[0], fork=fork, skip=skip)
     if (CONV_S2 and x.is_cuda and conv.stride == (2, 2) and conv.kernel_size in ((3, 3), (7, 7)) and conv.groups == 1
             and conv.padding == (conv.kernel_size[0] // 2,) * 2 and conv.dilation == (1, 1) and conv.bias is None
             and x.dtype == torch.float32 and _ops.conv_s2_supported(x, conv.weight)
             and ((conv.kernel_size == (7, 7) and not x.requires_grad)        # (the stem kernels have no data gradient)
                  or (conv.kernel_size == (3, 3) and conv.in_channels % 4 == 0 and conv.out_channels % 32 == 0))):
         # 7x7 / 2 stem and the 3x3 / 2 convolutions: implicit GEMMs on the matrix cores (dc_convs2_*)
-        if fork is not None:
+        if fork is not None and (not fork.pair or conv.kernel_size != (3, 3)):
             raise _ops.DepthcoreError("GradFork handed to a strided convolution")
-        return _ops.conv_s2(x, conv.weight)
+        return _ops.conv_s2(x, conv.weight, fork)
     if fork is not None:  # (_fork_for mirrors the two conditions above; a fork nobody collects would lose the skip's gradient)
         raise _ops.DepthcoreError("GradFork handed to a convolution that does not run on a kernel with the addend epilogue")
     if not x.is_cuda:
@@ -168,10 +182,17 @@ class BasicBlock(nn.Module):
         g = self._g[0]
         if self._fold_ok(x, g):
             return self._forward_fold(x, g)
-        idt = x if self.downsample is None else _bn_act(_conv(self.downsample[0], x), self.downsample[1], relu=False, groups=g)
-        fork = _fork_for(self, x)
-        out = _bn_act(_conv(self.conv1, x, fork), self.bn1, groups=g)
-        return _bn_act(_conv(self.conv2, out), self.bn2, res=idt, groups=g, fork=fork)   # relu(bn2(conv2) + identity), one pass
+        if self.downsample is None:
+            fork = _fork_for(self, x)
+            out = _bn_act(_conv(self.conv1, x, fork), self.bn1, groups=g)
+            return _bn_act(_conv(self.conv2, out), self.bn2, res=x, groups=g, fork=fork)   # relu(bn2(conv2) + identity), one pass
+        # x feeds the 3x3 / 2 conv1 AND the 1x1 / 2 `downsample` (and, as a feature map, the decoder's skip connection): a pair
+        # fork -- conv1's backward runs first (the skip branch is evaluated first here) and parks its data gradient, the
+        # downsample's data-gradient kernel adds it, and whatever the SkipSum of x collected, in its store epilogue
+        pair = _basic_pair_fork(self, x)
+        idt = _bn_act(_conv(self.downsample[0], x, pair, _ops.skip_of(x) if pair is not None else None), self.downsample[1], relu=False, groups=g)
+        out = _bn_act(_conv(self.conv1, x, pair), self.bn1, groups=g)
+        return _bn_act(_conv(self.conv2, out), self.bn2, res=idt, groups=g)
 
 
 class Bottleneck(nn.Module):
@@ -210,7 +231,8 @@ class Bottleneck(nn.Module):
             prev = _bnf.take_link(x, self.conv1, g) if fork is not None else None
         else:
             fork, prev = _pair_fork_for(self, x), None
-        y1, s1 = _bnf.conv1x1(x, self.conv1.weight, 1, g, fork=fork, prev=prev)
+        sk = _ops.skip_of(x) if (fork is not None and fork.pair) else None
+        y1, s1 = _bnf.conv1x1(x, self.conv1.weight, 1, g, fork=fork, prev=prev, skip=sk)
         lvl = _fold_level(True)
         wino2 = WINO_TRUNK and _bnf.wino_ok(self.conv2, tuple(y1.shape), g)
         if wino2 and lvl >= 3:
@@ -227,7 +249,7 @@ class Bottleneck(nn.Module):
         if self.downsample is None:
             return _bnf.bn_apply(y3, self.bn3, s3, res=x, groups=g, fork=fork, leave_link=link)
         d = self.downsample[0]
-        yd, sd = _bnf.conv1x1(x, d.weight, d.stride[0], g, fork=fork)
+        yd, sd = _bnf.conv1x1(x, d.weight, d.stride[0], g, fork=fork, skip=sk)
         idt = _bnf.bn_apply(yd, self.downsample[1], sd, relu=False, groups=g)
         return _bnf.bn_apply(y3, self.bn3, s3, res=idt, groups=g, leave_link=link)
 
@@ -242,12 +264,13 @@ class Bottleneck(nn.Module):
             return _bn_act(_conv(self.conv3, out), self.bn3, res=x, groups=g, fork=fork)
         # conv1 and the 1x1 `downsample` both read x: a pair fork sums their two data gradients in the second one's epilogue
         pair = _pair_fork_for(self, x)
-        out = _bn_act(_conv(self.conv1, x, pair), self.bn1, groups=g)
+        sk = _ops.skip_of(x) if pair is not None else None
+        out = _bn_act(_conv(self.conv1, x, pair, sk), self.bn1, groups=g)
         out = _bn_act(_conv(self.conv2, out), self.bn2, groups=g)
         out = _conv(self.conv3, out)
         # (the skip branch is evaluated last so that its backward runs first: the stride-1 conv1 -- whose kernel adds in its
         # store epilogue -- is then the second of the pair; either order is correct)
-        idt = _bn_act(_conv(self.downsample[0], x, pair), self.downsample[1], relu=False, groups=g)
+        idt = _bn_act(_conv(self.downsample[0], x, pair, sk), self.downsample[1], relu=False, groups=g)
         return _bn_act(out, self.bn3, res=idt, groups=g)
 
 
@@ -356,10 +379,19 @@ class ResnetEncoder(nn.Module):
         e._g[0] = int(bn_groups)
         self.features = []
         x = _bn_act(x, e.bn1, groups=e._g[0])
-        self.features.append(x)
-        self.features.append(e.layer1(_ops.maxpool3x3s2(x) if x.is_cuda else e.maxpool(x)))
-        self.features.append(e.layer2(self.features[-1]))
-        self.features.append(e.layer3(self.features[-1]))
+        tag = SKIP_SUMS and self.training and x.is_cuda and x.requires_grad and torch.is_grad_enabled()
+
+        def feature(t):
+            # a feature map has a primary consumer in the trunk (the max-pool, the next stage's first block) and, in the depth
+            # network, the decoder's skip connection: the SkipSum lets the primary's backward kernel add the latter's gradient
+            if tag:
+                t._dc_skip = _ops.SkipSum()
+            self.features.append(t)
+            return t
+        feature(x)
+        feature(e.layer1(_ops.maxpool3x3s2(x, _ops.skip_of(x)) if x.is_cuda else e.maxpool(x)))
+        feature(e.layer2(self.features[-1]))
+        feature(e.layer3(self.features[-1]))
         self.features.append(e.layer4(self.features[-1]))
         if self.training:   # nn.BatchNorm2d bookkeeping, one multi-tensor launch instead of one per layer
             if self._nbt is None:

@@ -693,6 +693,7 @@ class Trainer:
             self.buckets.zero()                     # model_optimizer.zero_grad(set_to_none=True)
             with ops.WgradLanes.active(self.wgrad_lanes):
                 losses["loss"].backward()
+            ops.assert_no_dangling_sums()       # (a gradient handed to a SkipSum that nobody collected would be a lost gradient)
         finally:
             self.wino_cache.invalidate()        # the optimiser step below rewrites the weights
         self.buckets.finish()                   # RCCL all-reduce (mean) launched from the backward hooks

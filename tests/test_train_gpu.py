@@ -872,3 +872,33 @@ def test_full_size_train_step_properties(cfg, monkeypatch):
     assert np.isfinite(res[0][0]) and bool(torch.isfinite(res[0][1]).all()) and float(res[0][1].abs().max()) > 0
     assert res[0][2].shape[-2:] == (192, 640)
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def test_gradient_sums_in_kernel_epilogues_change_nothing():
+    """The sums autograd would form for tensors with several consumers -- an encoder feature map (trunk + decoder skip), a stage
+    input (3x3 / 2 conv1 + 1x1 / 2 downsample), the decoder's x (dispconv + next upconv) -- ride in the store epilogues of the
+    data-gradient kernels (ops.SkipSum, pair ops.GradFork): every parameter gradient of a training step equals the
+    autograd-summed one to rounding (three-operand sums associate differently), and no gradient is left uncollected."""
+    from networks import resnet_encoder as RE, depth_decoder as DD
+    from depthcore import ops
+    for layers in (18, 50):
+        res = {}
+        for on in (True, False):
+            RE.SKIP_SUMS, DD.X_FORK, gf = on, on, RE.GRAD_FORK
+            RE.GRAD_FORK = on
+            try:
+                tr, state, inputs = _setup(2, 64, 128, num_layers=layers)
+                dev_in = {k: v.to(DEV) for k, v in inputs.items()}
+                torch.manual_seed(1234)
+                tr.buckets.zero()
+                _, losses = tr.process_batch(dict(dev_in))
+                losses["loss"].backward()
+                ops.assert_no_dangling_sums()
+                res[on] = {(k, n): p.grad.detach().clone() for k, m in tr.models.items() for n, p in m.named_parameters() if p.grad is not None}
+                res[on]["loss"] = losses["loss"].detach().clone()
+            finally:
+                RE.SKIP_SUMS, DD.X_FORK, RE.GRAD_FORK = True, True, gf
+        assert torch.equal(res[True]["loss"], res[False]["loss"])
+        assert set(res[True]) == set(res[False])
+        worst = max((rel_l2(res[True][k], res[False][k]), k) for k in res[True])
+        assert worst[0] < 1e-5, worst
