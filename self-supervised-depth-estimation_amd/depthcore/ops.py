@@ -16,6 +16,9 @@ from . import _lib
 from ._lib import PhotoDesc, check, ptr, stream
 
 
+DepthcoreError = _lib.DepthcoreError
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 

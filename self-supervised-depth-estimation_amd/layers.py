@@ -54,7 +54,7 @@ class Conv3x3(nn.Module):
         if H * W >= FUSED_CONV_MIN_PIXELS:
             return _ops.conv3x3_block(x, skip, self.conv.weight, self.conv.bias, up, act, self._pad_mode, fork)
         if fork is not None:
-            raise _ops.DepthcoreError("GradFork handed to the library comparison path")
+            raise _ops._lib.DepthcoreError("GradFork handed to the library comparison path")
         # comparison path for tools/time_decoder.py (DC_MIN_PIXELS): the same arithmetic as separate library launches
         if up:
             x = F.interpolate(x, scale_factor=2, mode="nearest")
