@@ -294,7 +294,7 @@ def _traffic_for(cfg_key):
     """HBM bytes per launch from the PMC passes kept under profiles/ (separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc
     WRITE_SIZE` runs, tools/pmc_traffic.sh; FETCH_SIZE x2.0 per the gfx950 calibration, WRITE_SIZE x1.0).  They are
     CITED, not measured in this run: a PMC pass serialises the step and cannot share a process with the timed region."""
-    for name in ("round4_traffic_%s.json" % cfg_key, "round3_traffic_%s.json" % cfg_key):
+    for name in ("round5_traffic_%s.json" % cfg_key, "round4_traffic_%s.json" % cfg_key, "round3_traffic_%s.json" % cfg_key):
         if not name:
             continue
         tf = os.path.join(REPO, "profiles", name)

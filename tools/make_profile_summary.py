@@ -9,8 +9,8 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r4final")
-RND = "round%s" % (sys.argv[2] if len(sys.argv) > 2 else "4")
+SRC = os.path.join(REPO, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r5final")
+RND = "round%s" % (sys.argv[2] if len(sys.argv) > 2 else "5")
 DST = os.path.join(REPO, "profiles")
 FAMILIES = [("c3b_conv_kernel", "3x3 convolution on the bf16 matrix cores: forward / data gradient"),
             ("c3b_wgrad_kernel", "3x3 weight gradient on the bf16 matrix cores"), ("c3b_", "bf16 weight packing"),

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the round's judged artefacts for one configuration -> gpurun_out/r4final/ (tools/make_profile_summary.py copies
+# GPU box: the round's judged artefacts for one configuration -> gpurun_out/${ROUND_DIR:-r5final}/ (tools/make_profile_summary.py copies
 # them into profiles/).  usage: bash tools/round_final.sh <cfg> [pmc]     cfg: c2 | c3 | c5 | c5bf16 | c1g | c4
 #   1. plain bench line        2. rocprofv3 --kernel-trace --stats of the same command with --wgrad-lanes 0 (cfg c2 / c3 / c5 /
 #      c5bf16): with the weight-gradient lanes the step has four streams and the profiler no longer serialises the dispatches
@@ -7,7 +7,7 @@
 #   3. with `pmc`: the three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU; tools/pmc_traffic.sh)
 set -e
 CFG=$1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r4final
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${ROUND_DIR:-r5final}
 mkdir -p $OUT
 case $CFG in
   c2) ARGS=""; ENVS="" ;;
