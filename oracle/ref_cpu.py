@@ -429,6 +429,57 @@ def predict_poses(inputs, pose_encoder_fn, pose_decoder_fn):
 
 
 # --------------------------------------------------------------------------
+# a16, the other pose modes                      networks/pose_cnn.py:14-53, trainer.py:378-442
+# --------------------------------------------------------------------------
+def pose_cnn_forward(state, x, num_input_frames):
+    """networks/pose_cnn.py:40-53: seven stride-2 convolutions (7x7, 5x5, 3x3 x 5) + ReLU, a 1x1 head, spatial mean, x 0.01."""
+    pads = (3, 2, 1, 1, 1, 1, 1)
+    out = x
+    for i in range(7):
+        out = F.relu(F.conv2d(out, state["net.%d.weight" % i], state["net.%d.bias" % i], stride=2, padding=pads[i]))
+    out = F.conv2d(out, state["pose_conv.weight"], state["pose_conv.bias"])
+    out = out.mean(3).mean(2)
+    out = 0.01 * out.view(-1, num_input_frames - 1, 1, 6)
+    return out[..., :3], out[..., 3:]
+
+
+def predict_poses_modes(inputs, features, pose_model_type, pose_model_input, frame_ids, pose_encoder_fn, pose_fn):
+    """trainer.py:378-442 for every pose_model_type / pose_model_input.  `features`: {frame id: encoder feature list} ("shared").
+    `pose_fn`: the pose network -- PoseDecoder on a list of feature lists ("separate_resnet", "shared") or PoseCNN on a
+    tensor; `pose_encoder_fn`: the pose encoder ("separate_resnet").  Frames are always passed in temporal order in pairs mode
+    (:396-399) and the pose to a PAST frame is inverted there (:417-419); "all" mode predicts every pose in one pass, in
+    frame_ids order, without inversion (:435-440)."""
+    outputs = {}
+    if pose_model_input == "pairs":
+        feats = {f: features[f] for f in frame_ids} if pose_model_type == "shared" else {f: inputs[("color_aug", f, 0)] for f in (-1, 0, 1)}
+        for f in (-1, 1):
+            pose_inputs = [feats[f], feats[0]] if f < 0 else [feats[0], feats[f]]
+            if pose_model_type == "separate_resnet":
+                pose_inputs = [pose_encoder_fn(torch.cat(pose_inputs, 1))]
+            elif pose_model_type == "posecnn":
+                pose_inputs = torch.cat(pose_inputs, 1)
+            axisangle, translation = pose_fn(pose_inputs)
+            outputs[("axisangle", 0, f)] = axisangle
+            outputs[("translation", 0, f)] = translation
+            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=(f < 0))
+        return outputs
+    ids = [i for i in frame_ids if i != "s"]
+    if pose_model_type in ("separate_resnet", "posecnn"):
+        pose_inputs = torch.cat([inputs[("color_aug", i, 0)] for i in ids], 1)
+        if pose_model_type == "separate_resnet":
+            pose_inputs = [pose_encoder_fn(pose_inputs)]
+    else:
+        pose_inputs = [features[i] for i in ids]
+    axisangle, translation = pose_fn(pose_inputs)
+    for i, f in enumerate(frame_ids[1:]):
+        if f != "s":
+            outputs[("axisangle", 0, f)] = axisangle
+            outputs[("translation", 0, f)] = translation
+            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle[:, i], translation[:, i])
+    return outputs
+
+
+# --------------------------------------------------------------------------
 # synthetic KITTI-shaped batch (SURVEY 8d)     datasets/mono_dataset.py:122-183
 # --------------------------------------------------------------------------
 KITTI_K = np.array([[0.58, 0, 0.5, 0],

@@ -2,5 +2,6 @@
 from .resnet_encoder import ResnetEncoder
 from .depth_decoder import DepthDecoder
 from .pose_decoder import PoseDecoder
+from .pose_cnn import PoseCNN
 from .fusion import Fusion_v3, FeatureFusionBlock_v3, ResidualAttentionUnit, AttentionConv, UpscalePS
 from .convgru import ConvGRUBlocks_v5, ConvGRUModel_v1, ConvGRUCell

@@ -70,8 +70,11 @@ class Trainer:
         self.rank, self.world_size = rank, world_size
         assert self.opt.height % 32 == 0 and self.opt.width % 32 == 0      # trainer.py:37-38
         assert self.opt.frame_ids[0] == 0
-        if self.opt.pose_model_type != "separate_resnet" or self.opt.pose_model_input != "pairs":
-            raise NotImplementedError("hot path covers pose_model_type=separate_resnet, pose_model_input=pairs")
+        if self.opt.pose_model_type not in ("separate_resnet", "shared", "posecnn") or self.opt.pose_model_input not in ("pairs", "all"):
+            raise ValueError("pose_model_type: separate_resnet | shared | posecnn; pose_model_input: pairs | all (options.py:63-64)")
+        if self.opt.pose_model_type == "shared" and (getattr(self.opt, "fusion", None) or getattr(self.opt, "gru", None)):
+            raise ValueError("the sequence front-ends (trainer_fusion_v3.py, trainer_gru.py) run their own encoder pass; "
+                             "pose_model_type='shared' belongs to the vanilla trainer (trainer.py:263-279)")
         if self.opt.predictive_mask and not self.opt.disable_automasking:       # trainer.py:116-117
             raise ValueError("When using predictive_mask, please disable automasking with disable_automasking")
         if getattr(self.opt, "fusion", None) not in (None, "v3"):
@@ -87,7 +90,11 @@ class Trainer:
         # images per loss evaluation: the reference's GRU trainer stacks the sequence along the batch (trainer_gru.py:256-263)
         self.loss_batch = self.opt.batch_size * (self.opt.len_sequence if self.opt.gru else 1)
         self.num_scales = len(self.opt.scales)
-        self.num_pose_frames = 2
+        self.num_input_frames = len(self.opt.frame_ids)                                   # trainer.py:50-51
+        self.num_pose_frames = 2 if self.opt.pose_model_input == "pairs" else self.num_input_frames
+        if self.opt.pose_model_input == "all" and self.opt.pose_model_type == "separate_resnet" and self.num_input_frames != 3:
+            raise ValueError("pose_model_input='all' with separate_resnet predicts two poses (trainer.py:100-103): frame_ids must be "
+                             "[0, a, b]")
 
         torch.manual_seed(seed)                                  # same initial weights on every rank
         self.models = {}
@@ -116,10 +123,15 @@ class Trainer:
             self.models["gru"] = networks.ConvGRUBlocks_v5(kernel_size=(3, 3), bias=True, device="cpu", height=self.opt.height,
                                                            width=self.opt.width,
                                                            num_ch_enc=tuple(int(c) for c in self.models["encoder"].num_ch_enc))
-        self.models["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, _init_for("pose_encoder"),
-                                                             num_input_images=self.num_pose_frames)
-        self.models["pose"] = networks.PoseDecoder(self.models["pose_encoder"].num_ch_enc, num_input_features=1,
-                                                   num_frames_to_predict_for=2)
+        if self.opt.pose_model_type == "separate_resnet":          # trainer.py:84-103
+            self.models["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, _init_for("pose_encoder"),
+                                                                 num_input_images=self.num_pose_frames)
+            self.models["pose"] = networks.PoseDecoder(self.models["pose_encoder"].num_ch_enc, num_input_features=1,
+                                                       num_frames_to_predict_for=2)
+        elif self.opt.pose_model_type == "shared":                 # trainer.py:104-106: the depth encoder's features of every frame
+            self.models["pose"] = networks.PoseDecoder(self.models["encoder"].num_ch_enc, self.num_pose_frames)
+        else:                                                      # trainer.py:107-109
+            self.models["pose"] = networks.PoseCNN(self.num_input_frames if self.opt.pose_model_input == "all" else 2)
         if self.opt.predictive_mask:                             # trainer.py:115-125: one mask per source frame
             self.models["predictive_mask"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, self.opt.scales,
                                                                    num_output_channels=2)
@@ -134,7 +146,7 @@ class Trainer:
         main = ["encoder"] + [k for k in ("gru",) if k in self.models] + ["depth"] + \
             [k for k in ("fusion", "predictive_mask") if k in self.models]
         order = (["pose_encoder", "pose"] + main) if getattr(self.opt, "overlap_streams", False) else (main + ["pose_encoder", "pose"])
-        order = order + [k for k in self.models if k not in order]
+        order = [k for k in order if k in self.models] + [k for k in self.models if k not in order]
         named = [(k + "." + n, p) for k in order for n, p in self.models[k].named_parameters()]
         self.buckets = GradBuckets(named, self.opt.bucket_mb, world_size, process_group)
         # hipGraph mode (opt.hip_graph, one GPU): the step is captured once and replayed, so everything that changes from
@@ -240,7 +252,12 @@ class Trainer:
                 inputs[key] = ipt.to(self.device)
         if self.opt.gru:
             inputs = self._stack_sequence(inputs)
-        if getattr(self.opt, "overlap_streams", False) and self.device.type == "cuda":
+        if self.opt.pose_model_type == "shared":
+            # trainer.py:263-279: every frame goes through the depth encoder (ONE pass, the frames stacked along the batch --
+            # BatchNorm statistics over all of them, as in the reference), the pose decoder reads the per-frame features
+            outputs, features = self._depth_branch_shared(inputs)
+            outputs.update(self.predict_poses(inputs, features))
+        elif getattr(self.opt, "overlap_streams", False) and self.device.type == "cuda":
             # The pose network (pose encoder + decoder) and the depth network are independent until the loss: run them
             # on two HIP streams so that one branch's kernels fill the other's tails and small launches.  Autograd
             # replays each backward op on its forward stream, so the backward overlaps the same way.
@@ -284,11 +301,24 @@ class Trainer:
             outputs["predictive_mask"] = self.models["predictive_mask"](features)
         return outputs
 
-    # ------------------------------------------------------------------ trainer.py:378-442 (pairs mode)
+    def _depth_branch_shared(self, inputs):
+        ids = list(self.opt.frame_ids)
+        B = self.opt.batch_size
+        all_features = self.models["encoder"](torch.cat([inputs[("color_aug", i, 0)] for i in ids], 0))
+        features = {k: [f[i * B:(i + 1) * B] for f in all_features] for i, k in enumerate(ids)}
+        outputs = dict(self.models["depth"](features[0]))
+        if self.opt.predictive_mask:
+            outputs["predictive_mask"] = self.models["predictive_mask"](features[0])
+        return outputs, features
+
+    # ------------------------------------------------------------------ trainer.py:378-442
     def predict_poses(self, inputs, features):
-        """Both temporally ordered pairs (-1,0), (0,+1) go through the pose encoder in ONE pass: they are stacked
-        along the batch and BatchNorm keeps separate statistics per pair (`bn_groups=2`), which is exactly the
-        arithmetic of the reference's two sequential passes (trainer.py:398-419) at twice the GEMM N."""
+        """Default (separate_resnet, pairs): both temporally ordered pairs (-1,0), (0,+1) go through the pose encoder in ONE
+        pass: they are stacked along the batch and BatchNorm keeps separate statistics per pair (`bn_groups=2`), which is
+        exactly the arithmetic of the reference's two sequential passes (trainer.py:398-419) at twice the GEMM N.
+        Every other pose_model_type / pose_model_input follows trainer.py:378-442 statement by statement."""
+        if self.opt.pose_model_type != "separate_resnet" or self.opt.pose_model_input != "pairs":
+            return self._predict_poses_modes(inputs, features)
         outputs = {}
         pose_feats = {f: inputs[("color_aug", f, 0)] for f in (-1, 0, 1)}
         B = pose_feats[0].shape[0]
@@ -300,6 +330,38 @@ class Trainer:
             outputs[("axisangle", 0, f)] = aa
             outputs[("translation", 0, f)] = tr
             outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(aa[:, 0], tr[:, 0], invert=(f < 0))
+        return outputs
+
+    def _predict_poses_modes(self, inputs, features):
+        o, outputs = self.opt, {}
+        pose = self.models["pose"]
+        if self.num_pose_frames == 2:                            # trainer.py:383-419: one pass per source frame
+            feats = {f: features[f] for f in o.frame_ids} if o.pose_model_type == "shared" else \
+                {f: inputs[("color_aug", f, 0)] for f in (-1, 0, 1)}
+            for f in (-1, 1):
+                pose_inputs = [feats[f], feats[0]] if f < 0 else [feats[0], feats[f]]        # temporal order
+                if o.pose_model_type == "separate_resnet":
+                    pose_inputs = [self.models["pose_encoder"](torch.cat(pose_inputs, 1))]
+                elif o.pose_model_type == "posecnn":
+                    pose_inputs = torch.cat(pose_inputs, 1)
+                axisangle, translation = pose(pose_inputs)
+                outputs[("axisangle", 0, f)] = axisangle
+                outputs[("translation", 0, f)] = translation
+                outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=(f < 0))
+            return outputs
+        ids = [i for i in o.frame_ids if i != "s"]               # trainer.py:421-440: all frames in, all poses out
+        if o.pose_model_type in ("separate_resnet", "posecnn"):
+            pose_inputs = torch.cat([inputs[("color_aug", i, 0)] for i in ids], 1)
+            if o.pose_model_type == "separate_resnet":
+                pose_inputs = [self.models["pose_encoder"](pose_inputs)]
+        else:
+            pose_inputs = [features[i] for i in ids]
+        axisangle, translation = pose(pose_inputs)
+        for i, f in enumerate(o.frame_ids[1:]):
+            if f != "s":
+                outputs[("axisangle", 0, f)] = axisangle
+                outputs[("translation", 0, f)] = translation
+                outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle[:, i], translation[:, i])
         return outputs
 
     # ------------------------------------------------------------------ fused a14 + a15
