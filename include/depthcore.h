@@ -180,6 +180,11 @@ int dc_photo_fwd(const dc_photo_desc* d, void* stream);
 int dc_photo_bwd(const dc_photo_desc* d, void* stream);
 /* Per-launch algorithmic bytes of the fused forward / backward kernel, for bench.py. */
 double dc_photo_algorithmic_bytes(const dc_photo_desc* d, int backward);
+/* 1 (default; env DC_PHOTO_FULL): the training forward of the default loss configuration contracts all the way to
+ * d(loss)/d(upsampled disp) and the pose sums (one float per pixel and scale leaves it; dc_photo_bwd is the transposed upsample
+ * alone).  0: the round-4 split -- the forward emits d(loss)/d(source coordinates), a pointwise backward chains them (A/Bs).
+ * Returns the previous setting.  Must not change between a dc_photo_fwd and its dc_photo_bwd. */
+int dc_set_photo_full(int mode);
 
 /* Measurement hook (bench.py `roofline`): when enabled, dc_photo_fwd / dc_photo_bwd bracket their
  * dominant kernel (photo_fwd_kernel / photo_bwd_kernel) AND their whole launch chain (forward: identity + smoothness +

@@ -76,6 +76,8 @@ struct PhotoArgs {
     int rows_g, rows_p;           // rows per block of the gradient-emitting forward / the pointwise backward
     float* part_dP;      // [ns][2][B][nblk_b_per_image][12]
     int nblk_f, nchunk, nblk_b_img;
+    int full;            // training forward of the default configuration went "all the way" (photo_fwdg_kernel<.., FULL>): gdup holds
+                         // the UNWEIGHTED d(sum to_optimise)/d(upsampled disp), part_dP the unweighted pose sums of the forward's blocks
 };
 
 __device__ __forceinline__ float uni(float v) {
@@ -219,6 +221,7 @@ struct Taps {
     f3 tap[2][4];        // [frame][nw, ne, sw, se] RGB pixels
     float wx1[2], wy1[2];
     float sx[2], sy[2];  // training forward only: d(ix)/du, d(iy)/dv incl. the border-clamp zero
+    float depth;         // training forward only: the pixel's depth (FULL: parked with the derivative terms for stage C)
 };
 struct RowLog {          // forward, only when the log tensors are requested
     float gx[2], gy[2], depth;
@@ -259,6 +262,7 @@ __device__ __forceinline__ void issue_row(Taps& r, const Geo& g, const Ctx& c, f
         cam[i] = depth * ray;
     }
     if (LOGS) lg.depth = depth;
+    if (GRAD) r.depth = depth;
     TapOff to[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -692,11 +696,44 @@ __global__ __launch_bounds__(1024) void finalize_kernel(PhotoArgs p) {
     }
 }
 
+constexpr int RING_FULL = 13;   // FULL: + the row's depth
 constexpr int RING_VALS = 12;   // d(warped)/d(x), d(warped)/d(y) of [2 frames][3 channels]: 3 slots (written at A, read at C two rows later)
 
 struct GAcc {
     float g[2][3];
 };
+
+struct ProjQ {
+    float u[2], v[2], zi[2], depth;
+};
+
+__device__ __forceinline__ void project_q(ProjQ& q, const Geo& g, const Ctx& c, float disp, int x, int y) {
+    const float scaled = c.min_disp + c.disp_range * disp;
+    const float depth = frcp(scaled);
+    const float xf = (float)x, yf = (float)y;
+    float cam[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float ray = g.iK[i * 3 + 0] * xf;
+        ray = fmaf(g.iK[i * 3 + 1], yf, ray);
+        ray = ray + g.iK[i * 3 + 2];
+        cam[i] = depth * ray;
+    }
+    q.depth = depth;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        float w[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float a = g.P[f][i * 4 + 0] * cam[0];
+            a = fmaf(g.P[f][i * 4 + 1], cam[1], a);
+            a = fmaf(g.P[f][i * 4 + 2], cam[2], a);
+            w[i] = a + g.P[f][i * 4 + 3];
+        }
+        const float zi = frcp(w[2] + 1e-7f);
+        q.u[f] = w[0] * zi; q.v[f] = w[1] * zi; q.zi[f] = zi;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Training forward: the forward pass that ALSO emits d(sum_p to_optimise(p)) / d(source coordinates u, v) of both source
@@ -723,8 +760,15 @@ struct GAcc {
 // SPEC >= 0: the option flags are compile-time constants (bit 0 no_ssim, 1 avg_reprojection, 2 automasking, 3 external noise
 // tensors) -- the default training configuration gets straight-line code the scheduler can interleave across channels and
 // frames; SPEC = -1 reads them at run time (every other combination).
-template <bool LOGS, int SPEC>
+// FULL (default configurations only, SPEC >= 0): the contraction goes all the way -- stage C chains (du, dv) through
+// Project3D / BackprojectDepth / disp_to_depth right there (the row's depth waits in the ring with the derivative terms, the
+// projection is re-derived from it), stores ONE float per pixel and scale, d(sum to_optimise)/d(upsampled disp) with unit
+// upstream weight, and accumulates the pose sums (9 accumulators per frame, as the pointwise backward did); the backward is
+// then the transposed upsample alone, scaled by the step's upstream weights (disp_grad_kernel), and photo_bwdg_kernel is not
+// launched: 16 B per pixel and scale less written and read back.
+template <bool LOGS, int SPEC, bool FULL = false>
 __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(PhotoArgs p) {
+    static_assert(!FULL || SPEC >= 0, "FULL exists for the specialised default configurations");
     const int lane = threadIdx.x & 63;
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
@@ -756,8 +800,16 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
     const unsigned idl_px = avg ? 4u : 8u;
     uint8_t* am = p.argmin[s] + (size_t)b * plane;
     float* isel = p.idsel[s] ? p.idsel[s] + (size_t)b * plane : nullptr;
-    __shared__ float dring[DC_MAX_SCALES][3 * RING_VALS * 64];       // [wave][slot i%3][(f*3+ch)*2 + {x,y}][lane]
+    constexpr int RV = FULL ? RING_FULL : RING_VALS;
+    __shared__ float dring[DC_MAX_SCALES][3 * RV * 64];       // [wave][slot i%3][(f*3+ch)*2 + {x,y} | depth][lane]
     float* ring = dring[s] + lane;
+    // FULL: pose-gradient accumulators (see photo_bwdg_kernel) and the output of stage C
+    float accA[FULL ? 2 : 1][3], accB[FULL ? 2 : 1][3], accC[FULL ? 2 : 1][3];
+#pragma unroll
+    for (int f = 0; f < (FULL ? 2 : 1); ++f)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) accA[f][k] = accB[f][k] = accC[f][k] = 0.f;
+    float* gout = FULL ? p.gdup[s] + (size_t)b * plane : nullptr;
     const rsrc_t gwb = make_rsrc(p.gw[s] + (size_t)b * plane * 4, plane * 16u);
     const float g_ssim = no_ssim ? 0.f : 0.85f / 3.f;
     const float g_l1 = (no_ssim ? 1.f / 3.f : 0.15f / 3.f) * (avg ? 0.5f : 1.f);
@@ -781,7 +833,8 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
         Row cur;
         blend_row(tp, cur);
         {
-            float* rs = ring + (size_t)slot3 * RING_VALS * 64;
+            float* rs = ring + (size_t)slot3 * RV * 64;
+            if (FULL) rs[RING_VALS * 64] = tp.depth;
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 const float wx1 = tp.wx1[f], wy1 = tp.wy1[f];
@@ -953,7 +1006,7 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
             const int qy = yy - 2;
             if (qy < H && q_lane) {
                 const int s2 = (slot3 == 0) ? 1 : ((slot3 == 1) ? 2 : 0);   // (i-2) % 3
-                const float* rq = ring + (size_t)s2 * RING_VALS * 64;
+                const float* rq = ring + (size_t)s2 * RV * 64;
                 float duv[2][2];
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
@@ -969,7 +1022,50 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
                     }
                     duv[f][0] = du; duv[f][1] = dv;
                 }
-                bstore4(gwb, (unsigned)(qy * W + x) * 16u, duv[0][0], duv[0][1], duv[1][0], duv[1][1]);
+                if constexpr (FULL) {
+                    // Project3D / BackprojectDepth / disp_to_depth backward with unit weight + pose sums (photo_bwdg_kernel's chain)
+                    const float depth = rq[RING_VALS * 64];
+                    const float xf = (float)x, yf = (float)qy;
+                    float ray[3], cam[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        float t = g.iK[r * 3 + 0] * xf;
+                        t = fmaf(g.iK[r * 3 + 1], yf, t);
+                        ray[r] = t + g.iK[r * 3 + 2];
+                        cam[r] = depth * ray[r];
+                    }
+                    float dcam[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        float w[3];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            float a_ = g.P[f][r * 4 + 0] * cam[0];
+                            a_ = fmaf(g.P[f][r * 4 + 1], cam[1], a_);
+                            a_ = fmaf(g.P[f][r * 4 + 2], cam[2], a_);
+                            w[r] = a_ + g.P[f][r * 4 + 3];
+                        }
+                        const float zi = frcp(w[2] + 1e-7f);
+                        const float uu = w[0] * zi, vv = w[1] * zi;
+                        float dq[3];
+                        dq[0] = duv[f][0] * zi;
+                        dq[1] = duv[f][1] * zi;
+                        dq[2] = -fmaf(duv[f][0], uu, duv[f][1] * vv) * zi;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const float dqd = dq[r] * depth;
+                            accA[f][r] += dqd;
+                            accB[f][r] = fmaf(dqd, yf, accB[f][r]);
+                            accC[f][r] += dq[r];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) dcam[j] = fmaf(dq[r], g.P[f][r * 4 + j], dcam[j]);
+                        }
+                    }
+                    const float dd = fmaf(dcam[0], ray[0], fmaf(dcam[1], ray[1], dcam[2] * ray[2]));
+                    gout[(unsigned)(qy * W + x)] = -dd * depth * depth * p.disp_range;
+                } else {
+                    bstore4(gwb, (unsigned)(qy * W + x) * 16u, duv[0][0], duv[0][1], duv[1][0], duv[1][1]);
+                }
             }
         }
         // rotate: the slots of row yy-2 now take row yy
@@ -996,6 +1092,26 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
         const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         p.part_photo[(size_t)s * p.nblk_f + blk] = acc;
     }
+    if constexpr (FULL) {
+        // pose-gradient partials of this wave's strip: the lane's column x is constant along the march, so
+        //   sum dq_r*cam_j = (iK_j0*x + iK_j2) * sum(dq_r*depth) + iK_j1 * sum(dq_r*depth*y);   fixed shuffle tree
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        const float xf = (float)xr;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float* o = p.part_dP + ((((size_t)s * 2 + f) * p.B + b) * p.nblk_b_img + blk) * 12;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float v = wave_sum((g.iK[j * 3 + 0] * xf + g.iK[j * 3 + 2]) * accA[f][r] + g.iK[j * 3 + 1] * accB[f][r]);
+                    if (lane == 0) o[r * 4 + j] = v;
+                }
+                const float v3 = wave_sum(accC[f][r]);
+                if (lane == 0) o[r * 4 + 3] = v3;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1008,38 +1124,6 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
 #ifndef BWDG_BLOCKS_PER_CU
 #define BWDG_BLOCKS_PER_CU 4
 #endif
-
-struct ProjQ {
-    float u[2], v[2], zi[2], depth;
-};
-
-__device__ __forceinline__ void project_q(ProjQ& q, const Geo& g, const Ctx& c, float disp, int x, int y) {
-    const float scaled = c.min_disp + c.disp_range * disp;
-    const float depth = frcp(scaled);
-    const float xf = (float)x, yf = (float)y;
-    float cam[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        float ray = g.iK[i * 3 + 0] * xf;
-        ray = fmaf(g.iK[i * 3 + 1], yf, ray);
-        ray = ray + g.iK[i * 3 + 2];
-        cam[i] = depth * ray;
-    }
-    q.depth = depth;
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        float w[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            float a = g.P[f][i * 4 + 0] * cam[0];
-            a = fmaf(g.P[f][i * 4 + 1], cam[1], a);
-            a = fmaf(g.P[f][i * 4 + 2], cam[2], a);
-            w[i] = a + g.P[f][i * 4 + 3];
-        }
-        const float zi = frcp(w[2] + 1e-7f);
-        q.u[f] = w[0] * zi; q.v[f] = w[1] * zi; q.zi[f] = zi;
-    }
-}
 
 #ifndef BWDG_ROWS_IN_FLIGHT
 #define BWDG_ROWS_IN_FLIGHT 4
@@ -1272,6 +1356,9 @@ __device__ __forceinline__ void disp_grad_tile(const PhotoArgs& p, int b, int ti
         __syncthreads();
     }
     // ---- y pass + smoothness gradient
+    // (FULL forward: gdup is d(sum to_optimise)/d(upsampled disp) with unit weight -- the upstream weight of this scale's loss,
+    // d loss / d to_optimise(pixel) = (g_s + g_total / ns) / (B H W), is applied here, after the linear transposed upsample)
+    const float wup = p.full ? (p.g_losses[S] + p.g_losses[p.ns] / (float)p.ns) / ((float)p.B * H * W) : 1.f;
     const float gsm = (p.g_losses[S] + p.g_losses[p.ns] / (float)p.ns) * p.smoothness / (float)(1 << S);
     const float* st = p.stats + ((size_t)S * p.B + b) * 3;
     const float A = 1.f / (st[0] + 1e-7f);
@@ -1295,7 +1382,7 @@ __device__ __forceinline__ void disp_grad_tile(const PhotoArgs& p, int b, int ti
         }
         // smoothness:  L = A*(cx*Sx + cy*Sy),  A = 1/(mean+eps)
         const float gs = A * smooth_grad(nb[k], x, y, w, h, cx_, cy_) - mean_term;
-        p.d_disp[S][(size_t)b * n + y * w + x] = u + gsm * gs;
+        p.d_disp[S][(size_t)b * n + y * w + x] = fmaf(wup, u, gsm * gs);
     }
 }
 
@@ -1307,9 +1394,10 @@ __device__ __forceinline__ void pose_grad_block(const PhotoArgs& p, int b, int f
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     for (int s = 0; s < p.ns; ++s) {
         const float* q = p.part_dP + (((size_t)s * 2 + f) * p.B + b) * p.nblk_b_img * 12;
+        const float wup = p.full ? (p.g_losses[s] + p.g_losses[p.ns] / (float)p.ns) / ((float)p.B * p.H * p.W) : 1.f;
         for (int k = threadIdx.x; k < p.nblk_b_img; k += 256) {
 #pragma unroll
-            for (int j = 0; j < 12; ++j) acc[j] += q[k * 12 + j];
+            for (int j = 0; j < 12; ++j) acc[j] = fmaf(wup, q[k * 12 + j], acc[j]);
         }
     }
 #pragma unroll
@@ -1359,7 +1447,19 @@ struct Carve {
     int nblk_f, nchunk, nblk_b_img, strips_f, strips_b, rows_f, rowblocks_f;
     int strips_p, rows_g, rows_p, rowblocks_g, rowblocks_p;   // training forward (60-lane strips) / pointwise backward
     bool packed_in;                                           // the caller supplied the RGBx copies: none in the workspace
+    bool full;                                                // the training forward goes all the way (photo_full_for)
 };
+
+// The all-the-way forward (photo_fwdg_kernel<.., FULL>): training, one of the specialised default configurations.
+// dc_set_photo_full(0) keeps the round-4 split (forward emits du, dv; pointwise backward) for A/Bs.
+static int g_photo_full = [] { const char* f = getenv("DC_PHOTO_FULL"); return f ? atoi(f) : 1; }();
+static bool photo_full_for(const dc_photo_desc* d) {
+    if (!g_photo_full || (d->flags & DC_OPT_NO_GRAD)) return false;
+    if (d->flags & (DC_OPT_NO_SSIM | DC_OPT_AVG_REPROJ | DC_OPT_NO_AUTOMASK | DC_OPT_PRED_MASK)) return false;
+    bool all_ext = true, none_ext = true;
+    for (int s = 0; s < d->num_scales; ++s) { all_ext = all_ext && d->noise[s]; none_ext = none_ext && !d->noise[s]; }
+    return all_ext || none_ext;
+}
 
 // Rows a wave marches per block.  Taller blocks spend fewer steps on the halo rows (a block costs rows + halo row-steps),
 // but the kernels are VALU-bound and need about two resident waves per SIMD: the tallest candidate that still leaves at
@@ -1403,7 +1503,8 @@ static Carve carve(const dc_photo_desc* d) {
     c.rowblocks_g = ceil_div(d->H, c.rows_g);
     c.rowblocks_p = ceil_div(d->H, c.rows_p);
     c.nblk_f = train ? c.strips_b * c.rowblocks_g * d->B : c.strips_f * c.rowblocks_f * d->B;
-    c.nblk_b_img = c.strips_p * c.rowblocks_p;
+    c.full = photo_full_for(d);
+    c.nblk_b_img = c.full ? c.strips_b * c.rowblocks_g : c.strips_p * c.rowblocks_p;      // blocks that write pose partials, per image
     c.nchunk = ceil_div(d->H * d->W, SM_CHUNK);
     size_t off = 0;
     c.idl = off; off += align256(N * 2 * 4);
@@ -1418,7 +1519,7 @@ static Carve carve(const dc_photo_desc* d) {
     }
     for (int s = 0; s < DC_MAX_SCALES; ++s) {
         c.gw[s] = off;
-        if (s < d->num_scales && train) off += align256(N * 16);
+        if (s < d->num_scales && train && !c.full) off += align256(N * 16);
         c.gpm[s] = off;
         if (s < d->num_scales && train && (d->flags & DC_OPT_PRED_MASK)) off += align256(N * 8);
     }
@@ -1495,6 +1596,7 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
     a.stats = (float*)(ws + c.stats);
     a.part_dP = (float*)(ws + c.part_dP);
     a.nblk_f = c.nblk_f; a.nchunk = c.nchunk; a.nblk_b_img = c.nblk_b_img;
+    a.full = c.full ? 1 : 0;
     a.rows_f = c.rows_f;
     a.rows_g = c.rows_g; a.rows_p = c.rows_p;
     if (backward && (d->flags & DC_OPT_NO_GRAD)) return DC_EINVAL;   // the forward emitted no gradient
@@ -1606,7 +1708,9 @@ extern "C" int dc_photo_fwd(const dc_photo_desc* d, void* stream) {
         const dim3 grid(c.strips_b, c.rowblocks_g, a.B), blk(64 * a.ns);
 #define DC_FWDG(LOGS_) \
         do { \
-            if (dflt && none_ext) hipLaunchKernelGGL((photo_fwdg_kernel<LOGS_, 4>), grid, blk, 0, st, a); \
+            if (c.full && none_ext) hipLaunchKernelGGL((photo_fwdg_kernel<LOGS_, 4, true>), grid, blk, 0, st, a); \
+            else if (c.full) hipLaunchKernelGGL((photo_fwdg_kernel<LOGS_, 12, true>), grid, blk, 0, st, a); \
+            else if (dflt && none_ext) hipLaunchKernelGGL((photo_fwdg_kernel<LOGS_, 4>), grid, blk, 0, st, a); \
             else if (dflt && all_ext) hipLaunchKernelGGL((photo_fwdg_kernel<LOGS_, 12>), grid, blk, 0, st, a); \
             else hipLaunchKernelGGL((photo_fwdg_kernel<LOGS_, -1>), grid, blk, 0, st, a); \
         } while (0)
@@ -1629,7 +1733,7 @@ extern "C" int dc_photo_bwd(const dc_photo_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t pc = prof_begin(3, st);
     hipEvent_t pe = prof_begin(1, st);
-    hipLaunchKernelGGL(photo_bwdg_kernel, dim3(c.strips_p, c.rowblocks_p, a.B), dim3(64 * a.ns), 0, st, a);
+    if (!c.full) hipLaunchKernelGGL(photo_bwdg_kernel, dim3(c.strips_p, c.rowblocks_p, a.B), dim3(64 * a.ns), 0, st, a);
     prof_end(pe, st);
     DC_CHECK_LAUNCH();
     {
@@ -1644,6 +1748,13 @@ extern "C" int dc_photo_bwd(const dc_photo_desc* d, void* stream) {
     prof_end(pc, st);
     DC_CHECK_LAUNCH();
     return DC_OK;
+}
+
+extern "C" int dc_set_photo_full(int mode) {
+    if (mode != 0 && mode != 1) return DC_EINVAL;
+    const int prev = g_photo_full;
+    g_photo_full = mode;
+    return prev;
 }
 
 // per scale fwd reads 36N + 16 n_s; bwd re-reads that and writes 4 n_s (fp32 bytes)

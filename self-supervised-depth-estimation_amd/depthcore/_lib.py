@@ -176,6 +176,7 @@ def _sig(lib):
         "dc_get_matrix_precision": (i, []),
         "dc_clear_error": (i, []),
         "dc_abort_capture": (i, [p]),
+        "dc_set_photo_full": (i, [i]),
         "dc_set_wino_f4": (i, [i]),
         "dc_set_wino_persist": (i, [i]),
         "dc_wino_cache_new_owner": (i, []),

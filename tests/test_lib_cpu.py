@@ -51,10 +51,18 @@ def test_workspace_and_bytes_queries_without_gpu():
     L = _lib.lib()
     d = _lib.PhotoDesc()
     d.B, d.H, d.W, d.num_scales = 12, 192, 640, 4
-    ws = L.dc_photo_workspace(ctypes.byref(d))
     N = 12 * 192 * 640
-    # training: idl 2N + three RGBx copies 12N + d(upsampled disp) 4N + the forward's d(loss)/d(source coords), 4 floats x 4 scales
-    assert ws > (17 + 16) * N * 4 and ws < (20 + 16) * N * 4
+    prev = L.dc_set_photo_full(0)
+    try:
+        ws = L.dc_photo_workspace(ctypes.byref(d))
+        # the round-4 split: idl 2N + three RGBx copies 12N + d(upsampled disp) 4N + the forward's d(loss)/d(source coords), 4 floats x 4 scales
+        assert ws > (17 + 16) * N * 4 and ws < (20 + 16) * N * 4
+        L.dc_set_photo_full(1)
+        ws_full = L.dc_photo_workspace(ctypes.byref(d))
+        # the forward that goes all the way (default): no d(loss)/d(source coords) buffers
+        assert ws_full > 17 * N * 4 and ws_full < 20 * N * 4
+    finally:
+        L.dc_set_photo_full(prev)
     d.flags = _lib.OPT_NO_GRAD                        # evaluation: no gradient emission, the smaller workspace
     ws_eval = L.dc_photo_workspace(ctypes.byref(d))
     assert ws_eval > 17 * N * 4 and ws_eval < 20 * N * 4

@@ -281,3 +281,37 @@ def test_packed_inputs_change_nothing(tag, kw):
     for k in range(3):
         d.packed[k] = packed[k].data_ptr()
     assert w_plain - L.dc_photo_workspace(ctypes.byref(d)) >= 3 * b * h * w * 16
+
+
+@pytest.mark.parametrize("shape,ext_noise,materialize", [((2, 64, 96), True, False), ((2, 64, 96), False, True), ((3, 40, 72), True, True),
+                                                          ((12, 192, 640), False, False)])
+def test_all_the_way_forward_equals_the_split_chain(shape, ext_noise, materialize):
+    """dc_set_photo_full: the training forward that contracts to d(loss)/d(upsampled disp) + pose sums (default) against the
+    round-4 split (forward emits d(loss)/d(source coords), pointwise backward chains them): same losses and outputs bit for bit
+    (the forward's loss arithmetic is untouched), gradients to rounding (same chain, the upstream weight applied after the
+    linear transposed upsample instead of before; pose sums over different block shapes)."""
+    from depthcore import _lib
+    b, h, w = shape
+    ns = 4 if h % 32 == 0 else 3
+    inputs = R.synthetic_inputs(b, h, w, num_scales=ns, seed=5)
+    g = torch.Generator().manual_seed(17)
+    disps = [torch.rand(b, 1, h >> s, w >> s, generator=g) for s in range(ns)]
+    Ts = random_poses(b, 8)
+    noise = R.tiebreak_noise(b, h, w, num_scales=ns) if ext_noise else None
+    L = _lib.lib()
+    res = {}
+    prev = L.dc_set_photo_full(1)
+    try:
+        for mode in (1, 0):
+            L.dc_set_photo_full(mode)
+            res[mode] = hip_photo(inputs, disps, Ts, noise, materialize=materialize)
+    finally:
+        L.dc_set_photo_full(prev)
+    for a, c in zip(res[1][0], res[0][0]):
+        assert torch.equal(a, c)
+    for s in range(ns):
+        assert torch.equal(res[1][1]["argmin"][s], res[0][1]["argmin"][s])
+        assert rel_l2(res[1][2][s], res[0][2][s]) < 2e-6, (s, rel_l2(res[1][2][s], res[0][2][s]))
+        close_frac(res[1][2][s], res[0][2][s], rtol=1e-4, atol=0, atol_rel=1e-5, bad=1e-4, msg="gdisp%d" % s)
+    for f in range(2):
+        assert rel_l2(res[1][3][f][:, :3, :], res[0][3][f][:, :3, :]) < 1e-4, f
