@@ -318,7 +318,9 @@ def test_all_the_way_forward_equals_the_split_chain(shape, ext_noise, materializ
         assert torch.equal(a, c)
     for s in range(ns):
         assert torch.equal(res[1][1]["argmin"][s], res[0][1]["argmin"][s])
-        assert rel_l2(res[1][2][s], res[0][2][s]) < 2e-6, (s, rel_l2(res[1][2][s], res[0][2][s]))
-        close_frac(res[1][2][s], res[0][2][s], rtol=1e-4, atol=0, atol_rel=1e-5, bad=1e-4, msg="gdisp%d" % s)
+        # (v_rcp-based projection re-derived from the parked depth instead of the re-read disparity taps, cancellation in
+        # d(depth): 1e-5 relative in the norm, no outliers)
+        assert rel_l2(res[1][2][s], res[0][2][s]) < 1e-4, (s, rel_l2(res[1][2][s], res[0][2][s]))
+        close_frac(res[1][2][s], res[0][2][s], rtol=1e-3, atol=0, atol_rel=1e-4, bad=1e-4, msg="gdisp%d" % s)
     for f in range(2):
         assert rel_l2(res[1][3][f][:, :3, :], res[0][3][f][:, :3, :]) < 1e-4, f
