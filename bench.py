@@ -556,10 +556,11 @@ def run_rank(args):
                                           "unit": "TFLOP/s", "frac": 0.0}
         dom_key = {0: "dc::wino_ps_kernel", 1: "dc::wino_wgrad_kernel", 2: "dc::c3b_conv_kernel", 3: "dc::c3b_wgrad_kernel", 4: "dc::g1_*"}.get(dom.get("family"))
         # ---- BASELINE metric 2: the fused warp + SSIM + smoothness kernels against HBM.  Round 4 moved the SSIM derivative, its
-        # transposed 3x3 spread and the contraction with d(warped)/d(coords) into the TRAINING FORWARD (dc::photo_fwdg_kernel emits
-        # du, dv per frame: 16 B per pixel and scale); the backward (dc::photo_bwdg_kernel) is pointwise.  The honest figure is
-        # therefore the PAIR: SURVEY 8d's algorithmic bytes of forward + backward over the time of both launch chains; each
-        # chain is also given on its own (the backward's own fraction flatters it: part of its work now runs in the forward).
+        # transposed 3x3 spread and the contraction with d(warped)/d(coords) into the TRAINING FORWARD; round 5 lets it go all the
+        # way (dc::photo_fwdg_kernel<.., FULL>: Project3D / BackprojectDepth / disp_to_depth backward and the pose sums in the
+        # same row march, ONE float per pixel and scale out), so the backward chain is dc::disp_grad_kernel alone (transposed
+        # upsample + smoothness gradient + pose reduction, scaled by the step's upstream weights).  The honest figure is the
+        # PAIR: SURVEY 8d's algorithmic bytes of forward + backward over the time of both launch chains.
         def chain(bytes_, ms):
             gbs = bytes_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {"algorithmic_bytes_per_launch": bytes_, "avg_chain_ms": round(ms, 4), "achieved": round(gbs, 1),
@@ -577,8 +578,8 @@ def run_rank(args):
         pair = chain(bytes_fwd + bytes_bwd, pair_ms)
         photometric = dict(pair, **{
             "kernel": "fused warp + SSIM + L1 + automask + smoothness, forward AND backward launch chains of a step (4 scales x 2 "
-                      "frames): identity + smooth + dc::photo_fwdg_kernel + finalize | dc::photo_bwdg_kernel + disp_grad (incl. the "
-                      "pose-gradient reduction)",
+                      "frames): identity + smooth + dc::photo_fwdg_kernel (contracts to d loss / d upsampled disp + pose sums) + "
+                      "finalize | dc::disp_grad_kernel (transposed upsample, smoothness gradient, pose-gradient reduction)",
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "traffic": (tr_bytes("dc::identity_kernel") or 0) + (tr_bytes("dc::photo_fwdg_kernel") or 0) + (tr_bytes("dc::smooth_fwd_kernel") or 0)
                        + (tr_bytes("dc::photo_bwdg_kernel") or 0) + (tr_bytes("dc::disp_grad_kernel") or 0)
@@ -588,14 +589,14 @@ def run_rank(args):
             # (only the PAIR is priced against SURVEY 8d's bytes: since round 4 the backward's window work runs in the forward, so a
             # per-chain fraction would credit the backward with bytes it no longer moves)
             "forward_chain": dict({"avg_chain_ms": round(fwd_chain_ms, 4)}, **kern("dc::photo_fwdg_kernel", fwd_ms, bytes_fwd + bytes_bwd, VALU_SLOTS_PER_INST["fwd"])),
-            "backward_chain": dict({"avg_chain_ms": round(bwd_chain_ms, 4)}, **kern("dc::photo_bwdg_kernel", bwd_ms, bytes_fwd + bytes_bwd, VALU_SLOTS_PER_INST["bwd"])),
+            "backward_chain": dict({"avg_chain_ms": round(bwd_chain_ms, 4)}, **kern("dc::disp_grad_kernel", bwd_chain_ms, bytes_fwd + bytes_bwd, VALU_SLOTS_PER_INST["bwd"])),
             "valu_wave_insts_per_step": (sum(valu(k) or 0 for k in ("dc::identity_kernel", "dc::smooth_fwd_kernel", "dc::photo_fwdg_kernel",
                                                                      "dc::finalize_kernel", "dc::photo_bwdg_kernel", "dc::disp_grad_kernel"))
                                          if valu("dc::photo_fwdg_kernel") else None),
             "round3": {"forward_chain_ms": 0.17, "backward_chain_ms": 0.2487, "pair_frac": 0.148,
                        "note": "forward without gradient emission + the window backward (profiles/round3_c2_bench_n1.json)"},
-            "limiter": "the training forward is VALU-issue bound (3 waves per SIMD at 145 VGPRs since its loads are issued behind "
-                       "stage B; 2 at 203 before); the pointwise backward and the transposed upsample are latency / HBM bound",
+            "limiter": "the training forward is VALU-issue bound (3 waves per SIMD at 167 VGPRs: loads issued behind stage B, the "
+                       "projection backward and the 18 pose accumulators in stage C); the transposed upsample is latency / HBM bound",
             "valu_note": "SQ_INSTS_VALU per launch (cited PMC pass) x issue slots per instruction from the ISA mix "
                          "(profiles/round4_photo_isa_mix.txt); 2 cycles per slot per SIMD-32"})
         out = {
