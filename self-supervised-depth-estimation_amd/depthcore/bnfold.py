@@ -241,7 +241,10 @@ class _ConvF(torch.autograd.Function):
         f = BnFold()
         f.groups = groups
         bwd = None
-        if ctx.needs_input_grad[0]:
+        # (the folded BatchNorm's dgamma / dbeta come out of the data-gradient epilogue's partials: that launch runs whenever
+        # they are wanted, even if the raw input itself needs no gradient -- a frozen producer)
+        bn_only = fold_in and not ctx.needs_input_grad[0] and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        if ctx.needs_input_grad[0] or bn_only:
             gx = torch.empty_like(xx)
             if fold_in or ctx.prev is not None:
                 ppg = _ival()
@@ -279,6 +282,8 @@ class _ConvF(torch.autograd.Function):
                 K.wgrad(L, xx, g_c, gw, B, Ci, Co, Hi, Wi, s_, fw)
         if fold_in and gx is not None:
             gx, dgamma, dbeta = _bwd_finish(L, xx, gx, bwd, g, tab, groups, ctx.slots[1:])
+            if bn_only:
+                gx = None
         return gx, gw, dgamma, dbeta, None
 
 
