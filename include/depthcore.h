@@ -515,6 +515,11 @@ int dc_gru_rh_bwd(const float* gates, const float* h, const float* g, float* d_g
 int dc_gru_blend_fwd(const float* gates, const float* h, const float* cnm, float* h_next, int B, int C, int P, void* stream);
 int dc_gru_blend_bwd(const float* gates, const float* h, const float* cnm, const float* g, float* d_gates, float* d_h, float* d_cnm,
                      int B, int C, int P, void* stream);
+/* accumulating forms for a backward that walks a sequence's frames in reverse (depthcore.ops._GruLevel): d_h += instead of =;
+ * dc_gru_rh_bwd_acc writes ONLY the reset half of d_gates (the blend backward of the same step wrote the update half) */
+int dc_gru_rh_bwd_acc(const float* gates, const float* h, const float* g, float* d_gates, float* d_h, int B, int C, int P, void* stream);
+int dc_gru_blend_bwd_acc(const float* gates, const float* h, const float* cnm, const float* g, float* d_gates, float* d_h, float* d_cnm,
+                         int B, int C, int P, void* stream);
 int dc_gru_residual_fwd(const float* f, const float* H, float* out, int n, size_t M, void* stream);
 int dc_gru_residual_bwd(const float* g, float* d_H, int n, size_t M, void* stream);
 

@@ -458,9 +458,9 @@ __device__ __forceinline__ float fold_at(const float* p, int r, int c, int H, in
 constexpr int FOLD_PPT = 1;      // (4 pixels per thread measured slower: 352 vs 307 us per decoder step -- it is not the block count)
 // add0 / add1 (nullable, shapes of dx0 / dx1): another consumer's gradient of the same input, added on the way out (the sum
 // autograd would otherwise form in a pass of its own)
-__global__ __launch_bounds__(256) void conv_fold_kernel(const float* __restrict__ dxpad, float* __restrict__ dx0, float* __restrict__ dx1,
+__global__ __launch_bounds__(256) void conv_fold_kernel(const float* __restrict__ dxpad, float* dx0, float* dx1,
                                                         int B, int C0, int C1, int up0, int H, int W, int pad, int pitch,
-                                                        const float* __restrict__ add0, const float* __restrict__ add1) {
+                                                        const float* add0, const float* add1) {      // (an addend may BE its output: in-place sum)
     const int Cin = C0 + C1;
     const int b = blockIdx.z, ch = blockIdx.y;
     const float* p = dxpad + ((size_t)b * Cin + ch) * (H + 2) * pitch;

@@ -34,6 +34,37 @@ __global__ __launch_bounds__(256) void gru_rh_bwd_kernel(const float* __restrict
         d_h[i] = gv * gates[gi];
     }
 }
+// The accumulating forms of the sequence backward (dc_gru_*_bwd_acc; ops._GruLevel walks the frames of a sequence backwards and
+// every step's gradient of h_i joins what the later steps and the residual already left in d_H[i]):
+//   rh:    d_gates[:, :C] = g * h   (ONLY the reset half is written -- the blend backward of the same step wrote the update half),
+//          d_h += g * r
+__global__ __launch_bounds__(256) void gru_rh_bwd_acc_kernel(const float* __restrict__ gates, const float* __restrict__ h, const float* __restrict__ g,
+                                                            float* __restrict__ d_gates, float* __restrict__ d_h, int B, int C, int P) {
+    const size_t n = (size_t)B * C * P;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / ((size_t)C * P), r = i - b * (size_t)C * P;
+        const size_t gi = b * 2 * C * P + r;
+        const float gv = g[i];
+        d_gates[gi] = gv * h[i];
+        d_h[i] += gv * gates[gi];
+    }
+}
+//   blend: d_gates = [0 | g * (cnm - h)], d_h += g * (1 - u), d_cnm = g * u
+__global__ __launch_bounds__(256) void gru_blend_bwd_acc_kernel(const float* __restrict__ gates, const float* __restrict__ h,
+                                                               const float* __restrict__ cnm, const float* __restrict__ g,
+                                                               float* __restrict__ d_gates, float* __restrict__ d_h, float* __restrict__ d_cnm,
+                                                               int B, int C, int P) {
+    const size_t n = (size_t)B * C * P;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / ((size_t)C * P), r = i - b * (size_t)C * P;
+        const size_t gi = b * 2 * C * P + r;
+        const float u = gates[gi + (size_t)C * P], gv = g[i];
+        d_gates[gi] = 0.f;
+        d_gates[gi + (size_t)C * P] = gv * (cnm[i] - h[i]);
+        d_h[i] += gv * (1.f - u);
+        d_cnm[i] = gv * u;
+    }
+}
 __global__ __launch_bounds__(256) void gru_blend_fwd_kernel(const float* __restrict__ gates, const float* __restrict__ h,
                                                            const float* __restrict__ cnm, float* __restrict__ out, int B, int C, int P) {
     const size_t n = (size_t)B * C * P;
@@ -124,6 +155,23 @@ extern "C" int dc_gru_residual_fwd(const float* f, const float* H, float* out, i
 extern "C" int dc_gru_residual_bwd(const float* g, float* d_H, int n, size_t M, void* stream) {
     if (!g || !d_H || n <= 0 || M == 0) return DC_EINVAL;
     hipLaunchKernelGGL(gru_residual_bwd_kernel, dim3(gru_grid((size_t)(n + 1) * M)), dim3(256), 0, (hipStream_t)stream, g, d_H, n, M);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_gru_rh_bwd_acc(const float* gates, const float* h, const float* g, float* d_gates, float* d_h, int B, int C, int P,
+                                 void* stream) {
+    if (!gates || !h || !g || !d_gates || !d_h || !gru_ok(B, C, P)) return DC_EINVAL;
+    hipLaunchKernelGGL(gru_rh_bwd_acc_kernel, dim3(gru_grid((size_t)B * C * P)), dim3(256), 0, (hipStream_t)stream, gates, h, g, d_gates,
+                       d_h, B, C, P);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+extern "C" int dc_gru_blend_bwd_acc(const float* gates, const float* h, const float* cnm, const float* g, float* d_gates, float* d_h,
+                                    float* d_cnm, int B, int C, int P, void* stream) {
+    if (!gates || !h || !cnm || !g || !d_gates || !d_h || !d_cnm || !gru_ok(B, C, P)) return DC_EINVAL;
+    hipLaunchKernelGGL(gru_blend_bwd_acc_kernel, dim3(gru_grid((size_t)B * C * P)), dim3(256), 0, (hipStream_t)stream, gates, h, cnm, g,
+                       d_gates, d_h, d_cnm, B, C, P);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }

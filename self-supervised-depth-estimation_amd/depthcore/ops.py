@@ -1507,3 +1507,108 @@ def gru_blend(gates, h, cnm):
 def gru_sequence_residual(features, hidden_states):
     """features (n,C,H,W) + (H[1:] + H[:-1]) / 2 with H (n+1,C,H,W)."""
     return _GruResidual.apply(features, hidden_states)
+
+
+class _GruLevel(torch.autograd.Function):
+    """One feature level of `run_gru_v5` for a sequence of n frames (batch_size 1, trainer_gru.py:607-639) as ONE autograd node:
+    the cell runs over the frames from the learned initial state, every tensor of every step lives in one buffer per kind
+    (gates / r*h / candidate / the n+1 hidden states -- a step reads and writes its slot by pointer, so there is neither a
+    per-frame slice node nor a torch.cat of the trace), and the backward walks the frames in reverse itself: each step's
+    gradient of h_i is ACCUMULATED into the slot that already holds the residual's and the later step's share
+    (dc_gru_blend_bwd_acc, dc_gru_rh_bwd_acc, the gate convolution's data-gradient store with the slot as its own addend), the
+    feature gradient leaves the gate convolution's store with the candidate convolution's and the residual's share added on the
+    way, and the four shared parameters get the sum of their n per-frame gradients in one reduction each.  Against the per-op
+    graph (ConvGRUCell.forward, kept for single calls) that is ~9 elementwise sums, 3 fills / copies and 1.7 concatenations
+    fewer per cell step: 137 + 47 + 25 launches of a C4 step."""
+
+    @staticmethod
+    def forward(ctx, feats, h0, wg, bg, wc, bc):
+        L = _lib.lib()
+        ff = _c(feats.detach())
+        n, C, H, W = ff.shape
+        P = H * W
+        if tuple(h0.shape) != (1, C, H, W) or tuple(wg.shape) != (2 * C, 2 * C, 3, 3) or tuple(wc.shape) != (C, 2 * C, 3, 3):
+            raise _lib.DepthcoreError("ConvGRU level: state %s / gate weights %s / candidate weights %s do not match features %s" % (
+                tuple(h0.shape), tuple(wg.shape), tuple(wc.shape), tuple(ff.shape)))
+        w_g, b_g, w_c, b_c = _c(wg.detach()), _c(bg.detach()), _c(wc.detach()), _c(bc.detach())
+        dev = ff.device
+        Hs = torch.empty(n + 1, C, H, W, dtype=torch.float32, device=dev)
+        Hs[0].copy_(h0.detach()[0])
+        gates = torch.empty(n, 2 * C, H, W, dtype=torch.float32, device=dev)
+        rh = torch.empty(n, C, H, W, dtype=torch.float32, device=dev)
+        cnm = torch.empty(n, C, H, W, dtype=torch.float32, device=dev)
+        ctx.prec = _use_precision(_precision[0])
+        ws = torch.empty(max(L.dc_conv3x3_fwd_workspace(C, C, 1, 2 * C, H, W), L.dc_conv3x3_fwd_workspace(C, C, 1, C, H, W)),
+                         dtype=torch.uint8, device=dev)
+        st = stream(ff)
+        for i in range(n):
+            x, h = ff[i:i + 1], Hs[i:i + 1]
+            # [reset | update] = sigmoid(conv_gates(cat(x, h)))                                       rnn.py:125-130
+            check(L.dc_conv3x3_fwd(ptr(x), C, 0, ptr(h), C, ptr(w_g), ptr(b_g), ptr(gates[i:i + 1]), ws.data_ptr(), 1, 2 * C, H, W,
+                                   ACT_SIGMOID, PAD_ZERO, st), "dc_conv3x3_fwd")
+            check(L.dc_gru_rh_fwd(ptr(gates[i:i + 1]), ptr(h), ptr(rh[i:i + 1]), 1, C, P, st), "dc_gru_rh_fwd")
+            # cnm = tanh(conv_can(cat(x, reset * h)))                                                   rnn.py:132-134
+            check(L.dc_conv3x3_fwd(ptr(x), C, 0, ptr(rh[i:i + 1]), C, ptr(w_c), ptr(b_c), ptr(cnm[i:i + 1]), ws.data_ptr(), 1, C, H, W,
+                                   ACT_TANH, PAD_ZERO, st), "dc_conv3x3_fwd")
+            check(L.dc_gru_blend_fwd(ptr(gates[i:i + 1]), ptr(h), ptr(cnm[i:i + 1]), ptr(Hs[i + 1:i + 2]), 1, C, P, st),
+                  "dc_gru_blend_fwd")                                                                # rnn.py:136
+        out = torch.empty_like(ff)
+        check(L.dc_gru_residual_fwd(ptr(ff), ptr(Hs), ptr(out), n, C * P, st), "dc_gru_residual_fwd")   # trainer_gru.py:637-639
+        ctx.save_for_backward(ff, Hs, gates, rh, cnm, w_g, w_c)
+        ctx.slots = tuple(_slot(t) for t in (wg, bg, wc, bc))
+        for t, k in ((wg, 2), (wc, 4)):
+            if ctx.needs_input_grad[k]:
+                WgradLanes.count_use(t)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        ff, Hs, gates, rh, cnm, w_g, w_c = ctx.saved_tensors
+        n, C, H, W = ff.shape
+        P = H * W
+        dev = ff.device
+        need = ctx.needs_input_grad
+        g_c = _c(g)
+        st = stream(ff)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dHs = torch.empty_like(Hs)
+        check(L.dc_gru_residual_bwd(ptr(g_c), ptr(dHs), n, C * P, st), "dc_gru_residual_bwd")
+        dfe = torch.empty_like(ff)
+        dgates = torch.empty(1, 2 * C, H, W, **f32)
+        dcn, dxc, drh = (torch.empty(1, C, H, W, **f32) for _ in range(3))
+        dwg, dbg = torch.empty((n,) + tuple(w_g.shape), **f32), torch.empty(n, 2 * C, **f32)
+        dwc, dbc = torch.empty((n,) + tuple(w_c.shape), **f32), torch.empty(n, C, **f32)
+        _use_precision(ctx.prec)
+        ws = torch.empty(max(L.dc_conv3x3_bwd_workspace(C, C, 1, 2 * C, H, W), L.dc_conv3x3_bwd_workspace(C, C, 1, C, H, W)),
+                         dtype=torch.uint8, device=dev)
+        for i in range(n - 1, -1, -1):
+            x, h, gt, dh = ff[i:i + 1], Hs[i:i + 1], gates[i:i + 1], dHs[i:i + 1]
+            # h_{i+1} = (1-u) h_i + u cnm: dHs[i+1] is complete here (residual + step i+1)
+            check(L.dc_gru_blend_bwd_acc(ptr(gt), ptr(h), ptr(cnm[i:i + 1]), ptr(dHs[i + 1:i + 2]), ptr(dgates), ptr(dh), ptr(dcn),
+                                         1, C, P, st), "dc_gru_blend_bwd_acc")
+            # candidate convolution over cat(x, r*h): its gradient of x takes the residual's share (g[i]) along
+            check(L.dc_conv3x3_bwd_add(ptr(x), C, 0, ptr(rh[i:i + 1]), C, ptr(w_c), ptr(cnm[i:i + 1]), ptr(dcn), ptr(dxc), ptr(drh),
+                                       ptr(g_c[i:i + 1]), None, ptr(dwc[i]), ptr(dbc[i]), ws.data_ptr(), 1, C, H, W, ACT_TANH, PAD_ZERO,
+                                       st), "dc_conv3x3_bwd_add")
+            check(L.dc_gru_rh_bwd_acc(ptr(gt), ptr(h), ptr(drh), ptr(dgates), ptr(dh), 1, C, P, st), "dc_gru_rh_bwd_acc")
+            # gate convolution over cat(x, h): d x = own + (candidate's + residual's), d h_i = own + what the slot holds
+            check(L.dc_conv3x3_bwd_add(ptr(x), C, 0, ptr(h), C, ptr(w_g), ptr(gt), ptr(dgates), ptr(dfe[i:i + 1]), ptr(dh),
+                                       ptr(dxc), ptr(dh), ptr(dwg[i]), ptr(dbg[i]), ws.data_ptr(), 1, 2 * C, H, W, ACT_SIGMOID, PAD_ZERO,
+                                       st), "dc_conv3x3_bwd_add")
+        outs = []
+        for k, (per_frame, like) in enumerate(((dwg, w_g), (dbg, None), (dwc, w_c), (dbc, None))):
+            if not need[2 + k]:
+                outs.append(None)
+                continue
+            dst = _grad_dst(ctx.slots[k], like)
+            if dst is None:
+                dst = torch.empty(per_frame.shape[1:], **f32)
+            outs.append(torch.sum(per_frame, 0, out=dst))
+        return (dfe if need[0] else None, dHs[0:1] if need[1] else None) + tuple(outs)
+
+
+def gru_level_sequence(features, h0, conv_gates, conv_can):
+    """features (n,C,H,W) of one sequence, h0 (1,C,H,W) -> features + (H[1:] + H[:-1]) / 2, H the hidden states of the cell
+    (conv_gates / conv_can: its two nn.Conv2d) run over the frames in order (trainer_gru.py:607-639 at one level)."""
+    return _GruLevel.apply(features, h0, conv_gates.weight, conv_gates.bias, conv_can.weight, conv_can.bias)

@@ -6,11 +6,15 @@ state_dict layout: `cgru_{0..4}.cgru_1.conv_gates.{weight,bias}`, `cgru_{k}.cgru
 A cell is four depthcore launches: the gate convolution over cat(x, h) and the candidate convolution over cat(x, r*h) are
 fused conv blocks (the concatenation is index arithmetic in their staging; bias + sigmoid / tanh in the epilogue), the two
 gate products are dc_gru_rh / dc_gru_blend."""
+import os
+
 import torch
 import torch.nn as nn
 
 from depthcore import ops as _ops
 from depthcore._lib import DepthcoreError
+
+LEVEL_NODES = os.environ.get("DC_GRU_LEVEL_NODES", "1") != "0"    # 0: the per-op graph (one node per gate product / convolution), for A/Bs
 
 
 class ConvGRUCell(nn.Module):
@@ -81,6 +85,10 @@ class ConvGRUBlocks_v5(nn.Module):
         """trainer_gru.py:607-639 for batch_size 1: `features[k]` (n, C_k, h_k, w_k) holds the encoder features of the n
         frames of one sequence; the cells run over the frames in order from the learned initial states; returns
         features[k] + (H[1:] + H[:-1]) / 2 with H the n+1 hidden states."""
+        if LEVEL_NODES and features[0].is_cuda:
+            # one autograd node per level: the frame loop, the trace and the reverse walk live inside it (ops._GruLevel)
+            return [_ops.gru_level_sequence(f, cell.h0_layer1, cell.cgru_1.conv_gates, cell.cgru_1.conv_can)
+                    for cell, f in zip(self.cells(), features)]
         n = features[0].shape[0]
         hidden = [cell.h0_layer1 for cell in self.cells()]
         trace = [[h] for h in hidden]

@@ -88,6 +88,39 @@ def test_blocks_v5_sequence_vs_reference_fixture(golden):
         close(MG.summ(gr[5 + j]), g["v5_g_" + k], rtol=5e-3, atol=5e-5, msg=k)
 
 
+def test_level_nodes_vs_per_op_graph():
+    """ops._GruLevel (one autograd node per level, frames walked inside it) against the per-op graph of the same module on a
+    4-frame sequence: same kernels for the convolutions and the gate products, so outputs and every gradient agree to rounding
+    of the differently ordered sums; with a frozen initial state (trainer_gru.py h_s_epoch) no gradient is reported for it."""
+    import networks
+    from networks import convgru as CG
+    torch.manual_seed(5)
+    blk = networks.ConvGRUBlocks_v5(kernel_size=(3, 3), bias=True, device="cpu", height=64, width=96).to(DEV)
+    for p_ in blk.parameters():
+        p_.data.normal_(0, 0.05)
+    n = 4
+    feats = [torch.randn(n, c, 64 >> (k + 1), 96 >> (k + 1), device=DEV).requires_grad_() for k, c in enumerate((64, 64, 128, 256, 512))]
+    cots = [torch.randn_like(f) for f in feats]
+    ps = list(blk.parameters())
+    res = {}
+    for mode in (True, False):
+        CG.LEVEL_NODES = mode
+        try:
+            outs = blk.run_sequence(feats)
+            gr = torch.autograd.grad(sum((o * c).sum() for o, c in zip(outs, cots)), feats + ps)
+        finally:
+            CG.LEVEL_NODES = True
+        res[mode] = ([o.detach() for o in outs], gr)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    for j, (a, b) in enumerate(zip(res[True][1], res[False][1])):
+        assert rel_l2(a, b) < 2e-6, (j, rel_l2(a, b))
+    blk.cgru_2.h0_layer1.requires_grad_(False)
+    outs = blk.run_sequence(feats)
+    sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+    assert blk.cgru_2.h0_layer1.grad is None and blk.cgru_1.h0_layer1.grad is not None
+
+
 def test_gru_training_steps():
     """BASELINE configs[3] wiring: one sequence of 3 frames (batch size 1), encoder -> ConvGRU v5 -> decoder, pose on the
     stacked pairs, loss on the stacked sequence; finite losses over Adam steps, the learned h0 states receive gradients."""
