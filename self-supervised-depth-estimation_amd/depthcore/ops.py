@@ -1517,7 +1517,8 @@ class _GruLevel(torch.autograd.Function):
     gradient of h_i is ACCUMULATED into the slot that already holds the residual's and the later step's share
     (dc_gru_blend_bwd_acc, dc_gru_rh_bwd_acc, the gate convolution's data-gradient store with the slot as its own addend), the
     feature gradient leaves the gate convolution's store with the candidate convolution's and the residual's share added on the
-    way, and the four shared parameters get the sum of their n per-frame gradients in one reduction each.  Against the per-op
+    way, and the shared parameters get their gradients from ONE weight-gradient pass per convolution over the n frames as a
+    batch once the walk is done (per-frame passes + a sum over frames otherwise).  Against the per-op
     graph (ConvGRUCell.forward, kept for single calls) that is ~9 elementwise sums, 3 fills / copies and 1.7 concatenations
     fewer per cell step: 137 + 47 + 25 launches of a C4 step."""
 
@@ -1575,36 +1576,41 @@ class _GruLevel(torch.autograd.Function):
         dHs = torch.empty_like(Hs)
         check(L.dc_gru_residual_bwd(ptr(g_c), ptr(dHs), n, C * P, st), "dc_gru_residual_bwd")
         dfe = torch.empty_like(ff)
-        dgates = torch.empty(1, 2 * C, H, W, **f32)
-        dcn, dxc, drh = (torch.empty(1, C, H, W, **f32) for _ in range(3))
-        dwg, dbg = torch.empty((n,) + tuple(w_g.shape), **f32), torch.empty(n, 2 * C, **f32)
-        dwc, dbc = torch.empty((n,) + tuple(w_c.shape), **f32), torch.empty(n, C, **f32)
+        dgates, dcn = torch.empty(n, 2 * C, H, W, **f32), torch.empty(n, C, H, W, **f32)     # g of the two convolutions' outputs, per frame
+        dxc, drh = torch.empty(1, C, H, W, **f32), torch.empty(1, C, H, W, **f32)
         _use_precision(ctx.prec)
-        ws = torch.empty(max(L.dc_conv3x3_bwd_workspace(C, C, 1, 2 * C, H, W), L.dc_conv3x3_bwd_workspace(C, C, 1, C, H, W)),
+        ws = torch.empty(max(L.dc_conv3x3_bwd_workspace(C, C, b, co, H, W) for b in (1, n) for co in (C, 2 * C)),
                          dtype=torch.uint8, device=dev)
         for i in range(n - 1, -1, -1):
             x, h, gt, dh = ff[i:i + 1], Hs[i:i + 1], gates[i:i + 1], dHs[i:i + 1]
+            dg, dc = dgates[i:i + 1], dcn[i:i + 1]
             # h_{i+1} = (1-u) h_i + u cnm: dHs[i+1] is complete here (residual + step i+1)
-            check(L.dc_gru_blend_bwd_acc(ptr(gt), ptr(h), ptr(cnm[i:i + 1]), ptr(dHs[i + 1:i + 2]), ptr(dgates), ptr(dh), ptr(dcn),
+            check(L.dc_gru_blend_bwd_acc(ptr(gt), ptr(h), ptr(cnm[i:i + 1]), ptr(dHs[i + 1:i + 2]), ptr(dg), ptr(dh), ptr(dc),
                                          1, C, P, st), "dc_gru_blend_bwd_acc")
-            # candidate convolution over cat(x, r*h): its gradient of x takes the residual's share (g[i]) along
-            check(L.dc_conv3x3_bwd_add(ptr(x), C, 0, ptr(rh[i:i + 1]), C, ptr(w_c), ptr(cnm[i:i + 1]), ptr(dcn), ptr(dxc), ptr(drh),
-                                       ptr(g_c[i:i + 1]), None, ptr(dwc[i]), ptr(dbc[i]), ws.data_ptr(), 1, C, H, W, ACT_TANH, PAD_ZERO,
-                                       st), "dc_conv3x3_bwd_add")
-            check(L.dc_gru_rh_bwd_acc(ptr(gt), ptr(h), ptr(drh), ptr(dgates), ptr(dh), 1, C, P, st), "dc_gru_rh_bwd_acc")
+            # candidate convolution over cat(x, r*h), data gradients only: that of x takes the residual's share (g[i]) along
+            check(L.dc_conv3x3_bwd_add(ptr(x), C, 0, ptr(rh[i:i + 1]), C, ptr(w_c), ptr(cnm[i:i + 1]), ptr(dc), ptr(dxc), ptr(drh),
+                                       ptr(g_c[i:i + 1]), None, None, None, ws.data_ptr(), 1, C, H, W, ACT_TANH, PAD_ZERO, st),
+                  "dc_conv3x3_bwd_add")
+            check(L.dc_gru_rh_bwd_acc(ptr(gt), ptr(h), ptr(drh), ptr(dg), ptr(dh), 1, C, P, st), "dc_gru_rh_bwd_acc")
             # gate convolution over cat(x, h): d x = own + (candidate's + residual's), d h_i = own + what the slot holds
-            check(L.dc_conv3x3_bwd_add(ptr(x), C, 0, ptr(h), C, ptr(w_g), ptr(gt), ptr(dgates), ptr(dfe[i:i + 1]), ptr(dh),
-                                       ptr(dxc), ptr(dh), ptr(dwg[i]), ptr(dbg[i]), ws.data_ptr(), 1, 2 * C, H, W, ACT_SIGMOID, PAD_ZERO,
-                                       st), "dc_conv3x3_bwd_add")
-        outs = []
-        for k, (per_frame, like) in enumerate(((dwg, w_g), (dbg, None), (dwc, w_c), (dbc, None))):
-            if not need[2 + k]:
-                outs.append(None)
+            check(L.dc_conv3x3_bwd_add(ptr(x), C, 0, ptr(h), C, ptr(w_g), ptr(gt), ptr(dg), ptr(dfe[i:i + 1]), ptr(dh),
+                                       ptr(dxc), ptr(dh), None, None, ws.data_ptr(), 1, 2 * C, H, W, ACT_SIGMOID, PAD_ZERO, st),
+                  "dc_conv3x3_bwd_add")
+        # the parameters are shared by the n steps and nothing downstream waits for their gradients: ONE weight-gradient pass
+        # per convolution with the n frames as its batch (sum over frames = sum over the batch), after the walk
+        outs = [None] * 4
+        for k, (like, x1, y, gy, co, act) in enumerate(((w_g, Hs, gates, dgates, 2 * C, ACT_SIGMOID), (w_c, rh, cnm, dcn, C, ACT_TANH))):
+            if not (need[2 + 2 * k] or need[3 + 2 * k]):
                 continue
-            dst = _grad_dst(ctx.slots[k], like)
-            if dst is None:
-                dst = torch.empty(per_frame.shape[1:], **f32)
-            outs.append(torch.sum(per_frame, 0, out=dst))
+            dw = _grad_dst(ctx.slots[2 * k], like) if need[2 + 2 * k] else None
+            db = None
+            if need[3 + 2 * k]:
+                db = _grad_dst(ctx.slots[2 * k + 1], None)
+                if db is None:
+                    db = torch.empty(co, **f32)
+            check(L.dc_conv3x3_bwd_add(ptr(ff), C, 0, ptr(x1), C, ptr(like), ptr(y), ptr(gy), None, None, None, None, ptr(dw), ptr(db),
+                                       ws.data_ptr(), n, co, H, W, act, PAD_ZERO, st), "dc_conv3x3_bwd_add")
+            outs[2 * k], outs[2 * k + 1] = dw, db
         return (dfe if need[0] else None, dHs[0:1] if need[1] else None) + tuple(outs)
 
 

@@ -114,7 +114,7 @@ def test_level_nodes_vs_per_op_graph():
     for a, b in zip(res[True][0], res[False][0]):
         assert torch.equal(a, b)
     for j, (a, b) in enumerate(zip(res[True][1], res[False][1])):
-        assert rel_l2(a, b) < 2e-6, (j, rel_l2(a, b))
+        assert rel_l2(a, b) < 1e-5, (j, rel_l2(a, b))
     blk.cgru_2.h0_layer1.requires_grad_(False)
     outs = blk.run_sequence(feats)
     sum((o * c).sum() for o, c in zip(outs, cots)).backward()
