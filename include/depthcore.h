@@ -64,6 +64,18 @@ int dc_pose_matrix_fwd(const float* axisangle, const float* translation, int inv
 int dc_pose_matrix_bwd(const float* axisangle, const float* translation, int invert, const float* dM,
                        float* d_axisangle, float* d_translation, int B, void* stream);
 
+/* The pose networks' tail and the cam_T_cam of their callers as ONE launch each way (networks/pose_decoder.py:50-54,
+ * networks/pose_cnn.py:48-52: out.mean(3).mean(2), 0.01 * out.view(-1, nf, 1, 6), [..., :3] / [..., 3:]; trainer.py:416-419,436-440:
+ * transformation_from_parameters(axisangle[:, i], translation[:, i], invert)).  y: the last convolution's output (N, 6 nf, P pixels);
+ * vec (N, 6 nf) = scale * mean over the pixels, read as (N, nf, [axisangle | translation]); group g: rows [row0, row0 + rows) of
+ * frame `slot` -> M[g] (rows,4,4) (`groups`, `M`, `dM` are HOST arrays of ngroups <= 8 entries; nf <= 8).  Backward: dM[g]
+ * (rows,4,4) or NULL -> d_y (N, 6 nf, P), zeros in channels no group reads. */
+typedef struct dc_pose_group { int row0, rows, slot, invert; } dc_pose_group;
+int dc_pose_head_fwd(const float* y, int N, int nf, int P, float scale, const dc_pose_group* groups, int ngroups, float* vec,
+                     float* const* M, void* stream);
+int dc_pose_head_bwd(const float* vec, int N, int nf, int P, float scale, const dc_pose_group* groups, int ngroups,
+                     const float* const* dM, float* d_y, void* stream);
+
 /* ------------------------------------------------------------------ a6 */
 /* layers.py:16-25 disp_to_depth: scaled = 1/max + (1/min-1/max)*disp; depth = 1/scaled. n elements. */
 int dc_disp_to_depth_fwd(const float* disp, float* scaled, float* depth, size_t n, float min_depth,

@@ -94,6 +94,69 @@ __global__ void pose_bwd_kernel(const float* aa, const float* tr, int invert, co
     for (int k = 0; k < 3; ++k) { daa[b * 3 + k] = g[k]; dtr[b * 3 + k] = g[3 + k]; }
 }
 
+// ---- the pose networks' tail as one launch each way (PoseDecoder / PoseCNN: networks/pose_decoder.py:50-54, pose_cnn.py:48-52, and
+// the cam_T_cam of trainer.py:416-419,436-440):  vec = scale * mean over the P pixels of y (N, 6 nf, P), viewed (N, nf, [axisangle |
+// translation]); group g takes rows [row0, row0 + rows) of frame `slot` to its own (rows, 4, 4) matrices.
+constexpr int POSE_MAXG = 8, POSE_MAXC = 6 * 8;
+struct PoseHead {
+    int ng, C, P;
+    float scale;
+    int row0[POSE_MAXG], rows[POSE_MAXG], slot[POSE_MAXG], invert[POSE_MAXG];
+    float* M[POSE_MAXG];
+    const float* dM[POSE_MAXG];
+};
+
+__global__ __launch_bounds__(256) void pose_head_fwd_kernel(const float* __restrict__ y, float* __restrict__ vec, PoseHead h) {
+    __shared__ float s_vec[POSE_MAXC];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = wv; c < h.C; c += 4) {
+        const float* src = y + ((size_t)n * h.C + c) * h.P;
+        float s = 0.f;
+        for (int p = lane; p < h.P; p += 64) s += src[p];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) { s = s * (h.scale / (float)h.P); s_vec[c] = s; vec[(size_t)n * h.C + c] = s; }
+    }
+    __syncthreads();
+    const int g = threadIdx.x;
+    if (g < h.ng && n >= h.row0[g] && n < h.row0[g] + h.rows[g]) {
+        F1 a[3], t[3], m[16];
+        for (int i = 0; i < 3; ++i) { a[i].v = s_vec[h.slot[g] * 6 + i]; t[i].v = s_vec[h.slot[g] * 6 + 3 + i]; }
+        pose_matrix(a, t, h.invert[g] != 0, m, [](float c) { return F1{c}; });
+        float* M = h.M[g] + (size_t)(n - h.row0[g]) * 16;
+        for (int i = 0; i < 16; ++i) M[i] = m[i].v;
+    }
+}
+
+// d_y[n, c, p] = scale / P * d_vec[n, c]; d_vec = the groups' matrix gradients through the same dual-number statement as
+// pose_bwd_kernel; channels no group reads get zeros (the reference predicts nf frames and uses one: trainer.py:416)
+__global__ __launch_bounds__(256) void pose_head_bwd_kernel(const float* __restrict__ vec, float* __restrict__ d_y, PoseHead h) {
+    __shared__ float s_d[POSE_MAXC];
+    const int n = blockIdx.x;
+    if (threadIdx.x < h.C) s_d[threadIdx.x] = 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int g = 0; g < h.ng; ++g) {
+            if (!h.dM[g] || n < h.row0[g] || n >= h.row0[g] + h.rows[g]) continue;
+            const float* v = vec + (size_t)n * h.C + h.slot[g] * 6;
+            Dual<6> a[3], t[3], m[16];
+            for (int i = 0; i < 3; ++i) {
+                a[i] = mk<6>(v[i]); a[i].d[i] = 1.f;
+                t[i] = mk<6>(v[3 + i]); t[i].d[3 + i] = 1.f;
+            }
+            pose_matrix(a, t, h.invert[g] != 0, m, [](float c) { return mk<6>(c); });
+            const float* dM = h.dM[g] + (size_t)(n - h.row0[g]) * 16;
+            for (int i = 0; i < 16; ++i) {
+                const float u = dM[i];
+                for (int k = 0; k < 6; ++k) s_d[h.slot[g] * 6 + k] += u * m[i].d[k];
+            }
+        }
+    }
+    __syncthreads();
+    const float k = h.scale / (float)h.P;
+    float* dst = d_y + (size_t)n * h.C * h.P;
+    for (int i = threadIdx.x; i < h.C * h.P; i += 256) dst[i] = s_d[i / h.P] * k;
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -112,6 +175,45 @@ extern "C" int dc_pose_matrix_bwd(const float* axisangle, const float* translati
     if (!axisangle || !translation || !dM || !d_axisangle || !d_translation || B <= 0) return DC_EINVAL;
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, axisangle,
                        translation, invert, dM, d_axisangle, d_translation, B);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+static int pose_head_pack(PoseHead& h, int N, int nf, int P, float scale, const dc_pose_group* groups, int ngroups) {
+    if (N <= 0 || nf <= 0 || 6 * nf > POSE_MAXC || P <= 0 || !groups || ngroups <= 0 || ngroups > POSE_MAXG) return DC_EINVAL;
+    h.ng = ngroups; h.C = 6 * nf; h.P = P; h.scale = scale;
+    for (int g = 0; g < ngroups; ++g) {
+        const dc_pose_group& q = groups[g];
+        if (q.row0 < 0 || q.rows <= 0 || q.row0 + q.rows > N || q.slot < 0 || q.slot >= nf) return DC_EINVAL;
+        h.row0[g] = q.row0; h.rows[g] = q.rows; h.slot[g] = q.slot; h.invert[g] = q.invert ? 1 : 0;
+        h.M[g] = nullptr; h.dM[g] = nullptr;
+    }
+    return DC_OK;
+}
+
+extern "C" int dc_pose_head_fwd(const float* y, int N, int nf, int P, float scale, const dc_pose_group* groups, int ngroups, float* vec,
+                                float* const* M, void* stream) {
+    PoseHead h{};
+    if (!y || !vec || !M) return DC_EINVAL;
+    const int rc = pose_head_pack(h, N, nf, P, scale, groups, ngroups);
+    if (rc != DC_OK) return rc;
+    for (int g = 0; g < ngroups; ++g) {
+        if (!M[g]) return DC_EINVAL;
+        h.M[g] = M[g];
+    }
+    hipLaunchKernelGGL(pose_head_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, y, vec, h);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_pose_head_bwd(const float* vec, int N, int nf, int P, float scale, const dc_pose_group* groups, int ngroups,
+                                const float* const* dM, float* d_y, void* stream) {
+    PoseHead h{};
+    if (!vec || !dM || !d_y) return DC_EINVAL;
+    const int rc = pose_head_pack(h, N, nf, P, scale, groups, ngroups);
+    if (rc != DC_OK) return rc;
+    for (int g = 0; g < ngroups; ++g) h.dM[g] = dM[g];          // (NULL: that group's matrices had no gradient)
+    hipLaunchKernelGGL(pose_head_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, vec, d_y, h);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }

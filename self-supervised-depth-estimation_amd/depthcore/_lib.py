@@ -74,6 +74,13 @@ class BnFold(Structure):
     _fields_ = [("groups", c_int32), ("in_scale", _F), ("in_shift", _F), ("stat_part", _F),
                 ("bn_x", _F), ("bn_mean", _F), ("bn_mask", _F), ("bwd_part", _F)]
 
+
+
+class PoseGroup(Structure):
+    """Mirror of `dc_pose_group` (include/depthcore.h: dc_pose_head_fwd / _bwd)."""
+    _fields_ = [("row0", c_int32), ("rows", c_int32), ("slot", c_int32), ("invert", c_int32)]
+
+
 _lib = None
 
 
@@ -84,6 +91,8 @@ def _sig(lib):
         "dc_arch": (c_char_p, []),
         "dc_pose_matrix_fwd": (i, [p, p, i, p, i, p]),
         "dc_pose_matrix_bwd": (i, [p, p, i, p, p, p, i, p]),
+        "dc_pose_head_fwd": (i, [p, i, i, i, f, p, i, p, p, p]),
+        "dc_pose_head_bwd": (i, [p, i, i, i, f, p, i, p, p, p]),
         "dc_disp_to_depth_fwd": (i, [p, p, p, z, f, f, p]),
         "dc_disp_to_depth_bwd": (i, [p, p, p, p, z, f, f, p]),
         "dc_pix_coords": (i, [p, i, i, i, p]),

@@ -386,6 +386,51 @@ def pose_matrix(axisangle, translation, invert=False):
     return _PoseMatrix.apply(axisangle, translation, invert)
 
 
+class _PoseHead(torch.autograd.Function):
+    """The tail of PoseDecoder / PoseCNN and the cam_T_cam of their callers as one launch each way (dc_pose_head_fwd / _bwd).
+    Outputs: vec (N, nf, 1, 6) -- NOT differentiable (the axisangle / translation entries of `outputs` are records; the loss
+    reaches the pose networks through the matrices) -- and one (rows,4,4) matrix tensor per group."""
+
+    @staticmethod
+    def forward(ctx, y, nf, groups):
+        L = _lib.lib()
+        yy = _c(y.detach())
+        N, C = yy.shape[0], yy.shape[1]
+        P = yy.shape[2] * yy.shape[3]
+        if C != 6 * nf:
+            raise _lib.DepthcoreError("pose head: %d channels for %d predicted frames" % (C, nf))
+        gs = (_lib.PoseGroup * len(groups))(*[_lib.PoseGroup(int(r0), int(rows), int(slot), int(bool(inv))) for r0, rows, slot, inv in groups])
+        vec = torch.empty(N, nf, 1, 6, dtype=torch.float32, device=yy.device)
+        Ms = [torch.empty(int(g[1]), 4, 4, dtype=torch.float32, device=yy.device) for g in groups]
+        mp = (ctypes.c_void_p * len(groups))(*[m.data_ptr() for m in Ms])
+        check(L.dc_pose_head_fwd(ptr(yy), N, nf, P, 0.01, gs, len(groups), ptr(vec), mp, stream(yy)), "dc_pose_head_fwd")
+        ctx.save_for_backward(vec)
+        ctx.cfg = (N, nf, P, yy.shape, tuple(groups))
+        ctx.mark_non_differentiable(vec)
+        return (vec,) + tuple(Ms)
+
+    @staticmethod
+    def backward(ctx, _gvec, *gMs):
+        L = _lib.lib()
+        vec, = ctx.saved_tensors
+        N, nf, P, yshape, groups = ctx.cfg
+        gs = (_lib.PoseGroup * len(groups))(*[_lib.PoseGroup(int(r0), int(rows), int(slot), int(bool(inv))) for r0, rows, slot, inv in groups])
+        keep = [None if g is None else _c(g) for g in gMs]       # named: alive until the launch is enqueued
+        dp = (ctypes.c_void_p * len(groups))(*[None if g is None else g.data_ptr() for g in keep])
+        dy = torch.empty(yshape, dtype=torch.float32, device=vec.device)
+        check(L.dc_pose_head_bwd(ptr(vec), N, nf, P, 0.01, gs, len(groups), dp, ptr(dy), stream(vec)), "dc_pose_head_bwd")
+        return dy, None, None
+
+
+def pose_head(y, nf, groups):
+    """y (N, 6 nf, h, w), the pose network's last convolution -> (axisangle (N,nf,1,3), translation (N,nf,1,3), [cam_T_cam per
+    group]); groups: (row0, rows, slot, invert) -- rows [row0, row0+rows) of predicted frame `slot`.  pose_decoder.py:50-54 +
+    trainer.py:416-419 / 436-440 in one launch each way."""
+    out = _PoseHead.apply(y, int(nf), tuple(tuple(int(v) for v in g) for g in groups))
+    vec = out[0]
+    return vec[..., :3], vec[..., 3:], list(out[1:])
+
+
 # ----------------------------------------------------------------------------------------------
 # a6  disp_to_depth                                                      (reference layers.py:16-25)
 # ----------------------------------------------------------------------------------------------

@@ -23,8 +23,8 @@ class PoseCNN(nn.Module):
         self.relu = nn.ReLU(True)
         self.net = nn.ModuleList(list(self.convs.values()))
 
-    def forward(self, out):
-        """networks/pose_cnn.py:40-53.  On the GPU the seven strided convolutions (7x7, 5x5, 3x3 with bias) run on depthcore's
+    def _trunk(self, out):
+        """networks/pose_cnn.py:40-48.  On the GPU the seven strided convolutions (7x7, 5x5, 3x3 with bias) run on depthcore's
         direct kernels (dc_conv2d_direct_*: this network is outside the BASELINE configurations, the plain kernels are the
         honest cost) and the 1x1 head on dc_conv1x1_bias_act_fwd; no library convolution."""
         if out.is_cuda:
@@ -36,6 +36,14 @@ class PoseCNN(nn.Module):
             for i in range(self.num_convs):
                 out = self.relu(self.convs[i](out))
             out = self.pose_conv(out)
-        out = out.mean(3).mean(2)
+        return out
+
+    def forward(self, out):
+        """networks/pose_cnn.py:40-53."""
+        out = self._trunk(out).mean(3).mean(2)
         out = 0.01 * out.view(-1, self.num_input_frames - 1, 1, 6)
         return out[..., :3], out[..., 3:]
+
+    def forward_poses(self, out, groups):
+        """forward() + the callers' cam_T_cam with the tail as one launch each way (as PoseDecoder.forward_poses)."""
+        return _ops.pose_head(self._trunk(out), self.num_input_frames - 1, groups)

@@ -24,9 +24,9 @@ class PoseDecoder(nn.Module):
         self.relu = nn.ReLU()
         self.net = nn.ModuleList(list(self.convs.values()))
 
-    def forward(self, input_features):
-        """networks/pose_decoder.py:40-54.  On the GPU every convolution is a depthcore launch with its bias and ReLU in
-        the epilogue (dc_conv1x1_bias_act_fwd, dc_conv3x3_fwd); there is no library convolution on this path."""
+    def _trunk(self, input_features):
+        """networks/pose_decoder.py:40-50: squeeze -> pose 0..2.  On the GPU every convolution is a depthcore launch with its
+        bias and ReLU in the epilogue (dc_conv1x1_bias_act_fwd, dc_conv3x3_fwd); there is no library convolution on this path."""
         last = [f[-1] for f in input_features]
         if last[0].is_cuda:
             sq = self.convs["squeeze"]
@@ -45,6 +45,18 @@ class PoseDecoder(nn.Module):
                 out = self.convs[("pose", i)](out)
                 if i != 2:
                     out = self.relu(out)
+        return out
+
+    def forward(self, input_features):
+        """networks/pose_decoder.py:40-54."""
+        out = self._trunk(input_features)
         out = out.mean(3).mean(2)
         out = 0.01 * out.view(-1, self.num_frames_to_predict_for, 1, 6)
         return out[..., :3], out[..., 3:]
+
+    def forward_poses(self, input_features, groups):
+        """forward() + the callers' transformation_from_parameters (trainer.py:416-419, 436-440) with the tail -- pixel mean,
+        0.01, the axisangle / translation split, the frame selection and the 4x4 matrices -- as one launch each way
+        (depthcore.ops.pose_head): -> axisangle, translation (records, not differentiable), [cam_T_cam per group];
+        groups: (row0, rows, predicted frame, invert)."""
+        return _ops.pose_head(self._trunk(input_features), self.num_frames_to_predict_for, groups)

@@ -324,12 +324,12 @@ class Trainer:
         B = pose_feats[0].shape[0]
         # (the pair tensors cat([f-1, f0], 1), cat([f0, f+1], 1) of trainer.py:398-412 are formed by the stem kernel's loader)
         feats = self.models["pose_encoder"].forward_pairs(pose_feats[-1], pose_feats[0], pose_feats[1])
-        axisangle, translation = self.models["pose"]([feats])
+        # rows [0, B): the pair (-1, 0), inverted (trainer.py:416-419); rows [B, 2B): the pair (0, +1); predicted frame 0 of each
+        axisangle, translation, Ts = self.models["pose"].forward_poses([feats], [(0, B, 0, 1), (B, B, 0, 0)])
         for i, f in enumerate((-1, 1)):
-            aa, tr = axisangle[i * B:(i + 1) * B], translation[i * B:(i + 1) * B]
-            outputs[("axisangle", 0, f)] = aa
-            outputs[("translation", 0, f)] = tr
-            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(aa[:, 0], tr[:, 0], invert=(f < 0))
+            outputs[("axisangle", 0, f)] = axisangle[i * B:(i + 1) * B]
+            outputs[("translation", 0, f)] = translation[i * B:(i + 1) * B]
+            outputs[("cam_T_cam", 0, f)] = Ts[i]
         return outputs
 
     def _predict_poses_modes(self, inputs, features):
@@ -344,10 +344,11 @@ class Trainer:
                     pose_inputs = [self.models["pose_encoder"](torch.cat(pose_inputs, 1))]
                 elif o.pose_model_type == "posecnn":
                     pose_inputs = torch.cat(pose_inputs, 1)
-                axisangle, translation = pose(pose_inputs)
+                B = inputs[("color_aug", 0, 0)].shape[0]
+                axisangle, translation, Ts = pose.forward_poses(pose_inputs, [(0, B, 0, int(f < 0))])
                 outputs[("axisangle", 0, f)] = axisangle
                 outputs[("translation", 0, f)] = translation
-                outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=(f < 0))
+                outputs[("cam_T_cam", 0, f)] = Ts[0]
             return outputs
         ids = [i for i in o.frame_ids if i != "s"]               # trainer.py:421-440: all frames in, all poses out
         if o.pose_model_type in ("separate_resnet", "posecnn"):
@@ -356,12 +357,13 @@ class Trainer:
                 pose_inputs = [self.models["pose_encoder"](pose_inputs)]
         else:
             pose_inputs = [features[i] for i in ids]
-        axisangle, translation = pose(pose_inputs)
-        for i, f in enumerate(o.frame_ids[1:]):
-            if f != "s":
-                outputs[("axisangle", 0, f)] = axisangle
-                outputs[("translation", 0, f)] = translation
-                outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle[:, i], translation[:, i])
+        B = inputs[("color_aug", 0, 0)].shape[0]
+        used = [(i, f) for i, f in enumerate(o.frame_ids[1:]) if f != "s"]
+        axisangle, translation, Ts = pose.forward_poses(pose_inputs, [(0, B, i, 0) for i, _ in used])
+        for (i, f), T_ in zip(used, Ts):
+            outputs[("axisangle", 0, f)] = axisangle
+            outputs[("translation", 0, f)] = translation
+            outputs[("cam_T_cam", 0, f)] = T_
         return outputs
 
     # ------------------------------------------------------------------ fused a14 + a15

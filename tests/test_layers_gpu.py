@@ -34,6 +34,38 @@ def test_transformation_from_parameters(golden):
     assert torch.isfinite(z.grad).all()
 
 
+def test_pose_head_vs_the_statements_it_fuses():
+    """dc_pose_head_fwd / _bwd (the pose networks' tail + the callers' cam_T_cam as one launch each way) against the statements
+    of pose_decoder.py:52-54 + trainer.py:416-419 / 436-440 written with torch and dc_pose_matrix (itself pinned by the
+    reference's fixture above): the pairs layout (two row groups, the first inverted, predicted frame 0 of 2), the `all` layout
+    (one row group per predicted frame), a group without a gradient, and channels nobody reads (zero gradient)."""
+    import layers
+    from depthcore import ops
+    torch.manual_seed(3)
+    for N, nf, h, w, groups in ((8, 2, 6, 20, [(0, 4, 0, 1), (4, 4, 0, 0)]), (5, 2, 3, 7, [(0, 5, 0, 0), (0, 5, 1, 0)]),
+                                (3, 3, 10, 32, [(0, 3, 2, 1)]), (6, 1, 5, 5, [(0, 2, 0, 0), (2, 4, 0, 1)])):
+        y = torch.randn(N, 6 * nf, h, w, device=DEV).requires_grad_()
+        aa, tr, Ms = ops.pose_head(y, nf, groups)
+        v = 0.01 * y.mean(3).mean(2).view(-1, nf, 1, 6)
+        close(aa, v[..., :3], rtol=1e-5, atol=1e-8)
+        close(tr, v[..., 3:], rtol=1e-5, atol=1e-8)
+        assert not aa.requires_grad and len(Ms) == len(groups)
+        cots = [torch.randn(g[1], 4, 4, device=DEV) for g in groups]
+        refs = [layers.transformation_from_parameters(v[r0:r0 + n, s, :, :3], v[r0:r0 + n, s, :, 3:], invert=bool(inv))
+                for r0, n, s, inv in groups]
+        for m, r in zip(Ms, refs):
+            close(m, r, rtol=1e-5, atol=1e-7)
+        gh, = torch.autograd.grad(sum((m * c).sum() for m, c in zip(Ms, cots)), y)
+        gr, = torch.autograd.grad(sum((m * c).sum() for m, c in zip(refs, cots)), y, retain_graph=True)
+        close(gh, gr, rtol=1e-4, atol=1e-9)
+        if len(groups) > 1:                      # only the last group's matrices reach the loss
+            y2 = y.detach().clone().requires_grad_()
+            _, _, Ms2 = ops.pose_head(y2, nf, groups)
+            g2, = torch.autograd.grad((Ms2[-1] * cots[-1]).sum(), y2)
+            g2r, = torch.autograd.grad((refs[-1] * cots[-1]).sum(), y)
+            close(g2, g2r, rtol=1e-4, atol=1e-9)
+
+
 def test_disp_to_depth(golden):
     import layers
     g = golden["layers_ops"]

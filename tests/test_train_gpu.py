@@ -93,7 +93,7 @@ def test_all_parameter_gradients_vs_oracle(fusion):
             tapes[name] = t.entries
             return out
         setattr(mod, method, fwd)
-    for name, method in (("encoder", "forward"), ("pose_encoder", "forward_pairs"), ("pose", "forward")):
+    for name, method in (("encoder", "forward"), ("pose_encoder", "forward_pairs"), ("pose", "forward_poses")):
         taped(name, method)
     torch.manual_seed(1234)
     tr.buckets.zero()
