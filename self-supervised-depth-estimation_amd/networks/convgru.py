@@ -14,6 +14,20 @@ import torch.nn as nn
 from depthcore import ops as _ops
 from depthcore._lib import DepthcoreError
 
+# the levels' nodes on a stream each: measured SLOWER (C4 --graph 332 vs 359 frames/s, eager 264 vs 303 on the same box: the
+# cross-queue dependencies cost more than the overlap of ~10 us kernels gains) -- off, kept for the A/B
+LEVEL_STREAMS = os.environ.get("DC_GRU_LEVEL_STREAMS", "0") == "1"
+_streams = {}
+
+
+def _level_streams(device, cur, n):
+    """n side streams per (device, stream the step runs on): the same ones every step (a captured graph forks into them)."""
+    key = (device.index, cur.cuda_stream)
+    if key not in _streams or len(_streams[key]) < n:
+        _streams[key] = [torch.cuda.Stream(device) for _ in range(n)]
+    return _streams[key][:n]
+
+
 LEVEL_NODES = os.environ.get("DC_GRU_LEVEL_NODES", "1") != "0"    # 0: the per-op graph (one node per gate product / convolution), for A/Bs
 
 
@@ -87,8 +101,24 @@ class ConvGRUBlocks_v5(nn.Module):
         features[k] + (H[1:] + H[:-1]) / 2 with H the n+1 hidden states."""
         if LEVEL_NODES and features[0].is_cuda:
             # one autograd node per level: the frame loop, the trace and the reverse walk live inside it (ops._GruLevel)
-            return [_ops.gru_level_sequence(f, cell.h0_layer1, cell.cgru_1.conv_gates, cell.cgru_1.conv_can)
-                    for cell, f in zip(self.cells(), features)]
+            if not LEVEL_STREAMS:
+                return [_ops.gru_level_sequence(f, cell.h0_layer1, cell.cgru_1.conv_gates, cell.cgru_1.conv_can)
+                        for cell, f in zip(self.cells(), features)]
+            # the five levels do not depend on each other and each is a chain of small dependent launches: every level on its
+            # own stream (autograd runs a node's backward on the stream of its forward, so the reverse walks overlap too)
+            cur = torch.cuda.current_stream(features[0].device)
+            side = _level_streams(features[0].device, cur, len(features))
+            outs = []
+            for cell, f, st in zip(self.cells(), features, side):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    o = _ops.gru_level_sequence(f, cell.h0_layer1, cell.cgru_1.conv_gates, cell.cgru_1.conv_can)
+                f.record_stream(st)
+                o.record_stream(cur)
+                outs.append(o)
+            for st in side:
+                cur.wait_stream(st)
+            return outs
         n = features[0].shape[0]
         hidden = [cell.h0_layer1 for cell in self.cells()]
         trace = [[h] for h in hidden]
