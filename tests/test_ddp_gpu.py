@@ -26,12 +26,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("front", ["vanilla", "fusion"])
+@pytest.mark.parametrize("front", ["vanilla", "fusion", "gru"])
 def test_bucketed_exchange_over_rccl_with_stream_overlap(front):
     """`fusion`: the Fusion_v3 parameters (3-element rel_h / rel_w, 1-element biases) sit between the others in the flat
-    bucket -- every slice must still start on a 16-byte boundary for the kernels' vector stores."""
+    bucket -- every slice must still start on a 16-byte boundary for the kernels' vector stores.  `gru`: the ConvGRU level
+    nodes write the cells' shared weights' gradients (one pass over the sequence's frames) straight into their slices; only
+    the five learned initial states are packed."""
     import trainer as T
-    from depthcore.synthetic import synthetic_batch
+    from depthcore.synthetic import synthetic_batch, synthetic_sequence_batch
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
@@ -39,6 +41,9 @@ def test_bucketed_exchange_over_rccl_with_stream_overlap(front):
         B, H, W = 2, 64, 128
         kw = dict(fusion="v3", frame_ids=[0, -2, -1, 1]) if front == "fusion" else {}
         inputs = synthetic_batch(B, H, W, torch.device(DEV), seed=5, frame_ids=(0, -2, -1, 1) if front == "fusion" else (0, -1, 1))
+        if front == "gru":
+            B, kw = 1, dict(gru="v5", len_sequence=3)
+            inputs = synthetic_sequence_batch(3, H, W, torch.device(DEV), seed=5)
         ref = T.Trainer(T.default_options(batch_size=B, height=H, width=W, **kw), device=DEV, seed=11)
         ddp = T.Trainer(T.default_options(batch_size=B, height=H, width=W, **kw), device=DEV, rank=0, world_size=2, seed=11)
         for k in ref.models:
@@ -78,7 +83,9 @@ def test_bucketed_exchange_over_rccl_with_stream_overlap(front):
             # (Fusion_v3: the 192 AttentionConv parameter tensors -- 2 to 16 floats each -- leave dc_attnconv_bwd as one packed
             # vector per unit and reach their slices through the bucket's single multi-tensor copy.)
             n_attn = sum(1 for n, _ in ddp.models["fusion"].named_parameters() if ".atten" in n) if front == "fusion" else 0
-            assert ddp.buckets.packed == n_attn and n_attn in (0, 192), (ddp.buckets.packed, n_attn)
+            if front == "gru":
+                n_attn = 5                                 # the learned initial states h0_layer1 of the five levels
+            assert ddp.buckets.packed == n_attn and n_attn in (0, 5, 192), (ddp.buckets.packed, n_attn)
             assert ddp.buckets.launch_order == sorted(ddp.buckets.launch_order)
             # move on to another point of weight space for the next round (the ddp copy is re-synchronised there)
             ref.model_optimizer.step()
