@@ -532,6 +532,9 @@ int dc_gru_blend_bwd(const float* gates, const float* h, const float* cnm, const
 int dc_gru_rh_bwd_acc(const float* gates, const float* h, const float* g, float* d_gates, float* d_h, int B, int C, int P, void* stream);
 int dc_gru_blend_bwd_acc(const float* gates, const float* h, const float* cnm, const float* g, float* d_gates, float* d_h, float* d_cnm,
                          int B, int C, int P, void* stream);
+/* The sequence trainer's stacking of per-frame tensors along the batch (trainer_gru.py:819-821, 886-896, 943-944: torch.cat over
+ * the frames at every use) as ONE launch: segment i copies n[i] floats src[i] -> dst[i] (HOST arrays, nseg <= 96). */
+int dc_gather_copy(const float* const* src, float* const* dst, const size_t* n, int nseg, void* stream);
 int dc_gru_residual_fwd(const float* f, const float* H, float* out, int n, size_t M, void* stream);
 int dc_gru_residual_bwd(const float* g, float* d_H, int n, size_t M, void* stream);
 

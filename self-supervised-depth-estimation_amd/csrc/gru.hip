@@ -65,6 +65,29 @@ __global__ __launch_bounds__(256) void gru_blend_bwd_acc_kernel(const float* __r
         d_cnm[i] = gv * u;
     }
 }
+// The sequence trainer stacks the frames of one sequence along the batch at every use (trainer_gru.py:819-821, 886-896, 943-944:
+// torch.cat of ("color", f, s, j), ("K", s, j), ("inv_K", s, j) over j): 20 concatenations of 3 tensors each per step.  One launch
+// copies every segment to its place (segments as kernel arguments: no table upload).
+constexpr int GATHER_MAX = 96;
+struct GatherArgs {
+    const float* src[GATHER_MAX];
+    float* dst[GATHER_MAX];
+    unsigned n[GATHER_MAX];          // floats
+};
+__global__ __launch_bounds__(256) void gather_copy_kernel(GatherArgs a) {
+    const int s = blockIdx.y;
+    const unsigned n = a.n[s];
+    const float* __restrict__ src = a.src[s];
+    float* __restrict__ dst = a.dst[s];
+    if ((((size_t)src | (size_t)dst) & 15) == 0) {
+        const unsigned n4 = n >> 2;
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (unsigned i = (n4 << 2) + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+    } else {
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+    }
+}
 __global__ __launch_bounds__(256) void gru_blend_fwd_kernel(const float* __restrict__ gates, const float* __restrict__ h,
                                                            const float* __restrict__ cnm, float* __restrict__ out, int B, int C, int P) {
     const size_t n = (size_t)B * C * P;
@@ -172,6 +195,21 @@ extern "C" int dc_gru_blend_bwd_acc(const float* gates, const float* h, const fl
     if (!gates || !h || !cnm || !g || !d_gates || !d_h || !d_cnm || !gru_ok(B, C, P)) return DC_EINVAL;
     hipLaunchKernelGGL(gru_blend_bwd_acc_kernel, dim3(gru_grid((size_t)B * C * P)), dim3(256), 0, (hipStream_t)stream, gates, h, cnm, g,
                        d_gates, d_h, d_cnm, B, C, P);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
+extern "C" int dc_gather_copy(const float* const* src, float* const* dst, const size_t* n, int nseg, void* stream) {
+    if (!src || !dst || !n || nseg <= 0 || nseg > GATHER_MAX) return DC_EINVAL;
+    GatherArgs a{};
+    size_t most = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (!src[i] || !dst[i] || n[i] == 0 || n[i] > 0xffffffffull) return DC_EINVAL;
+        a.src[i] = src[i]; a.dst[i] = dst[i]; a.n[i] = (unsigned)n[i];
+        most = std::max(most, n[i]);
+    }
+    const unsigned gx = (unsigned)std::min<size_t>((most / 4 + 1023) / 1024 + 1, 256);
+    hipLaunchKernelGGL(gather_copy_kernel, dim3(gx, nseg), dim3(256), 0, (hipStream_t)stream, a);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }

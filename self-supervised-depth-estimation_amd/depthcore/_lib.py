@@ -181,6 +181,7 @@ def _sig(lib):
         "dc_gru_blend_bwd": (i, [p, p, p, p, p, p, p, i, i, i, p]),
         "dc_gru_rh_bwd_acc": (i, [p, p, p, p, p, i, i, i, p]),
         "dc_gru_blend_bwd_acc": (i, [p, p, p, p, p, p, p, i, i, i, p]),
+        "dc_gather_copy": (i, [p, p, p, i, p]),
         "dc_gru_residual_fwd": (i, [p, p, p, i, z, p]),
         "dc_gru_residual_bwd": (i, [p, p, i, z, p]),
         "dc_set_matrix_precision": (i, [i]),

@@ -1539,6 +1539,30 @@ class _GruResidual(torch.autograd.Function):
         return g_c, dH
 
 
+def stack_frames(groups):
+    """[[t_0, t_1, ...], ...] -> [torch.cat(group, 0) for group in groups] in ONE launch (dc_gather_copy): the sequence trainer's
+    stacking of the frames of a sequence along the batch (trainer_gru.py:819-821, 886-896, 943-944).  float32 device tensors
+    without a gradient (inputs of the step); a group's members share their trailing shape."""
+    L = _lib.lib()
+    outs, src, dst, n, keep = [], [], [], [], []
+    for g in groups:
+        ts = [_c(t.detach()) for t in g]
+        if any(t.dtype != torch.float32 or not t.is_cuda or t.shape[1:] != ts[0].shape[1:] for t in ts):
+            raise _lib.DepthcoreError("stack_frames takes float32 device tensors that agree in their trailing shape")
+        out = torch.empty((sum(t.shape[0] for t in ts),) + tuple(ts[0].shape[1:]), dtype=torch.float32, device=ts[0].device)
+        off = 0
+        for t in ts:
+            src.append(t.data_ptr()); dst.append(out.data_ptr() + 4 * off); n.append(t.numel())
+            off += t.numel()
+        keep.append(ts)
+        outs.append(out)
+    for i in range(0, len(src), 96):
+        k = len(src[i:i + 96])
+        check(L.dc_gather_copy((ctypes.c_void_p * k)(*src[i:i + 96]), (ctypes.c_void_p * k)(*dst[i:i + 96]),
+                               (ctypes.c_size_t * k)(*n[i:i + 96]), k, stream(outs[0])), "dc_gather_copy")
+    return outs
+
+
 def gru_reset_times_state(gates, h):
     """r * h with r = gates[:, :C]."""
     return _GruRH.apply(gates, h)

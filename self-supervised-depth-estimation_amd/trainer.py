@@ -228,15 +228,17 @@ class Trainer:
         of the sequence) -> the ordinary dict with the sequence stacked along the batch, as trainer_gru.py:819-821,886-896,
         943-944 concatenate it at every use.  The GRU trainer feeds the un-augmented images to both networks."""
         n = self.opt.len_sequence
-        out = {}
-        for f in (0, -1, 1):
-            for s in self.opt.scales:
-                if ("color", f, s, 0) in inputs:
-                    out[("color", f, s)] = torch.cat([inputs[("color", f, s, j)] for j in range(n)], 0)
-                    out[("color_aug", f, s)] = out[("color", f, s)]
-        for s in self.opt.scales:
-            for k in ("K", "inv_K"):
-                out[(k, s)] = torch.cat([inputs[(k, s, j)] for j in range(n)], 0)
+        keys = [("color", f, s) for f in (0, -1, 1) for s in self.opt.scales if ("color", f, s, 0) in inputs]
+        keys += [(k, s) for s in self.opt.scales for k in ("K", "inv_K")]
+        groups = [[inputs[key + (j,)] for j in range(n)] for key in keys]
+        if groups[0][0].is_cuda and all(t.dtype == torch.float32 for g in groups for t in g):
+            stacked = ops.stack_frames(groups)                   # one launch for the 20 concatenations
+        else:
+            stacked = [torch.cat(g, 0) for g in groups]
+        out = dict(zip(keys, stacked))
+        for key in keys:
+            if key[0] == "color":
+                out[("color_aug",) + key[1:]] = out[key]
         return out
 
     def process_batch(self, inputs):

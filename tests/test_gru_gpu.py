@@ -88,6 +88,22 @@ def test_blocks_v5_sequence_vs_reference_fixture(golden):
         close(MG.summ(gr[5 + j]), g["v5_g_" + k], rtol=5e-3, atol=5e-5, msg=k)
 
 
+def test_stack_frames_is_torch_cat():
+    """dc_gather_copy (ops.stack_frames): the sequence trainer's per-step concatenations in one launch -- bitwise torch.cat,
+    incl. 4x4 intrinsics (64-byte segments), odd element counts and an unaligned view."""
+    from depthcore import ops
+    g = torch.Generator().manual_seed(9)
+    groups = [[torch.rand(1, 3, 24, 40, generator=g).to(DEV) for _ in range(3)], [torch.rand(1, 4, 4, generator=g).to(DEV) for _ in range(3)],
+              [torch.rand(2, 5, 7, generator=g).to(DEV), torch.rand(1, 5, 7, generator=g).to(DEV)],
+              [torch.rand(1, 3, 9, generator=g).to(DEV)[:, :, 1:], torch.rand(1, 3, 8, generator=g).to(DEV)]]
+    outs = ops.stack_frames(groups)
+    for o, grp in zip(outs, groups):
+        assert torch.equal(o, torch.cat(grp, 0))
+    many = [[torch.rand(1, 17, generator=g).to(DEV) for _ in range(3)] for _ in range(40)]       # 120 segments: two launches
+    for o, grp in zip(ops.stack_frames(many), many):
+        assert torch.equal(o, torch.cat(grp, 0))
+
+
 def test_level_nodes_vs_per_op_graph():
     """ops._GruLevel (one autograd node per level, frames walked inside it) against the per-op graph of the same module on a
     4-frame sequence: same kernels for the convolutions and the gate products, so outputs and every gradient agree to rounding
