@@ -317,6 +317,11 @@ __global__ __launch_bounds__(512, 2) void c3b_conv_kernel(C3bArgs a) {
                 const int g = wave * RWV + j;
                 bfr[j] = *reinterpret_cast<const bf8*>(pim + ((S * (g >> 1) + ky) * PW + S * (16 * (g & 1) + n) + kx) * BPX + kk * 8);
             }
+#ifndef C3B_REP
+#define C3B_REP 1          // diagnostic builds only: the MFMA work of a tap issued C3B_REP times (cost model of split-operand products)
+#endif
+#pragma unroll
+            for (int rep = 0; rep < C3B_REP; ++rep)
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -445,7 +450,9 @@ __global__ __launch_bounds__(512, 2) void c3b_wgrad_kernel(C3bWgArgs a) {
                 const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base));
                 const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base + 4 * S * BPX));
                 const s8 bv = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf8, bv), acc[t], 0, 0, 0);
+#pragma unroll
+                for (int rep = 0; rep < C3B_REP; ++rep)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf8, bv), acc[t], 0, 0, 0);
             }
         }
     }
