@@ -507,6 +507,81 @@ __global__ __launch_bounds__(256) void conv_fold_kernel(const float* __restrict_
     }
 }
 
+// Four consecutive pixels of a row per thread (maps of >= 4 x 4 with whole quads per row): the padded-domain reads sit one float
+// off a 16-byte boundary -- dword-aligned 16-byte loads (the hardware takes them) -- and the gradient leaves as one aligned
+// 16-byte store: 4 x the bytes in flight per thread of conv_fold_kernel (which ran at ~2 TB/s; 0.40 ms of a C2 step).  Same sums
+// in the same order: results are bitwise those of conv_fold_kernel.  grid (ceil(max quads per plane / 256), Cin, B).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(256) void conv_fold4_kernel(const float* __restrict__ dxpad, float* dx0, float* dx1,
+                                                         int B, int C0, int C1, int up0, int H, int W, int pad, int pitch,
+                                                         const float* add0, const float* add1) {
+    const int Cin = C0 + C1;
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const float* p = dxpad + ((size_t)b * Cin + ch) * (H + 2) * pitch;
+    const bool refl = pad == PAD_REFLECT;
+    const bool first = ch < C0;
+    float* dst = first ? dx0 : dx1;
+    if (!dst) return;
+    const int upx = first ? up0 : 0;
+    const int h0 = H >> upx, w0 = W >> upx, wq = w0 >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h0 * wq) return;
+    const int y = i / wq, x = (i - y * wq) * 4;
+    const size_t o = ((size_t)b * (first ? C0 : C1) + (first ? ch : ch - C0)) * h0 * w0 + (size_t)y * w0 + x;
+    const float* add = first ? add0 : add1;
+    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (add) av = *reinterpret_cast<const float4*>(add + o);
+    float v[4];
+    if (upx) {
+        const float* r0 = p + (size_t)(2 * y + 1) * pitch + 1 + 2 * x;
+        const f4u a0 = *reinterpret_cast<const f4u*>(r0), a1 = *reinterpret_cast<const f4u*>(r0 + 4);
+        const f4u b0 = *reinterpret_cast<const f4u*>(r0 + pitch), b1 = *reinterpret_cast<const f4u*>(r0 + pitch + 4);
+        v[0] = (a0.x + a0.y) + (b0.x + b0.y); v[1] = (a0.z + a0.w) + (b0.z + b0.w);
+        v[2] = (a1.x + a1.y) + (b1.x + b1.y); v[3] = (a1.z + a1.w) + (b1.z + b1.w);
+        if (refl) {
+            const bool er = y == 0 || 2 * y + 1 == H - 2 || 2 * y == H - 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xk = x + k;
+                if (er || xk == 0 || 2 * xk + 1 == W - 2 || 2 * xk == W - 2)
+                    v[k] = (fold_at(p, 2 * y, 2 * xk, H, W, pad, pitch) + fold_at(p, 2 * y, 2 * xk + 1, H, W, pad, pitch)) +
+                           (fold_at(p, 2 * y + 1, 2 * xk, H, W, pad, pitch) + fold_at(p, 2 * y + 1, 2 * xk + 1, H, W, pad, pitch));
+            }
+        }
+    } else {
+        const f4u a = *reinterpret_cast<const f4u*>(p + (size_t)(y + 1) * pitch + 1 + x);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        if (refl) {
+            const bool er = y == 1 || y == H - 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xk = x + k;
+                if (er || xk == 1 || xk == W - 2) v[k] = fold_at(p, y, xk, H, W, pad, pitch);
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(dst + o) = make_float4(v[0] + av.x, v[1] + av.y, v[2] + av.z, v[3] + av.w);
+}
+
+static int conv_fold(const float* dxpad, float* dx0, float* dx1, int B, int C0, int C1, int up0, int H, int W, int pad, int pitch,
+                     const float* add0, const float* add1, hipStream_t st) {
+    const int Cin = C0 + C1;
+    static const bool fold4 = !(std::getenv("DC_FOLD4") && std::getenv("DC_FOLD4")[0] == '0');      // (0: the one-pixel kernel, for A/Bs)
+    const bool quads = fold4 && H >= 4 && W >= 4 && W % 4 == 0 && (W >> up0) % 4 == 0 && ((H >> up0) >= 1) &&
+                       !(((size_t)dx0 | (size_t)dx1 | (size_t)add0 | (size_t)add1) & 15);
+    if (quads) {
+        const int nq = std::max(C1 > 0 ? H * (W / 4) : 0, C0 > 0 ? (H >> up0) * ((W >> up0) / 4) : 0);
+        hipLaunchKernelGGL(conv_fold4_kernel, dim3(ceil_div(nq, 256), Cin, B), dim3(256), 0, st, dxpad, dx0, dx1, B, C0, C1, up0, H, W, pad,
+                           pitch, add0, add1);
+    } else {
+        const int npix = std::max(H * W, (H >> up0) * (W >> up0));
+        hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256 * FOLD_PPT), Cin, B), dim3(256), 0, st, dxpad, dx0, dx1, B, C0, C1, up0,
+                           H, W, pad, pitch, add0, add1);
+    }
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad: dW[co][ci][t] = sum_{b,y,x} g'[b,co,y,x] * xpad[b,ci,y+ky-1,x+kx-1]
 // GEMM M = Co (16*MR per block), N = 16 (ci) per n-subtile x 9 taps, K = pixels (4 per MFMA).
@@ -1069,19 +1144,15 @@ extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float*
         } else {
             const int rc = c3b_conv(gp, Co, 0, nullptr, 0, weight, Co, Cin, 1, 1, nullptr, dxpad, wd, B, H, W, ACT_NONE, PAD_ZERO, 1, ST);
             if (rc != DC_OK) return rc;
-            const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
-            hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256 * FOLD_PPT), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0, C1,
-                               up0 ? 1 : 0, H, W, pad_mode, c3b_dpad_pitch(W), addend0, addend1);
-            DC_CHECK_LAUNCH();
+            const int rcf = conv_fold(dxpad, dx0, dx1, B, C0, C1, up0 ? 1 : 0, H, W, pad_mode, c3b_dpad_pitch(W), addend0, addend1, ST);
+            if (rcf != DC_OK) return rcf;
         }
     } else if (w_dx) {
         // full correlation of g' with the rotated weights in the Winograd domain, then the same fold as below
         const int rc = wino_conv_full_dgrad(gp, weight, dxpad, wws, B, Cin, Co, H, W, ST);
         if (rc != DC_OK) return rc;
-        const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
-        hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256 * FOLD_PPT), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0, C1,
-                           up0 ? 1 : 0, H, W, pad_mode, W + 2, addend0, addend1);
-        DC_CHECK_LAUNCH();
+        const int rcf = conv_fold(dxpad, dx0, dx1, B, C0, C1, up0 ? 1 : 0, H, W, pad_mode, W + 2, addend0, addend1, ST);
+        if (rcf != DC_OK) return rcf;
     } else if (dx0 || dx1) {
         hipLaunchKernelGGL(conv_wprep_kernel, dim3(ceil_div((int)nW, 256)), dim3(256), 0, ST, weight, (float*)nullptr, wd,
                            Co, Cin);
@@ -1102,10 +1173,8 @@ extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float*
             else hipLaunchKernelGGL((conv_gemm_kernel<1, true>), grid, dim3(256), 0, ST, a);
         }
         DC_CHECK_LAUNCH();
-        const int npix = std::max(H * W, (H >> (up0 ? 1 : 0)) * (W >> (up0 ? 1 : 0)));
-        hipLaunchKernelGGL(conv_fold_kernel, dim3(ceil_div(npix, 256 * FOLD_PPT), Cin, B), dim3(256), 0, ST, dxpad, dx0, dx1, B, C0,
-                           C1, up0 ? 1 : 0, H, W, pad_mode, W + 2, addend0, addend1);
-        DC_CHECK_LAUNCH();
+        const int rcf = conv_fold(dxpad, dx0, dx1, B, C0, C1, up0 ? 1 : 0, H, W, pad_mode, W + 2, addend0, addend1, ST);
+        if (rcf != DC_OK) return rcf;
     }
     if (head_dw) {
         // (scratch: the padded-domain buffer -- the head's data gradient does not use it, and any other data-gradient path has
