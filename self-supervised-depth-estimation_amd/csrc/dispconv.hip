@@ -13,6 +13,7 @@
 #include "conv_bf16.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace dc {
 
@@ -66,6 +67,50 @@ __global__ __launch_bounds__(256) void dispconv_fwd_kernel(const float* __restri
     }
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy < H && ox < W) y[((size_t)b * H + oy) * W + ox] = act_fwd(acc + (bias ? bias[0] : 0.f), act);
+}
+
+// Four consecutive pixels of a row per thread, no LDS patch: a block is 8 rows x 128 columns (32 x 8 threads), a thread reads,
+// per channel and window row, one aligned 16-byte vector and the two columns beside it (lines its neighbours fetch anyway:
+// the three row shifts and the side columns hit in L1 / L2), and 16-byte stores.  The 16 x 16 tiles of dispconv_fwd_kernel moved
+// 72-byte row segments (half lines) through scalar loads into LDS: 1.9 TB/s for 16 -> 1 at 192 x 640.  Same products in the
+// same order (channel, ky, kx): results are bitwise those of dispconv_fwd_kernel.  W % 4 == 0.
+// grid (ceil(W / 128), ceil(H / 8), B)
+__global__ __launch_bounds__(256) void dispconv_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int C, int H,
+                                                            int W, int act, int pad) {
+    extern __shared__ float wsm[];                       // C * 9 weights
+    for (int e = threadIdx.x; e < C * 9; e += 256) wsm[e] = w[e];
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ox = blockIdx.x * 128 + tx * 4, oy = blockIdx.y * 8 + ty, b = blockIdx.z;
+    if (ox >= W || oy >= H) return;
+    int ry[3];
+    bool rok[3], lok, rrok;
+    ry[0] = dpad_index(oy - 1, H, pad, rok[0]); ry[1] = oy; rok[1] = true; ry[2] = dpad_index(oy + 1, H, pad, rok[2]);
+    const int xl = dpad_index(ox - 1, W, pad, lok), xr = dpad_index(ox + 4, W, pad, rrok);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t HW = (size_t)H * W;
+    const float* pl = x + (size_t)b * C * HW;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c, pl += HW) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float* row = pl + (size_t)ry[r] * W;
+            const float4 m = *reinterpret_cast<const float4*>(row + ox);
+            const float l = row[xl], rr = row[xr];
+            const bool ok = rok[r];
+            const float v[6] = {(ok && lok) ? l : 0.f, ok ? m.x : 0.f, ok ? m.y : 0.f, ok ? m.z : 0.f, ok ? m.w : 0.f, (ok && rrok) ? rr : 0.f};
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float wv = wsm[c * 9 + r * 3 + kx];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, v[j + kx], acc[j]);
+            }
+        }
+    }
+    const float bv = bias ? bias[0] : 0.f;
+    *reinterpret_cast<float4*>(y + ((size_t)b * H + oy) * W + ox) =
+        make_float4(act_fwd(acc[0] + bv, act), act_fwd(acc[1] + bv, act), act_fwd(acc[2] + bv, act), act_fwd(acc[3] + bv, act));
 }
 
 // folded g' window of pixel (qy, qx): G[ky][kx] = sum over padded rows r in Ry(qy), columns c in Rx(qx) of g'[r+1-ky][c+1-kx]
@@ -214,6 +259,13 @@ bool dispconv_eligible(int C0, int C1, int up0, int Co, int H, int W) {
 
 int dispconv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int act, int pad,
                  hipStream_t st) {
+    static const bool quads = !(std::getenv("DC_DISP4") && std::getenv("DC_DISP4")[0] == '0');      // (0: the tile kernels, for A/Bs)
+    if (quads && W % 4 == 0 && !(((size_t)x | (size_t)y) & 15)) {
+        hipLaunchKernelGGL(dispconv_fwd4_kernel, dim3(ceil_div(W, 128), ceil_div(H, 8), B), dim3(256), (size_t)C * 9 * sizeof(float), st, x, w,
+                           bias, y, C, H, W, act, pad);
+        DC_CHECK_LAUNCH();
+        return DC_OK;
+    }
     const int tiles_x = ceil_div(W, DT), tiles_y = ceil_div(H, DT);
     hipLaunchKernelGGL(dispconv_fwd_kernel, dim3(tiles_x * tiles_y, B), dim3(256), 0, st, x, w, bias, y, C, H, W, act, pad, tiles_x);
     DC_CHECK_LAUNCH();
@@ -222,6 +274,8 @@ int dispconv_fwd(const float* x, const float* w, const float* bias, float* y, in
 
 int dispconv_dx(const float* w, const float* y, const float* gy, float* dx, const float* addend, int B, int C, int H, int W, int act,
                 int pad, hipStream_t st) {
+    // (a four-pixels-per-thread form of this kernel measured SLOWER, 38 vs 35 us per launch: the 36 accumulators of four windows
+    // cost more occupancy than the wider stores gain)
     hipLaunchKernelGGL(dispconv_dx_kernel, dim3(ceil_div(H * W, 256), B), dim3(256), (size_t)C * 9 * sizeof(float), st, gy, y, w, dx, C, H,
                        W, act, pad, addend);
     DC_CHECK_LAUNCH();
