@@ -15,9 +15,14 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     dev = torch.device("cuda:0")
     B, H, W, NL = (int(os.environ.get(k, d)) for k, d in (("DC_B", 12), ("DC_H", 192), ("DC_W", 640), ("DC_LAYERS", 18)))
-    tr = T.Trainer(T.default_options(batch_size=B, height=H, width=W, num_layers=NL), device=dev)
+    if os.environ.get("DC_FRONT") == "gru":        # BASELINE configs[3]: sequences of 3 frames, batch size 1
+        from depthcore.synthetic import synthetic_sequence_batch
+        tr = T.Trainer(T.default_options(batch_size=1, height=H, width=W, num_layers=NL, gru="v5", len_sequence=3), device=dev)
+        batches = [synthetic_sequence_batch(3, H, W, dev, seed=s) for s in range(4)]
+    else:
+        tr = T.Trainer(T.default_options(batch_size=B, height=H, width=W, num_layers=NL), device=dev)
+        batches = [synthetic_batch(B, H, W, dev, seed=s) for s in range(4)]
     tr.set_train()
-    batches = [synthetic_batch(B, H, W, dev, seed=s) for s in range(4)]
     losses = []
     mem0 = None
     trace = []
