@@ -570,6 +570,8 @@ int dc_get_matrix_precision(void);
  *   dc_wino_cache_clear(): drop ALL owners and free every buffer (device-synchronising; only when no captured graph that
  *     used the cache will be replayed again).
  *   dc_wino_cache_variants(): number of cached variants over all owners (diagnostics / tests).
+ * The prepared bf16 weights of the bf16 direct kernels (DC_PREC_BF16: [m-block][chunk][tap][k-group][m][8], one ~8 us packing launch
+ * in front of every forward / data-gradient call otherwise) are variants of the same registry and ride in the same refresh launch.
  * A convolution whose weight is not registered, or met before the first refresh, transforms in place exactly as before:
  * the cache changes launch counts, never results (the transform is the same device function).  Nothing here allocates,
  * synchronises or copies while `stream` is being captured into a hipGraph: a variant first met inside a capture keeps its

@@ -8,6 +8,40 @@ namespace dc {
 
 int matrix_precision();       // the calling thread's DC_PREC_* (dc_set_matrix_precision)
 
+constexpr int C3B_BC = 32;    // reduction channels per chunk = the K of one v_mfma_f32_16x16x32_bf16
+
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned c3b_pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 c3b_bf2;
+    const c3b_bf2 p = {(__bf16)lo, (__bf16)hi};          // v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN)
+    return __builtin_bit_cast(unsigned, p);
+}
+// One 16-byte item of the prepared bf16 weights [m-block][chunk][tap][k-group 4][m MT][8] (conv_bf16.hip: c3b_wprep_kernel, and the
+// weight cache's batched refresh in wino.hip): forward M = Co, K = Cin, value w[m][k][tap]; data gradient M = Cin, K = Co, value
+// w[k][m][8 - tap] (rotated, transposed filter).
+__device__ __forceinline__ void c3b_wprep_item(const float* __restrict__ w, uint4* __restrict__ wb, int idx, int Co, int Cin, int dgrad,
+                                               int MT, int nmblk, int nchunks) {
+    if (idx >= nmblk * nchunks * 36 * MT) return;
+    const int m = idx % MT, cg = (idx / MT) & 3, tap = (idx / (4 * MT)) % 9;
+    const int chunk = (idx / (36 * MT)) % nchunks, mblk = idx / (36 * MT * nchunks);
+    const int M = dgrad ? Cin : Co, K = dgrad ? Co : Cin;
+    const int mm = mblk * MT + m;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = chunk * C3B_BC + cg * 8 + j;
+        float t = 0.f;
+        if (mm < M && k < K) t = dgrad ? w[((size_t)k * Cin + mm) * 9 + 8 - tap] : w[((size_t)mm * Cin + k) * 9 + tap];
+        v[j] = t;
+    }
+    wb[idx] = make_uint4(c3b_pack_bf16(v[0], v[1]), c3b_pack_bf16(v[2], v[3]), c3b_pack_bf16(v[4], v[5]), c3b_pack_bf16(v[6], v[7]));
+}
+#endif
+
+// the prepared bf16 weights of (weight, pass, MT) from the per-step weight cache (wino.hip: dc_wino_cache_*), or nullptr: then the
+// caller packs them into its workspace as before.  Same rules as the Winograd variants (registered weights, fresh after a refresh).
+const void* wc_lookup_c3b(const float* w, int Ci, int Co, int dgrad, int MT, int nmblk, int nchunks, hipStream_t st);
+
 // shapes the bf16 kernels take (16-byte staging): stride 1: W % 4 == 0 (W % 8 == 0 when x0 is upsampled / dilated), concat
 // boundary on a 32-channel chunk; stride 2: W % 8 == 0, single source.  Anything else keeps the fp32 kernels.
 bool c3b_eligible(int C0, int C1, int up0, int H, int W, int stride);

@@ -43,7 +43,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 thread_local int g_matrix_prec = DC_PREC_F32;
 int matrix_precision() { return g_matrix_prec; }
 
-constexpr int BC = 32;        // reduction channels per chunk = the K of one v_mfma_f32_16x16x32_bf16
+constexpr int BC = C3B_BC;    // reduction channels per chunk = the K of one v_mfma_f32_16x16x32_bf16
 constexpr int BPX = 40;       // bf16 per pixel of the LDS image: 32 channels + 8 (80-byte pixels spread the b128 reads over the banks)
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
@@ -70,21 +70,7 @@ __device__ __forceinline__ int pad_index_b(int i, int n, int pad, bool& ok) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void c3b_wprep_kernel(const float* __restrict__ w, uint4* __restrict__ wb, int Co, int Cin, int dgrad,
                                                         int MT, int nmblk, int nchunks) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nmblk * nchunks * 36 * MT) return;
-    const int m = idx % MT, cg = (idx / MT) & 3, tap = (idx / (4 * MT)) % 9;
-    const int chunk = (idx / (36 * MT)) % nchunks, mblk = idx / (36 * MT * nchunks);
-    const int M = dgrad ? Cin : Co, K = dgrad ? Co : Cin;
-    const int mm = mblk * MT + m;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = chunk * BC + cg * 8 + j;
-        float t = 0.f;
-        if (mm < M && k < K) t = dgrad ? w[((size_t)k * Cin + mm) * 9 + 8 - tap] : w[((size_t)mm * Cin + k) * 9 + tap];
-        v[j] = t;
-    }
-    wb[idx] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+    c3b_wprep_item(w, wb, blockIdx.x * 256 + threadIdx.x, Co, Cin, dgrad, MT, nmblk, nchunks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,10 +494,16 @@ int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const fl
     if (K != (dgrad ? Co : Cin)) return DC_EINVAL;
     const int mr = c3b_mr(M), MT = 16 * mr;
     const int mblocks = ceil_div(M, MT), nchunks = ceil_div(K, BC);
-    uint4* wb = (uint4*)ws;
-    const int nitems = mblocks * nchunks * 36 * MT;
-    hipLaunchKernelGGL(c3b_wprep_kernel, dim3(ceil_div(nitems, 256)), dim3(256), 0, st, weight, wb, Co, Cin, dgrad, MT, mblocks, nchunks);
-    DC_CHECK_LAUNCH();
+    // prepared weights: from the per-step cache when the weight is registered and fresh (one batched launch per step packs
+    // every variant: 100 launches of ~8 us per C5 step otherwise), else packed here into the workspace
+    const uint4* wb = (const uint4*)wc_lookup_c3b(weight, Cin, Co, dgrad, MT, mblocks, nchunks, st);
+    if (!wb) {
+        const int nitems = mblocks * nchunks * 36 * MT;
+        hipLaunchKernelGGL(c3b_wprep_kernel, dim3(ceil_div(nitems, 256)), dim3(256), 0, st, weight, (uint4*)ws, Co, Cin, dgrad, MT, mblocks,
+                           nchunks);
+        DC_CHECK_LAUNCH();
+        wb = (const uint4*)ws;
+    }
     C3bArgs a{};
     const size_t e0 = (size_t)B * C0 * (H >> (up0 & 1)) * (W >> (up0 & 1)) * 4, e1 = (size_t)B * C1 * H * W * 4;
     if (e0 >= 0x7fffffffull || e1 >= 0x7fffffffull) return DC_EINVAL;            // 32-bit buffer offsets

@@ -104,13 +104,14 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 // dgrad, MT) variant with the first block of its range; a block finds its descriptor by binary search.
 struct WinoWDesc {
     const float* w; float* uhat;
-    int Co, Ci, MT, Mp, Kp, dgrad, block0, pad_;
+    int Co, Ci, MT, Mp, Kp, dgrad, block0, kind;      // kind 1: the bf16 direct kernels' prepared weights (Mp = m-blocks, Kp = chunks)
 };
 __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const WinoWDesc* __restrict__ table, const int* __restrict__ blk2desc, int WK) {
     // (a per-block binary search over the table -- eight dependent global loads in front of every block -- made this launch
     // 310 us for 0.5 GB; the host uploads the block -> descriptor map next to the table instead)
     const WinoWDesc d = table[blk2desc[blockIdx.x]];
     const int idx = ((int)blockIdx.x - d.block0) * 256 + threadIdx.x;
+    if (d.kind == 1) { c3b_wprep_item(d.w, reinterpret_cast<uint4*>(d.uhat), idx, d.Co, d.Ci, d.dgrad, d.MT, d.Mp, d.Kp); return; }
     if (d.dgrad) wino_weight_one<true>(d.w, d.uhat, idx, d.Co, d.Ci, d.MT, d.Mp, d.Kp, WK);
     else wino_weight_one<false>(d.w, d.uhat, idx, d.Co, d.Ci, d.MT, d.Mp, d.Kp, WK);
 }
@@ -694,7 +695,7 @@ static inline size_t wino_uhat_bytes(int Ci, int Co) {
 // step -- ONE launch that transforms every variant seen so far instead of one 8 us launch in front of every convolution
 // -- and dc_wino_cache_invalidate when the step's backward is done.  Between the two, wino_launch takes U from the
 // cache; a variant (dgrad, MT) it has not met yet is transformed in place as before and joins the next refresh.
-struct WcVariant { int dgrad, MT, Mp, Kp; float* buf; bool fresh, in_table; };
+struct WcVariant { int dgrad, MT, Mp, Kp; float* buf; bool fresh, in_table; int kind; };     // kind 0 Winograd U, 1 bf16 prepared weights
 struct WcEntry { const float* w; int Ci, Co, owner; std::vector<WcVariant> v; };
 // One descriptor table PER OWNER (= per model / Trainer).  A refresh transforms -- and a captured hipGraph replays the
 // transform of -- the owner's own weights only, which the owner keeps alive; weights of another owner never enter its
@@ -729,7 +730,13 @@ static WcOwner* wc_owner(int id) {
 
 // -> cached U for this launch, or nullptr (then the caller transforms into its workspace).  Nothing is allocated while
 // `st` is being captured (hipMalloc is illegal there): an unseen variant is then transformed per launch, as before.
-static const float* wc_lookup(const float* w, int Ci, int Co, bool dgrad, int MT, int Mp, int Kp, hipStream_t st) {
+static inline size_t wc_variant_bytes(int kind, int MT, int Mp, int Kp) {
+    return kind == 1 ? (size_t)Mp * Kp * 36 * MT * 16 : (size_t)Mp * Kp * 16 * sizeof(float);
+}
+static inline int wc_variant_blocks(int kind, int MT, int Mp, int Kp) {
+    return kind == 1 ? ceil_div(Mp * Kp * 36 * MT, 256) : wino_wblocks(Mp, Kp);
+}
+static const float* wc_lookup_kind(int kind, const float* w, int Ci, int Co, bool dgrad, int MT, int Mp, int Kp, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_wc_mu);
     for (auto& e : g_wc) {
         if (e.w != w) continue;
@@ -737,15 +744,21 @@ static const float* wc_lookup(const float* w, int Ci, int Co, bool dgrad, int MT
         WcOwner* o = wc_owner(e.owner);
         if (!o) return nullptr;
         for (auto& v : e.v)
-            if (v.dgrad == (int)dgrad && v.MT == MT) return (o->valid && v.fresh) ? v.buf : nullptr;
+            if (v.kind == kind && v.dgrad == (int)dgrad && v.MT == MT) return (o->valid && v.fresh) ? v.buf : nullptr;
         if (wc_capturing(st)) return nullptr;
-        WcVariant v{(int)dgrad, MT, Mp, Kp, nullptr, false, false};
-        if (hipMalloc((void**)&v.buf, (size_t)Mp * Kp * 16 * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        WcVariant v{(int)dgrad, MT, Mp, Kp, nullptr, false, false, kind};
+        if (hipMalloc((void**)&v.buf, wc_variant_bytes(kind, MT, Mp, Kp)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         e.v.push_back(v);
         o->dirty = true;
         return nullptr;
     }
     return nullptr;
+}
+static const float* wc_lookup(const float* w, int Ci, int Co, bool dgrad, int MT, int Mp, int Kp, hipStream_t st) {
+    return wc_lookup_kind(0, w, Ci, Co, dgrad, MT, Mp, Kp, st);
+}
+const void* wc_lookup_c3b(const float* w, int Ci, int Co, int dgrad, int MT, int nmblk, int nchunks, hipStream_t st) {
+    return wc_lookup_kind(1, w, Ci, Co, dgrad != 0, MT, nmblk, nchunks, st);
 }
 
 #ifdef WINO_DIAG
@@ -1127,9 +1140,9 @@ extern "C" int dc_wino_cache_refresh(int owner, void* stream) {
         for (auto& e : g_wc) {
             if (e.owner != owner) continue;
             for (auto& v : e.v) {
-                const int nb = wino_wblocks(v.Mp, v.Kp);
+                const int nb = wc_variant_blocks(v.kind, v.MT, v.Mp, v.Kp);
                 b2d.insert(b2d.end(), nb, (int)host.size());
-                host.push_back(WinoWDesc{e.w, v.buf, e.Co, e.Ci, v.MT, v.Mp, v.Kp, v.dgrad, blocks, 0});
+                host.push_back(WinoWDesc{e.w, v.buf, e.Co, e.Ci, v.MT, v.Mp, v.Kp, v.dgrad, blocks, v.kind});
                 blocks += nb;
             }
         }

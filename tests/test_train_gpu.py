@@ -530,17 +530,18 @@ def test_fusion_v3_training_steps():
         assert (p.grad is None) == n.startswith("fusion_block_4.upscale"), n
 
 
-@pytest.mark.parametrize("gru", [None, "v5"])
-def test_wino_weight_cache_changes_nothing(gru):
+@pytest.mark.parametrize("gru,dtype", [(None, "f32"), ("v5", "f32"), (None, "bf16")])
+def test_wino_weight_cache_changes_nothing(gru, dtype):
     """dc_wino_cache_*: one batched weight transform per step instead of one launch per convolution.  Same device function,
     so the first step's loss agrees to the last bits with and without the cache and the following steps to the rounding of
-    the few order-dependent reductions; the set of cached variants is complete after the first step."""
+    the few order-dependent reductions; the set of cached variants is complete after the first step.  `bf16`: the prepared
+    weights of the bf16 direct kernels (c3b_wprep_item) ride in the same table."""
     import trainer as T
     from depthcore.synthetic import synthetic_batch, synthetic_sequence_batch
 
     def run(cache):
         kw = dict(gru="v5", len_sequence=3, batch_size=1) if gru else dict(batch_size=2)
-        opt = T.default_options(height=64, width=96, wino_weight_cache=cache, **kw)
+        opt = T.default_options(height=64, width=96, wino_weight_cache=cache, nets_dtype=dtype, **kw)
         tr = T.Trainer(opt, device=DEV, seed=5)
         tr.set_train()
         inputs = synthetic_sequence_batch(3, 64, 96, torch.device(DEV), seed=2) if gru else synthetic_batch(2, 64, 96, torch.device(DEV), seed=2)
