@@ -1138,8 +1138,7 @@ extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float*
         // bf16 matrix cores: a zero-padded single-source block gets its data gradient directly (convolution of g' with the
         // rotated, transposed filter); reflection / upsample / concat go through the padded domain and the fold below
         if (pad_mode == PAD_ZERO && !up0 && C1 == 0) {
-            int rc = c3b_conv(gp, Co, 0, nullptr, 0, weight, Co, Cin, 1, 0, nullptr, dx0, wd, B, H, W, ACT_NONE, PAD_ZERO, 1, ST);
-            if (rc == DC_OK && addend0) rc = add_inplace(dx0, addend0, (size_t)B * C0 * H * W, ST);
+            const int rc = c3b_conv(gp, Co, 0, nullptr, 0, weight, Co, Cin, 1, 0, nullptr, dx0, wd, B, H, W, ACT_NONE, PAD_ZERO, 1, ST, addend0);
             if (rc != DC_OK) return rc;
         } else {
             const int rc = c3b_conv(gp, Co, 0, nullptr, 0, weight, Co, Cin, 1, 1, nullptr, dxpad, wd, B, H, W, ACT_NONE, PAD_ZERO, 1, ST);

@@ -55,7 +55,8 @@ int c3b_dpad_pitch(int W);
 // up0: 0 plain, 1 nearest-x2 upsampled x0, 3 DILATED x0 (full[2y][2x] = x0[y][x], zeros between: with dgrad = 1 and zero
 // padding that is the data gradient of the stride-2 convolution).
 int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight, int Co, int Cin, int dgrad, int dpad,
-             const float* bias, float* out, void* ws, int B, int H, int W, int act, int pad, int stride, hipStream_t st);
+             const float* bias, float* out, void* ws, int B, int H, int W, int act, int pad, int stride, hipStream_t st,
+             const float* addend = nullptr);       // addend (dpad = 0 only): same shape as out, added in the store epilogue
 // part[split][Co][Cin*9] from x = cat(up2?(x0), x1) and g' (B,Co,H/stride,W/stride)
 int c3b_wgrad(const float* x0, int C0, int up0, const float* x1, int C1, const float* gp, float* part, int split, int B, int Co, int H,
               int W, int pad, int stride, hipStream_t st);

@@ -215,6 +215,7 @@ struct C3bArgs {
     PatchSrc src;
     const uint4* wb;        // prepared weights of this pass
     const float* bias;
+    const float* addend;    // !DPAD: (B, M, OH, OW) or NULL -- another consumer's gradient of the same tensor, added on the way out
     float* out;             // (B, M, OH, OW)
     int B, M, K;            // M output channels, K = C0 + C1 reduction channels
     int OH, OW, opitch;     // output maps; row pitch of `out` in floats (multiple of 4)
@@ -333,6 +334,23 @@ __global__ __launch_bounds__(512, 2) void c3b_conv_kernel(C3bArgs a) {
             for (int j = 0; j < RWV; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv[i], a.act);
+    }
+    if (!DPAD && a.addend) {          // (all the addend loads first, then the adds: the stores below stay behind no pending load)
+        f4 av[MR][RWV];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < RWV; ++j) {
+                const int g = wave * RWV + j;
+                const int py = oy0 + (g >> 1), px = ox0 + 16 * (g & 1) + 4 * kk;
+                const int m = m0 + i * 16 + n;
+                const bool ok = m < a.M && py < a.OH && px < a.opitch;
+                av[i][j] = ok ? *reinterpret_cast<const f4*>(a.addend + (((size_t)b * a.M + m) * a.OH + py) * a.opitch + px) : f4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < RWV; ++j) acc[i][j] += av[i][j];
     }
 #pragma unroll
     for (int i = 0; i < MR; ++i)
@@ -489,8 +507,10 @@ int c3b_wgrad_split(int B, int OH, int OW, int Co, int Cin, int stride) {
 //   dgrad = 0: forward (M = Co) with bias + activation;  dgrad = 1: rotated, transposed filter (M = Cin).
 //   dpad = 1: input = g' (B,K,H,W), output over the padded domain (H+2, W+2) (decoder data gradient; fold afterwards).
 int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const float* weight, int Co, int Cin, int dgrad, int dpad,
-             const float* bias, float* out, void* ws, int B, int H, int W, int act, int pad, int stride, hipStream_t st) {
+             const float* bias, float* out, void* ws, int B, int H, int W, int act, int pad, int stride, hipStream_t st,
+             const float* addend) {
     const int M = dgrad ? Cin : Co, K = C0 + C1;
+    if (addend && dpad) return DC_EINVAL;
     if (K != (dgrad ? Co : Cin)) return DC_EINVAL;
     const int mr = c3b_mr(M), MT = 16 * mr;
     const int mblocks = ceil_div(M, MT), nchunks = ceil_div(K, BC);
@@ -508,7 +528,7 @@ int c3b_conv(const float* x0, int C0, int up0, const float* x1, int C1, const fl
     const size_t e0 = (size_t)B * C0 * (H >> (up0 & 1)) * (W >> (up0 & 1)) * 4, e1 = (size_t)B * C1 * H * W * 4;
     if (e0 >= 0x7fffffffull || e1 >= 0x7fffffffull) return DC_EINVAL;            // 32-bit buffer offsets
     a.src = PatchSrc{x0, C0, up0 & 1, x1, C1, H, W, pad, (up0 >> 1) & 1, (unsigned)e0, (unsigned)e1};
-    a.wb = wb; a.bias = bias; a.out = out; a.B = B; a.M = M; a.K = K; a.act = act;
+    a.wb = wb; a.bias = bias; a.addend = addend; a.out = out; a.B = B; a.M = M; a.K = K; a.act = act;
     a.OH = dpad ? H + 2 : H / stride; a.OW = dpad ? W + 2 : W / stride;
     a.opitch = (a.OW + 3) & ~3;          // padded domain: W + 2 rounded up (c3b_dpad_pitch); otherwise OW itself (W % 4 == 0)
     const int TH = stride == 1 ? 8 : 4;

@@ -1024,9 +1024,7 @@ static int wino_run(const float* x, const float* w, float* y, const float* adden
     // reduced-precision policy: direct implicit GEMM on the bf16 matrix cores (conv_bf16.hip; the data gradient of a
     // zero-padded convolution is the convolution with the rotated, transposed filter)
     if (matrix_precision() == DC_PREC_BF16 && c3b_eligible(dgrad ? Co : Ci, 0, 0, H, W, 1)) {
-        const int rc = c3b_conv(x, dgrad ? Co : Ci, 0, nullptr, 0, w, Co, Ci, dgrad ? 1 : 0, 0, nullptr, y, ws, B, H, W, ACT_NONE, PAD_ZERO, 1, st);
-        if (rc != DC_OK || !addend) return rc;
-        return add_inplace(y, addend, (size_t)B * (dgrad ? Ci : Co) * H * W, st);
+        return c3b_conv(x, dgrad ? Co : Ci, 0, nullptr, 0, w, Co, Ci, dgrad ? 1 : 0, 0, nullptr, y, ws, B, H, W, ACT_NONE, PAD_ZERO, 1, st, addend);
     }
     // F(4x4,3x3) (wino4.hip): opt-in (dc_set_wino_f4) for maps its tile groups cover well -- measured against this file's
     // F(2x2,3x3) in tests/test_wino_gpu.py and tools/bench_wino.py; DESIGN 4a has the verdict

@@ -136,6 +136,24 @@ def test_trunk_entry_points_under_bf16(shape):
     assert 1e-5 < rel_l2(y, y32) < 1e-2
 
 
+def test_trunk_data_gradient_addend_under_bf16():
+    """The residual fork's addend rides in the bf16 kernel's store epilogue (c3b_conv_kernel: acc + addend, one rounding, as the
+    separate add pass it replaces): with a GradFork the gradient of x is bitwise conv-gradient + parked gradient."""
+    from depthcore import ops
+    g = torch.Generator().manual_seed(11)
+    for B, C, H, W in ((2, 64, 24, 32), (1, 128, 12, 40)):
+        x = torch.randn(B, C, H, W, generator=g).to(DEV).requires_grad_()
+        w = (torch.randn(C, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).to(DEV)
+        gy, skip = torch.randn(B, C, H, W, generator=g).to(DEV), torch.randn(B, C, H, W, generator=g).to(DEV)
+        with ops.matrix_precision("bf16"):
+            (plain,) = torch.autograd.grad(ops.wino_conv3x3(x, w), x, gy)
+            fork = ops.GradFork()
+            y = ops.wino_conv3x3(x, w, fork)
+        fork.park(skip)                       # what the block's last BatchNorm would leave for conv1
+        (summed,) = torch.autograd.grad(y, x, gy)
+        assert torch.equal(summed, plain + skip)
+
+
 def test_bf16_block_is_deterministic_at_full_size():
     """Decoder level 1 at the BASELINE size (B = 12, 32 + 64 channels, 96 x 320): bitwise reproducible forward and gradients."""
     from depthcore import ops
