@@ -1045,7 +1045,10 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
     DC_CHECK_LAUNCH();
     if (a.splits > 1) {
         const int n = Co * a.K;
-        hipLaunchKernelGGL(slab_reduce16_kernel<float>, dim3(ceil_div(n, 16)), dim3(256), 0, st, (const float*)ws, dweight, a.splits, n);
+        if (n % 4 == 0 && !(((size_t)ws | (size_t)dweight) & 15))      // 16-byte form: same order per element, 4 x the bytes per thread
+            hipLaunchKernelGGL(slab_reduce16_kernel<gf4>, dim3(ceil_div(n / 4, 16)), dim3(256), 0, st, (const gf4*)ws, (gf4*)dweight, a.splits, n / 4);
+        else
+            hipLaunchKernelGGL(slab_reduce16_kernel<float>, dim3(ceil_div(n, 16)), dim3(256), 0, st, (const float*)ws, dweight, a.splits, n);
         DC_CHECK_LAUNCH();
     }
     return DC_OK;
