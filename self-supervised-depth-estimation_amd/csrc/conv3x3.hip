@@ -1150,8 +1150,10 @@ extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float*
     float* pbias = (float*)p; p += al256((size_t)std::max(split_ws, DB_SPLIT) * Co * 4);
     float* gpbuf = (float*)p; p += al256((size_t)B * Co * H * W * 4);
     const bool b16 = bf16_path(C0, C1, up0 ? 1 : 0, H, W) && wino_gp_ok(B, Co, H, W, act);
-    // (the bf16 weight-gradient kernel tiles 64 output channels: the thin 16 / 32-channel levels keep the fp32 direct kernel)
-    const bool b16_dw = b16 && Co >= 64;
+    // (the bf16 weight-gradient kernel tiles 64 output channels; a quarter- or half-filled tile still beats the fp32 direct
+    // kernel on the thin 16 / 32-channel levels -- 879 -> 328 us for 96 -> 32 at 96 x 320, B = 36 -- DC_B16_DW_MIN restores 64 for A/Bs)
+    static const int b16_dw_min = std::getenv("DC_B16_DW_MIN") ? atoi(std::getenv("DC_B16_DW_MIN")) : 16;
+    const bool b16_dw = b16 && Co >= b16_dw_min;
     const bool w_dx = !b16 && (dx0 || dx1) && wino_dx(C0, C1, B, Co, H, W, act);
     const bool w_dw = !b16 && dweight && wino_dw(C0, C1, B, Co, H, W, act);
     // bias gradient from the same pass that forms g' (whole float4s per channel plane)

@@ -93,10 +93,11 @@ def test_block_forward_and_backward_exact_vs_rounded_operand_oracle(case):
     assert rel_l2(grads["x0"], dx0) < 5e-6, rel_l2(grads["x0"], dx0)
     if C1:
         assert rel_l2(grads["x1"], dxc[:, C0:]) < 5e-6
-    # weight gradient: rounded input patch against rounded g' -- from 64 output channels; the thin 16 / 32-channel levels keep
-    # the fp32 direct weight-gradient kernel (the bf16 one tiles 64 output channels), i.e. unrounded operands
+    # weight gradient: rounded input patch against rounded g' -- from 16 output channels (round 5: the thin 16 / 32-channel
+    # levels take the bf16 weight-gradient kernel too, a partly filled 64-channel tile still beats the fp32 direct kernel 2.7x);
+    # below that the fp32 direct kernel, i.e. unrounded operands
     wl = torch.zeros(Co, C0 + C1, 3, 3, dtype=torch.float64, requires_grad=True)
-    if Co >= 64:
+    if Co >= 16:
         (dw,) = torch.autograd.grad(F.conv2d(xp, wl), wl, gpr)
     else:
         xp32 = F.pad(xc, (1, 1, 1, 1), mode="reflect" if pad == "reflect" else "constant")
