@@ -582,6 +582,112 @@ static int conv_fold(const float* dxpad, float* dx0, float* dx1, int B, int C0, 
     return DC_OK;
 }
 
+// ---- the padded ring of the full correlation, for the data gradient that is written without a padded scratch (wino.h:
+// wino_conv_dgrad_split).  ReflectionPad2d makes padded row -1 a copy of row 1, row H of row H-2, and the same for columns: the
+// correlation's values on that ring belong to rows 1 / H-2 and columns 1 / W-2 of the gradient.  A ring value has only the taps
+// that reach inside the image: one kernel row (or column) of g' row 0 / H-1 (column 0 / W-1).  One thread per AFFECTED gradient
+// element (2 W + 2 (H - 2) per plane; of the half-resolution plane for an upsampled x0: the elements whose 2 x 2 block touches an
+// affected pixel) sums its ring terms over the output channels in a fixed order and adds them to what the split store wrote.
+// element t of the border set of an h x w plane whose rows r0, r1 and columns c0, c1 are affected: the two rows first, then the two
+// columns without the rows' elements
+__device__ __forceinline__ bool ring_element(int t, int h, int w, int r0, int r1, int c0, int c1, int& y, int& x) {
+    if (t < w) { y = r0; x = t; return true; }
+    if (t < 2 * w) { y = r1; x = t - w; return r1 != r0; }
+    t -= 2 * w;
+    const int nrest = h - (r1 != r0 ? 2 : 1);
+    if (t >= 2 * nrest) return false;
+    const int j = t % nrest;
+    x = t < nrest ? c0 : c1;
+    if (t >= nrest && c1 == c0) return false;
+    y = j < r0 ? j : (j + 1 < r1 || r1 == r0 ? j + 1 : j + 2);          // the j-th row that is neither r0 nor r1
+    return true;
+}
+// Phase 1 -- the ring itself, four strips per (image, input channel) into a small scratch R[b][c][strip][LP]:
+//   strip 0 / 1 (padded row -1 / H):    R[pos] = sum_co sum_kx g'[co][0 | H-1][pos - 1 + 1 - kx] w[co][c][0 | 2][kx],  pos - 1 = x in [-1, W]
+//   strip 2 / 3 (padded column -1 / W): R[pos] = sum_co sum_ky g'[co][pos - 1 + 1 - ky][0 | W-1] w[co][c][ky][0 | 2],  pos - 1 = y in [-1, H]
+// (x = -1 and x = W are the corners of the padded domain).  A small dense product per strip -- M = Cin, N = strip length, K = 3 Co --
+// as plain FMAs: a block takes 256 positions x RING_CB channels, the strip's g' line and the weights of RING_CO output channels at a
+// time through LDS.  grid (ceil((max(H, W) + 2) / 256), 4 * ceil(Cin / RING_CB), B)
+constexpr int RING_CB = 8, RING_CO = 16;
+__global__ __launch_bounds__(256) void conv_ring_strips_kernel(const float* __restrict__ gp, const float* __restrict__ w, float* __restrict__ R,
+                                                               int Cin, int Co, int H, int W, int LP) {
+    __shared__ float line[RING_CO][256 + 4];
+    __shared__ float wl[RING_CO][RING_CB][3];
+    const int t = threadIdx.x, strip = blockIdx.y & 3, c0 = (blockIdx.y >> 2) * RING_CB, b = blockIdx.z;
+    const int L = strip < 2 ? W : H, p0 = blockIdx.x * 256;
+    if (p0 >= L + 2) return;
+    const size_t HW = (size_t)H * W;
+    const float* gpb = gp + (size_t)b * Co * HW;
+    const int fixed = (strip & 1) ? (strip < 2 ? H - 1 : W - 1) : 0;            // the row (strips 0, 1) / column (2, 3) of g' the strip reads
+    float acc[RING_CB];
+#pragma unroll
+    for (int i = 0; i < RING_CB; ++i) acc[i] = 0.f;
+    for (int cb = 0; cb < Co; cb += RING_CO) {
+        __syncthreads();
+        for (int e = t; e < RING_CO * 258; e += 256) {
+            const int co = e / 258, j = e - co * 258, i = p0 - 2 + j;
+            float v = 0.f;
+            if (cb + co < Co && i >= 0 && i < L) v = gpb[(size_t)(cb + co) * HW + (strip < 2 ? (size_t)fixed * W + i : (size_t)i * W + fixed)];
+            line[co][j] = v;
+        }
+        for (int e = t; e < RING_CO * RING_CB * 3; e += 256) {
+            const int co = e / (RING_CB * 3), rem = e - co * (RING_CB * 3), cc = rem / 3, k = rem - cc * 3;
+            float v = 0.f;
+            if (cb + co < Co && c0 + cc < Cin) {
+                const float* wk = w + ((size_t)(cb + co) * Cin + c0 + cc) * 9;
+                v = strip < 2 ? wk[((strip & 1) ? 6 : 0) + k] : wk[k * 3 + ((strip & 1) ? 2 : 0)];
+            }
+            wl[co][cc][k] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int co = 0; co < RING_CO; ++co) {
+            const float l0 = line[co][t + 2], l1 = line[co][t + 1], l2 = line[co][t];          // taps k = 0, 1, 2: position pos - k
+#pragma unroll
+            for (int cc = 0; cc < RING_CB; ++cc) acc[cc] = fmaf(l2, wl[co][cc][2], fmaf(l1, wl[co][cc][1], fmaf(l0, wl[co][cc][0], acc[cc])));
+        }
+    }
+    const int pos = p0 + t;
+    if (pos < L + 2)
+#pragma unroll
+        for (int cc = 0; cc < RING_CB; ++cc)
+            if (c0 + cc < Cin) R[(((size_t)b * Cin + c0 + cc) * 4 + strip) * LP + pos] = acc[cc];
+}
+// Phase 2 -- one thread per AFFECTED gradient element adds what the ring folds onto it.  An element covers full-resolution pixels
+// [ya, yb] x [xa, xb] (one pixel; a 2 x 2 block of the half-resolution plane of an upsampled x0): the row strip's values of its
+// columns if it contains row 1 / H-2, the column strip's values of its rows if it contains column 1 / W-2, the corner if both.
+// grid (ceil((2 W + 2 H) / 256), Cin, B)
+__global__ __launch_bounds__(256) void conv_ring_kernel(const float* __restrict__ R, float* dx0, float* dx1, int C0, int C1, int up0, int H,
+                                                        int W, int LP) {
+    const int Cin = C0 + C1, c = blockIdx.y, b = blockIdx.z;
+    const bool first = c < C0;
+    float* dst = first ? dx0 : dx1;
+    if (!dst) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const bool up = first && up0;
+    int ey, ex;
+    const int eh = up ? H >> 1 : H, ew = up ? W >> 1 : W;
+    if (!(up ? ring_element(t, eh, ew, 0, eh - 1, 0, ew - 1, ey, ex) : ring_element(t, H, W, 1, H - 2, 1, W - 2, ey, ex))) return;
+    const int ya = up ? 2 * ey : ey, yb = up ? 2 * ey + 1 : ey, xa = up ? 2 * ex : ex, xb = up ? 2 * ex + 1 : ex;
+    const bool top = ya <= 1 && 1 <= yb, bot = ya <= H - 2 && H - 2 <= yb;          // (H >= 4: never both)
+    const bool lef = xa <= 1 && 1 <= xb, rig = xa <= W - 2 && W - 2 <= xb;
+    const float* Rc = R + ((size_t)b * Cin + c) * 4 * LP;
+    float r = 0.f;
+    if (top || bot) {
+        const float* Rr = Rc + (top ? 0 : 1) * LP;
+        r += Rr[xa + 1];
+        if (xb > xa) r += Rr[xb + 1];
+        if (lef || rig) r += Rr[lef ? 0 : W + 1];
+    }
+    if (lef || rig) {
+        const float* Rl = Rc + (lef ? 2 : 3) * LP;
+        r += Rl[ya + 1];
+        if (yb > ya) r += Rl[yb + 1];
+    }
+    const size_t plane = first ? (size_t)b * C0 + c : (size_t)b * C1 + (c - C0);
+    dst[(plane * eh + ey) * ew + ex] += r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad: dW[co][ci][t] = sum_{b,y,x} g'[b,co,y,x] * xpad[b,ci,y+ky-1,x+kx-1]
 // GEMM M = Co (16*MR per block), N = 16 (ci) per n-subtile x 9 taps, K = pixels (4 per MFMA).
@@ -1052,6 +1158,14 @@ int conv_wreduce(const float* part, const float* pbias, float* dw, float* db, in
     return DC_OK;
 }
 
+// dc_set_dgrad_split: 1 (default; DC_DGRAD_SPLIT=0 in the environment starts with 0) = the fused blocks' Winograd data gradient is
+// written without the padded-domain scratch (wino_conv_dgrad_split + conv_ring_kernel); 0 = full correlation + fold pass
+int g_dgrad_split = !(std::getenv("DC_DGRAD_SPLIT") && std::getenv("DC_DGRAD_SPLIT")[0] == '0');
+// Under ReflectionPad the ring costs Cin x Co x perimeter multiplies on plain FMAs while the fold pass it replaces costs Cin x H x W
+// bytes: the wide shallow levels (48 x 160 and up at 192 x 640) gain, the deep 6 x 20 ... 24 x 80 levels (256 ... 512 channels) would
+// pay 10-50 us of ring for a 3-8 us fold.  Zero padding has no ring: always.
+int g_dgrad_split_min_pixels = std::getenv("DC_DGRAD_SPLIT_MIN") ? atoi(std::getenv("DC_DGRAD_SPLIT_MIN")) : 6000;
+
 // bf16 matrix-core kernels (conv_bf16.hip) instead of the fp32 ones: thread precision + shapes of their 16-byte staging
 static inline bool bf16_path(int C0, int C1, int up0, int H, int W) {
     return matrix_precision() == DC_PREC_BF16 && c3b_eligible(C0, C1, up0, H, W, 1);
@@ -1200,6 +1314,23 @@ extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float*
             const int rcf = conv_fold(dxpad, dx0, dx1, B, C0, C1, up0 ? 1 : 0, H, W, pad_mode, c3b_dpad_pitch(W), addend0, addend1, ST);
             if (rcf != DC_OK) return rcf;
         }
+    } else if (w_dx && g_dgrad_split && wino_dgrad_split_ok(B, C0, C1, up0 ? 1 : 0, Co, H, W) &&
+               (pad_mode == PAD_ZERO || H * W >= g_dgrad_split_min_pixels)) {
+        // the interior of the correlation written straight to dx0 / dx1 (concat split, 2 x 2 sums of the upsampled half and the
+        // addends in the Winograd kernel's store epilogue), then the few ring terms ReflectionPad folds back: no padded-domain
+        // scratch (B x Cin x (H+2) x (W+2) written and read again) and no fold pass
+        const int rc = wino_conv_dgrad_split(gp, weight, dx0, dx1, addend0, addend1, wws, B, C0, C1, up0 ? 1 : 0, Co, H, W, ST);
+        if (rc != DC_OK) return rc;
+        if (pad_mode == PAD_REFLECT) {
+            // (scratch: the padded-domain buffer, which this path does not use -- 4 strips of max(H, W) + 2 floats per plane)
+            const int LP = std::max(H, W) + 2;
+            hipLaunchKernelGGL(conv_ring_strips_kernel, dim3(ceil_div(LP, 256), 4 * ceil_div(Cin, RING_CB), B), dim3(256), 0, ST, gp, weight,
+                               dxpad, Cin, Co, H, W, LP);
+            DC_CHECK_LAUNCH();
+            hipLaunchKernelGGL(conv_ring_kernel, dim3(ceil_div(2 * W + 2 * H, 256), Cin, B), dim3(256), 0, ST, (const float*)dxpad, dx0, dx1,
+                               C0, C1, up0 ? 1 : 0, H, W, LP);
+            DC_CHECK_LAUNCH();
+        }
     } else if (w_dx) {
         // full correlation of g' with the rotated weights in the Winograd domain, then the same fold as below
         const int rc = wino_conv_full_dgrad(gp, weight, dxpad, wws, B, Cin, Co, H, W, ST);
@@ -1289,4 +1420,11 @@ extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float*
         }
     }
     return DC_OK;
+}
+
+extern "C" int dc_set_dgrad_split(int mode) {
+    if (mode != 0 && mode != 1) return DC_EINVAL;
+    const int prev = dc::g_dgrad_split;
+    dc::g_dgrad_split = mode;
+    return prev;
 }

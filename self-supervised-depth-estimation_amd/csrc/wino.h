@@ -13,6 +13,13 @@ int wino_conv_fused_fwd(const float* x0, int C0, int up0, const float* x1, int C
 int wino_conv_full_dgrad(const float* gp, const float* weight, float* dxpad, void* ws, int B, int Ci, int Co, int H, int W,
                          hipStream_t st);
 
+// the same data gradient written where it belongs (no padded-domain scratch, no fold pass): dx0 (B,C0,H>>up0,W>>up0) and dx1
+// (B,C1,H,W) from the interior of the correlation, addends added on the way out (nullable; may alias their output); the terms
+// ReflectionPad folds back from the padded ring are NOT included (conv3x3.hip: conv_ring_kernel adds them).  dx0 / dx1 nullable.
+bool wino_dgrad_split_ok(int B, int C0, int C1, int up0, int Co, int H, int W);
+int wino_conv_dgrad_split(const float* gp, const float* weight, float* dx0, float* dx1, const float* add0, const float* add1, void* ws,
+                          int B, int C0, int C1, int up0, int Co, int H, int W, hipStream_t st);
+
 // weight gradient of the fused block from gp = gy * act'(y): dweight (Co, C0+C1, 3, 3)
 size_t wino_wgrad_ws_bytes(int B, int Ci, int Co, int H, int W);
 int wino_wgrad_fused(const float* x0, int C0, int up0, const float* x1, int C1, int pad, const float* gp, float* dweight, void* ws,

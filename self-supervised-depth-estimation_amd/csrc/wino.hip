@@ -130,6 +130,12 @@ struct WinoPsArgs {
     // FUSED only: x = cat(up2?(x0), x1) along channels, padding mode, patch origin = output - P, bias + activation
     const float* x1; const float* bias;
     const float* addend;              // !FUSED only: same shape as y, added in the store epilogue (the other gradient of a residual fork)
+    // FUSED, MODE 4 (the data gradient of a fused block written where it belongs -- no padded-domain scratch, no fold pass): the first
+    // split_c0 output rows are the channels of x0 -- at half resolution when split_up (the 2 x 2 output tile of a lane IS one
+    // upsampled pixel: summed in registers) -- and go to y; the rest are the channels of x1 and go to out1; add0 / add1 (nullable,
+    // shapes of y / out1; may alias their output) are added on the way out
+    float* out1; const float* add0; const float* add1;
+    int split_c0, split_up;
     int C0, up0, pad, P, act;
     unsigned x1bytes;
     int RH, RW, RS, SUBS;             // sub-region shape in tiles, LDS row stride, plane floats (rows * RS)
@@ -164,10 +170,12 @@ __device__ __forceinline__ float wrow16_sum(float v) {
 }
 
 // MODE (plain, non-persistent launches only): 0 none (+ optional statistics epilogue), 1 BatchNorm + ReLU folded into the loader
-// (+ optional statistics epilogue), 2 / 3 BatchNorm-backward epilogue of a data gradient (ReLU decision re-derived / from bits)
+// (+ optional statistics epilogue), 2 / 3 BatchNorm-backward epilogue of a data gradient (ReLU decision re-derived / from bits);
+// 4 (FUSED launches): split store of a fused block's data gradient (WinoPsArgs::split_c0)
 template <int MR, int NR, bool FUSED, bool PERSIST = false, int MODE = 0>
 __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) void wino_ps_kernel(WinoPsArgs a) {
-    static_assert(MODE == 0 || (!FUSED && !PERSIST), "the BatchNorm fold exists for the plain trunk launches");
+    static_assert(MODE == 0 || (MODE == 4 && FUSED && !PERSIST) || (MODE < 4 && !FUSED && !PERSIST),
+                  "the BatchNorm fold exists for the plain trunk launches, the split store for the fused data gradient");
     constexpr int MT = 16 * MR, G = NR / 2;
     constexpr int UF4 = PSK * 4 * MT;                 // f4 items of one U chunk in global memory
     static_assert(NR % 2 == 0 && NR * 2048 <= 2 * PSK * G * PSUB, "the row exchange aliases the slab double buffer");
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
             }
         }
         // BatchNorm epilogues: the lane's 2 x 2 block of the BatchNorm's raw input and the row constants, requested before the barrier too
-        constexpr bool BNE = MODE >= 2;
+        constexpr bool BNE = MODE == 2 || MODE == 3;
         const bool stats = MODE <= 1 && a.stat_part != nullptr && gridDim.z == 1;
         f2w bx[BNE ? RPW : 1][2];
         float bmean[BNE ? RPW : 1], bsc[BNE ? RPW : 1], bsh[BNE ? RPW : 1];
@@ -595,6 +603,30 @@ __global__ __launch_bounds__(256, (MR * NR >= 8 ? 2 : (MR * NR >= 4 ? 3 : 4))) v
                     const float bv = a.bias ? a.bias[m] : 0.f;
                     y00 = act_fwd(y00 + bv, a.act); y01 = act_fwd(y01 + bv, a.act);
                     y10 = act_fwd(y10 + bv, a.act); y11 = act_fwd(y11 + bv, a.act);
+                }
+                if constexpr (MODE == 4) {
+                    const bool row1 = oy + 1 < Ho;
+                    if (m < a.split_c0 ? a.y == nullptr : a.out1 == nullptr) continue;       // (that input needs no gradient)
+                    if (m < a.split_c0 && a.split_up) {              // (Ho, Wo even: the whole 2 x 2 tile is inside)
+                        const size_t o = (((size_t)ob * a.split_c0 + m) * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1);
+                        float v = (y00 + y01) + (y10 + y11);
+                        if (a.add0) v += a.add0[o];
+                        a.y[o] = v;
+                    } else {
+                        const bool first = m < a.split_c0;
+                        const int mm = first ? m : m - a.split_c0, MM = first ? a.split_c0 : a.M - a.split_c0;
+                        const size_t o = (((size_t)ob * MM + mm) * Ho + oy) * Wo + ox;
+                        const float* ap = first ? a.add0 : a.add1;
+                        float* dst = (first ? a.y : a.out1) + o;
+                        if (ap) {
+                            const f2w a0 = *reinterpret_cast<const f2w*>(ap + o);
+                            y00 += a0.x; y01 += a0.y;
+                            if (row1) { const f2w a1 = *reinterpret_cast<const f2w*>(ap + o + Wo); y10 += a1.x; y11 += a1.y; }
+                        }
+                        *reinterpret_cast<f2w*>(dst) = f2w{y00, y01};
+                        if (row1) *reinterpret_cast<f2w*>(dst + Wo) = f2w{y10, y11};
+                    }
+                    continue;
                 }
                 const size_t o = (((size_t)ob * a.M + m) * Ho + oy) * Wo + ox;
                 if (has_add) { y00 += ad[rr][0].x; y01 += ad[rr][0].y; y10 += ad[rr][1].x; y11 += ad[rr][1].y; }
@@ -826,6 +858,9 @@ struct WinoLaunch {
     const float* weight; int Co, Ci; bool dgrad;                         // nn.Conv2d weight (Co,Ci,3,3) and the transform
     const float* bias; int act, pad, P;                                  // FUSED options (P: 1 same, 2 full correlation)
     const float* addend;                                                 // plain launches: added to the result (may be null)
+    // fused data gradient with the split store (wino_conv_dgrad_split): rows [0, split_c0) -> out (half resolution when split_up),
+    // the rest -> out1; add0 / add1 nullable
+    bool split = false; int split_c0 = 0, split_up = 0; float* out1 = nullptr; const float* add0 = nullptr; const float* add1 = nullptr;
     float* out; void* ws;
     int B, H, W, M;
     bool fused;
@@ -940,7 +975,13 @@ static int wino_launch(const WinoLaunch& d, hipStream_t st) {
     hipEvent_t pe = conv_prof_begin(0, 2.0 * d.B * (double)M * K * 9.0 * H * W,
                                     2.0 * 16.0 * (double)a.nsub * 32.0 * (double)Mp * Kp,
                                     (double)b0 + (double)b1 + 4.0 * (double)nout + 36.0 * d.Co * d.Ci, st);
-    if (d.fused) {
+    if (d.fused && d.split) {
+        if (ksplit != 1) return DC_EINVAL;                 // (wino_dgrad_split_ok: the split store exists for the unsplit reduction)
+        a.out1 = d.out1; a.add0 = d.add0; a.add1 = d.add1; a.split_c0 = d.split_c0; a.split_up = d.split_up;
+        if (MT == 16) hipLaunchKernelGGL((wino_ps_kernel<1, 2, true, false, 4>), grid, dim3(256), 0, st, a);
+        else if (G == 1) hipLaunchKernelGGL((wino_ps_kernel<2, 2, true, false, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wino_ps_kernel<2, 4, true, false, 4>), grid, dim3(256), 0, st, a);
+    } else if (d.fused) {
         if (MT == 16) hipLaunchKernelGGL((wino_ps_kernel<1, 2, true>), grid, dim3(256), 0, st, a);
         else if (G == 1) hipLaunchKernelGGL((wino_ps_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wino_ps_kernel<2, 4, true>), grid, dim3(256), 0, st, a);
@@ -998,6 +1039,26 @@ int wino_conv_full_dgrad(const float* gp, const float* weight, float* dxpad, voi
     d.src0 = gp; d.C0 = Co; d.up0 = 0; d.src1 = nullptr; d.C1 = 0; d.weight = weight; d.Co = Co; d.Ci = Ci; d.dgrad = true;
     d.bias = nullptr; d.act = ACT_NONE; d.pad = PAD_ZERO; d.P = 2; d.out = dxpad; d.ws = ws; d.B = B; d.H = H; d.W = W; d.M = Ci;
     d.fused = true;
+    return wino_launch(d, st);
+}
+
+// The data gradient of a fused block (conv3x3.hip) WITHOUT the padded-domain scratch: the interior of the full correlation is the
+// zero-padded "same" correlation of g' with the rotated, transposed filter (P = 1), and its 2 x 2 output tiles coincide with the
+// pixels of a nearest-x2 upsampled x0; the store epilogue splits the concat, sums the upsampled half's tiles and adds the addends.
+// What ReflectionPad folds back from the padded ring (rows -1 / H, columns -1 / W) is added afterwards by conv_ring_kernel.
+bool wino_dgrad_split_ok(int B, int C0, int C1, int up0, int Co, int H, int W) {
+    const int Ci = C0 + C1;
+    if (H < 4 || W < 4 || (H & 1) || (W & 1) || C0 <= 0) return false;
+    if ((size_t)B * Co * H * W * 4 >= 0x7fffffffull) return false;
+    return wino_plan(B, Co, Ci, H, W).ksplit == 1;
+}
+int wino_conv_dgrad_split(const float* gp, const float* weight, float* dx0, float* dx1, const float* add0, const float* add1, void* ws,
+                          int B, int C0, int C1, int up0, int Co, int H, int W, hipStream_t st) {
+    WinoLaunch d{};
+    d.src0 = gp; d.C0 = Co; d.up0 = 0; d.src1 = nullptr; d.C1 = 0; d.weight = weight; d.Co = Co; d.Ci = C0 + C1; d.dgrad = true;
+    d.bias = nullptr; d.act = ACT_NONE; d.pad = PAD_ZERO; d.P = 1; d.out = dx0; d.ws = ws; d.B = B; d.H = H; d.W = W; d.M = C0 + C1;
+    d.fused = true;
+    d.split = true; d.split_c0 = C0; d.split_up = up0 ? 1 : 0; d.out1 = dx1; d.add0 = add0; d.add1 = add1;
     return wino_launch(d, st);
 }
 

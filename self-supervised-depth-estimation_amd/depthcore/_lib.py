@@ -191,6 +191,7 @@ def _sig(lib):
         "dc_set_photo_full": (i, [i]),
         "dc_set_wino_f4": (i, [i]),
         "dc_set_wino_persist": (i, [i]),
+        "dc_set_dgrad_split": (i, [i]),
         "dc_wino_cache_new_owner": (i, []),
         "dc_wino_cache_register": (i, [i, p, i, i]),
         "dc_wino_cache_release_owner": (i, [i]),

@@ -82,6 +82,67 @@ def test_block_vs_oracle(case):
         close(a, c, rtol=1e-3, atol=1e-3 * float(c.abs().max()), msg=name)
 
 
+SPLIT_CASES = [
+    # B, C0, C1, Co, H, W, up, act, pad -- shapes whose data gradient runs on the Winograd kernels with an unsplit reduction
+    (2, 32, 64, 32, 24, 40, True, 1, 0), (2, 64, 64, 64, 48, 160, True, 1, 0), (1, 64, 0, 32, 48, 160, False, 1, 0),
+    (2, 32, 0, 16, 96, 320, False, 1, 0), (1, 16, 16, 24, 32, 64, True, 1, 0), (2, 64, 64, 128, 24, 80, False, 2, 1),
+    (1, 128, 128, 128, 24, 80, True, 1, 0), (2, 40, 24, 72, 18, 22, True, 1, 0), (2, 64, 0, 64, 4, 8, False, 1, 0),
+    (1, 32, 32, 32, 4, 4, True, 4, 0), (1, 24, 8, 16, 30, 34, False, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_data_gradient_without_the_padded_scratch(case):
+    """dc_set_dgrad_split: the fused block's data gradient written straight to dx0 / dx1 from the interior of the correlation
+    (+ conv_ring_kernel for what ReflectionPad folds back) against the full correlation + fold pass -- the same sums in
+    another order -- and against the oracle; with addends (in place for dx1, as the ConvGRU level node uses it)."""
+    import ctypes
+    from depthcore import _lib, ops
+    from depthcore._lib import check, ptr, stream
+    L = _lib.lib()
+    B, C0, C1, Co, H, W, up, act, pad = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x0 = torch.randn(B, C0, H >> up, W >> up, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    w = torch.randn(Co, C0 + C1, 3, 3, generator=g) / (3.0 * (C0 + C1) ** 0.5)
+    b = 0.1 * torch.randn(Co, generator=g)
+    gy = torch.randn(B, Co, H, W, generator=g)
+    a0 = torch.randn(x0.shape, generator=g)
+    a1 = torch.randn(x1.shape, generator=g) if C1 else None
+    res = {}
+    for mode in (1, 0):
+        prev = L.dc_set_dgrad_split(mode)
+        try:
+            hx0, hx1 = x0.to(DEV).requires_grad_(), (x1.to(DEV).requires_grad_() if C1 else None)
+            hw, hb = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+            y = ops.conv3x3_block(hx0, hx1, hw, hb, up, act, pad)
+            res[mode] = torch.autograd.grad(y, [t for t in (hx0, hx1, hw, hb) if t is not None], gy.to(DEV))
+            # the C entry with addends: addend0 a separate tensor, addend1 the output itself
+            yy = y.detach()
+            gyd, a0d = gy.to(DEV), a0.to(DEV)           # (named: alive until the launches are enqueued)
+            d0 = torch.empty_like(hx0)
+            d1 = a1.to(DEV).clone() if C1 else None
+            ws = torch.empty(L.dc_conv3x3_bwd_workspace(C0, C1, B, Co, H, W), dtype=torch.uint8, device=DEV)
+            check(L.dc_conv3x3_bwd_add(ptr(hx0.detach()), C0, int(up), ptr(hx1.detach()) if C1 else None, C1, ptr(hw.detach()), ptr(yy),
+                                       ptr(gyd), ptr(d0), ptr(d1) if C1 else None, ptr(a0d), ptr(d1) if C1 else None, None, None,
+                                       ws.data_ptr(), B, Co, H, W, act, pad, stream(yy)), "dc_conv3x3_bwd_add")
+            res[(mode, "add")] = (d0, d1)
+        finally:
+            L.dc_set_dgrad_split(prev)
+    for a, c in zip(res[1], res[0]):
+        assert rel_l2(a, c) < 2e-6, rel_l2(a, c)
+    assert rel_l2(res[(1, "add")][0], res[1][0] + a0.to(DEV)) < 1e-6
+    if C1:
+        assert rel_l2(res[(1, "add")][1], res[1][1] + a1.to(DEV)) < 1e-6
+        assert rel_l2(res[(0, "add")][1], res[(1, "add")][1]) < 2e-6
+    # and against the oracle
+    ox0, ox1 = x0.clone().requires_grad_(), (x1.clone().requires_grad_() if C1 else None)
+    oy = oracle_block(ox0, ox1, w, b, up, act, pad)
+    og = torch.autograd.grad(oy, [t for t in (ox0, ox1) if t is not None], gy)
+    for a, c in zip(res[1], og):
+        assert rel_l2(a, c) < 1e-5, rel_l2(a, c)
+
+
 def test_convblock_golden(golden):
     import layers
     g = golden["layers_ops"]
