@@ -1163,7 +1163,8 @@ int conv_wreduce(const float* part, const float* pbias, float* dw, float* db, in
 int g_dgrad_split = !(std::getenv("DC_DGRAD_SPLIT") && std::getenv("DC_DGRAD_SPLIT")[0] == '0');
 // Under ReflectionPad the ring costs Cin x Co x perimeter multiplies on plain FMAs while the fold pass it replaces costs Cin x H x W
 // bytes: the wide shallow levels (48 x 160 and up at 192 x 640) gain, the deep 6 x 20 ... 24 x 80 levels (256 ... 512 channels) would
-// pay 10-50 us of ring for a 3-8 us fold.  Zero padding has no ring: always.
+// pay 10-50 us of ring for a 3-8 us fold, and at batch 1 the ring's two launches cost more than a fold of < 16 MB (C1 under a
+// graph 3.23 -> 3.32 ms).  Zero padding has no ring: always.
 int g_dgrad_split_min_pixels = std::getenv("DC_DGRAD_SPLIT_MIN") ? atoi(std::getenv("DC_DGRAD_SPLIT_MIN")) : 6000;
 
 // bf16 matrix-core kernels (conv_bf16.hip) instead of the fp32 ones: thread precision + shapes of their 16-byte staging
@@ -1315,7 +1316,7 @@ extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float*
             if (rcf != DC_OK) return rcf;
         }
     } else if (w_dx && g_dgrad_split && wino_dgrad_split_ok(B, C0, C1, up0 ? 1 : 0, Co, H, W) &&
-               (pad_mode == PAD_ZERO || H * W >= g_dgrad_split_min_pixels)) {
+               (pad_mode == PAD_ZERO || (H * W >= g_dgrad_split_min_pixels && (size_t)B * Cin * H * W >= ((size_t)4 << 20)))) {
         // the interior of the correlation written straight to dx0 / dx1 (concat split, 2 x 2 sums of the upsampled half and the
         // addends in the Winograd kernel's store epilogue), then the few ring terms ReflectionPad folds back: no padded-domain
         // scratch (B x Cin x (H+2) x (W+2) written and read again) and no fold pass
