@@ -382,8 +382,9 @@ def run_rank(args):
     loss0 = None
     # set-up steps BEFORE the contract's W warm-up steps (untimed, like building the trainer): the first steps of a process size
     # the workspaces, fill the allocator's pools and meet the weight-cache variants (refreshed from the second step on); with a
-    # small W they would otherwise reach into the timed region.  Reported as config.setup_steps.
-    SETUP_STEPS = 3
+    # small W they would otherwise reach into the timed region (and the clocks of a GPU that was idle a moment ago are still ramping:
+    # the first 20-step window after 3 + 5 steps read 11.26 / 11.58 ms where the following ones read 11.20-11.25).  config.setup_steps.
+    SETUP_STEPS = int(os.environ.get("DC_BENCH_SETUP", "12"))
     for _ in range(SETUP_STEPS):
         _, losses = tr.train_step(inputs)
         loss0 = losses["loss"].detach().clone() if loss0 is None else loss0
