@@ -590,8 +590,9 @@ int dc_set_wino_persist(int mode);
 /* Data gradient of the fused blocks on the Winograd kernels (dc_conv3x3_bwd / _bwd_add): 1 (default) writes the interior of the
  * correlation straight to dx0 / dx1 -- concat split, the 2 x 2 sums of an upsampled x0 and the addends in the store epilogue -- and
  * adds what ReflectionPad folds back from the padded ring in one small launch; 0 = the full correlation over the padded domain into a
- * scratch + a fold pass (same sums in another order: results agree to rounding).  Process-global; the initial mode comes from
- * DC_DGRAD_SPLIT (default 1); returns the previous mode, or DC_EINVAL. */
+ * scratch + a fold pass (same sums in another order: results agree to rounding).  Mode 1 takes the new path where it pays (every
+ * zero-padded block; under ReflectionPad the wide levels: >= 6000 pixels, <= 64 output channels, a fold pass of >= 16 MB); 2 = wherever it
+ * exists (tests).  Process-global; the initial mode comes from DC_DGRAD_SPLIT (default 1); returns the previous mode, or DC_EINVAL. */
 int dc_set_dgrad_split(int mode);
 int dc_wino_cache_new_owner(void);
 int dc_wino_cache_register(int owner, const float* weight, int Ci, int Co);

@@ -608,50 +608,62 @@ __device__ __forceinline__ bool ring_element(int t, int h, int w, int r0, int r1
 // (x = -1 and x = W are the corners of the padded domain).  A small dense product per strip -- M = Cin, N = strip length, K = 3 Co --
 // as plain FMAs: a block takes 256 positions x RING_CB channels, the strip's g' line and the weights of RING_CO output channels at a
 // time through LDS.  grid (ceil((max(H, W) + 2) / 256), 4 * ceil(Cin / RING_CB), B)
-constexpr int RING_CB = 8, RING_CO = 16;
+// A block stages the strip's g' line for ALL output channels once (Co <= RING_MAXCO: the wide levels) and walks its share of the
+// input channels in chunks of RING_CB; 128 positions x two channel halves per block.  (The first version re-staged the line for every
+// channel chunk: the column strips -- one cache line per element -- made it 25 us per launch.)
+// grid (ceil((max(H, W) + 2) / 128), 4 * cgroups, B), dynamic LDS (Co * 132 + Co * RING_CB * 3) floats
+constexpr int RING_CB = 8, RING_MAXCO = 64, RING_SEG = 128;
 __global__ __launch_bounds__(256) void conv_ring_strips_kernel(const float* __restrict__ gp, const float* __restrict__ w, float* __restrict__ R,
-                                                               int Cin, int Co, int H, int W, int LP) {
-    __shared__ float line[RING_CO][256 + 4];
-    __shared__ float wl[RING_CO][RING_CB][3];
-    const int t = threadIdx.x, strip = blockIdx.y & 3, c0 = (blockIdx.y >> 2) * RING_CB, b = blockIdx.z;
-    const int L = strip < 2 ? W : H, p0 = blockIdx.x * 256;
+                                                               int Cin, int Co, int H, int W, int LP, int cgroups) {
+    extern __shared__ float ring_lds[];
+    float* line = ring_lds;                                   // [Co][RING_SEG + 4]
+    float* wl = ring_lds + Co * (RING_SEG + 4);               // [Co][RING_CB][3]
+    const int t = threadIdx.x, tp = t & (RING_SEG - 1), half = t >> 7;
+    const int strip = blockIdx.y & 3, grp = blockIdx.y >> 2, b = blockIdx.z;
+    const int L = strip < 2 ? W : H, p0 = blockIdx.x * RING_SEG;
     if (p0 >= L + 2) return;
     const size_t HW = (size_t)H * W;
     const float* gpb = gp + (size_t)b * Co * HW;
     const int fixed = (strip & 1) ? (strip < 2 ? H - 1 : W - 1) : 0;            // the row (strips 0, 1) / column (2, 3) of g' the strip reads
-    float acc[RING_CB];
-#pragma unroll
-    for (int i = 0; i < RING_CB; ++i) acc[i] = 0.f;
-    for (int cb = 0; cb < Co; cb += RING_CO) {
-        __syncthreads();
-        for (int e = t; e < RING_CO * 258; e += 256) {
-            const int co = e / 258, j = e - co * 258, i = p0 - 2 + j;
-            float v = 0.f;
-            if (cb + co < Co && i >= 0 && i < L) v = gpb[(size_t)(cb + co) * HW + (strip < 2 ? (size_t)fixed * W + i : (size_t)i * W + fixed)];
-            line[co][j] = v;
-        }
-        for (int e = t; e < RING_CO * RING_CB * 3; e += 256) {
+    for (int e = t; e < Co * (RING_SEG + 2); e += 256) {
+        const int co = e / (RING_SEG + 2), j = e - co * (RING_SEG + 2), i = p0 - 2 + j;
+        float v = 0.f;
+        if (i >= 0 && i < L) v = gpb[(size_t)co * HW + (strip < 2 ? (size_t)fixed * W + i : (size_t)i * W + fixed)];
+        line[co * (RING_SEG + 4) + j] = v;
+    }
+    const int nchunk = (Cin + RING_CB - 1) / RING_CB, per = (nchunk + cgroups - 1) / cgroups;
+    const int pos = p0 + tp;
+    for (int ch = grp * per; ch < min(nchunk, (grp + 1) * per); ++ch) {
+        const int c0 = ch * RING_CB;
+        __syncthreads();                                      // the line (first round) / the previous chunk's weights are free
+        for (int e = t; e < Co * RING_CB * 3; e += 256) {
             const int co = e / (RING_CB * 3), rem = e - co * (RING_CB * 3), cc = rem / 3, k = rem - cc * 3;
             float v = 0.f;
-            if (cb + co < Co && c0 + cc < Cin) {
-                const float* wk = w + ((size_t)(cb + co) * Cin + c0 + cc) * 9;
+            if (c0 + cc < Cin) {
+                const float* wk = w + ((size_t)co * Cin + c0 + cc) * 9;
                 v = strip < 2 ? wk[((strip & 1) ? 6 : 0) + k] : wk[k * 3 + ((strip & 1) ? 2 : 0)];
             }
-            wl[co][cc][k] = v;
+            wl[e] = v;
         }
         __syncthreads();
+        float acc[RING_CB / 2];
+#pragma unroll
+        for (int i = 0; i < RING_CB / 2; ++i) acc[i] = 0.f;
 #pragma unroll 4
-        for (int co = 0; co < RING_CO; ++co) {
-            const float l0 = line[co][t + 2], l1 = line[co][t + 1], l2 = line[co][t];          // taps k = 0, 1, 2: position pos - k
+        for (int co = 0; co < Co; ++co) {
+            const float* ln = line + co * (RING_SEG + 4) + tp;
+            const float l0 = ln[2], l1 = ln[1], l2 = ln[0];                    // taps k = 0, 1, 2: position pos - k
+            const float* wq = wl + (co * RING_CB + half * (RING_CB / 2)) * 3;
 #pragma unroll
-            for (int cc = 0; cc < RING_CB; ++cc) acc[cc] = fmaf(l2, wl[co][cc][2], fmaf(l1, wl[co][cc][1], fmaf(l0, wl[co][cc][0], acc[cc])));
+            for (int cc = 0; cc < RING_CB / 2; ++cc) acc[cc] = fmaf(l2, wq[cc * 3 + 2], fmaf(l1, wq[cc * 3 + 1], fmaf(l0, wq[cc * 3], acc[cc])));
         }
-    }
-    const int pos = p0 + t;
-    if (pos < L + 2)
+        if (pos < L + 2)
 #pragma unroll
-        for (int cc = 0; cc < RING_CB; ++cc)
-            if (c0 + cc < Cin) R[(((size_t)b * Cin + c0 + cc) * 4 + strip) * LP + pos] = acc[cc];
+            for (int cc = 0; cc < RING_CB / 2; ++cc) {
+                const int c = c0 + half * (RING_CB / 2) + cc;
+                if (c < Cin) R[(((size_t)b * Cin + c) * 4 + strip) * LP + pos] = acc[cc];
+            }
+    }
 }
 // Phase 2 -- one thread per AFFECTED gradient element adds what the ring folds onto it.  An element covers full-resolution pixels
 // [ya, yb] x [xa, xb] (one pixel; a 2 x 2 block of the half-resolution plane of an upsampled x0): the row strip's values of its
@@ -1316,7 +1328,8 @@ extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float*
             if (rcf != DC_OK) return rcf;
         }
     } else if (w_dx && g_dgrad_split && wino_dgrad_split_ok(B, C0, C1, up0 ? 1 : 0, Co, H, W) &&
-               (pad_mode == PAD_ZERO || (H * W >= g_dgrad_split_min_pixels && (size_t)B * Cin * H * W >= ((size_t)4 << 20)))) {
+               (pad_mode == PAD_ZERO || (Co <= RING_MAXCO && (g_dgrad_split == 2 || (H * W >= g_dgrad_split_min_pixels &&
+                                                                                  (size_t)B * Cin * H * W >= ((size_t)4 << 20)))))) {
         // the interior of the correlation written straight to dx0 / dx1 (concat split, 2 x 2 sums of the upsampled half and the
         // addends in the Winograd kernel's store epilogue), then the few ring terms ReflectionPad folds back: no padded-domain
         // scratch (B x Cin x (H+2) x (W+2) written and read again) and no fold pass
@@ -1325,8 +1338,10 @@ extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float*
         if (pad_mode == PAD_REFLECT) {
             // (scratch: the padded-domain buffer, which this path does not use -- 4 strips of max(H, W) + 2 floats per plane)
             const int LP = std::max(H, W) + 2;
-            hipLaunchKernelGGL(conv_ring_strips_kernel, dim3(ceil_div(LP, 256), 4 * ceil_div(Cin, RING_CB), B), dim3(256), 0, ST, gp, weight,
-                               dxpad, Cin, Co, H, W, LP);
+            const int segs = ceil_div(LP, RING_SEG), nchunk = ceil_div(Cin, RING_CB);
+            const int cgroups = std::max(1, std::min(nchunk, ceil_div(512, segs * 4 * B)));       // ~two blocks per CU
+            hipLaunchKernelGGL(conv_ring_strips_kernel, dim3(segs, 4 * cgroups, B), dim3(256),
+                               (size_t)(Co * (RING_SEG + 4) + Co * RING_CB * 3) * sizeof(float), ST, gp, weight, dxpad, Cin, Co, H, W, LP, cgroups);
             DC_CHECK_LAUNCH();
             hipLaunchKernelGGL(conv_ring_kernel, dim3(ceil_div(2 * W + 2 * H, 256), Cin, B), dim3(256), 0, ST, (const float*)dxpad, dx0, dx1,
                                C0, C1, up0 ? 1 : 0, H, W, LP);
@@ -1424,7 +1439,7 @@ extern "C" int dc_conv3x3_bwd_add(const float* x0, int C0, int up0, const float*
 }
 
 extern "C" int dc_set_dgrad_split(int mode) {
-    if (mode != 0 && mode != 1) return DC_EINVAL;
+    if (mode < 0 || mode > 2) return DC_EINVAL;
     const int prev = dc::g_dgrad_split;
     dc::g_dgrad_split = mode;
     return prev;

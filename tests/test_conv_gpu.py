@@ -110,7 +110,7 @@ def test_data_gradient_without_the_padded_scratch(case):
     a0 = torch.randn(x0.shape, generator=g)
     a1 = torch.randn(x1.shape, generator=g) if C1 else None
     res = {}
-    for mode in (1, 0):
+    for mode in (2, 0):          # 2: the new path wherever it exists (mode 1 keeps it for the shapes where it pays)
         prev = L.dc_set_dgrad_split(mode)
         try:
             hx0, hx1 = x0.to(DEV).requires_grad_(), (x1.to(DEV).requires_grad_() if C1 else None)
@@ -129,17 +129,17 @@ def test_data_gradient_without_the_padded_scratch(case):
             res[(mode, "add")] = (d0, d1)
         finally:
             L.dc_set_dgrad_split(prev)
-    for a, c in zip(res[1], res[0]):
+    for a, c in zip(res[2], res[0]):
         assert rel_l2(a, c) < 2e-6, rel_l2(a, c)
-    assert rel_l2(res[(1, "add")][0], res[1][0] + a0.to(DEV)) < 1e-6
+    assert rel_l2(res[(2, "add")][0], res[2][0] + a0.to(DEV)) < 1e-6
     if C1:
-        assert rel_l2(res[(1, "add")][1], res[1][1] + a1.to(DEV)) < 1e-6
-        assert rel_l2(res[(0, "add")][1], res[(1, "add")][1]) < 2e-6
+        assert rel_l2(res[(2, "add")][1], res[2][1] + a1.to(DEV)) < 1e-6
+        assert rel_l2(res[(0, "add")][1], res[(2, "add")][1]) < 2e-6
     # and against the oracle
     ox0, ox1 = x0.clone().requires_grad_(), (x1.clone().requires_grad_() if C1 else None)
     oy = oracle_block(ox0, ox1, w, b, up, act, pad)
     og = torch.autograd.grad(oy, [t for t in (ox0, ox1) if t is not None], gy)
-    for a, c in zip(res[1], og):
+    for a, c in zip(res[2], og):
         assert rel_l2(a, c) < 1e-5, rel_l2(a, c)
 
 
