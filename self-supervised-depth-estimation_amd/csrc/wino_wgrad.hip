@@ -485,7 +485,10 @@ static WgPlan wg_plan(int B, int Ci, int Co, int H, int W) {
     // something to overlap
     p.ng = (p.mr == 4 && p.nsub >= 4 * ceil_div(256, nmk)) ? 2 : 1;
     if (const char* f = getenv("DC_WGRAD_NG")) { const int v = atoi(f); if (v == 1 || (v == 2 && p.mr == 4)) p.ng = v; }      // experiments
-    p.splits = std::max(1, std::min(std::max(1, p.nsub / (2 * p.ng)), ceil_div(512 / p.ng, nmk)));
+    // (32-channel tiles on a big map -- 96 -> 32 at 96 x 320 -- : three blocks per CU, 768 in all, measured 119 us against 158 us at 512;
+    // the 64-channel tiles and the small maps are best at 512 / 256: tools/sweep_wgrad.py, round 5)
+    const int target = (p.mr == 2 && p.nsub >= 4096) ? 768 : 512 / p.ng;
+    p.splits = std::max(1, std::min(std::max(1, p.nsub / (2 * p.ng)), ceil_div(target, nmk)));
     if (const char* f = getenv("DC_WGRAD_BLOCKS")) {         // experiments (tools/sweep_wgrad.py): target block count
         const int tb = atoi(f);
         if (tb > 0) p.splits = std::max(1, std::min(std::max(1, p.nsub / (2 * p.ng)), ceil_div(tb, nmk)));
