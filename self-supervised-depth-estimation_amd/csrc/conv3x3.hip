@@ -1105,7 +1105,8 @@ static inline bool wino_fwd(int C0, int C1, int B, int Co, int H, int W) {
 }
 static inline bool wino_gp_ok(int B, int Co, int H, int W, int act) { return act == ACT_NONE || ((size_t)B * Co * H * W) % 4 == 0; }
 static inline bool wino_dx(int C0, int C1, int B, int Co, int H, int W, int act) {
-    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && wino_gp_ok(B, Co, H, W, act) && wino_fits(B, C0, C1, Co, H, W);
+    static const int min_cin = std::getenv("DC_WINO_DX_MIN") ? atoi(std::getenv("DC_WINO_DX_MIN")) : 16;      // (32 before the split store: the 16-channel level then paid the padded scratch + fold on its 192 x 640 map)
+    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= min_cin && wino_gp_ok(B, Co, H, W, act) && wino_fits(B, C0, C1, Co, H, W);
 }
 static inline bool wino_dw(int C0, int C1, int B, int Co, int H, int W, int act) {
     return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && Co >= 32 && wino_gp_ok(B, Co, H, W, act) &&
