@@ -1109,7 +1109,9 @@ static inline bool wino_dx(int C0, int C1, int B, int Co, int H, int W, int act)
     return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= min_cin && wino_gp_ok(B, Co, H, W, act) && wino_fits(B, C0, C1, Co, H, W);
 }
 static inline bool wino_dw(int C0, int C1, int B, int Co, int H, int W, int act) {
-    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= 32 && Co >= 32 && wino_gp_ok(B, Co, H, W, act) &&
+    static const int min_co = std::getenv("DC_WINO_DW_MIN") ? atoi(std::getenv("DC_WINO_DW_MIN")) : 32;
+    static const int min_ci = std::getenv("DC_WINO_DW_MINCI") ? atoi(std::getenv("DC_WINO_DW_MINCI")) : 32;
+    return wino_enabled() && wino_conv_eligible(C0, C1, H, W) && C0 + C1 >= min_ci && Co >= min_co && wino_gp_ok(B, Co, H, W, act) &&
            wino_fits(B, C0, C1, Co, H, W);
 }
 
