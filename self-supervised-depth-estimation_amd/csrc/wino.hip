@@ -854,7 +854,10 @@ static double wino_ps_cost(int v, int ksplit, int nsub, int M, int nchunks, size
 // Largest reduction split a launch may use: 2 in general; 4 or 8 for SMALL outputs (<= 2 MB: the deep, low-resolution layers
 // at batch 1-3 -- 512 channels on a 6 x 20 map is ONE sub-region per image and 64 dependent chunks per block: 44 us for 3.6 us
 // of matrix work; its slabs are a few hundred KB).  Workspace sizes follow the same rule (wino_slab_bytes).
-static int wino_ksplit_cap(size_t nout) { return nout * 4 <= (2u << 20) ? 8 : 2; }
+static int wino_ksplit_cap(size_t nout) {
+    static const size_t small = getenv("DC_WINO_KSCAP_BYTES") ? (size_t)atol(getenv("DC_WINO_KSCAP_BYTES")) : (size_t)(2u << 20);      // experiments
+    return nout * 4 <= small ? 8 : 2;
+}
 static size_t wino_slab_bytes(size_t nout) { return (size_t)wino_ksplit_cap(nout) * nout * sizeof(float); }
 
 static int g_wino_persist = [] { const char* f = getenv("DC_WINO_PERSIST"); return f ? atoi(f) : 0; }();      // dc_set_wino_persist
