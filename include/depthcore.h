@@ -40,6 +40,10 @@ extern "C" {
 #define DC_OPT_ALIGN_CORNERS 8u /* grid_sample(align_corners=True); default False = installed-torch default */
 #define DC_OPT_PRED_MASK 32u    /* opt.predictive_mask (trainer.py:571-584): reprojection losses are multiplied by `pred_mask[s]`; needs
                                    DC_OPT_NO_AUTOMASK (trainer.py:116-117).  The BCE weighting term of the masks is the caller's */
+#define DC_OPT_PHOTO_SPLIT 64u  /* pin the training forward's mode for THIS desc, whatever dc_set_photo_full says when its backward runs: */
+#define DC_OPT_PHOTO_FULL 128u  /* SPLIT = the round-4 split, FULL = all the way (see dc_set_photo_full).  dc_photo_bwd must get the same bit
+                                   as its dc_photo_fwd (it re-derives the workspace layout from it); with neither bit the process-wide
+                                   setting decides at each call */
 #define DC_OPT_NO_GRAD 16u      /* dc_photo_fwd only: evaluation -- the forward does not emit d(loss)/d(warped), the workspace
                                    is smaller and dc_photo_bwd on this descriptor returns DC_EINVAL */
 
@@ -185,6 +189,11 @@ typedef struct dc_photo_desc {
     /* scratch */
     void* workspace;              /* dc_photo_workspace(desc) bytes, same buffer for fwd and bwd */
     size_t workspace_bytes;
+    /* optional per-scale poses: `--pose_model_type posecnn` rebuilds T at every scale from the translation scaled by that
+     * scale's mean inverse depth (trainer.py:490-499).  T_scale[s][f] != NULL replaces T[f] at scale s (all 2*num_scales or
+     * none); the backward then writes d_T_scale[s][f] (B,4,4) per scale and leaves d_T[] untouched (it may be NULL). */
+    const float* T_scale[DC_MAX_SCALES][2];
+    float* d_T_scale[DC_MAX_SCALES][2];
 } dc_photo_desc;
 
 size_t dc_photo_workspace(const dc_photo_desc* d);
@@ -197,6 +206,9 @@ double dc_photo_algorithmic_bytes(const dc_photo_desc* d, int backward);
  * alone).  0: the round-4 split -- the forward emits d(loss)/d(source coordinates), a pointwise backward chains them (A/Bs).
  * Returns the previous setting.  Must not change between a dc_photo_fwd and its dc_photo_bwd. */
 int dc_set_photo_full(int mode);
+/* The current process-wide setting.  Callers that may see the setter between a forward and its backward read it once, at the forward,
+ * and pin it in the desc with DC_OPT_PHOTO_FULL / DC_OPT_PHOTO_SPLIT (depthcore/ops.py does). */
+int dc_get_photo_full(void);
 
 /* Measurement hook (bench.py `roofline`): when enabled, dc_photo_fwd / dc_photo_bwd bracket their
  * dominant kernel (photo_fwd_kernel / photo_bwd_kernel) AND their whole launch chain (forward: identity + smoothness +

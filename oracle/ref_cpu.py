@@ -258,6 +258,7 @@ class Opt:
     predictive_mask = False
     no_ssim = False
     align_corners = False      # installed-torch default of F.grid_sample
+    pose_model_type = "separate_resnet"
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -278,6 +279,11 @@ def generate_images_pred(inputs, outputs, opt):
         outputs[("depth", 0, s)] = depth
         for f in (-1, 1):
             T = outputs[("cam_T_cam", 0, f)]
+            if opt.pose_model_type == "posecnn":
+                # trainer.py:490-499: the translation is rescaled by this scale's mean inverse depth and T rebuilt
+                mean_inv_depth = (1 / depth).mean(3, True).mean(2, True)
+                T = transformation_from_parameters(
+                    outputs[("axisangle", 0, f)][:, 0], outputs[("translation", 0, f)][:, 0] * mean_inv_depth[:, 0], f < 0)
             cam = backproject(depth, inputs[("inv_K", src)])
             grid = project3d(cam, inputs[("K", src)], T, H, W)
             outputs[("sample", f, s)] = grid

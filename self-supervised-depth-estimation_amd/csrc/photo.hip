@@ -44,7 +44,7 @@ struct PhotoArgs {
     const float* src[2];
     const float* K;
     const float* invK;
-    const float* T[2];
+    const float* T[DC_MAX_SCALES][2];   // per scale: d->T_scale[s][f] (posecnn, trainer.py:490-499) or d->T[f] at every scale
     const float* disp[DC_MAX_SCALES];
     const float* color_s[DC_MAX_SCALES];
     int hs[DC_MAX_SCALES], ws[DC_MAX_SCALES];
@@ -64,6 +64,8 @@ struct PhotoArgs {
     const float* g_losses;
     float* d_disp[DC_MAX_SCALES];
     float* d_T[2];
+    float* d_Ts[DC_MAX_SCALES][2];     // per-scale pose gradients (T_scale given), else null
+    int per_scale_T;
     // workspace carve
     float* part_photo;   // [ns][nblk_f]
     float* part_smooth;  // [ns][B][nchunk][3]
@@ -130,7 +132,7 @@ struct Geo {
     float P[2][12];
 };
 
-__device__ __forceinline__ void load_geo(Geo& g, const PhotoArgs& p, int b) {
+__device__ __forceinline__ void load_geo(Geo& g, const PhotoArgs& p, int b, int s) {
     const float* k = p.K + b * 16;
     const float* ik = p.invK + b * 16;
 #pragma unroll
@@ -139,7 +141,7 @@ __device__ __forceinline__ void load_geo(Geo& g, const PhotoArgs& p, int b) {
         for (int j = 0; j < 3; ++j) g.iK[i * 3 + j] = uni(ik[i * 4 + j]);
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        const float* t = p.T[f] + b * 16;
+        const float* t = p.T[s][f] + b * 16;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void photo_fwd_kernel(PhotoArgs p) 
     const bool avg = p.flags & DC_OPT_AVG_REPROJ;
     const bool lane_ok = lane >= 1 && lane <= 62 && x < W;
     Geo g;
-    load_geo(g, p, b);
+    load_geo(g, p, b, s);
     const unsigned nch4 = (avg ? 1u : 2u) * c.plane4;
     const bool ext_noise = p.noise[s] != nullptr;
     const bool pm = p.flags & DC_OPT_PRED_MASK;        // the mask planes ride in the noise load slots (photo_fwdg_kernel)
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(256, FWDG_BLOCKS_PER_CU) void photo_fwdg_kernel(Pho
     const bool col_ok = x >= 0 && x < W;
     const bool q_lane = lane >= 2 && lane <= 61 && col_ok;
     Geo g;
-    load_geo(g, p, b);
+    load_geo(g, p, b, s);
     const unsigned nch4 = (avg ? 1u : 2u) * c.plane4;
     const bool ext_noise = SPEC >= 0 ? bool(SPEC & 8) : p.noise[s] != nullptr;
     // predictive mask (trainer.py:571-584; automasking is off with it): the two mask planes (B,2,H,W) travel in the load slots
@@ -1144,7 +1146,7 @@ __global__ __launch_bounds__(256, BWDG_BLOCKS_PER_CU) void photo_bwdg_kernel(Pho
     make_ctx(c, p, b, s);
     const unsigned plane = c.plane4 / 4;
     Geo g;
-    load_geo(g, p, b);
+    load_geo(g, p, b, s);
     const rsrc_t gwb = make_rsrc(p.gw[s] + (size_t)b * plane * 4, plane * 16u);
     // d loss / d to_optimise(pixel) for this scale: mean over B*H*W, total = mean over scales
     const float wgt = col_ok ? uni((p.g_losses[s] + p.g_losses[p.ns] / (float)p.ns) / ((float)p.B * H * W)) : 0.f;
@@ -1386,20 +1388,10 @@ __device__ __forceinline__ void disp_grad_tile(const PhotoArgs& p, int b, int ti
     }
 }
 
-// d_T[f][b] = K[b][:3,:]^T @ sum_{s,blk} dP, one 256-thread block per (b, f): fixed-order sums
-__device__ __forceinline__ void pose_grad_block(const PhotoArgs& p, int b, int f, float* sm) {
+// d_T[f][b] = K[b][:3,:]^T @ sum_{s,blk} dP, one 256-thread block per (b, f): fixed-order sums.  With per-scale poses
+// (p.per_scale_T: posecnn, trainer.py:490-499) the sum over blocks is closed per scale into d_Ts[s][f][b].
+__device__ __forceinline__ void pose_grad_close(const PhotoArgs& p, int b, float* out, const float (&acc)[12], float* sm) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float acc[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-    for (int s = 0; s < p.ns; ++s) {
-        const float* q = p.part_dP + (((size_t)s * 2 + f) * p.B + b) * p.nblk_b_img * 12;
-        const float wup = p.full ? (p.g_losses[s] + p.g_losses[p.ns] / (float)p.ns) / ((float)p.B * p.H * p.W) : 1.f;
-        for (int k = threadIdx.x; k < p.nblk_b_img; k += 256) {
-#pragma unroll
-            for (int j = 0; j < 12; ++j) acc[j] = fmaf(wup, q[k * 12 + j], acc[j]);
-        }
-    }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
         const float v = wave_sum(acc[k]);
@@ -1415,8 +1407,29 @@ __device__ __forceinline__ void pose_grad_block(const PhotoArgs& p, int b, int f
             const float dp = (sm[0 * 12 + i * 4 + c] + sm[1 * 12 + i * 4 + c]) + (sm[2 * 12 + i * 4 + c] + sm[3 * 12 + i * 4 + c]);
             v = (i == 0) ? K[i * 4 + r] * dp : v + K[i * 4 + r] * dp;
         }
-        p.d_T[f][b * 16 + threadIdx.x] = v;
+        out[b * 16 + threadIdx.x] = v;
     }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void pose_grad_block(const PhotoArgs& p, int b, int f, float* sm) {
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int s = 0; s < p.ns; ++s) {
+        const float* q = p.part_dP + (((size_t)s * 2 + f) * p.B + b) * p.nblk_b_img * 12;
+        const float wup = p.full ? (p.g_losses[s] + p.g_losses[p.ns] / (float)p.ns) / ((float)p.B * p.H * p.W) : 1.f;
+        for (int k = threadIdx.x; k < p.nblk_b_img; k += 256) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) acc[j] = fmaf(wup, q[k * 12 + j], acc[j]);
+        }
+        if (p.per_scale_T) {
+            pose_grad_close(p, b, p.d_Ts[s][f], acc, sm);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+        }
+    }
+    if (!p.per_scale_T) pose_grad_close(p, b, p.d_T[f], acc, sm);
 }
 
 struct DgPlan { int start[DC_MAX_SCALES + 1]; };   // first block of scale s; start[ns] = the two pose blocks
@@ -1454,7 +1467,9 @@ struct Carve {
 // dc_set_photo_full(0) keeps the round-4 split (forward emits du, dv; pointwise backward) for A/Bs.
 static int g_photo_full = [] { const char* f = getenv("DC_PHOTO_FULL"); return f ? atoi(f) : 1; }();
 static bool photo_full_for(const dc_photo_desc* d) {
-    if (!g_photo_full || (d->flags & DC_OPT_NO_GRAD)) return false;
+    if ((d->flags & DC_OPT_PHOTO_SPLIT) && (d->flags & DC_OPT_PHOTO_FULL)) return false;       // (rejected by fill_args)
+    const bool want = (d->flags & DC_OPT_PHOTO_SPLIT) ? false : (d->flags & DC_OPT_PHOTO_FULL) ? true : g_photo_full != 0;
+    if (!want || (d->flags & DC_OPT_NO_GRAD)) return false;
     if (d->flags & (DC_OPT_NO_SSIM | DC_OPT_AVG_REPROJ | DC_OPT_NO_AUTOMASK | DC_OPT_PRED_MASK)) return false;
     bool all_ext = true, none_ext = true;
     for (int s = 0; s < d->num_scales; ++s) { all_ext = all_ext && d->noise[s]; none_ext = none_ext && !d->noise[s]; }
@@ -1531,11 +1546,15 @@ static Carve carve(const dc_photo_desc* d) {
 static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backward) {
     if (!d || d->B <= 0 || d->H < 4 || d->W < 4 || d->num_scales < 1 || d->num_scales > DC_MAX_SCALES)
         return DC_EINVAL;
-    if (!d->target || !d->source[0] || !d->source[1] || !d->K || !d->inv_K || !d->T[0] || !d->T[1] ||
+    int nTs = 0;                                                     // per-scale poses: all 2 * num_scales or none
+    for (int s = 0; s < d->num_scales; ++s) nTs += (d->T_scale[s][0] ? 1 : 0) + (d->T_scale[s][1] ? 1 : 0);
+    if (nTs != 0 && nTs != 2 * d->num_scales) return DC_EINVAL;
+    if (!d->target || !d->source[0] || !d->source[1] || !d->K || !d->inv_K || (!nTs && (!d->T[0] || !d->T[1])) ||
         !d->workspace)
         return DC_EINVAL;
     if (!(d->min_depth > 0.f) || !(d->max_depth > d->min_depth)) return DC_EINVAL;
     if ((d->flags & DC_OPT_PRED_MASK) && !(d->flags & DC_OPT_NO_AUTOMASK)) return DC_EINVAL;    // trainer.py:116-117
+    if ((d->flags & DC_OPT_PHOTO_SPLIT) && (d->flags & DC_OPT_PHOTO_FULL)) return DC_EINVAL;
     const int npk = (d->packed[0] ? 1 : 0) + (d->packed[1] ? 1 : 0) + (d->packed[2] ? 1 : 0);
     if (npk != 0 && npk != 3) return DC_EINVAL;                      // all three or none
     for (int k = 0; k < npk; ++k)
@@ -1550,7 +1569,10 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
     a.inv_Hm1 = 1.f / (float)(d->H - 1);
     a.smoothness = d->smoothness;
     a.target = d->target; a.src[0] = d->source[0]; a.src[1] = d->source[1];
-    a.K = d->K; a.invK = d->inv_K; a.T[0] = d->T[0]; a.T[1] = d->T[1];
+    a.K = d->K; a.invK = d->inv_K;
+    a.per_scale_T = nTs ? 1 : 0;
+    for (int s = 0; s < d->num_scales; ++s)
+        for (int f = 0; f < 2; ++f) a.T[s][f] = nTs ? d->T_scale[s][f] : d->T[f];
     a.seed = d->rng_seed;
     a.seed_ptr = (const unsigned long long*)d->rng_seed_dev;
     char* ws = (char*)d->workspace;
@@ -1583,8 +1605,13 @@ static int fill_args(const dc_photo_desc* d, PhotoArgs& a, Carve& c, bool backwa
         }
     }
     if (backward) {
-        if (!d->g_losses || !d->d_T[0] || !d->d_T[1]) return DC_EINVAL;
+        if (!d->g_losses || (!nTs && (!d->d_T[0] || !d->d_T[1]))) return DC_EINVAL;
         a.g_losses = d->g_losses; a.d_T[0] = d->d_T[0]; a.d_T[1] = d->d_T[1];
+        for (int s = 0; nTs && s < d->num_scales; ++s)
+            for (int f = 0; f < 2; ++f) {
+                if (!d->d_T_scale[s][f]) return DC_EINVAL;
+                a.d_Ts[s][f] = d->d_T_scale[s][f];
+            }
     } else if (!d->losses) {
         return DC_EINVAL;
     }
@@ -1749,6 +1776,8 @@ extern "C" int dc_photo_bwd(const dc_photo_desc* d, void* stream) {
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
+
+extern "C" int dc_get_photo_full(void) { return g_photo_full; }
 
 extern "C" int dc_set_photo_full(int mode) {
     if (mode != 0 && mode != 1) return DC_EINVAL;

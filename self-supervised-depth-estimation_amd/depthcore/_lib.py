@@ -25,6 +25,7 @@ OPT_NO_SSIM = 4
 OPT_ALIGN_CORNERS = 8
 OPT_NO_GRAD = 16
 OPT_PRED_MASK = 32
+OPT_PHOTO_SPLIT, OPT_PHOTO_FULL = 64, 128
 PREC_F32, PREC_BF16 = 0, 1
 
 _ERR = {-1: "DC_EINVAL (bad shape / null pointer / unsupported option)",
@@ -53,6 +54,7 @@ class PhotoDesc(Structure):
         ("g_losses", _F), ("d_disp", _F * MAX_SCALES), ("d_T", _F * 2),
         ("pred_mask", _F * MAX_SCALES), ("d_pred_mask", _F * MAX_SCALES),
         ("workspace", _F), ("workspace_bytes", c_size_t),
+        ("T_scale", (_F * 2) * MAX_SCALES), ("d_T_scale", (_F * 2) * MAX_SCALES),
     ]
 
 
@@ -189,6 +191,7 @@ def _sig(lib):
         "dc_clear_error": (i, []),
         "dc_abort_capture": (i, [p]),
         "dc_set_photo_full": (i, [i]),
+        "dc_get_photo_full": (i, []),
         "dc_set_wino_f4": (i, [i]),
         "dc_set_wino_persist": (i, [i]),
         "dc_set_dgrad_split": (i, [i]),

@@ -209,3 +209,17 @@ def broadcast_parameters(modules, src=0, process_group=None):
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
             dist.broadcast(t.data, src=src, group=process_group)
+
+
+def agree_all(ok, process_group=None, device=None):
+    """A per-rank yes/no made collective: True only if EVERY rank of `process_group` said yes (all-reduce MIN of a flag).
+    Decisions that choose which communicator the next collectives run on (graph replay on the capture group vs eager steps on
+    the base group, Trainer.train_step) must be taken through this, or one rank's fallback leaves the others waiting on a
+    communicator it never enters.  Every rank must call it at the same point of the same step.  The flag lives where the group's
+    backend reduces (device memory for RCCL, host memory for gloo)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return bool(ok)
+    on_host = dist.get_backend(process_group) == "gloo" or device is None
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if on_host else device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+    return bool(int(flag.item()))

@@ -208,9 +208,10 @@ class PhotoConfig:
         self.rng_seed = 0 if torch.is_tensor(rng_seed) else int(rng_seed)
         self.extras = {}          # filled by forward: argmin maps + optional log tensors
         self.n_masks = 0          # set by photometric_loss(pred_masks=...)
+        self.n_Ts = 0             # set by photometric_loss(T_scales=...): 2 * num_scales per-scale poses, else 0
 
 
-def _fill_desc(cfg, T0, T1, disps, no_grad=False, masks=()):
+def _fill_desc(cfg, T0, T1, disps, no_grad=False, masks=(), Ts=(), mode=0):
     B, _, H, W = cfg.target.shape
     ns = len(disps)
     if ns < 1 or ns > _lib.MAX_SCALES:
@@ -219,7 +220,7 @@ def _fill_desc(cfg, T0, T1, disps, no_grad=False, masks=()):
         raise _lib.DepthcoreError("images must be (B,3,H,W)")
     d = PhotoDesc()
     d.B, d.H, d.W, d.num_scales = B, H, W, ns
-    d.flags = cfg.flags | (_lib.OPT_NO_GRAD if no_grad else 0) | (_lib.OPT_PRED_MASK if masks else 0)
+    d.flags = cfg.flags | (_lib.OPT_NO_GRAD if no_grad else 0) | (_lib.OPT_PRED_MASK if masks else 0) | mode
     if masks:
         if not (cfg.flags & _lib.OPT_NO_AUTOMASK):
             raise _lib.DepthcoreError("predictive masks need disable_automasking (reference trainer.py:116-117)")
@@ -233,11 +234,17 @@ def _fill_desc(cfg, T0, T1, disps, no_grad=False, masks=()):
         if cfg.src[f].shape != cfg.target.shape:
             raise _lib.DepthcoreError("source / target shape mismatch")
         d.source[f] = ptr(cfg.src[f])
-    for t in (cfg.K, cfg.inv_K, T0, T1):
+    if Ts and len(Ts) != 2 * ns:
+        raise _lib.DepthcoreError("per-scale poses: one (T_-1, T_+1) pair per scale")
+    for t in (cfg.K, cfg.inv_K, *((T0, T1) if not Ts else Ts)):
         if tuple(t.shape) != (B, 4, 4):
             raise _lib.DepthcoreError("K / inv_K / T must be (B,4,4), got %s" % (tuple(t.shape),))
     d.K, d.inv_K = ptr(cfg.K), ptr(cfg.inv_K)
-    d.T[0], d.T[1] = ptr(T0), ptr(T1)
+    if Ts:                                    # posecnn: one pose per (scale, frame), trainer.py:490-499
+        for s in range(ns):
+            d.T_scale[s][0], d.T_scale[s][1] = ptr(Ts[2 * s]), ptr(Ts[2 * s + 1])
+    else:
+        d.T[0], d.T[1] = ptr(T0), ptr(T1)
     if cfg.packed is not None:
         if len(cfg.packed) != 3 or any(tuple(t.shape) != (B, H, W, 4) for t in cfg.packed):
             raise _lib.DepthcoreError("packed must be three (B,H,W,4) RGBx tensors (target, source -1, source +1)")
@@ -266,8 +273,11 @@ class _PhotoLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, T0, T1, *tensors):
         L = _lib.lib()
-        T0, T1 = _c(T0.detach()), _c(T1.detach())
-        nm = cfg.n_masks                      # the last `nm` tensors are the predictive masks (one per scale), else none
+        # tensors = disps..., [predictive masks (one per scale)], [per-scale poses (T_-1, T_+1 per scale)]
+        nm, nT = cfg.n_masks, cfg.n_Ts
+        Ts = [_c(x.detach()) for x in tensors[len(tensors) - nT:]] if nT else []
+        tensors = tensors[:len(tensors) - nT]
+        T0, T1 = (None, None) if nT else (_c(T0.detach()), _c(T1.detach()))
         disps = [_c(x.detach()) for x in tensors[:len(tensors) - nm]]
         masks = [_c(x.detach()) for x in tensors[len(tensors) - nm:]] if nm else []
         dev = cfg.target.device
@@ -275,7 +285,10 @@ class _PhotoLoss(torch.autograd.Function):
         ns = len(disps)
         # evaluation (nothing requires a gradient): the forward skips the gradient emission and its 24 B/pixel/scale
         ctx.no_grad = not any(ctx.needs_input_grad)
-        d = _fill_desc(cfg, T0, T1, disps, ctx.no_grad, masks)
+        # the all-the-way / split choice (dc_set_photo_full) is read ONCE, here, and pinned in the desc of the forward and of its
+        # backward: the workspace layout both derive cannot change between them whatever the setter does in the meantime
+        ctx.mode = _lib.OPT_PHOTO_FULL if L.dc_get_photo_full() else _lib.OPT_PHOTO_SPLIT
+        d = _fill_desc(cfg, T0, T1, disps, ctx.no_grad, masks, Ts, ctx.mode)
         wsz = L.dc_photo_workspace(ctypes.byref(d))
         ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
         d.workspace, d.workspace_bytes = ws.data_ptr(), wsz
@@ -300,31 +313,37 @@ class _PhotoLoss(torch.autograd.Function):
                     d.identity_selection[s] = ptr(ex["identity_selection"][s])
         check(L.dc_photo_fwd(ctypes.byref(d), stream(cfg.target)), "dc_photo_fwd")
         cfg.extras = ex
-        ctx.cfg, ctx.ws, ctx.argmin, ctx.nm = cfg, ws, argmin, nm
-        ctx.save_for_backward(T0, T1, *disps, *masks)
+        ctx.cfg, ctx.ws, ctx.argmin, ctx.nm, ctx.nT = cfg, ws, argmin, nm, nT
+        ctx.save_for_backward(*(() if nT else (T0, T1)), *disps, *masks, *Ts)
         return losses
 
     @staticmethod
     def backward(ctx, g_losses):
         L = _lib.lib()
         cfg = ctx.cfg
-        T0, T1, *rest = ctx.saved_tensors
+        rest = list(ctx.saved_tensors)
+        T0, T1 = (None, None) if ctx.nT else (rest.pop(0), rest.pop(0))
+        Ts = [rest.pop() for _ in range(ctx.nT)][::-1]
         disps, masks = (rest[:len(rest) - ctx.nm], rest[len(rest) - ctx.nm:]) if ctx.nm else (rest, [])
-        d = _fill_desc(cfg, T0, T1, disps, ctx.no_grad, masks)
+        d = _fill_desc(cfg, T0, T1, disps, ctx.no_grad, masks, Ts, ctx.mode)
         d.workspace, d.workspace_bytes = ctx.ws.data_ptr(), ctx.ws.numel()
         g = _c(g_losses.to(torch.float32))
         d.g_losses = ptr(g)
         d_disp = [torch.empty_like(x) for x in disps]
-        dT = [torch.empty_like(T0), torch.empty_like(T1)]
+        dT = [None, None] if ctx.nT else [torch.empty_like(T0), torch.empty_like(T1)]
+        dTs = [torch.empty_like(t) for t in Ts]
         for s in range(len(disps)):
             d.argmin[s] = ctx.argmin[s].data_ptr()
             d.d_disp[s] = ptr(d_disp[s])
-        d.d_T[0], d.d_T[1] = ptr(dT[0]), ptr(dT[1])
+            if ctx.nT:
+                d.d_T_scale[s][0], d.d_T_scale[s][1] = ptr(dTs[2 * s]), ptr(dTs[2 * s + 1])
+        if not ctx.nT:
+            d.d_T[0], d.d_T[1] = ptr(dT[0]), ptr(dT[1])
         d_masks = [torch.empty_like(m) for m in masks]
         for s in range(len(d_masks)):
             d.d_pred_mask[s] = ptr(d_masks[s])
         check(L.dc_photo_bwd(ctypes.byref(d), stream(cfg.target)), "dc_photo_bwd")
-        return (None, dT[0], dT[1], *d_disp, *d_masks)
+        return (None, dT[0], dT[1], *d_disp, *d_masks, *dTs)
 
 
 def pack_rgbx(x):
@@ -339,13 +358,17 @@ def pack_rgbx(x):
     return out
 
 
-def photometric_loss(cfg, T_m1, T_p1, disps, pred_masks=None):
+def photometric_loss(cfg, T_m1, T_p1, disps, pred_masks=None, T_scales=None):
     """-> losses tensor (num_scales+1,): [loss/0, ..., loss]  (trainer.py:618-621).
+    T_scales: `pose_model_type == "posecnn"` (trainer.py:490-499) -- a list of (T_-1, T_+1) pairs, one per scale, each built from
+    the translation scaled by that scale's mean inverse depth; replaces T_m1 / T_p1 (pass None) and each gets its own gradient.
     pred_masks: opt.predictive_mask (trainer.py:571-584, needs disable_automasking) -- one FULL-resolution (B,2,H,W) mask per
     scale (the caller upsamples, trainer.py:574-577); the reprojection losses are multiplied by them inside the kernels and
     the masks get their gradient.  The BCE weighting term (trainer.py:579-581) is not part of this op."""
     cfg.n_masks = len(pred_masks) if pred_masks else 0
-    return _PhotoLoss.apply(cfg, T_m1, T_p1, *disps, *(pred_masks or []))
+    flat_T = [t for pair in (T_scales or []) for t in pair]
+    cfg.n_Ts = len(flat_T)
+    return _PhotoLoss.apply(cfg, T_m1, T_p1, *disps, *(pred_masks or []), *flat_T)
 
 
 def photo_algorithmic_bytes(cfg, T0, T1, disps, backward):
@@ -782,8 +805,11 @@ class GradFork:
     conv1's output feeds it -- parks the skip's gradient here and reports NO gradient for its `res` input; conv1's backward
     picks it up and its data-gradient kernel adds it in the store epilogue (dc_wino3x3_dgrad_add / dc_conv1x1_dgrad_add), so
     x receives the complete gradient from conv1 alone.  One backward pass per forward (no double backward / retain_graph
-    replays): a fork that is asked twice, or whose parked gradient is never collected, raises."""
-    __slots__ = ("addend", "armed", "pair", "arrived")
+    replays): a fork that is asked twice, or whose parked gradient is never collected, raises -- the latter from
+    `assert_no_dangling_sums()` (a pair fork whose second reader never runs its backward, e.g. a ("disp", i > 0) output of
+    the depth decoder that is left out of the loss: the parked gradient would be lost silently otherwise)."""
+    __slots__ = ("addend", "armed", "pair", "arrived", "__weakref__")
+    _parked = weakref.WeakSet()
 
     def __init__(self, pair=False):
         self.addend = None
@@ -804,12 +830,14 @@ class GradFork:
         if not self.armed or self.addend is not None:
             raise _lib.DepthcoreError("GradFork: the skip gradient was produced twice (a second backward through the same block?)")
         self.addend = dres
+        GradFork._parked.add(self)
 
     def take(self):
         if not self.armed:
             raise _lib.DepthcoreError("GradFork: conv1's backward ran twice for one forward")
         self.armed = False
         a, self.addend = self.addend, None
+        GradFork._parked.discard(self)
         if self.pair and a is None:
             raise _lib.DepthcoreError("GradFork: the first convolution's data gradient was never parked")
         return a
@@ -856,8 +884,16 @@ def assert_no_dangling_sums():
     left = [s for s in SkipSum._pending if s.addend is not None]
     for s in left:
         s.take()
+    forks = [f for f in GradFork._parked if f.addend is not None]
+    for f in forks:
+        f.addend, f.armed = None, False
+        GradFork._parked.discard(f)
     if left:
         raise _lib.DepthcoreError("%d gradient(s) were handed to a SkipSum whose primary consumer never collected them" % len(left))
+    if forks:
+        raise _lib.DepthcoreError("%d gradient(s) were parked in a GradFork whose other reader never ran its backward (an output "
+                                  "of the fused decoder left out of the loss?): the gradient below that point is incomplete"
+                                  % len(forks))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -32,7 +32,7 @@ from layers import (BackprojectDepth, Project3D, SSIM, disp_to_depth, get_smooth
                     interpolate_bilinear, transformation_from_parameters)
 from depthcore import ops
 from depthcore.ops import WinoWeightCache
-from depthcore.ddp import GradBuckets, broadcast_parameters
+from depthcore.ddp import GradBuckets, agree_all, broadcast_parameters
 
 
 def default_options(**kw):
@@ -393,8 +393,12 @@ class Trainer:
             avg_reprojection=o.avg_reprojection, no_ssim=o.no_ssim, materialize=materialize, packed=packed,
             rng_seed=self._seed_dev if self._seed_dev is not None else self.step * 1000003 + self.rank)
         masks, bce = self._predictive_masks(outputs, full_res=True)
-        lv = ops.photometric_loss(cfg, outputs[("cam_T_cam", 0, -1)], outputs[("cam_T_cam", 0, 1)],
-                                  [outputs[("disp", s)] for s in o.scales], pred_masks=masks)
+        if o.pose_model_type == "posecnn":                       # trainer.py:490-499: one pose per (scale, frame)
+            lv = ops.photometric_loss(cfg, None, None, [outputs[("disp", s)] for s in o.scales], pred_masks=masks,
+                                      T_scales=self._posecnn_T_scales(outputs))
+        else:
+            lv = ops.photometric_loss(cfg, outputs[("cam_T_cam", 0, -1)], outputs[("cam_T_cam", 0, 1)],
+                                      [outputs[("disp", s)] for s in o.scales], pred_masks=masks)
         if masks is None:
             losses = {"loss/{}".format(s): lv[i] for i, s in enumerate(o.scales)}
             losses["loss"] = lv[len(o.scales)]
@@ -444,8 +448,13 @@ class Trainer:
                 max_depth=o.max_depth, smoothness=o.disparity_smoothness / (2 ** s), disable_automasking=o.disable_automasking,
                 avg_reprojection=o.avg_reprojection, no_ssim=o.no_ssim, materialize=materialize,
                 rng_seed=(self._seed_dev + i) if self._seed_dev is not None else self.step * 1000003 + self.rank + 7919 * i)
-            lv = ops.photometric_loss(cfg, outputs[("cam_T_cam", 0, -1)], outputs[("cam_T_cam", 0, 1)], [outputs[("disp", s)]],
-                                      pred_masks=None if masks is None else [masks[i]])
+            if o.pose_model_type == "posecnn":                   # trainer.py:490-499 at this scale's own resolution
+                _, depth = disp_to_depth(outputs[("disp", s)], o.min_depth, o.max_depth)
+                lv = ops.photometric_loss(cfg, None, None, [outputs[("disp", s)]], pred_masks=None if masks is None else [masks[i]],
+                                          T_scales=[tuple(self._posecnn_T(outputs, f, depth) for f in (-1, 1))])
+            else:
+                lv = ops.photometric_loss(cfg, outputs[("cam_T_cam", 0, -1)], outputs[("cam_T_cam", 0, 1)], [outputs[("disp", s)]],
+                                          pred_masks=None if masks is None else [masks[i]])
             losses["loss/{}".format(s)] = lv[0] if masks is None else lv[0] + bce[i]
             total = total + losses["loss/{}".format(s)]
             ex = cfg.extras
@@ -462,6 +471,25 @@ class Trainer:
         losses["loss"] = total / self.num_scales
         return losses
 
+    def _posecnn_T(self, outputs, frame_id, depth):
+        """trainer.py:490-499 (`pose_model_type == "posecnn"`, after arXiv:1712.00175): the predicted translation is rescaled by
+        the mean inverse depth of THIS scale's (upsampled) depth map and the pose matrix rebuilt from it."""
+        inv_depth = 1 / depth
+        mean_inv_depth = inv_depth.mean(3, True).mean(2, True)
+        return transformation_from_parameters(
+            outputs[("axisangle", 0, frame_id)][:, 0], outputs[("translation", 0, frame_id)][:, 0] * mean_inv_depth[:, 0],
+            frame_id < 0)
+
+    def _posecnn_T_scales(self, outputs):
+        """The per-scale pose pairs of the fused loss in posecnn mode: depth of scale s = disp_to_depth(upsampled disp_s), as
+        generate_images_pred forms it."""
+        o, pairs = self.opt, []
+        for s in o.scales:
+            disp = interpolate_bilinear(outputs[("disp", s)], [o.height, o.width])
+            _, depth = disp_to_depth(disp, o.min_depth, o.max_depth)
+            pairs.append(tuple(self._posecnn_T(outputs, f, depth) for f in (-1, 1)))
+        return pairs
+
     # ------------------------------------------------------------------ trainer.py:465-515
     def generate_images_pred(self, inputs, outputs):
         o = self.opt
@@ -475,6 +503,8 @@ class Trainer:
             outputs[("depth", 0, scale)] = depth
             for frame_id in (-1, 1):
                 T = outputs[("cam_T_cam", 0, frame_id)]
+                if o.pose_model_type == "posecnn":                # trainer.py:490-499
+                    T = self._posecnn_T(outputs, frame_id, depth)
                 cam_points = self.backproject_depth[source_scale](depth, inputs[("inv_K", source_scale)])
                 pix_coords = self.project_3d[source_scale](cam_points, inputs[("K", source_scale)], T)
                 outputs[("sample", frame_id, scale)] = pix_coords
@@ -631,13 +661,18 @@ class Trainer:
                 # its watchdog only ever queries events of an eager stream; the capture group's watchdog has nothing to query,
                 # since torch does not enqueue collectives issued during a capture.  A condition, not a sleep.)
                 cap_pg = self._capture_group()
-                if cap_pg is None:           # no communicator without a collective on this stack: this trainer stays eager
+                # (the decision is COLLECTIVE: a rank that stays eager on the base group while the others replay graphs on the
+                # capture group would leave both sides waiting on communicators the other never enters)
+                if not self._agree(cap_pg is not None):     # no communicator without a collective on some rank: all stay eager
                     self.graph_enabled = False
                     return self._eager_on_graph_stream(inputs)
             g = torch.cuda.CUDAGraph()
             step0 = self.step
             stream0 = torch.cuda.current_stream(self.device)
+            err = None
             try:
+                if self._fail_capture_for_test():
+                    raise RuntimeError("capture failure forced by DC_TEST_FAIL_CAPTURE_RANK")
                 # (world > 1: RCCL's watchdog thread polls events while we capture -- legal, but only in thread-local mode)
                 mode = {} if self.world_size == 1 else {"capture_error_mode": "thread_local"}
                 pg0 = self.buckets.pg
@@ -651,10 +686,9 @@ class Trainer:
             except Exception as e:       # a launch refused inside the capture, or the capture was invalidated
                 # Nothing of a captured step has run (capture records, it does not execute): host state is rolled back, the
                 # shape is marked eager-only and the step is done eagerly -- a failed capture costs speed, never the process.
-                import warnings
                 from depthcore import _lib
+                err = e
                 self.step = step0
-                self._graphs[key] = None
                 self._graph_failed = getattr(self, "_graph_failed", 0) + 1
                 torch.cuda.set_stream(stream0)          # (torch.cuda.graph.__exit__ does not restore it when capture_end raises)
                 # an invalidated capture leaves its origin stream capturing (every later launch on it would fail): end it
@@ -668,8 +702,21 @@ class Trainer:
                     torch._C._cuda_releasePool(self.device.index or 0, g.pool())
                 except Exception:
                     pass
+            # World > 1: the outcome is agreed over the ranks (on the eager base group, outside any capture).  If the capture failed
+            # anywhere, every rank discards its graph for this shape and all of them run it eagerly on the base group -- the
+            # replays' collectives live on the capture group, the eager steps' on the base group, and mixed ranks never meet.
+            if self.world_size > 1 and err is None:
+                torch.cuda.synchronize(self.device)
+            if not self._agree(err is None) and err is None:
+                err = RuntimeError("the capture failed on another rank")
+                self.step = step0
+                self._graph_agreed_off = getattr(self, "_graph_agreed_off", 0) + 1
+                g.reset()
+            if err is not None:
+                import warnings
+                self._graphs[key] = None
                 warnings.warn("hip_graph: capture of the training step failed (%s: %s); this input shape runs eagerly"
-                              % (type(e).__name__, e))
+                              % (type(err).__name__, err))
                 try:
                     torch.cuda.synchronize(self.device)
                     return self._eager_on_graph_stream(inputs)
@@ -677,7 +724,7 @@ class Trainer:
                     # an ILLEGAL call inside the capture (a synchronisation, an allocation by foreign code) can leave the HIP
                     # runtime's capture state beyond repair for this process: say so instead of failing somewhere else
                     raise RuntimeError("hip_graph: the capture failed (%s: %s) and the streams could not be recovered (%s: %s); "
-                                       "run without opt.hip_graph" % (type(e).__name__, e, type(e2).__name__, e2)) from e
+                                       "run without opt.hip_graph" % (type(err).__name__, err, type(e2).__name__, e2)) from err
             entry = self._graphs[key] = (g, static_in, static_out)
             self.step -= 1                      # (the recorded step has not run yet: the replay below is that step)
         else:
@@ -688,6 +735,18 @@ class Trainer:
         entry[0].replay()
         self.step += 1
         return entry[2]                       # static tensors: rewritten by every replay of this graph
+
+    def _agree(self, ok):
+        """`ok` made collective over the gradient exchange's ranks (depthcore.ddp.agree_all on the EAGER base group); plain `ok`
+        at world size 1."""
+        if self.world_size == 1:
+            return bool(ok)
+        return agree_all(ok, self.buckets.pg, self.device)
+
+    def _fail_capture_for_test(self):
+        """tests/ddp_graph_child.py: DC_TEST_FAIL_CAPTURE_RANK=<rank> makes that rank's first capture attempt fail."""
+        r = os.environ.get("DC_TEST_FAIL_CAPTURE_RANK")
+        return r is not None and int(r) == self.rank and not getattr(self, "_graph_failed", 0)
 
     def _capture_group(self):
         """The process group of the captured steps' collectives: same ranks as the gradient exchange's group, RCCL, its
@@ -751,6 +810,13 @@ class Trainer:
         """Drop the captured graphs (they name the weight cache's buffers) and this trainer's cache registrations."""
         self.reset_graphs()
         self.wino_cache.close()
+        if self._capture_pg:                    # the capture-only communicator (one per trainer that captured at world > 1)
+            import torch.distributed as dist
+            try:
+                dist.destroy_process_group(self._capture_pg)
+            except Exception:
+                pass
+            self._capture_pg = None
 
     def _train_step_eager(self, inputs):
         self.wino_cache.refresh()               # every 3x3 weight -> Winograd domain, one launch per step

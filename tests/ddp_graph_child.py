@@ -5,6 +5,8 @@ cannot be captured on some stack must fail this test, not take the whole test se
 live; the mean over one rank is the local gradient).  An eager DDP trainer and a graph-mode DDP trainer start from the same
 state and see the same batches: the captured step -- both compute streams, the backward with its hooks' all-reduces recorded on
 the communication stream in bucket order, finish(), Adam -- must replay to the eager trainer's losses and weights.
+DC_TEST_FAIL_CAPTURE_RANK=0 forces the graph trainer's first capture attempt to fail: the outcome is agreed over the ranks
+(depthcore.ddp.agree_all on the eager base group) and the steps go on eagerly on that group.
 Prints one JSON line."""
 import json
 import os
@@ -42,12 +44,13 @@ def main():
             torch.cuda.synchronize()
             w = torch.cat([p.detach().flatten() for p in tr.parameters_to_train])
             runs[name] = dict(losses=losses, w=w.clone(), captured=tr._graph is not None, failed=getattr(tr, "_graph_failed", 0),
+                              agreed_off=getattr(tr, "_graph_agreed_off", 0), had_capture_pg=bool(tr._capture_pg),
                               host_ms=[round(h * 1e3, 3) for h in host], launch_order=list(tr.buckets.launch_order),
                               packed=tr.buckets.packed)
             tr.close()
         e, g = runs["eager"], runs["graph"]
         out = dict(eager_losses=e["losses"], graph_losses=g["losses"], captured=g["captured"], capture_failed=g["failed"],
-                   eager_captured=e["captured"], host_ms_eager=e["host_ms"], host_ms_graph=g["host_ms"],
+                   eager_captured=e["captured"], agreed_off=g["agreed_off"], had_capture_pg=g["had_capture_pg"], host_ms_eager=e["host_ms"], host_ms_graph=g["host_ms"],
                    weight_rel_diff=float((e["w"] - g["w"]).norm() / e["w"].norm()),
                    weight_max_abs_diff=float((e["w"] - g["w"]).abs().max()), launch_order=g["launch_order"], packed=g["packed"])
     finally:

@@ -129,3 +129,36 @@ def test_two_rank_gradient_mean():
     for rank in range(world):
         for a, b in zip(res[rank], want):
             assert torch.allclose(torch.from_numpy(a), b, rtol=1e-5, atol=1e-7)
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from depthcore.ddp import agree_all
+    res = [agree_all(True), agree_all(rank != 1), agree_all(rank == 1), agree_all(False)]
+    sub = dist.new_group(ranks=[0, 1])
+    res.append(agree_all(rank == 0, sub))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_agree_all_is_the_minimum_over_the_ranks():
+    """The collective yes/no behind Trainer.train_step's capture decisions: one rank's "no" is everybody's."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == [True, False, False, False, False]
+
+
+def test_agree_all_without_a_process_group_is_the_local_answer():
+    from depthcore.ddp import agree_all
+    assert agree_all(True) is True and agree_all(False) is False

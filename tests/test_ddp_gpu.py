@@ -151,6 +151,48 @@ def test_graph_mode_with_bucketed_exchange_over_rccl():
     print("host ms per step: eager DDP %s | graph DDP %s" % (d["host_ms_eager"], d["host_ms_graph"]))
 
 
+def test_graph_mode_capture_failure_is_agreed_over_the_ranks_and_falls_back_to_eager():
+    """with the captured collectives on a group of their own, a capture that fails on ONE rank must turn every
+    rank eager (the decision is an all-reduce(MIN) on the eager base group), or the ranks wait on different communicators.  Here
+    on the one GPU a box has: the graph trainer's capture is forced to fail (DC_TEST_FAIL_CAPTURE_RANK=0), the flag travels
+    through the 1-rank RCCL group, the shape is marked eager-only, and the run follows the eager trainer step for step; the
+    capture-only communicator is destroyed by close().  (Two ranks, one failing: tests/test_ddp_cpu.py on gloo for the
+    agreement, test_two_gpus_capture_failure_on_one_rank below for the whole path on a multi-GPU box.)"""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), DC_TEST_FAIL_CAPTURE_RANK="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(here, "ddp_graph_child.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stderr[:4000], r.stderr[-2000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert not d["captured"] and d["capture_failed"] == 1 and d["had_capture_pg"], d
+    el, gl = d["eager_losses"], d["graph_losses"]
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(el, gl)), (el, gl)     # eager all the way: the same kernels
+    assert d["weight_rel_diff"] <= 1e-6, d["weight_rel_diff"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: runs by itself on a multi-GPU box")
+def test_two_gpus_capture_failure_on_one_rank():
+    """Two real ranks over RCCL, graph mode, rank 1's capture forced to fail: both ranks must finish (no hang on mismatched
+    communicators), both eager, replicas identical (bench.py's own divergence guard)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(_free_port()), DC_TEST_FAIL_CAPTURE_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DC_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "5", "--graph",
+                        "--batch", "2", "--height", "64", "--width", "128", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: runs by itself on a multi-GPU box")
 def test_two_gpus_bench_step_over_rccl():
     """`bench.py --gpus 2` on two real GPUs over RCCL/xGMI (fresh child processes, one rank per GPU): one JSON line, the

@@ -79,3 +79,26 @@ def test_pair_fork_of_bottleneck_with_downsample_equals_autograd_sum(shape, plan
     assert torch.equal(gx1, gx0), float((gx1 - gx0).abs().max())
     for n in gp0:
         assert torch.equal(gp1[n], gp0[n]), n
+
+
+def test_decoder_output_left_out_of_the_loss_is_reported_not_lost():
+    """the depth decoder's pair fork between dispconv(i) and upconv(i-1, 0) assumes both backwards run.  A loss
+    that uses only the finest scale leaves a parked gradient nobody collects: `assert_no_dangling_sums()` (the
+    Trainer calls it after every backward) must raise instead of letting the levels below train on an incomplete gradient; a loss
+    over every scale passes."""
+    import numpy as np
+    import networks
+    from depthcore import ops
+    from depthcore._lib import DepthcoreError
+    torch.manual_seed(0)
+    nce = np.array([64, 64, 128, 256, 512])
+    dec = networks.DepthDecoder(nce).to(DEV).train()
+    feats = [torch.randn(2, c, 64 >> (i + 1), 128 >> (i + 1), device=DEV).requires_grad_() for i, c in enumerate(nce)]
+    out = dec([f * 1.0 for f in feats])
+    sum(out[("disp", s)].mean() for s in range(4)).backward()
+    ops.assert_no_dangling_sums()                                  # every reader ran: nothing parked
+    out = dec([f * 1.0 for f in feats])
+    out[("disp", 0)].mean().backward()                             # scales 1..3 left out: dispconv(1..3) never run backward
+    with pytest.raises(DepthcoreError, match="GradFork"):
+        ops.assert_no_dangling_sums()
+    ops.assert_no_dangling_sums()                                  # (reported once, then cleared)

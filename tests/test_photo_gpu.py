@@ -324,3 +324,49 @@ def test_all_the_way_forward_equals_the_split_chain(shape, ext_noise, materializ
         close_frac(res[1][2][s], res[0][2][s], rtol=1e-3, atol=0, atol_rel=1e-3, bad=1e-3, msg="gdisp%d" % s)
     for f in range(2):
         assert rel_l2(res[1][3][f][:, :3, :], res[0][3][f][:, :3, :]) < 1e-4, f
+
+
+@pytest.mark.parametrize("fwd_mode", [1, 0])
+def test_photo_mode_is_pinned_at_the_forward(fwd_mode):
+    """dc_set_photo_full toggled BETWEEN a forward and its backward (another thread, a test fixture): the op read the mode once at
+    the forward and pinned it in both descs (DC_OPT_PHOTO_FULL / DC_OPT_PHOTO_SPLIT), so the backward carves the workspace the
+    forward wrote -- gradients bit-identical to an undisturbed run; a desc carrying both bits is refused."""
+    import ctypes
+    from depthcore import _lib, ops
+    b, h, w = 2, 64, 96
+    inputs = R.synthetic_inputs(b, h, w, seed=5)
+    g = torch.Generator().manual_seed(17)
+    disps = [torch.rand(b, 1, h >> s, w >> s, generator=g) for s in range(4)]
+    Ts = random_poses(b, 8)
+    noise = R.tiebreak_noise(b, h, w)
+    L = _lib.lib()
+    prev = L.dc_set_photo_full(fwd_mode)
+    try:
+        want = hip_photo(inputs, disps, Ts, noise)
+        dev = torch.device("cuda:0")
+        cfg = ops.PhotoConfig(
+            inputs[("color", 0, 0)].to(dev), inputs[("color", -1, 0)].to(dev), inputs[("color", 1, 0)].to(dev),
+            [inputs[("color", 0, s)].to(dev) for s in range(4)], inputs[("K", 0)].to(dev), inputs[("inv_K", 0)].to(dev),
+            noise=[n.to(dev) for n in noise])
+        d = [x.to(dev).requires_grad_() for x in disps]
+        t = [x.to(dev).requires_grad_() for x in Ts]
+        losses = ops.photometric_loss(cfg, t[0], t[1], d)
+        L.dc_set_photo_full(1 - fwd_mode)            # ... the setter moves under the op's feet
+        grads = torch.autograd.grad(losses[4], d + t)
+        torch.cuda.synchronize()
+    finally:
+        L.dc_set_photo_full(prev)
+    for a, c in zip(grads[:4], want[2]):
+        assert torch.equal(a, c)
+    for a, c in zip(grads[4:], want[3]):
+        assert torch.equal(a, c)
+    ws = torch.empty(1 << 26, dtype=torch.uint8, device=dev)
+    lo = torch.empty(5, device=dev)
+    am = [torch.empty(b, h, w, dtype=torch.uint8, device=dev) for _ in range(4)]
+    for mode, rc in ((_lib.OPT_PHOTO_FULL, 0), (_lib.OPT_PHOTO_FULL | _lib.OPT_PHOTO_SPLIT, -1)):      # -1 = DC_EINVAL
+        desc = ops._fill_desc(cfg, t[0].detach(), t[1].detach(), [x.detach() for x in d], mode=mode)
+        desc.workspace, desc.workspace_bytes, desc.losses = ws.data_ptr(), ws.numel(), lo.data_ptr()
+        for s in range(4):
+            desc.argmin[s] = am[s].data_ptr()
+        assert L.dc_photo_fwd(ctypes.byref(desc), None) == rc
+    torch.cuda.synchronize()

@@ -10,7 +10,10 @@ import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "photo_bwdg_kernel" in r["Kernel_Name"]]
+# one launch per step in every mode (Adam over the flat parameter list), as tools/step_census.py marks steps
+marks = [i for i, r in enumerate(rows) if "adam_apply" in r["Kernel_Name"] and (i == 0 or "adam_apply" not in rows[i - 1]["Kernel_Name"])]
+if len(marks) < 2:
+    sys.exit("prof_step: fewer than two adam_apply launches in the trace (%d): no step boundary to cut at" % len(marks))
 a, b = marks[-2], marks[-1]
 wall = (int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e6
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[a:b]) / 1e6
