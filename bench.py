@@ -52,14 +52,19 @@ FAMILIES = {
     2: ("dc::c3b_conv_kernel (direct 3x3 convolution on the bf16 matrix cores, fp32 tensors in HBM: forward + data gradient)", "hbm"),
     3: ("dc::c3b_wgrad_kernel (3x3 weight gradient on the bf16 matrix cores, transposed LDS reads, fp32 tensors in HBM)", "hbm"),
     4: ("dc::g1_* (1x1 convolutions as NCHW fp32-MFMA GEMMs: forward, data gradient, weight gradient)", "mfma"),
+    5: ("dc::cg_* (3x3 stride-2 convolutions as implicit fp32-MFMA GEMMs: forward, data gradient split by output parity, weight "
+        "gradient; main kernels, without the slab sums)", "mfma"),
+    6: ("dc::stem_* (7x7 stride-2 stem, patch-staged fp32-MFMA: forward and weight gradient incl. the input normalisation and "
+        "the pose pairs' concat in the loader)", "mfma"),
 }
 VALU_LANE_OPS_PEAK = 78.6e12   # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: wave-level VALU instructions x 64 lanes per second
-# Issue slots per counted VALU instruction of the photometric kernels' main loops (tools/isa_mix.py on the gfx950 ISA, kept in
-# profiles/round4_photo_isa_mix.txt): SQ_INSTS_VALU counts a packed-fp32 or a transcendental instruction once, the SIMD-32 issues
-# them over twice the cycles (MI355X_MICROARCH.md "vector-instruction ISSUE cost").  Training forward (photo_fwdg_kernel<false, 4>):
-# 1076 plain + 168 DPP + 21 lane + 2 x (318 packed + 24 transcendental) = 1949 slots per 1607 instructions; pointwise backward
-# (photo_bwdg_kernel): 387 + 4 + 2 x (80 + 12) = 575 per 483.
-VALU_SLOTS_PER_INST = {"bwd": 575.0 / 483.0, "fwd": 1949.0 / 1607.0}
+# Issue slots per counted VALU instruction of the photometric kernels' main loops (tools/isa_mix.py on the gfx950 ISA of THIS
+# tree's kernels, kept in profiles/round6_photo_isa_mix.txt): SQ_INSTS_VALU counts a packed-fp32 or a transcendental instruction
+# once, the SIMD-32 issues them over twice the cycles (MI355X_MICROARCH.md "vector-instruction ISSUE cost").  Training forward,
+# the all-the-way instantiation that is timed (photo_fwdg_kernel<false, 4, true>, two rows per loop trip): 1235 plain + 168 DPP +
+# 18 lane + 2 x (342 packed + 28 transcendental) = 2161 slots per 1791 instructions; backward chain (disp_grad_kernel):
+# 143 plain + 2 x (11 packed + 2 transcendental) = 169 per 156.
+VALU_SLOTS_PER_INST = {"bwd": 169.0 / 156.0, "fwd": 2161.0 / 1791.0}
 
 
 # ------------------------------------------------------------------------------------------------ launcher (N > 1)
@@ -294,7 +299,7 @@ def _traffic_for(cfg_key):
     """HBM bytes per launch from the PMC passes kept under profiles/ (separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc
     WRITE_SIZE` runs, tools/pmc_traffic.sh; FETCH_SIZE x2.0 per the gfx950 calibration, WRITE_SIZE x1.0).  They are
     CITED, not measured in this run: a PMC pass serialises the step and cannot share a process with the timed region."""
-    for name in ("round5_traffic_%s.json" % cfg_key, "round4_traffic_%s.json" % cfg_key, "round3_traffic_%s.json" % cfg_key):
+    for name in ("round6_traffic_%s.json" % cfg_key, "round5_traffic_%s.json" % cfg_key, "round4_traffic_%s.json" % cfg_key):
         if not name:
             continue
         tf = os.path.join(REPO, "profiles", name)
@@ -344,13 +349,20 @@ def run_rank(args):
     elif args.front == "fusion":     # BASELINE configs[4]: frames [-2, -1, 0] stacked through encoder + decoder, then Fusion_v3
         front = dict(fusion="v3", frame_ids=[0, -2, -1, 1])
     opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
-                            nets_dtype=args.nets_dtype, torch_adam=args.torch_adam,
+                            nets_dtype=args.nets_dtype,
                             cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap,
                             wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph),
                             wgrad_lanes=int(args.wgrad_lanes), **front)
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    if args.bucket_mb > 0:
+        opt.bucket_mb = args.bucket_mb
     tr = T.Trainer(opt, device=device, rank=rank, world_size=world)
     tr.set_train()
+    dist_info = None
+    if world > 1:        # who is really in the group: every rank reports (rank, device ordinal, device name)
+        mine = (rank, local, torch.cuda.get_device_name(device))
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        dist_info = {"ranks": dist.get_world_size(), "devices": [list(e) for e in sorted(everyone)]}
     if args.front == "gru":
         from depthcore.synthetic import synthetic_sequence_batch
         inputs = synthetic_sequence_batch(args.len_sequence, args.height, args.width, device, seed=100 + rank)
@@ -384,7 +396,9 @@ def run_rank(args):
     # the workspaces, fill the allocator's pools and meet the weight-cache variants (refreshed from the second step on); with a
     # small W they would otherwise reach into the timed region (and the clocks of a GPU that was idle a moment ago are still ramping:
     # the first 20-step window after 3 + 5 steps read 11.26 / 11.58 ms where the following ones read 11.20-11.25).  config.setup_steps.
-    SETUP_STEPS = int(os.environ.get("DC_BENCH_SETUP", "12"))
+    # Default 0 since round 6: the headline follows the contract's protocol -- W warm-up steps, then K timed ones --
+    # as BENCH_r01..r04 did; the steady state is reported beside it (`steady_state_ms_per_step`: median of the later windows).
+    SETUP_STEPS = int(os.environ.get("DC_BENCH_SETUP", "0"))
     for _ in range(SETUP_STEPS):
         _, losses = tr.train_step(inputs)
         loss0 = losses["loss"].detach().clone() if loss0 is None else loss0
@@ -426,6 +440,23 @@ def run_rank(args):
     ops.conv_profile_enable(0, 1)
 
     # ---- wall split of a step: forward / backward / exposed exchange / Adam (host-synchronised, after the timed region)
+    # per-bucket timeline of the exchange (world > 1): one pipelined eager step with event pairs around every bucket's all-reduce
+    bucket_order, bucket_offsets_ms = [], None
+    if world > 1:
+        from depthcore.ddp import bucket_timeline
+        tr.buckets.timing = True
+        _o, _l = tr.process_batch(inputs)
+        tr.buckets.zero()
+        _l["loss"].backward()
+        tr.buckets.finish()
+        tr.model_optimizer.step()
+        tr.step += 1
+        torch.cuda.synchronize()
+        tl = bucket_timeline(tr.buckets)
+        tr.buckets.timing = False
+        bucket_order = [b for b, _, _, _ in tl]
+        bucket_offsets_ms = [{"bucket": b, "bytes": nb, "starts_ms_after_backward_start": t0, "all_reduce_ms": d} for b, nb, t0, d in tl]
+        del _o, _l
     PH = 4
     ph = [0.0, 0.0, 0.0, 0.0]
     for _ in range(PH):
@@ -562,7 +593,8 @@ def run_rank(args):
         fams.sort(key=lambda e: -e["ms_per_step"])
         dom = dict(fams[0]) if fams else {"kernel": None, "bound": "mfma", "achieved": 0.0, "peak": MFMA_F32_PEAK_TFLOPS,
                                           "unit": "TFLOP/s", "frac": 0.0}
-        dom_key = {0: "dc::wino_ps_kernel", 1: "dc::wino_wgrad_kernel", 2: "dc::c3b_conv_kernel", 3: "dc::c3b_wgrad_kernel", 4: "dc::g1_*"}.get(dom.get("family"))
+        dom_key = {0: "dc::wino_ps_kernel", 1: "dc::wino_wgrad_kernel", 2: "dc::c3b_conv_kernel", 3: "dc::c3b_wgrad_kernel", 4: "dc::g1_*",
+                   5: "dc::cg_*", 6: "dc::stem_*"}.get(dom.get("family"))
         # ---- BASELINE metric 2: the fused warp + SSIM + smoothness kernels against HBM.  Round 4 moved the SSIM derivative, its
         # transposed 3x3 spread and the contraction with d(warped)/d(coords) into the TRAINING FORWARD; round 5 lets it go all the
         # way (dc::photo_fwdg_kernel<.., FULL>: Project3D / BackprojectDepth / disp_to_depth backward and the pose sums in the
@@ -606,7 +638,7 @@ def run_rank(args):
             "limiter": "the training forward is VALU-issue bound (3 waves per SIMD at 167 VGPRs: loads issued behind stage B, the "
                        "projection backward and the 18 pose accumulators in stage C); the transposed upsample is latency / HBM bound",
             "valu_note": "SQ_INSTS_VALU per launch (cited PMC pass) x issue slots per instruction from the ISA mix "
-                         "(profiles/round4_photo_isa_mix.txt); 2 cycles per slot per SIMD-32"})
+                         "(profiles/round6_photo_isa_mix.txt); 2 cycles per slot per SIMD-32"})
         out = {
             "metric": "training images/sec at %dx%d bs%d (resnet%d depth+pose, 4-scale photometric+smoothness)"
                       % (args.height, args.width, args.batch, args.num_layers),
@@ -617,6 +649,7 @@ def run_rank(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.nets_dtype == "f32" else "bf16-nets/f32-loss", "data": "synthetic",
             "windows_ms_per_step": [round(w, 3) for w in windows],
+            "steady_state_ms_per_step": round(sorted(windows[1:])[len(windows[1:]) // 2], 3) if len(windows) > 1 else None,
             "config": {"workload": "%sresnet%d depth+pose, %dx%d, per-GPU batch %d, 4 scales, "
                                    "frames {0,-1,+1}, automasking, Adam lr 1e-4; random-init weights"
                                    % (label, args.num_layers, args.height, args.width, args.batch),
@@ -632,7 +665,10 @@ def run_rank(args):
                        "streams": ("depth and pose branches on two HIP streams" if tr.opt.overlap_streams else "one HIP stream")
                                   + ("; weight-gradient kernels on a companion stream of each (opt.wgrad_lanes)" if tr.wgrad_lanes else "")},
             "roofline": dict(dom, **{
-                         "traffic": tr_bytes(dom_key) if dom_key else None, "traffic_source": traffic_src if dom_key and tr_bytes(dom_key) else None,
+                         # HBM bytes per launch from the PMC counters: CITED from the separate `rocprofv3 --pmc` passes kept under
+                         # profiles/ (a counter pass serialises the step and cannot share a process with the timed region)
+                         "traffic": tr_bytes(dom_key) if dom_key else None, "traffic_cited": bool(dom_key and tr_bytes(dom_key)),
+                         "traffic_source": traffic_src if dom_key and tr_bytes(dom_key) else None,
                          "measured_in": roof_src,
                          "selection": "the instrumented kernel family with the largest GPU time per step; all of them under `families`",
                          "timed_region_note": "two-stream overlap: a launch shares the GPU with the other branch's kernels "
@@ -653,6 +689,13 @@ def run_rank(args):
             "grad_buckets": len(tr.buckets.buckets) if world > 1 else 0,
             "grads_packed_by_copy_per_step": packed if world > 1 else 0,
             "dist_backend": (backend if world > 1 else None),
+            # what the exchange actually ran on (checkable against the driver's launch): ranks the process group connected, the
+            # device ordinal of every rank, the buckets in launch order with their bytes, and the communicator settings in effect
+            "rccl_ranks": dist_info["ranks"] if world > 1 else None,
+            "rank_devices": dist_info["devices"] if world > 1 else None,
+            "grad_bucket_bytes_in_launch_order": [tr.buckets.flat[b].numel() * 4 for b in bucket_order] if world > 1 else None,
+            "grad_bucket_launch_ms_after_backward_start": bucket_offsets_ms if world > 1 else None,
+            "rccl_env": {k: os.environ[k] for k in sorted(os.environ) if k.startswith(("NCCL_", "RCCL_"))} if world > 1 else None,
         }
         if world > 1 and (backend != "nccl" or args.oversubscribe):
             out["rehearsal"] = "backend %s%s: not an RCCL/xGMI measurement" % (backend, ", ranks share GPUs" if args.oversubscribe else "")
@@ -677,11 +720,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-probe", type=int, default=0, help="internal: child process of cpu_baseline (one B=1 oracle step at N threads)")
     ap.add_argument("--cpu-noise", action="store_true", help="reference-style CPU randn tie-break noise + H2D copy")
-    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--front", choices=["none", "gru", "fusion"], default="none",
                     help="sequence front-end: gru = ConvGRU v5 (configs[3], batch 1 x --len-sequence frames), fusion = Fusion_v3 (configs[4])")
     ap.add_argument("--len-sequence", type=int, default=3)
-    ap.add_argument("--torch-adam", action="store_true", help="A/B: ATen's fused Adam instead of dc_adam_step")
     ap.add_argument("--nets-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: the reduced-precision-networks policy of BASELINE configs[4] (convolution operands rounded to bf16 "
                          "for the matrix cores, fp32 accumulate; tensors, master weights, BatchNorm and the loss stay fp32); "
@@ -697,7 +738,18 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: let ranks share GPUs (use with DC_DIST_BACKEND=gloo)")
     ap.add_argument("--rehearse", action="store_true", help="rehearsal: CPU stand-in step over gloo (launcher / exchange plumbing only)")
+    ap.add_argument("--rccl-algo", default=None, help="world > 1: NCCL_ALGO for the gradient exchange (Ring | Tree; RCCL's own choice "
+                    "when absent).  xGMI is point-to-point (7 links per GPU): DESIGN 4 'exchange budget' prices ring vs direct")
+    ap.add_argument("--rccl-proto", default=None, help="world > 1: NCCL_PROTO (Simple | LL | LL128)")
+    ap.add_argument("--rccl-channels", type=int, default=0, help="world > 1: NCCL_MIN_NCHANNELS (0: RCCL's default)")
+    ap.add_argument("--bucket-mb", type=float, default=0.0, help="world > 1: gradient bucket size in MB (0: opt.bucket_mb's default, 32)")
     args = ap.parse_args()
+    # communicator settings are environment variables read when the process group connects: set them here, before any rank starts
+    # (the launcher's children inherit them; under torchrun every rank parses the same flags before init_process_group)
+    for flag, var in ((args.rccl_algo, "NCCL_ALGO"), (args.rccl_proto, "NCCL_PROTO"),
+                      (str(args.rccl_channels) if args.rccl_channels > 0 else None, "NCCL_MIN_NCHANNELS")):
+        if flag:
+            os.environ[var] = flag
     if args.cpu_probe > 0:
         return cpu_probe(args.cpu_probe, args.height, args.width, args.num_layers)
     from depthcore import _lib as _dc_lib

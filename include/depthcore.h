@@ -118,6 +118,10 @@ int dc_grid_sample_bwd(const float* img, const float* grid, const float* g_out, 
 
 /* ------------------------------------------------------------------ a10 */
 /* F.interpolate(x, [Ho,Wo], mode="bilinear", align_corners=False) (trainer.py:474-475), x (B,C,h,w). */
+/* upsample(x) = F.interpolate(x, scale_factor=2, mode="nearest") (layers.py:196-199): (BC,h,w) -> (BC,2h,2w); backward = 2x2 block sums.
+ * (The depth decoder does not call it: its nearest-x2 is folded into dc_conv3x3_fwd's loader.) */
+int dc_upsample_nearest2x_fwd(const float* x, float* out, int BC, int h, int w, void* stream);
+int dc_upsample_nearest2x_bwd(const float* g_out, float* d_x, int BC, int h, int w, void* stream);
 int dc_upsample_bilinear_fwd(const float* x, float* out, int BC, int h, int w, int Ho, int Wo, void* stream);
 int dc_upsample_bilinear_bwd(const float* g_out, float* d_x, int BC, int h, int w, int Ho, int Wo,
                              void* stream);

@@ -24,6 +24,7 @@
 #include "dc_common.h"
 #include "conv_bf16.h"
 #include "gemm_tiles.h"
+#include "wino.h"
 
 #include <stdlib.h>
 
@@ -958,7 +959,10 @@ extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void
     if (stem_ok(Ci, Co, ksize)) {
         StemArgs sa = stem_args(B, Ci, Co, Hi, Wi);
         sa.x = x; sa.w = a.w; sa.out = y;
+        hipEvent_t pe = conv_prof_begin(6, 2.0 * B * (double)Co * a.K * a.Ho * a.Wo, 2.0 * B * (double)Co * sa.Kp * a.Ho * a.Wo,
+                                        4.0 * ((double)B * Ci * Hi * Wi + (double)B * Co * a.Ho * a.Wo + (double)Co * a.K), st);
         hipLaunchKernelGGL(stem_fwd_kernel<false>, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(Ci, sa.Kp), st, sa);
+        conv_prof_end(pe, st);
         DC_CHECK_LAUNCH();
         return DC_OK;
     }
@@ -972,8 +976,12 @@ extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void
         static const bool attr3 = cg_set_lds(cg_fwd3_kernel<2, 4>, ((size_t)64 * (96 + RP) + (size_t)96 * 128) * sizeof(float));
         if (!attr3) return DC_ELAUNCH;
         const dim3 grid(a.mtiles * a.ntiles, sp);
+        // 2 MAC of the convolution; executed = the padded 64 x (32 nt) tiles over the whole reduction
+        hipEvent_t pe = conv_prof_begin(5, 2.0 * (double)N * Co * a.K, 2.0 * (double)a.mtiles * 64.0 * (double)a.ntiles * 32.0 * t.nt * a.K,
+                                        4.0 * ((double)B * Ci * Hi * Wi + (double)N * Co + (double)Co * a.K), st);
         if (t.nt == 4) hipLaunchKernelGGL((cg_fwd3_kernel<2, 4>), grid, dim3(256), lds3, st, a);
         else hipLaunchKernelGGL((cg_fwd3_kernel<2, 2>), grid, dim3(256), lds3, st, a);
+        conv_prof_end(pe, st);
         DC_CHECK_LAUNCH();
         if (sp > 1) {
             const size_t n4 = (size_t)B * Co * a.Ho * a.Wo / 4;
@@ -1026,8 +1034,11 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
         StemArgs sa = stem_args(B, Ci, Co, Hi, Wi);
         sa.x = x; sa.gy = gy; sa.out = (float*)ws;
         const size_t lds = stem_lds_wgrad(Ci);
+        hipEvent_t pe = conv_prof_begin(6, 2.0 * B * (double)Co * sa.K * (Hi / 2) * (Wi / 2), 2.0 * B * (double)Co * sa.Kp * (Hi / 2) * (Wi / 2),
+                                        4.0 * ((double)B * Ci * Hi * Wi + (double)B * Co * (Hi / 2) * (Wi / 2) + (double)Co * sa.K), st);
         if (Ci == 3) hipLaunchKernelGGL((stem_wgrad_kernel<5, false>), dim3(sa.nblocks), dim3(256), lds, st, sa);
         else hipLaunchKernelGGL((stem_wgrad_kernel<10, false>), dim3(sa.nblocks), dim3(256), lds, st, sa);
+        conv_prof_end(pe, st);
         DC_CHECK_LAUNCH();
         hipLaunchKernelGGL(stem_wreduce_kernel, dim3(ceil_div(64 * sa.Kp / 4, 16)), dim3(256), 0, st, (const float*)ws, dweight, sa.nblocks, sa.K, sa.Kp);
         DC_CHECK_LAUNCH();
@@ -1044,9 +1055,13 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
     a.out = a.splits > 1 ? (float*)ws : dweight;
     const dim3 grid(a.mtiles * a.ntiles, a.splits);
     const size_t lds = trip ? (size_t)2 * (64 + 96) * (GKC + RP) * sizeof(float) : cg_lds_wgrad({2, 2});
+    hipEvent_t pe = ksize == 3 ? conv_prof_begin(5, 2.0 * (double)B * a.Ho * a.Wo * Co * a.K,
+                                                 2.0 * (double)a.chunks * GKC * (double)a.mtiles * 64.0 * (double)a.ntiles * (trip ? 96.0 : 64.0),
+                                                 4.0 * ((double)B * Ci * Hi * Wi + (double)B * a.Ho * a.Wo * Co + (double)Co * a.K), st) : nullptr;
     if (trip) hipLaunchKernelGGL(cg_wgrad3_kernel, grid, dim3(256), lds, st, a);
     else if (ksize == 3) hipLaunchKernelGGL((cg_wgrad_kernel<2, 2, 3>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((cg_wgrad_kernel<2, 2, 7>), grid, dim3(256), lds, st, a);
+    conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     if (a.splits > 1) {
         const int n = Co * a.K;
@@ -1086,7 +1101,11 @@ extern "C" int dc_stem_fwd(const float* const* frames, int nf, float mean, float
     hipLaunchKernelGGL(cg_wpad_kernel, dim3(ceil_div(Co * sa.Kp, 256)), dim3(256), 0, st, weight, (float*)ws, Co, sa.K, sa.Kp);
     DC_CHECK_LAUNCH();
     sa.w = (const float*)ws; sa.out = y;
+    const double npix = (double)sa.B * (Hi / 2) * (Wi / 2);
+    hipEvent_t pe = conv_prof_begin(6, 2.0 * npix * Co * sa.K, 2.0 * npix * Co * sa.Kp,
+                                    4.0 * ((double)sa.B * sa.Ci * Hi * Wi + npix * Co + (double)Co * sa.K), st);
     hipLaunchKernelGGL(stem_fwd_kernel<true>, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(sa.Ci, sa.Kp), st, sa);
+    conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
@@ -1098,8 +1117,12 @@ extern "C" int dc_stem_wgrad(const float* const* frames, int nf, float mean, flo
     hipStream_t st = (hipStream_t)stream;
     sa.gy = gy; sa.out = (float*)ws;
     const size_t lds = stem_lds_wgrad(sa.Ci);
+    const double npix = (double)sa.B * (Hi / 2) * (Wi / 2);
+    hipEvent_t pe = conv_prof_begin(6, 2.0 * npix * Co * sa.K, 2.0 * npix * Co * sa.Kp,
+                                    4.0 * ((double)sa.B * sa.Ci * Hi * Wi + npix * Co + (double)Co * sa.K), st);
     if (sa.Ci == 3) hipLaunchKernelGGL((stem_wgrad_kernel<5, true>), dim3(sa.nblocks), dim3(256), lds, st, sa);
     else hipLaunchKernelGGL((stem_wgrad_kernel<10, true>), dim3(sa.nblocks), dim3(256), lds, st, sa);
+    conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     hipLaunchKernelGGL(stem_wreduce_kernel, dim3(ceil_div(64 * sa.Kp / 4, 16)), dim3(256), 0, st, (const float*)ws, dweight, sa.nblocks, sa.K, sa.Kp);
     DC_CHECK_LAUNCH();
@@ -1146,7 +1169,11 @@ extern "C" int dc_convs2_dgrad(const float* gy, const float* weight, float* dx, 
     a.mtiles = ceil_div(Ci, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
     const dim3 grid(a.mtiles * a.ntiles, 2, sp);
     const size_t lds = cg_lds_dgrad(t);
+    // (split by output parity: no multiply meets a structural zero -- executed = the padded tiles of the same 2 MAC count)
+    hipEvent_t pe = conv_prof_begin(5, 2.0 * (double)N * Co * Ci * 9.0, 2.0 * (double)a.mtiles * 64.0 * (double)a.ntiles * 64.0 * Co * 9.0,
+                                    4.0 * ((double)B * Ci * Hi * Wi + (double)N * Co + 9.0 * Co * Ci), st);
     hipLaunchKernelGGL((cg_dgrad3_kernel<2, 2>), grid, dim3(256), lds, st, a);
+    conv_prof_end(pe, st);
     if (sp > 1) {
         DC_CHECK_LAUNCH();
         const size_t n4 = (size_t)B * Ci * Hi * Wi / 4;

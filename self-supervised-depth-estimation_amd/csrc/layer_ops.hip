@@ -559,6 +559,41 @@ extern "C" int dc_upsample_bilinear_bwd(const float* g_out, float* d_x, int BC, 
     DC_CHECK_LAUNCH();
     return DC_OK;
 }
+// ---- upsample(x) = F.interpolate(x, scale_factor=2, mode="nearest")  (layers.py:196-199): out[y][x] = in[y/2][x/2];
+// backward = the 2x2 block sum.  One thread per INPUT pixel: a float2 pair of each of the two output rows it owns.
+__global__ __launch_bounds__(256) void nearest2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int BC, int h, int w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, xx = i - y * w;
+    for (int bc = blockIdx.y; bc < BC; bc += gridDim.y) {
+        const float v = x[(size_t)bc * h * w + i];
+        float2* o = reinterpret_cast<float2*>(out + ((size_t)bc * 2 * h + 2 * y) * 2 * w) + xx;
+        o[0] = make_float2(v, v);
+        o[w] = make_float2(v, v);
+    }
+}
+__global__ __launch_bounds__(256) void nearest2x_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int BC, int h, int w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, xx = i - y * w;
+    for (int bc = blockIdx.y; bc < BC; bc += gridDim.y) {
+        const float2* q = reinterpret_cast<const float2*>(g + ((size_t)bc * 2 * h + 2 * y) * 2 * w) + xx;
+        const float2 a = q[0], b = q[w];
+        dx[(size_t)bc * h * w + i] = (a.x + a.y) + (b.x + b.y);
+    }
+}
+extern "C" int dc_upsample_nearest2x_fwd(const float* x, float* out, int BC, int h, int w, void* stream) {
+    if (!x || !out || BC <= 0 || h <= 0 || w <= 0 || ((size_t)out & 7)) return DC_EINVAL;
+    hipLaunchKernelGGL(nearest2x_fwd_kernel, dim3(ceil_div(h * w, 256), BC < 65535 ? BC : 65535), dim3(256), 0, ST, x, out, BC, h, w);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+extern "C" int dc_upsample_nearest2x_bwd(const float* g_out, float* d_x, int BC, int h, int w, void* stream) {
+    if (!g_out || !d_x || BC <= 0 || h <= 0 || w <= 0 || ((size_t)g_out & 7)) return DC_EINVAL;
+    hipLaunchKernelGGL(nearest2x_bwd_kernel, dim3(ceil_div(h * w, 256), BC < 65535 ? BC : 65535), dim3(256), 0, ST, g_out, d_x, BC, h, w);
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
 extern "C" int dc_ssim_fwd(const float* x, const float* y, float* out, int BC, int H, int W, void* stream) {
     if (!x || !y || !out || BC <= 0 || H < 2 || W < 2) return DC_EINVAL;
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3(ceil_div(W, ST_W), ceil_div(H, ST_H), BC), dim3(256), 0, ST, x, y, out, H, W);

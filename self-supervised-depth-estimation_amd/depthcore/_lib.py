@@ -105,6 +105,8 @@ def _sig(lib):
         "dc_project3d_bwd": (i, [p, p, p, p, p, p, p, i, i, i, f, p]),
         "dc_grid_sample_fwd": (i, [p, p, p, i, i, i, i, i, i, i, p]),
         "dc_grid_sample_bwd": (i, [p, p, p, p, i, i, i, i, i, i, i, p]),
+        "dc_upsample_nearest2x_fwd": (i, [p, p, i, i, i, p]),
+        "dc_upsample_nearest2x_bwd": (i, [p, p, i, i, i, p]),
         "dc_upsample_bilinear_fwd": (i, [p, p, i, i, i, i, i, p]),
         "dc_upsample_bilinear_bwd": (i, [p, p, i, i, i, i, i, p]),
         "dc_ssim_fwd": (i, [p, p, p, i, i, i, p]),

@@ -89,6 +89,9 @@ class GradBuckets:
         self.packed = 0         # gradients that had to be copied into their slice this step (0 on the all-depthcore path)
         self.streams = []       # streams on which gradients are produced besides the current one (Trainer.overlap_streams)
         self.comm = None        # communication stream (created on first use)
+        self.timing = False     # diagnostics (bench.py, after its timed region): event pairs around every bucket's exchange
+        self._t0 = None         # ... and one at zero(), the start of the backward they are measured from
+        self._tev = []
         self.nbytes = sum((p.numel() + 3) // 4 * 16 for plist in self.buckets for p in plist)    # bytes exchanged per step
         if self.world == 1:
             return
@@ -150,7 +153,18 @@ class GradBuckets:
                         plist[i].grad.record_stream(self.comm)
                 self.packed += len(stray)
             op = self.avg_op if self.avg_op is not None else dist.ReduceOp.SUM
+            ev = None
+            if self.timing and flat.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(self.comm)
             self.handles.append(dist.all_reduce(flat, op=op, group=self.pg, async_op=True))
+            if ev is not None:
+                if dist.get_backend(self.pg) == "nccl":      # (RCCL enqueues on the current = communication stream)
+                    ev[1].record(self.comm)
+                else:                                        # gloo (rehearsal): the handle completes on the host
+                    self.handles[-1].wait()
+                    ev[1].record(self.comm)
+                self._tev.append((bi, ev))
         self.launched[bi] = True
         self.launch_order.append(bi)
 
@@ -177,6 +191,10 @@ class GradBuckets:
         self.launch_order = []
         self.packed = 0
         self.next = 0
+        if self.timing and self.flat and self.flat[0].is_cuda:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(torch.cuda.current_stream(self.flat[0].device))
+            self._tev = []
 
     def finish(self):
         """Wait for the exchanges; afterwards every bucketed parameter's `.grad` is its (averaged) slice.
@@ -223,3 +241,12 @@ def agree_all(ok, process_group=None, device=None):
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if on_host else device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
     return bool(int(flag.item()))
+
+
+def bucket_timeline(gb):
+    """After a step run with `gb.timing = True` (and a device synchronisation): per bucket in launch order, the GPU time from
+    the start of the backward (zero()) at which its exchange could start -- the communication stream has waited for every
+    producing stream -- and its duration: [(bucket, bytes, start_ms, ms)]."""
+    if gb._t0 is None:
+        return []
+    return [(bi, gb.flat[bi].numel() * 4, round(gb._t0.elapsed_time(e0), 3), round(e0.elapsed_time(e1), 3)) for bi, (e0, e1) in gb._tev]

@@ -619,6 +619,31 @@ def upsample_bilinear(x, Ho, Wo):
 
 
 # ----------------------------------------------------------------------------------------------
+# a3  upsample(x): nearest x2                                          (reference layers.py:196-199)
+# ----------------------------------------------------------------------------------------------
+class _UpsampleNearest2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xx = _c(x.detach())
+        B, C, h, w = xx.shape
+        out = torch.empty(B, C, 2 * h, 2 * w, dtype=torch.float32, device=xx.device)
+        check(_lib.lib().dc_upsample_nearest2x_fwd(ptr(xx), ptr(out), B * C, h, w, stream(xx)), "dc_upsample_nearest2x_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        g = _c(go)
+        B, C, H2, W2 = g.shape
+        dx = torch.empty(B, C, H2 // 2, W2 // 2, dtype=torch.float32, device=g.device)
+        check(_lib.lib().dc_upsample_nearest2x_bwd(ptr(g), ptr(dx), B * C, H2 // 2, W2 // 2, stream(g)), "dc_upsample_nearest2x_bwd")
+        return dx
+
+
+def upsample_nearest2x(x):
+    return _UpsampleNearest2x.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
 # a11 SSIM                                                              (reference layers.py:218-248)
 # ----------------------------------------------------------------------------------------------
 class _SSIM(torch.autograd.Function):

@@ -34,13 +34,11 @@ def rot_from_axisangle(vec):
     return _ops.pose_matrix(vec, torch.zeros_like(vec), False)
 
 
-FUSED_CONV_MIN_PIXELS = 0     # output pixels per image from which dc_conv3x3 is used (0: every layer; CPU tensors never)
-
-
 class Conv3x3(nn.Module):
     """layers.py:119-136: pad (reflection or zero) + 3x3 conv, as one dc_conv3x3 launch.  Sub-modules `.pad`,
     `.conv` are kept as in the reference so state_dict keys match (`conv.weight`, `conv.bias`); `.conv` only
-    holds the parameters."""
+    holds the parameters.  (The same arithmetic as separate library launches, for timing comparisons, lives in
+    tools/time_decoder.py -- not in this module.)"""
 
     def __init__(self, in_channels, out_channels, use_refl=True):
         super().__init__()
@@ -50,18 +48,7 @@ class Conv3x3(nn.Module):
 
     def forward(self, x, skip=None, up=False, act=_ops.ACT_NONE, fork=None):
         """`fork`: a pair ops.GradFork shared with the other fused block that reads x (DepthDecoder)."""
-        H, W = (x.shape[2] * 2, x.shape[3] * 2) if up else (x.shape[2], x.shape[3])
-        if H * W >= FUSED_CONV_MIN_PIXELS:
-            return _ops.conv3x3_block(x, skip, self.conv.weight, self.conv.bias, up, act, self._pad_mode, fork)
-        if fork is not None:
-            raise _ops._lib.DepthcoreError("GradFork handed to the library comparison path")
-        # comparison path for tools/time_decoder.py (DC_MIN_PIXELS): the same arithmetic as separate library launches
-        if up:
-            x = F.interpolate(x, scale_factor=2, mode="nearest")
-        if skip is not None:
-            x = torch.cat([x, skip], 1)
-        y = self.conv(self.pad(x))
-        return F.elu(y) if act == _ops.ACT_ELU else (torch.sigmoid(y) if act == _ops.ACT_SIGMOID else y)
+        return _ops.conv3x3_block(x, skip, self.conv.weight, self.conv.bias, up, act, self._pad_mode, fork)
 
 
 class ConvBlock(nn.Module):
@@ -114,8 +101,9 @@ class Project3D(nn.Module):
 
 
 def upsample(x):
-    """layers.py:196-199: nearest x2."""
-    return F.interpolate(x, scale_factor=2, mode="nearest")
+    """layers.py:196-199: nearest x2 (dc_upsample_nearest2x_*).  The depth decoder does not call it: its upsample is folded
+    into the next convolution's loader (ConvBlock.forward(up=True))."""
+    return _ops.upsample_nearest2x(x)
 
 
 def get_smooth_loss(disp, img):

@@ -55,8 +55,7 @@ class DepthDecoder(nn.Module):
                 else:
                     # level i's x feeds dispconv(i) AND upconv(i-1, 0): a pair GradFork -- upconv's backward runs first and
                     # parks its gradient of x, dispconv's data-gradient pass adds it (no elementwise sum by autograd)
-                    if (X_FORK and i > 0 and self.training and x.is_cuda and x.requires_grad and torch.is_grad_enabled()
-                            and x.shape[2] * x.shape[3] >= _layers.FUSED_CONV_MIN_PIXELS):      # (both readers on dc_conv3x3)
+                    if X_FORK and i > 0 and self.training and x.is_cuda and x.requires_grad and torch.is_grad_enabled():
                         fork = _ops.GradFork(pair=True)
                     self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act=_ACT_SIGMOID, fork=fork)
         return self.outputs

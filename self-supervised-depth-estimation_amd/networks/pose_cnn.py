@@ -27,16 +27,12 @@ class PoseCNN(nn.Module):
         """networks/pose_cnn.py:40-48.  On the GPU the seven strided convolutions (7x7, 5x5, 3x3 with bias) run on depthcore's
         direct kernels (dc_conv2d_direct_*: this network is outside the BASELINE configurations, the plain kernels are the
         honest cost) and the 1x1 head on dc_conv1x1_bias_act_fwd; no library convolution."""
-        if out.is_cuda:
-            for i in range(self.num_convs):
-                c = self.convs[i]
-                out = torch.relu(_ops.conv2d_direct(out, c.weight, c.bias, 2, c.padding[0]))
-            out = _ops.conv1x1(out, self.pose_conv.weight, 1, self.pose_conv.bias, _ops.ACT_NONE)
-        else:               # CPU: module bookkeeping / export only, not a compute path of this package
-            for i in range(self.num_convs):
-                out = self.relu(self.convs[i](out))
-            out = self.pose_conv(out)
-        return out
+        if not out.is_cuda:     # no CPU fallback anywhere in this package (layers.py)
+            raise _ops.DepthcoreError("PoseCNN on a %s tensor: depthcore's modules compute on the GPU only" % out.device)
+        for i in range(self.num_convs):
+            c = self.convs[i]
+            out = torch.relu(_ops.conv2d_direct(out, c.weight, c.bias, 2, c.padding[0]))
+        return _ops.conv1x1(out, self.pose_conv.weight, 1, self.pose_conv.bias, _ops.ACT_NONE)
 
     def forward(self, out):
         """networks/pose_cnn.py:40-53."""

@@ -115,8 +115,8 @@ def _conv(conv, x, fork=None, skip=None):
         return _ops.conv_s2(x, conv.weight, fork)
     if fork is not None:  # (_fork_for mirrors the two conditions above; a fork nobody collects would lose the skip's gradient)
         raise _ops.DepthcoreError("GradFork handed to a convolution that does not run on a kernel with the addend epilogue")
-    if not x.is_cuda:
-        return conv(x)      # CPU: module bookkeeping / export only, not a compute path of this package
+    if not x.is_cuda:       # no CPU fallback anywhere in this package (layers.py): the oracle under oracle/ is the CPU statement
+        raise _ops.DepthcoreError("convolution on a %s tensor: depthcore's modules compute on the GPU only" % x.device)
     # shapes outside the tiled kernels' 16-byte staging (odd or tiny maps, a stem whose input needs a gradient): depthcore's
     # plain direct kernels -- on the GPU no shape reaches the framework's convolution
     k, s_, p_ = conv.kernel_size, conv.stride, conv.padding

@@ -93,5 +93,7 @@ def test_posecnn_whole_step_uses_the_rescaled_pose():
     tr.generate_images_pred(batch, ref_out)
     ref = tr.compute_losses(batch, ref_out)
     close(losses["loss"], ref["loss"], rtol=1e-4, atol=0)
+    tr.buckets.zero()
     losses["loss"].backward()
+    tr.buckets.finish()                    # (gradients are written into the flat buckets' slices; finish() binds p.grad)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in tr.models["pose"].parameters())

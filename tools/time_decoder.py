@@ -1,22 +1,42 @@
 #!/usr/bin/env python3
-"""DepthDecoder forward+backward at BASELINE config 2 shapes (B=12, resnet18 features of a 192x640 image);
-run under tools/prof_decoder.sh for per-kernel times.  DC_MIN_PIXELS overrides layers.FUSED_CONV_MIN_PIXELS."""
+"""DepthDecoder forward+backward at BASELINE config 2 shapes (B=12, resnet18 features of a 192x640 image); run under
+tools/prof_decoder.sh for per-kernel times.
+
+    python tools/time_decoder.py            # the product: networks.DepthDecoder on dc_conv3x3
+    python tools/time_decoder.py --library  # the same arithmetic as separate library launches (ATen pad / conv / ELU / nearest / cat):
+                                            # the COMPARISON path -- it lives here, not in the drop-in modules
+"""
 import os
 import sys
 import time
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "self-supervised-depth-estimation_amd"))
-import layers  # noqa: E402
 import networks  # noqa: E402
 
 
+def library_decoder(dec, feats):
+    """reference networks/depth_decoder.py:50-66 with the reference's own op sequence (layers.py:106-136, 196-199) on `dec`'s weights."""
+    def conv3x3(m, x):
+        return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), m.conv.weight, m.conv.bias)
+    out, x = {}, feats[-1]
+    for i in range(4, -1, -1):
+        x = F.elu(conv3x3(dec.convs[("upconv", i, 0)].conv, x))
+        x = [F.interpolate(x, scale_factor=2, mode="nearest")]
+        if dec.use_skips and i > 0:
+            x += [feats[i - 1]]
+        x = F.elu(conv3x3(dec.convs[("upconv", i, 1)].conv, torch.cat(x, 1)))
+        if i in dec.scales:
+            out[("disp", i)] = torch.sigmoid(conv3x3(dec.convs[("dispconv", i)], x))
+    return out
+
+
 def main():
-    if "DC_MIN_PIXELS" in os.environ:
-        layers.FUSED_CONV_MIN_PIXELS = int(os.environ["DC_MIN_PIXELS"])
+    lib = "--library" in sys.argv[1:]
     dev = torch.device("cuda:0")
     nce = np.array([64, 64, 128, 256, 512])
     torch.manual_seed(0)
@@ -24,8 +44,9 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1)
     feats = [torch.randn(12, int(c), 96 >> i, 320 >> i, device=dev, generator=g, requires_grad=True)
              for i, c in enumerate(nce)]
+
     def step():
-        o = dec(feats)
+        o = library_decoder(dec, feats) if lib else dec(feats)
         tot = sum(o[("disp", s)].sum() for s in range(4))
         torch.autograd.grad(tot, feats + list(dec.parameters()))
     for _ in range(3):
@@ -36,7 +57,7 @@ def main():
     for _ in range(n):
         step()
     torch.cuda.synchronize()
-    print("decoder fwd+bwd: %.3f ms per step (min_pixels=%d)" % ((time.perf_counter() - t0) / n * 1e3, layers.FUSED_CONV_MIN_PIXELS))
+    print("decoder fwd+bwd: %.3f ms per step (%s)" % ((time.perf_counter() - t0) / n * 1e3, "library launches" if lib else "depthcore"))
 
 
 if __name__ == "__main__":
