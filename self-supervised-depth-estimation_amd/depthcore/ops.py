@@ -823,6 +823,9 @@ def conv3x3_block(x0, x1, weight, bias, up0=False, act=ACT_NONE, pad=PAD_REFLECT
 # ----------------------------------------------------------------------------------------------
 # a1 the gradient of a residual block's input: summed inside conv1's data-gradient kernel, not by autograd
 # ----------------------------------------------------------------------------------------------
+_parked_forks = weakref.WeakSet()     # GradForks holding a parked gradient (assert_no_dangling_sums)
+
+
 class GradFork:
     """The input x of a residual block without a downsample branch has two consumers: conv1 and the skip connection into the
     last BatchNorm (+ add + ReLU).  Autograd would add their two gradients in a separate elementwise pass (31 such passes per
@@ -834,7 +837,6 @@ class GradFork:
     `assert_no_dangling_sums()` (a pair fork whose second reader never runs its backward, e.g. a ("disp", i > 0) output of
     the depth decoder that is left out of the loss: the parked gradient would be lost silently otherwise)."""
     __slots__ = ("addend", "armed", "pair", "arrived", "__weakref__")
-    _parked = weakref.WeakSet()
 
     def __init__(self, pair=False):
         self.addend = None
@@ -855,14 +857,14 @@ class GradFork:
         if not self.armed or self.addend is not None:
             raise _lib.DepthcoreError("GradFork: the skip gradient was produced twice (a second backward through the same block?)")
         self.addend = dres
-        GradFork._parked.add(self)
+        _parked_forks.add(self)
 
     def take(self):
         if not self.armed:
             raise _lib.DepthcoreError("GradFork: conv1's backward ran twice for one forward")
         self.armed = False
         a, self.addend = self.addend, None
-        GradFork._parked.discard(self)
+        _parked_forks.discard(self)
         if self.pair and a is None:
             raise _lib.DepthcoreError("GradFork: the first convolution's data gradient was never parked")
         return a
@@ -909,10 +911,10 @@ def assert_no_dangling_sums():
     left = [s for s in SkipSum._pending if s.addend is not None]
     for s in left:
         s.take()
-    forks = [f for f in GradFork._parked if f.addend is not None]
+    forks = [f for f in _parked_forks if f.addend is not None]
     for f in forks:
         f.addend, f.armed = None, False
-        GradFork._parked.discard(f)
+        _parked_forks.discard(f)
     if left:
         raise _lib.DepthcoreError("%d gradient(s) were handed to a SkipSum whose primary consumer never collected them" % len(left))
     if forks:

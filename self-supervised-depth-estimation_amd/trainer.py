@@ -334,6 +334,18 @@ class Trainer:
             outputs[("cam_T_cam", 0, f)] = Ts[i]
         return outputs
 
+    def _poses(self, pose, pose_inputs, groups):
+        """(axisangle, translation, [cam_T_cam per group]).  The fused tail (`forward_poses`: one launch each way) hands out
+        axisangle / translation as RECORDS -- the loss reaches the network through the matrices.  posecnn mode is the one place
+        where the loss reads the vectors themselves (generate_images_pred rebuilds the pose from them at every scale,
+        trainer.py:490-499), so there the module's plain forward (differentiable outputs) + transformation_from_parameters."""
+        if self.opt.pose_model_type != "posecnn":
+            return pose.forward_poses(pose_inputs, groups)
+        axisangle, translation = pose(pose_inputs)
+        Ts = [transformation_from_parameters(axisangle[r0:r0 + rows, slot], translation[r0:r0 + rows, slot], invert=bool(inv))
+              for r0, rows, slot, inv in groups]
+        return axisangle, translation, Ts
+
     def _predict_poses_modes(self, inputs, features):
         o, outputs = self.opt, {}
         pose = self.models["pose"]
@@ -347,7 +359,7 @@ class Trainer:
                 elif o.pose_model_type == "posecnn":
                     pose_inputs = torch.cat(pose_inputs, 1)
                 B = inputs[("color_aug", 0, 0)].shape[0]
-                axisangle, translation, Ts = pose.forward_poses(pose_inputs, [(0, B, 0, int(f < 0))])
+                axisangle, translation, Ts = self._poses(pose, pose_inputs, [(0, B, 0, int(f < 0))])
                 outputs[("axisangle", 0, f)] = axisangle
                 outputs[("translation", 0, f)] = translation
                 outputs[("cam_T_cam", 0, f)] = Ts[0]
@@ -361,7 +373,7 @@ class Trainer:
             pose_inputs = [features[i] for i in ids]
         B = inputs[("color_aug", 0, 0)].shape[0]
         used = [(i, f) for i, f in enumerate(o.frame_ids[1:]) if f != "s"]
-        axisangle, translation, Ts = pose.forward_poses(pose_inputs, [(0, B, i, 0) for i, _ in used])
+        axisangle, translation, Ts = self._poses(pose, pose_inputs, [(0, B, i, 0) for i, _ in used])
         for (i, f), T_ in zip(used, Ts):
             outputs[("axisangle", 0, f)] = axisangle
             outputs[("translation", 0, f)] = translation
