@@ -56,6 +56,8 @@ FAMILIES = {
         "gradient; main kernels, without the slab sums)", "mfma"),
     6: ("dc::stem_* (7x7 stride-2 stem, patch-staged fp32-MFMA: forward and weight gradient incl. the input normalisation and "
         "the pose pairs' concat in the loader)", "mfma"),
+    7: ("dc::g1x3_* (1x1 convolutions as fp32-accurate GEMMs on the bf16 matrix cores: three bf16 pieces per fp32 operand, six "
+        "partial products, fp32 accumulation; forward, data gradient, weight gradient)", "mfma_bf16"),
 }
 VALU_LANE_OPS_PEAK = 78.6e12   # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: wave-level VALU instructions x 64 lanes per second
 # Issue slots per counted VALU instruction of the photometric kernels' main loops (tools/isa_mix.py on the gfx950 ISA of THIS
@@ -528,6 +530,8 @@ def run_rank(args):
     if not (loss_last == loss_last):
         raise SystemExit("loss is NaN")
 
+    from depthcore import _lib as _dcl
+    split_on = bool(_dcl.lib().dc_get_gemm_split()) and fam.get(7, {}).get("launches", 0) > 0
     if rank == 0:
         cfg = (args.num_layers, args.height, args.width, args.batch)
         cfg_key = {(18, 192, 640, 12): "c2", (50, 320, 1024, 8): "c3"}.get(cfg, "other") if args.front == "none" else "other"
@@ -581,6 +585,13 @@ def run_rank(args):
                           "issued_frac_of_peak": round(ex / MFMA_F32_PEAK_TFLOPS, 4),
                           "direct_conv_equivalent_tflops": round(tf, 2),
                           "direct_conv_equivalent_frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
+            elif bound == "mfma_bf16":
+                # split operands: `achieved` / `frac` = the bf16 matrix FLOPs actually issued (six products per fp32 multiply, padded
+                # tiles) against the dense bf16 peak; the fp32 GEMM it stands for (SURVEY 8d's 2 MAC) beside it
+                e.update({"bound": "mfma", "achieved": round(ex, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(ex / MFMA_BF16_PEAK_TFLOPS, 4),
+                          "flops_definition": "bf16 matrix FLOPs issued: 6 partial products per fp32 multiply-add, padded tiles",
+                          "fp32_equivalent_tflops": round(tf, 2), "fp32_equivalent_frac_of_fp32_matrix_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
             else:
                 gbs = d["bytes"] / sec / 1e9
                 e.update({"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -594,7 +605,7 @@ def run_rank(args):
         dom = dict(fams[0]) if fams else {"kernel": None, "bound": "mfma", "achieved": 0.0, "peak": MFMA_F32_PEAK_TFLOPS,
                                           "unit": "TFLOP/s", "frac": 0.0}
         dom_key = {0: "dc::wino_ps_kernel", 1: "dc::wino_wgrad_kernel", 2: "dc::c3b_conv_kernel", 3: "dc::c3b_wgrad_kernel", 4: "dc::g1_*",
-                   5: "dc::cg_*", 6: "dc::stem_*"}.get(dom.get("family"))
+                   5: "dc::cg_*", 6: "dc::stem_*", 7: "dc::g1x3_*"}.get(dom.get("family"))
         # ---- BASELINE metric 2: the fused warp + SSIM + smoothness kernels against HBM.  Round 4 moved the SSIM derivative, its
         # transposed 3x3 spread and the contraction with d(warped)/d(coords) into the TRAINING FORWARD; round 5 lets it go all the
         # way (dc::photo_fwdg_kernel<.., FULL>: Project3D / BackprojectDepth / disp_to_depth backward and the pose sums in the
@@ -647,7 +658,8 @@ def run_rank(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.nets_dtype == "f32" else "bf16-nets/f32-loss", "data": "synthetic",
+            "dtype": ("f32" if not split_on else "f32 (1x1 convolutions: bf16x3 split operands, fp32 accumulate)") if args.nets_dtype == "f32"
+                     else "bf16-nets/f32-loss", "data": "synthetic",
             "windows_ms_per_step": [round(w, 3) for w in windows],
             "steady_state_ms_per_step": round(sorted(windows[1:])[len(windows[1:]) // 2], 3) if len(windows) > 1 else None,
             "config": {"workload": "%sresnet%d depth+pose, %dx%d, per-GPU batch %d, 4 scales, "

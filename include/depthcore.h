@@ -418,6 +418,40 @@ int dc_conv1x1_dgrad_bn(const float* gy, const float* weight, float* dx, const f
 int dc_conv1x1_wgrad_bn(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
                         const dc_bn_fold* bn, void* stream);
 
+/* The same GEMMs on the bf16 matrix cores with SPLIT fp32 operands (csrc/gemm1x1_x3.hip): every fp32 operand is the sum of three
+ * bf16 pieces and the six partial products down to 2^-16 |a||b| are accumulated in fp32 -- fp32 inputs, fp32 outputs, an error
+ * below that of an fp32 multiply-add chain of the same length, at 6/16 of the fp32 matrix time.  Shapes: dc_gemm1x1x3_*_ok
+ * (pixels per image a multiple of 16, reduction extent a multiple of 32, >= 64 output rows; the data gradient at stride 1);
+ * ws = dc_gemm1x1x3_workspace(Ci, Co) bytes, 16-byte aligned (the split weights of the launch).  dc_set_gemm_split(1) (env
+ * DC_G1_X3) makes dc_conv1x1_* callers with a workspace take this path where it applies (depthcore/ops.py does). */
+int dc_set_gemm_split(int mode);
+int dc_get_gemm_split(void);
+int dc_gemm1x1x3_fwd_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);
+int dc_gemm1x1x3_dgrad_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);
+size_t dc_gemm1x1x3_workspace(int Ci, int Co);
+int dc_gemm1x1x3_fwd(const float* x, const float* weight, const float* bias, float* y, void* ws, int B, int Ci, int Co, int Hi, int Wi,
+                     int stride, int act, void* stream);
+int dc_gemm1x1x3_dgrad(const float* gy, const float* weight, float* dx, void* ws, const float* addend, const float* addend2, int B,
+                       int Ci, int Co, int Hi, int Wi, int stride, void* stream);
+/* ... with a BatchNorm folded in (dc_bn_fold; `bn` nullable): the contract of dc_conv1x1_*_bn on the split kernels -- loader
+ * relu(scale x + shift) in the forward and the weight gradient, statistics epilogue of the forward, BatchNorm-backward epilogue of
+ * the data gradient; the *_parts queries size the partial buffers for THESE kernels' tiles. */
+int dc_gemm1x1x3_bn_ok(int B, int Ci, int Co, int Hi, int Wi);
+int dc_gemm1x1x3_stat_parts(int B, int Ci, int Co, int Hi, int Wi, int stride, int groups, int* ppg);
+int dc_gemm1x1x3_bwd_parts(int B, int Ci, int Co, int Hi, int Wi, int groups, int* ppg);
+int dc_gemm1x1x3_fwd_bn(const float* x, const float* weight, const float* bias, float* y, void* ws, int B, int Ci, int Co, int Hi, int Wi,
+                        int stride, int act, const dc_bn_fold* bn, void* stream);
+int dc_gemm1x1x3_dgrad_bn(const float* gy, const float* weight, float* dx, void* ws, const float* addend, const float* addend2, int B,
+                          int Ci, int Co, int Hi, int Wi, int stride, const dc_bn_fold* bn, void* stream);
+int dc_gemm1x1x3_wgrad_bn(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                          const dc_bn_fold* bn, void* stream);
+/* weight gradient: both operands split while staging, reduction split over blocks into fp32 slabs (ws = dc_gemm1x1x3_wgrad_workspace
+ * bytes, 16-byte aligned), summed in fixed order: deterministic */
+int dc_gemm1x1x3_wgrad_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);
+size_t dc_gemm1x1x3_wgrad_workspace(int B, int Ci, int Co, int Hi, int Wi, int stride);
+int dc_gemm1x1x3_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, int stride,
+                       void* stream);
+
 /* The same convolution with bias and activation fused into the epilogue: y = act(conv1x1(x) + bias), act as in
  * dc_conv3x3_fwd (0 none, 1 ELU, 2 sigmoid, 3 ReLU, 4 tanh); bias may be NULL.  This is `relu(squeeze(f))` and the final
  * `pose_2` convolution of networks/pose_decoder.py:25,30,40-48.

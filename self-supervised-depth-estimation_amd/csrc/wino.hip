@@ -807,7 +807,7 @@ struct ConvProf {
     int used = 0;
     double flops = 0.0, exec = 0.0, bytes = 0.0;
 };
-constexpr int NPROF = 8;       // 0 wino_ps, 1 wino_wgrad, 2 c3b_conv (bf16), 3 c3b_wgrad (bf16), 4 1x1 GEMM family, 5 cg_ (3x3 / 2), 6 stem (7x7 / 2), 7 reserved
+constexpr int NPROF = 8;       // 0 wino_ps, 1 wino_wgrad, 2 c3b_conv (bf16), 3 c3b_wgrad (bf16), 4 1x1 GEMM family, 5 cg_ (3x3 / 2), 6 stem (7x7 / 2), 7 g1x3 (split-operand 1x1 GEMMs)
 ConvProf g_cprof[NPROF];
 int g_cprof_cap = 0, g_cprof_every = 1;
 unsigned g_cprof_seen[NPROF] = {0, 0, 0, 0, 0, 0, 0, 0};

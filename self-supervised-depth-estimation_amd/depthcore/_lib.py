@@ -192,6 +192,22 @@ def _sig(lib):
         "dc_get_matrix_precision": (i, []),
         "dc_clear_error": (i, []),
         "dc_abort_capture": (i, [p]),
+        "dc_set_gemm_split": (i, [i]),
+        "dc_get_gemm_split": (i, []),
+        "dc_gemm1x1x3_fwd_ok": (i, [i, i, i, i, i, i]),
+        "dc_gemm1x1x3_dgrad_ok": (i, [i, i, i, i, i, i]),
+        "dc_gemm1x1x3_workspace": (c_size_t, [i, i]),
+        "dc_gemm1x1x3_fwd": (i, [p, p, p, p, p, i, i, i, i, i, i, i, p]),
+        "dc_gemm1x1x3_dgrad": (i, [p, p, p, p, p, p, i, i, i, i, i, i, p]),
+        "dc_gemm1x1x3_bn_ok": (i, [i, i, i, i, i]),
+        "dc_gemm1x1x3_stat_parts": (i, [i, i, i, i, i, i, i, POINTER(c_int)]),
+        "dc_gemm1x1x3_bwd_parts": (i, [i, i, i, i, i, i, POINTER(c_int)]),
+        "dc_gemm1x1x3_fwd_bn": (i, [p, p, p, p, p, i, i, i, i, i, i, i, POINTER(BnFold), p]),
+        "dc_gemm1x1x3_dgrad_bn": (i, [p, p, p, p, p, p, i, i, i, i, i, i, POINTER(BnFold), p]),
+        "dc_gemm1x1x3_wgrad_bn": (i, [p, p, p, p, i, i, i, i, i, i, POINTER(BnFold), p]),
+        "dc_gemm1x1x3_wgrad_ok": (i, [i, i, i, i, i, i]),
+        "dc_gemm1x1x3_wgrad_workspace": (c_size_t, [i, i, i, i, i, i]),
+        "dc_gemm1x1x3_wgrad": (i, [p, p, p, p, i, i, i, i, i, i, p]),
         "dc_set_photo_full": (i, [i]),
         "dc_get_photo_full": (i, []),
         "dc_set_wino_f4": (i, [i]),

@@ -103,34 +103,69 @@ def _bn_buffers(bn):
 # the BatchNorm-backward epilogue.  kind "g1": 1x1 on the tiled GEMMs (dc_conv1x1_*_bn); "wino": stride-1 3x3 (dc_wino3x3_*_bn)
 # ----------------------------------------------------------------------------------------------
 class _K1:
-    """1x1 (stride 1 / 2) on the tiled GEMM kernels"""
+    """1x1 (stride 1 / 2) on the tiled GEMM kernels: fp32-MFMA (csrc/gemm1x1.hip) or, under dc_set_gemm_split, the split-operand
+    kernels (csrc/gemm1x1_x3.hip) where they take the shape -- decided per pass, by the SAME predicate in the partial-count query
+    and in the launch (the epilogues' partial layouts follow each kernel family's own tiles)"""
     @staticmethod
     def out_hw(Hi, Wi, s_):
         return Hi // s_, Wi // s_
 
     @staticmethod
+    def _x3_fwd(L, B, Ci, Co, Hi, Wi, s_, groups):
+        return bool(L.dc_get_gemm_split()) and L.dc_gemm1x1x3_stat_parts(B, Ci, Co, Hi, Wi, s_, groups, None) > 0
+
+    @staticmethod
+    def _x3_dgrad(L, B, Ci, Co, Hi, Wi, s_, groups):
+        return bool(L.dc_get_gemm_split()) and s_ == 1 and L.dc_gemm1x1x3_bwd_parts(B, Ci, Co, Hi, Wi, groups, None) > 0
+
+    @staticmethod
     def stat_parts(L, B, Ci, Co, Hi, Wi, s_, groups, ppg):
+        if _K1._x3_fwd(L, B, Ci, Co, Hi, Wi, s_, groups):
+            return L.dc_gemm1x1x3_stat_parts(B, Ci, Co, Hi, Wi, s_, groups, ppg)
         return L.dc_conv1x1_stat_parts(B, Ci, Co, Hi, Wi, s_, groups, ppg)
 
     @staticmethod
     def bwd_parts(L, B, Ci, Co, Hi, Wi, s_, groups, ppg):
+        if _K1._x3_dgrad(L, B, Ci, Co, Hi, Wi, s_, groups):
+            return L.dc_gemm1x1x3_bwd_parts(B, Ci, Co, Hi, Wi, groups, ppg)
         return L.dc_conv1x1_bwd_parts(B, Ci, Co, Hi, Wi, groups, ppg) if s_ == 1 else 0
 
     @staticmethod
     def fwd(L, xx, ww, y, B, Ci, Co, Hi, Wi, s_, f):
+        if _K1._x3_fwd(L, B, Ci, Co, Hi, Wi, s_, f.groups):
+            ws = torch.empty(L.dc_gemm1x1x3_workspace(Ci, Co), dtype=torch.uint8, device=xx.device)
+            check(L.dc_gemm1x1x3_fwd_bn(ptr(xx), ptr(ww), None, ptr(y), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, 0, ctypes.byref(f), stream(xx)),
+                  "dc_gemm1x1x3_fwd_bn")
+            return
         check(L.dc_conv1x1_fwd_bn(ptr(xx), ptr(ww), ptr(y), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(xx)), "dc_conv1x1_fwd_bn")
 
     @staticmethod
     def dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f, add2=None):
+        x3 = _K1._x3_dgrad(L, B, Ci, Co, Hi, Wi, s_, f.groups)
         if add2 is not None:      # (a stage's first block: no BatchNorm epilogue on this launch, two addends)
+            if x3:
+                ws = torch.empty(L.dc_gemm1x1x3_workspace(Ci, Co), dtype=torch.uint8, device=gx.device)
+                check(L.dc_gemm1x1x3_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), ptr(add), ptr(add2), B, Ci, Co, Hi, Wi, s_, stream(gx)),
+                      "dc_gemm1x1x3_dgrad")
+                return
             check(L.dc_conv1x1_dgrad_add2(ptr(g_c), ptr(ww), ptr(gx), ptr(add), ptr(add2), B, Ci, Co, Hi, Wi, s_, stream(gx)),
                   "dc_conv1x1_dgrad_add2")
+            return
+        if x3:
+            ws = torch.empty(L.dc_gemm1x1x3_workspace(Ci, Co), dtype=torch.uint8, device=gx.device)
+            check(L.dc_gemm1x1x3_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), ptr(add), None, B, Ci, Co, Hi, Wi, s_, ctypes.byref(f),
+                                          stream(gx)), "dc_gemm1x1x3_dgrad_bn")
             return
         check(L.dc_conv1x1_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ptr(add), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(gx)),
               "dc_conv1x1_dgrad_bn")
 
     @staticmethod
     def wgrad(L, xx, g_c, gw, B, Ci, Co, Hi, Wi, s_, f):
+        if L.dc_get_gemm_split() and L.dc_gemm1x1x3_wgrad_ok(B, Ci, Co, Hi, Wi, s_):
+            ws = torch.empty(L.dc_gemm1x1x3_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
+            check(L.dc_gemm1x1x3_wgrad_bn(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(xx)),
+                  "dc_gemm1x1x3_wgrad_bn")
+            return
         ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
         check(L.dc_conv1x1_wgrad_bn(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(xx)),
               "dc_conv1x1_wgrad_bn")

@@ -1165,8 +1165,15 @@ class _Conv1x1(torch.autograd.Function):
         if ww.numel() != Co * Ci or (bs is not None and bs.numel() != Co):
             raise _lib.DepthcoreError("1x1 weight %s / bias do not match %d input channels" % (tuple(ww.shape), Ci))
         y = torch.empty(B, Co, Hi // stride, Wi // stride, dtype=torch.float32, device=xx.device)
-        check(L.dc_conv1x1_bias_act_fwd(ptr(xx), ptr(ww), ptr(bs), ptr(y), B, Ci, Co, Hi, Wi, int(stride), int(act), stream(xx)),
-              "dc_conv1x1_bias_act_fwd")
+        # dc_set_gemm_split: the same fp32 GEMM through three bf16 pieces per operand on the bf16 matrix cores (csrc/gemm1x1_x3.hip)
+        ctx.split = bool(L.dc_get_gemm_split())
+        if ctx.split and L.dc_gemm1x1x3_fwd_ok(B, Ci, Co, Hi, Wi, int(stride)):
+            ws = torch.empty(L.dc_gemm1x1x3_workspace(Ci, Co), dtype=torch.uint8, device=xx.device)
+            check(L.dc_gemm1x1x3_fwd(ptr(xx), ptr(ww), ptr(bs), ptr(y), ws.data_ptr(), B, Ci, Co, Hi, Wi, int(stride), int(act), stream(xx)),
+                  "dc_gemm1x1x3_fwd")
+        else:
+            check(L.dc_conv1x1_bias_act_fwd(ptr(xx), ptr(ww), ptr(bs), ptr(y), B, Ci, Co, Hi, Wi, int(stride), int(act), stream(xx)),
+                  "dc_conv1x1_bias_act_fwd")
         plain = bias is None and act == ACT_NONE
         if act == ACT_RELU:
             _record_kink("relu", y)
@@ -1208,8 +1215,13 @@ class _Conv1x1(torch.autograd.Function):
             add2 = ctx.skip.take() if (ctx.skip is not None and not first_of_pair) else None
             if add2 is not None and (add2.shape != xx.shape or not add2.is_contiguous()):
                 raise _lib.DepthcoreError("SkipSum: gradient %s does not match the input %s" % (tuple(add2.shape), tuple(xx.shape)))
-            check(L.dc_conv1x1_dgrad_add2(ptr(g_c), ptr(ww), ptr(gx), ptr(add), ptr(add2), B, Ci, Co, Hi, Wi, s_, stream(xx)),
-                  "dc_conv1x1_dgrad_add2")
+            if ctx.split and L.dc_gemm1x1x3_dgrad_ok(B, Ci, Co, Hi, Wi, s_):
+                ws = torch.empty(L.dc_gemm1x1x3_workspace(Ci, Co), dtype=torch.uint8, device=xx.device)
+                check(L.dc_gemm1x1x3_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), ptr(add), ptr(add2), B, Ci, Co, Hi, Wi, s_, stream(xx)),
+                      "dc_gemm1x1x3_dgrad")
+            else:
+                check(L.dc_conv1x1_dgrad_add2(ptr(g_c), ptr(ww), ptr(gx), ptr(add), ptr(add2), B, Ci, Co, Hi, Wi, s_, stream(xx)),
+                      "dc_conv1x1_dgrad_add2")
             if first_of_pair:
                 ctx.fork.park(gx)          # the other convolution of the pair adds it and returns the sum
                 gx = None
@@ -1218,9 +1230,14 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             with WgradLanes.lane(ctx.param, xx, g_c):
                 gw = _grad_dst(ctx.slots[0], ww)
-                ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
-                check(L.dc_conv1x1_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream(xx)),
-                      "dc_conv1x1_wgrad")
+                if ctx.split and L.dc_gemm1x1x3_wgrad_ok(B, Ci, Co, Hi, Wi, s_):
+                    ws = torch.empty(L.dc_gemm1x1x3_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
+                    check(L.dc_gemm1x1x3_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream(xx)),
+                          "dc_gemm1x1x3_wgrad")
+                else:
+                    ws = torch.empty(L.dc_conv1x1_wgrad_workspace(B, Ci, Co, Hi, Wi, s_), dtype=torch.uint8, device=xx.device)
+                    check(L.dc_conv1x1_wgrad(ptr(xx), ptr(g_c), ptr(gw), ws.data_ptr(), B, Ci, Co, Hi, Wi, s_, stream(xx)),
+                          "dc_conv1x1_wgrad")
         return gx, gw, gb, None, None, None, None
 
 

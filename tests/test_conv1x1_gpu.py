@@ -91,3 +91,92 @@ def test_conv1x1_bias_act_vs_torch(B, Ci, Co, H, W, act):
     for name, got, ref in (("y", y, yr), ("dx", x.grad, xr.grad), ("dw", w.grad, wr.grad), ("db", b.grad, br.grad)):
         err = (got.double() - ref).abs().max().item()
         assert err <= 1e-5 * max(ref.abs().max().item(), 1e-6), "%s: %.3e" % (name, err)
+
+
+# ---- split-operand GEMMs: fp32 through three bf16 pieces per operand on the bf16 matrix cores (csrc/gemm1x1_x3.hip) ----
+X3_CASES = [
+    # B, Ci, Co, H, W, stride
+    (2, 256, 64, 80, 256, 1),      # layer1.x.conv1: half-empty 128-row tile
+    (2, 64, 256, 80, 256, 1),      # layer1.x.conv3: two reduction chunks
+    (2, 256, 512, 80, 256, 2),     # layer2.0.downsample: stride-2 gather (forward / weight gradient; the data gradient stays fp32-MFMA)
+    (3, 2048, 512, 10, 32, 1),     # layer4.x.conv1: tiles span images (P = 320), N = 960 not a multiple of the 128-pixel tile
+    (3, 512, 2048, 10, 32, 1),
+    (2, 128, 96, 12, 40, 1),       # 96 output rows (row padding), P = 480
+    (1, 96, 160, 8, 16, 1),        # 160 rows: one full + one partial row tile; 96 input channels (dgrad: partial tile), P = 128
+]
+
+
+def _x3_run(B, Ci, Co, H, W, s, split, bias=False, act=0, seed=0):
+    from depthcore import ops, _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(1000 + seed + B * 100 + Ci + s)
+    x = torch.relu(torch.randn(B, Ci, H, W, generator=g)).cuda().requires_grad_(True)       # post-ReLU activations: what these layers read
+    w = (torch.randn(Co, Ci, 1, 1, generator=g) * (2.0 / Ci) ** 0.5).cuda().requires_grad_(True)
+    b = (0.1 * torch.randn(Co, generator=g)).cuda().requires_grad_(True) if bias else None
+    prev = L.dc_set_gemm_split(int(split))
+    try:
+        y = ops.conv1x1(x, w, s, b, act)
+        gy = torch.randn(y.shape, generator=g).cuda()
+        y.backward(gy)
+    finally:
+        L.dc_set_gemm_split(prev)
+    torch.cuda.synchronize()
+    return x, w, b, gy, y.detach(), x.grad.clone(), w.grad.clone(), (b.grad.clone() if bias else None)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,s", X3_CASES)
+def test_split_operand_gemms_are_fp32_accurate(B, Ci, Co, H, W, s):
+    """The gate of VERDICT round 5 (item 1b): error against an fp64 GEMM no worse than the fp32-MFMA kernels' own.  Norm-wise error of
+    y, dx, dw of both paths against torch's fp64 convolution: the split path may be at most 1.25x the fp32-MFMA path (+ 2e-8), and
+    within the absolute 5e-6-of-the-maximum bound the fp32 kernels are held to above."""
+    from depthcore import _lib
+    L = _lib.lib()
+    assert L.dc_gemm1x1x3_fwd_ok(B, Ci, Co, H, W, s) and L.dc_gemm1x1x3_wgrad_ok(B, Ci, Co, H, W, s)
+    r32 = _x3_run(B, Ci, Co, H, W, s, 0)
+    r3 = _x3_run(B, Ci, Co, H, W, s, 1)
+    x, w, _, gy = r32[:4]
+    xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, s)
+    yr.backward(gy.double())
+    report = []
+    for name, i, ref in (("y", 4, yr.detach()), ("dx", 5, xr.grad), ("dw", 6, wr.grad)):
+        e32 = float((r32[i].double() - ref).norm() / ref.norm())
+        e3 = float((r3[i].double() - ref).norm() / ref.norm())
+        report.append((name, e3, e32))
+        assert e3 <= 1.25 * e32 + 2e-8, report
+        err = (r3[i].double() - ref).abs().max().item()
+        assert err <= 5e-6 * max(ref.abs().max().item(), 1e-6), "%s: %.3e" % (name, err)
+    print("split-operand 1x1 %s: (tensor, |x3 - f64| / |f64|, |f32-MFMA - f64| / |f64|) %s" % ((B, Ci, Co, H, W, s), report))
+    if s == 2:
+        assert torch.count_nonzero(r3[5][:, :, 1::2, :]) == 0 and torch.count_nonzero(r3[5][:, :, :, 1::2]) == 0
+
+
+def test_split_operand_gemm_epilogues_and_determinism():
+    """bias + activation in the forward's epilogue, the residual fork's addend in the data gradient's, bitwise run-to-run."""
+    from depthcore import ops, _lib
+    L = _lib.lib()
+    B, Ci, Co, H, W = 2, 128, 256, 16, 32
+    a = _x3_run(B, Ci, Co, H, W, 1, 1, bias=True, act=3)
+    b = _x3_run(B, Ci, Co, H, W, 1, 1, bias=True, act=3)
+    for i in (4, 5, 6, 7):
+        assert torch.equal(a[i], b[i])
+    x, w, bs, gy = a[:4]
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, bs))
+    yr = torch.relu(F.conv2d(xr, wr, br, 1))
+    yr.backward(gy.double())
+    for got, ref in ((a[4], yr.detach()), (a[5], xr.grad), (a[6], wr.grad), (a[7], br.grad)):
+        assert float((got.double() - ref).norm() / ref.norm()) <= 3e-7
+    # addend epilogue: dc_gemm1x1x3_dgrad(addend) == dc_gemm1x1x3_dgrad() + addend, one fp32 addition either way
+    gyc = torch.randn(B, Co, H, W, device="cuda")
+    add = torch.randn(B, Ci, H, W, device="cuda")
+    ww = w.detach().reshape(Co, Ci).contiguous()
+    ws = torch.empty(L.dc_gemm1x1x3_workspace(Ci, Co), dtype=torch.uint8, device="cuda")
+    d0, d1 = torch.empty_like(add), torch.empty_like(add)
+    assert L.dc_gemm1x1x3_dgrad(gyc.data_ptr(), ww.data_ptr(), d0.data_ptr(), ws.data_ptr(), None, None, B, Ci, Co, H, W, 1, None) == 0
+    assert L.dc_gemm1x1x3_dgrad(gyc.data_ptr(), ww.data_ptr(), d1.data_ptr(), ws.data_ptr(), add.data_ptr(), None, B, Ci, Co, H, W, 1, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d0 + add)
+    # shapes outside the split kernels are refused by the _ok queries (the callers then keep the fp32-MFMA kernels)
+    assert not L.dc_gemm1x1x3_fwd_ok(24, 512, 256, 6, 20, 1)        # P = 120: pixel runs of 16 would straddle images
+    assert not L.dc_gemm1x1x3_dgrad_ok(2, 256, 512, 80, 256, 2)     # stride-2 data gradient
+    assert not L.dc_gemm1x1x3_fwd_ok(5, 260, 12, 6, 20, 1)
