@@ -422,8 +422,10 @@ int dc_conv1x1_wgrad_bn(const float* x, const float* gy, float* dweight, void* w
  * bf16 pieces and the six partial products down to 2^-16 |a||b| are accumulated in fp32 -- fp32 inputs, fp32 outputs, an error
  * below that of an fp32 multiply-add chain of the same length, at 6/16 of the fp32 matrix time.  Shapes: dc_gemm1x1x3_*_ok
  * (pixels per image a multiple of 16, reduction extent a multiple of 32, >= 64 output rows; the data gradient at stride 1);
- * ws = dc_gemm1x1x3_workspace(Ci, Co) bytes, 16-byte aligned (the split weights of the launch).  dc_set_gemm_split(1) (env
- * DC_G1_X3) makes dc_conv1x1_* callers with a workspace take this path where it applies (depthcore/ops.py does). */
+ * ws = dc_gemm1x1x3_workspace(Ci, Co) bytes, 16-byte aligned (the split weights of the launch; weights registered with the
+ * per-step weight cache, dc_wino_cache_*, are split once per step by its refresh instead).  dc_set_gemm_split (default 1; env
+ * DC_G1_X3): whether callers that can supply the workspace (depthcore/ops.py, depthcore/bnfold.py) take this path where it
+ * applies; 0 keeps the fp32-MFMA kernels (the A/B). */
 int dc_set_gemm_split(int mode);
 int dc_get_gemm_split(void);
 int dc_gemm1x1x3_fwd_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);

@@ -31,6 +31,7 @@
 //     two barriers per chunk (the co-resident block computes meanwhile).
 #include "dc_common.h"
 #include "gemm1x1.h"
+#include "gemm1x1_x3.h"
 #include "wino.h"
 
 #include <algorithm>
@@ -91,41 +92,12 @@ __device__ __forceinline__ float x3_row16_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ unsigned x3_pack(float lo, float hi) {
-    const x3bf2 p = {(__bf16)lo, (__bf16)hi};          // v_cvt_pk_bf16_f32 (round to nearest even)
-    return __builtin_bit_cast(unsigned, p);
-}
-__device__ __forceinline__ float x3_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float x3_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-// (a, b) -> the three packed bf16 pairs of their pieces
-__device__ __forceinline__ void x3_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-    p0 = x3_pack(a, b);
-    const float ra = a - x3_lo(p0), rb = b - x3_hi(p0);            // exact (Sterbenz-like: the residual of a rounding)
-    p1 = x3_pack(ra, rb);
-    const float sa = ra - x3_lo(p1), sb = rb - x3_hi(p1);
-    p2 = x3_pack(sa, sb);
-}
+__device__ __forceinline__ void x3_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) { x3h_split2(a, b, p0, p1, p2); }
 
-// ---- weights -> [piece][Mp][K] bf16, reduction permuted inside each chunk of 32: position 8 kg + e <-> k = e < 4 ? 4 kg + e : 16 + 4 kg + e - 4
-//   forward (tr = 0): A[m][k] = w[m][k]  (M = Co, K = Ci);   data gradient (tr = 1): A[m][k] = w[k][m]  (M = Ci, K = Co)
-// one thread per (row, 4 consecutive positions): 8-byte stores
-__global__ __launch_bounds__(256) void g1x3_prep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wa, int Co, int Ci, int tr,
+// ---- weights -> [piece][Mp][K] bf16 (g1x3_prep_item, gemm1x1_x3.h): once per launch, or once per step by the weight cache's refresh
+__global__ __launch_bounds__(256) void g1x3_prep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wa, int Ci, int tr,
                                                         int M, int Mp, int K) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int q = K >> 2;
-    if (idx >= Mp * q) return;
-    const int m = idx / q, pos4 = (idx - m * q) * 4;
-    const int c = pos4 >> 5, pl = pos4 & 31, kg = pl >> 3, e = pl & 7;
-    const int k0 = c * 32 + (e < 4 ? 4 * kg : 16 + 4 * kg);
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = m < M ? (tr ? w[(size_t)(k0 + j) * Ci + m] : w[(size_t)m * Ci + k0 + j]) : 0.f;
-    unsigned p[3][2];
-    x3_split2(v[0], v[1], p[0][0], p[1][0], p[2][0]);
-    x3_split2(v[2], v[3], p[0][1], p[1][1], p[2][1]);
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-        *reinterpret_cast<x3u2*>(wa + ((size_t)s * Mp + m) * K + pos4) = x3u2{p[s][0], p[s][1]};
+    g1x3_prep_item(w, wa, blockIdx.x * 256 + threadIdx.x, Ci, tr, M, Mp, K);
 }
 
 // element offset of (b, channel 0, first pixel) of a 4-pixel group of the flattened (b, p) dimension, clamped to the last group
@@ -150,10 +122,12 @@ extern __shared__ unsigned short g1x3_smem[];
 
 // MODE 0: plain (EPI: bias + activation + addends); 1: forward with the BatchNorm + ReLU of its input in the loader; 2 / 3: data gradient
 // with the BatchNorm-backward epilogue (ReLU decision re-derived from the raw input / read from the forward's bit mask, + addend).
-// MODE 0 / 1 take the statistics epilogue when a.stat_part is set.
+// MODE 0 / 1 take the statistics epilogue when a.stat_part is set.  MODE 4: data gradient of a STRIDE-2 convolution -- the GEMM over the
+// output pixels is the stride-1 one; the store scatters each value to (2 py, 2 px) of the input map and writes the zeros of the cells
+// the stride skips, plus the addends of the input's other consumers over the whole cell block (every cell written exactly once).
 template <int MT, int NT, int S, bool EPI, int MODE = 0>
 __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Args a) {
-    static_assert(MODE == 0 || (S == 1 && !EPI), "the BatchNorm fold exists at stride 1 without bias / activation");
+    static_assert(MODE == 0 || (S == 1 && !EPI), "the BatchNorm fold / the stride-2 scatter run the stride-1 GEMM without bias / activation");
     using T = X3T<MT, NT>;
     constexpr int BST = X3B<NT>::ST;
     constexpr int NA = 3 * MT / 2;             // 16-byte A items per thread per chunk (3 pieces x BM rows x 4)
@@ -165,7 +139,7 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
     const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
     const int m0 = (lb % a.mtiles) * T::BM, n0 = (lb / a.mtiles) * T::BN;
     const int P = a.Ho * a.Wo, N = a.B * P;
-    const size_t plane = (size_t)a.Hi * a.Wi;
+    const size_t plane = MODE == 4 ? (size_t)P : (size_t)a.Hi * a.Wi;      // channel stride of the B operand's source (MODE 4: a.Hi x a.Wi is the scatter target)
     const int nch = a.K / X3_KC;
 
     // ---- staging roles
@@ -280,7 +254,7 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
     const int nn = nok ? nb : 0;
     const int b = nn / P, p = nn - b * P;
     const int slot = (lb / a.mtiles) * 2 + wn;    // partial number of the statistics / BatchNorm-backward epilogues: (pixel tile, wave column)
-    if constexpr (MODE >= 2) {
+    if constexpr (MODE == 2 || MODE == 3) {
         // BatchNorm-backward epilogue (csrc/gemm1x1.hip g1_dgrad_kernel<.., BNE>): the data gradient [+ the skip's gradient] is
         // masked with the ReLU decision of the activation the forward read, stored as g', and the wave column's partial
         // {sum g', sum g' (x - mean)} per channel goes to a.bwd_part
@@ -339,6 +313,58 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
                         if constexpr (NT == 4) *reinterpret_cast<x3f4*>(dst) = x3f4{g[0], g[1], g[2], g[3]};
                         else *reinterpret_cast<float2*>(dst) = make_float2(g[0], g[1]);
                     }
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (MODE == 4) {
+        // a.Hi x a.Wi = the INPUT map (2 Ho x 2 Wo); this lane's NT output pixels lie in one output row (Wo % 4 == 0)
+        if (!nok) return;
+        const int Wo = a.Wi >> 1, Po = (a.Hi >> 1) * Wo;
+        const int bo = nb / Po, po = nb - bo * Po;
+        const int py = po / Wo, px = po - py * Wo;
+        const size_t plane = (size_t)a.Hi * a.Wi;
+        const size_t pix = (size_t)(2 * py) * a.Wi + 2 * px;
+        constexpr int CV = NT / 2;                // 16-byte vectors per cell row (2 NT floats)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            x3f4 c0[4][CV], c1[4][CV];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int v = 0; v < CV; ++v) { c0[r][v] = x3f4{0.f, 0.f, 0.f, 0.f}; c1[r][v] = x3f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+            for (int which = 0; which < 2; ++which) {
+                const float* addp = which == 0 ? a.addend : a.addend2;
+                if (!addp) continue;
+                x3f4 t0[4][CV], t1[4][CV];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = min(m0 + wm * 16 * MT + mt * 16 + kg * 4 + r, a.M - 1);
+                    const float* src = addp + ((size_t)bo * a.M + ci) * plane + pix;
+#pragma unroll
+                    for (int v = 0; v < CV; ++v) {
+                        t0[r][v] = *reinterpret_cast<const x3f4*>(src + 4 * v);
+                        t1[r][v] = *reinterpret_cast<const x3f4*>(src + a.Wi + 4 * v);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int v = 0; v < CV; ++v) { c0[r][v] += t0[r][v]; c1[r][v] += t1[r][v]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = m0 + wm * 16 * MT + mt * 16 + kg * 4 + r;
+                if (ci >= a.M) continue;
+                float* dst = a.out + ((size_t)bo * a.M + ci) * plane + pix;
+#pragma unroll
+                for (int v = 0; v < CV; ++v) {
+                    x3f4 o = c0[r][v];
+                    o.x += acc[mt][2 * v][r]; o.z += acc[mt][2 * v + 1][r];
+                    *reinterpret_cast<x3f4*>(dst + 4 * v) = o;
+                    *reinterpret_cast<x3f4*>(dst + a.Wi + 4 * v) = c1[r][v];
                 }
             }
         }
@@ -540,7 +566,10 @@ __global__ __launch_bounds__(256) void g1x3_slabsum_kernel(const x3f4* __restric
     }
 }
 
-static int g_g1x3 = [] { const char* f = getenv("DC_G1_X3"); return f ? atoi(f) : 0; }();
+// default ON (env DC_G1_X3=0 / dc_set_gemm_split(0): the fp32-MFMA kernels of gemm1x1.hip, the A/B): the gate of VERDICT round 5 item 1
+// -- error vs fp64 no worse than the fp32-MFMA kernels', every fp64-calibrated test green with unchanged thresholds -- is met
+// (tests/test_conv1x1_gpu.py, tests/test_encoder_gpu.py, tests/test_train_gpu.py under this default)
+static int g_g1x3 = [] { const char* f = getenv("DC_G1_X3"); return f ? atoi(f) : 1; }();
 
 template <typename K>
 static bool x3_set_lds(K kernel, size_t bytes) {
@@ -601,7 +630,7 @@ extern "C" int dc_gemm1x1x3_fwd_ok(int B, int Ci, int Co, int Hi, int Wi, int st
     return g1x3_common(B, Ci, Co, Hi, Wi, stride) && Ci % 32 == 0 && Co >= 32;
 }
 extern "C" int dc_gemm1x1x3_dgrad_ok(int B, int Ci, int Co, int Hi, int Wi, int stride) {
-    return stride == 1 && g1x3_common(B, Ci, Co, Hi, Wi, stride) && Co % 32 == 0 && Ci >= 32;
+    return g1x3_common(B, Ci, Co, Hi, Wi, stride) && Co % 32 == 0 && Ci >= 32;
 }
 // bytes of the split weights of one launch (either direction): 3 bf16 pieces, rows padded to 128
 extern "C" size_t dc_gemm1x1x3_workspace(int Ci, int Co) {
@@ -635,9 +664,10 @@ static int g1x3_go(const G1x3Args& a, dim3 grid, int stride, bool epi, int mode,
     static const bool attr = x3_set_lds(g1x3_kernel<MT, NT, 1, false>, T::LDS) && x3_set_lds(g1x3_kernel<MT, NT, 1, true>, T::LDS) &&
                              x3_set_lds(g1x3_kernel<MT, NT, 2, false>, T::LDS) && x3_set_lds(g1x3_kernel<MT, NT, 2, true>, T::LDS) &&
                              x3_set_lds(g1x3_kernel<MT, NT, 1, false, 1>, T::LDS) && x3_set_lds(g1x3_kernel<MT, NT, 1, false, 2>, T::LDS) &&
-                             x3_set_lds(g1x3_kernel<MT, NT, 1, false, 3>, T::LDS);
+                             x3_set_lds(g1x3_kernel<MT, NT, 1, false, 3>, T::LDS) && x3_set_lds(g1x3_kernel<MT, NT, 1, false, 4>, T::LDS);
     if (!attr) return DC_ELAUNCH;
-    if (mode == 1) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 1, false, 1>), grid, dim3(256), T::LDS, st, a);
+    if (mode == 4) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 1, false, 4>), grid, dim3(256), T::LDS, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 1, false, 1>), grid, dim3(256), T::LDS, st, a);
     else if (mode == 2) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 1, false, 2>), grid, dim3(256), T::LDS, st, a);
     else if (mode == 3) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 1, false, 3>), grid, dim3(256), T::LDS, st, a);
     else if (stride == 1) {
@@ -656,13 +686,15 @@ static int g1x3_launch(const float* src, const float* weight, float* out, void* 
                        hipStream_t st) {
     if (((size_t)ws & 15) || ((size_t)src & 15) || ((size_t)out & 15)) return DC_EINVAL;
     G1x3Args a{};
+    const bool scatter = stride == -2;            // data gradient of a stride-2 convolution: (Hi, Wi) is the OUTPUT map here
+    if (scatter) stride = 1;
     a.Mp = ceil_div(M, 128) * 128;
     a.wa = (unsigned short*)ws; a.x = src; a.out = out; a.bias = bias; a.addend = addend; a.addend2 = addend2; a.act = act;
     a.B = B; a.M = M; a.K = K; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / stride; a.Wo = Wi / stride;
     const int N = B * a.Ho * a.Wo;
     const X3Tile t = x3_pick(M, N, stride);
     a.mtiles = ceil_div(M, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
-    int mode = 0;
+    int mode = scatter ? 4 : 0;
     if (bn) {
         if (bn->groups < 1 || B % bn->groups) return DC_EINVAL;
         a.npg = B / bn->groups;
@@ -687,9 +719,15 @@ static int g1x3_launch(const float* src, const float* weight, float* out, void* 
             mode = bn->bn_mask ? 3 : 2;
         }
     }
-    hipLaunchKernelGGL(g1x3_prep_kernel, dim3(ceil_div(a.Mp * (K / 4), 256)), dim3(256), 0, st, weight, (unsigned short*)ws, Co, Ci, tr, M, a.Mp, K);
-    DC_CHECK_LAUNCH();
+    // split weights: from the per-step cache (registered weights, after its refresh) or prepared here
+    if (const void* cached = wc_lookup_x3(weight, Ci, Co, tr, a.Mp, K, st)) {
+        a.wa = (const unsigned short*)cached;
+    } else {
+        hipLaunchKernelGGL(g1x3_prep_kernel, dim3(ceil_div(a.Mp * (K / 4), 256)), dim3(256), 0, st, weight, (unsigned short*)ws, Ci, tr, M, a.Mp, K);
+        DC_CHECK_LAUNCH();
+    }
     const dim3 grid(a.mtiles * a.ntiles);
+    if (scatter) { a.Hi = 2 * Hi; a.Wi = 2 * Wi; }          // (the loads use Ho x Wo = the gy map; the scatter epilogue the input map)
     const bool epi = mode == 0 && (bias || act != ACT_NONE || addend || addend2);
     // family 7: algorithmic = 2 MAC of the GEMM; executed = the six bf16 products of every padded tile (bf16 matrix FLOPs)
     hipEvent_t pe = conv_prof_begin(7, 2.0 * (double)N * M * K, 12.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * K,
@@ -717,6 +755,11 @@ extern "C" int dc_gemm1x1x3_fwd(const float* x, const float* weight, const float
 extern "C" int dc_gemm1x1x3_dgrad_bn(const float* gy, const float* weight, float* dx, void* ws, const float* addend, const float* addend2,
                                      int B, int Ci, int Co, int Hi, int Wi, int stride, const dc_bn_fold* bn, void* stream) {
     if (!gy || !weight || !dx || !ws || !dc_gemm1x1x3_dgrad_ok(B, Ci, Co, Hi, Wi, stride)) return DC_EINVAL;
+    if (stride == 2) {
+        // the GEMM runs over the OUTPUT pixels (Hi/2 x Wi/2, stride 1); the scatter epilogue knows the input map through args_s2
+        if (bn && (bn->bwd_part || bn->in_scale || bn->stat_part)) return DC_EINVAL;
+        return g1x3_launch(gy, weight, dx, ws, nullptr, ACT_NONE, addend, addend2, B, Ci, Co, Co, Ci, 1, Hi / 2, Wi / 2, -2, nullptr, (hipStream_t)stream);
+    }
     return g1x3_launch(gy, weight, dx, ws, nullptr, ACT_NONE, addend, addend2, B, Ci, Co, Co, Ci, 1, Hi, Wi, 1, bn, (hipStream_t)stream);
 }
 extern "C" int dc_gemm1x1x3_dgrad(const float* gy, const float* weight, float* dx, void* ws, const float* addend, const float* addend2, int B,

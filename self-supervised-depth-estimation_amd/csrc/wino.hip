@@ -37,6 +37,7 @@
 #include "conv_bf16.h"
 #include "wino.h"
 #include "wino4.h"
+#include "gemm1x1_x3.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -113,6 +114,10 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const WinoWDe
     const WinoWDesc d = table[blk2desc[blockIdx.x]];
     const int idx = ((int)blockIdx.x - d.block0) * 256 + threadIdx.x;
     if (d.kind == 1) { c3b_wprep_item(d.w, reinterpret_cast<uint4*>(d.uhat), idx, d.Co, d.Ci, d.dgrad, d.MT, d.Mp, d.Kp); return; }
+    if (d.kind == 2) {       // split-operand 1x1 GEMMs: (Mp, Kp) = (padded rows, reduction extent) of this direction
+        g1x3_prep_item(d.w, reinterpret_cast<unsigned short*>(d.uhat), idx, d.Ci, d.dgrad, d.dgrad ? d.Ci : d.Co, d.Mp, d.Kp);
+        return;
+    }
     if (d.dgrad) wino_weight_one<true>(d.w, d.uhat, idx, d.Co, d.Ci, d.MT, d.Mp, d.Kp, WK);
     else wino_weight_one<false>(d.w, d.uhat, idx, d.Co, d.Ci, d.MT, d.Mp, d.Kp, WK);
 }
@@ -728,7 +733,7 @@ static inline size_t wino_uhat_bytes(int Ci, int Co) {
 // step -- ONE launch that transforms every variant seen so far instead of one 8 us launch in front of every convolution
 // -- and dc_wino_cache_invalidate when the step's backward is done.  Between the two, wino_launch takes U from the
 // cache; a variant (dgrad, MT) it has not met yet is transformed in place as before and joins the next refresh.
-struct WcVariant { int dgrad, MT, Mp, Kp; float* buf; bool fresh, in_table; int kind; };     // kind 0 Winograd U, 1 bf16 prepared weights
+struct WcVariant { int dgrad, MT, Mp, Kp; float* buf; bool fresh, in_table; int kind; };     // kind 0 Winograd U, 1 bf16 prepared weights, 2 split 1x1 weights
 struct WcEntry { const float* w; int Ci, Co, owner; std::vector<WcVariant> v; };
 // One descriptor table PER OWNER (= per model / Trainer).  A refresh transforms -- and a captured hipGraph replays the
 // transform of -- the owner's own weights only, which the owner keeps alive; weights of another owner never enter its
@@ -764,9 +769,11 @@ static WcOwner* wc_owner(int id) {
 // -> cached U for this launch, or nullptr (then the caller transforms into its workspace).  Nothing is allocated while
 // `st` is being captured (hipMalloc is illegal there): an unseen variant is then transformed per launch, as before.
 static inline size_t wc_variant_bytes(int kind, int MT, int Mp, int Kp) {
+    if (kind == 2) return (size_t)Mp * Kp * 3 * 2 + 256;
     return kind == 1 ? (size_t)Mp * Kp * 36 * MT * 16 : (size_t)Mp * Kp * 16 * sizeof(float);
 }
 static inline int wc_variant_blocks(int kind, int MT, int Mp, int Kp) {
+    if (kind == 2) return ceil_div(Mp * (Kp / 4), 256);
     return kind == 1 ? ceil_div(Mp * Kp * 36 * MT, 256) : wino_wblocks(Mp, Kp);
 }
 static const float* wc_lookup_kind(int kind, const float* w, int Ci, int Co, bool dgrad, int MT, int Mp, int Kp, hipStream_t st) {
@@ -792,6 +799,9 @@ static const float* wc_lookup(const float* w, int Ci, int Co, bool dgrad, int MT
 }
 const void* wc_lookup_c3b(const float* w, int Ci, int Co, int dgrad, int MT, int nmblk, int nchunks, hipStream_t st) {
     return wc_lookup_kind(1, w, Ci, Co, dgrad != 0, MT, nmblk, nchunks, st);
+}
+const void* wc_lookup_x3(const float* w, int Ci, int Co, int tr, int Mp, int K, hipStream_t st) {
+    return wc_lookup_kind(2, w, Ci, Co, tr != 0, 0, Mp, K, st);
 }
 
 #ifdef WINO_DIAG

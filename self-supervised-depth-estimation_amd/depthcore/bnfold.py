@@ -141,23 +141,25 @@ class _K1:
 
     @staticmethod
     def dgrad(L, g_c, ww, gx, add, B, Ci, Co, Hi, Wi, s_, f, add2=None):
-        x3 = _K1._x3_dgrad(L, B, Ci, Co, Hi, Wi, s_, f.groups)
-        if add2 is not None:      # (a stage's first block: no BatchNorm epilogue on this launch, two addends)
-            if x3:
+        if f.bwd_part:            # BatchNorm-backward epilogue (stride 1): the kernel family the partials were sized for
+            if add2 is not None:
+                raise _lib.DepthcoreError("the BatchNorm epilogues take one addend")
+            if _K1._x3_dgrad(L, B, Ci, Co, Hi, Wi, s_, f.groups):
                 ws = torch.empty(L.dc_gemm1x1x3_workspace(Ci, Co), dtype=torch.uint8, device=gx.device)
-                check(L.dc_gemm1x1x3_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), ptr(add), ptr(add2), B, Ci, Co, Hi, Wi, s_, stream(gx)),
-                      "dc_gemm1x1x3_dgrad")
-                return
+                check(L.dc_gemm1x1x3_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), ptr(add), None, B, Ci, Co, Hi, Wi, s_, ctypes.byref(f),
+                                              stream(gx)), "dc_gemm1x1x3_dgrad_bn")
+            else:
+                check(L.dc_conv1x1_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ptr(add), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(gx)),
+                      "dc_conv1x1_dgrad_bn")
+            return
+        # plain data gradient (+ the addends of the input's other consumers; stride 2: the cell-block scatter)
+        if L.dc_get_gemm_split() and L.dc_gemm1x1x3_dgrad_ok(B, Ci, Co, Hi, Wi, s_):
+            ws = torch.empty(L.dc_gemm1x1x3_workspace(Ci, Co), dtype=torch.uint8, device=gx.device)
+            check(L.dc_gemm1x1x3_dgrad(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), ptr(add), ptr(add2), B, Ci, Co, Hi, Wi, s_, stream(gx)),
+                  "dc_gemm1x1x3_dgrad")
+        else:
             check(L.dc_conv1x1_dgrad_add2(ptr(g_c), ptr(ww), ptr(gx), ptr(add), ptr(add2), B, Ci, Co, Hi, Wi, s_, stream(gx)),
                   "dc_conv1x1_dgrad_add2")
-            return
-        if x3:
-            ws = torch.empty(L.dc_gemm1x1x3_workspace(Ci, Co), dtype=torch.uint8, device=gx.device)
-            check(L.dc_gemm1x1x3_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ws.data_ptr(), ptr(add), None, B, Ci, Co, Hi, Wi, s_, ctypes.byref(f),
-                                          stream(gx)), "dc_gemm1x1x3_dgrad_bn")
-            return
-        check(L.dc_conv1x1_dgrad_bn(ptr(g_c), ptr(ww), ptr(gx), ptr(add), B, Ci, Co, Hi, Wi, s_, ctypes.byref(f), stream(gx)),
-              "dc_conv1x1_dgrad_bn")
 
     @staticmethod
     def wgrad(L, xx, g_c, gw, B, Ci, Co, Hi, Wi, s_, f):

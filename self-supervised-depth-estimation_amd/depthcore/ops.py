@@ -1122,7 +1122,8 @@ class WinoWeightCache:
         self._keep = []
         self._owner = int(L.dc_wino_cache_new_owner())
         for p_ in params:
-            if p_.dim() == 4 and tuple(p_.shape[2:]) == (3, 3) and p_.is_cuda and p_.dtype == torch.float32 and p_.is_contiguous():
+            # (3x3: Winograd U / prepared bf16 weights; 1x1: the split-operand GEMMs' three bf16 pieces, csrc/gemm1x1_x3.hip)
+            if p_.dim() == 4 and tuple(p_.shape[2:]) in ((3, 3), (1, 1)) and p_.is_cuda and p_.dtype == torch.float32 and p_.is_contiguous():
                 check(L.dc_wino_cache_register(self._owner, p_.data_ptr(), int(p_.shape[1]), int(p_.shape[0])),
                       "dc_wino_cache_register")
                 self._keep.append(p_)           # the registry holds raw addresses: keep the tensors alive with it

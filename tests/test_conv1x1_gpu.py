@@ -98,7 +98,8 @@ X3_CASES = [
     # B, Ci, Co, H, W, stride
     (2, 256, 64, 80, 256, 1),      # layer1.x.conv1: half-empty 128-row tile
     (2, 64, 256, 80, 256, 1),      # layer1.x.conv3: two reduction chunks
-    (2, 256, 512, 80, 256, 2),     # layer2.0.downsample: stride-2 gather (forward / weight gradient; the data gradient stays fp32-MFMA)
+    (2, 256, 512, 80, 256, 2),     # layer2.0.downsample: stride-2 gather (forward / weight gradient), cell-block scatter (data gradient)
+    (3, 1024, 2048, 20, 64, 2),    # layer4.0.downsample
     (3, 2048, 512, 10, 32, 1),     # layer4.x.conv1: tiles span images (P = 320), N = 960 not a multiple of the 128-pixel tile
     (3, 512, 2048, 10, 32, 1),
     (2, 128, 96, 12, 40, 1),       # 96 output rows (row padding), P = 480
@@ -176,7 +177,21 @@ def test_split_operand_gemm_epilogues_and_determinism():
     assert L.dc_gemm1x1x3_dgrad(gyc.data_ptr(), ww.data_ptr(), d1.data_ptr(), ws.data_ptr(), add.data_ptr(), None, B, Ci, Co, H, W, 1, None) == 0
     torch.cuda.synchronize()
     assert torch.equal(d1, d0 + add)
+    # stride 2: every cell of the 2 x 2 blocks is written once -- value + addends at (2 py, 2 px), the addends alone elsewhere
+    Bs, Cis, Cos, Hs, Wsz = 2, 64, 128, 16, 32
+    gys = torch.randn(Bs, Cos, Hs // 2, Wsz // 2, device="cuda")
+    w2 = torch.randn(Cos, Cis, device="cuda") / 8
+    a1, a2 = torch.randn(Bs, Cis, Hs, Wsz, device="cuda"), torch.randn(Bs, Cis, Hs, Wsz, device="cuda")
+    ws2 = torch.empty(L.dc_gemm1x1x3_workspace(Cis, Cos), dtype=torch.uint8, device="cuda")
+    e0, e1 = torch.full_like(a1, float("nan")), torch.full_like(a1, float("nan"))
+    assert L.dc_gemm1x1x3_dgrad(gys.data_ptr(), w2.data_ptr(), e0.data_ptr(), ws2.data_ptr(), None, None, Bs, Cis, Cos, Hs, Wsz, 2, None) == 0
+    assert L.dc_gemm1x1x3_dgrad(gys.data_ptr(), w2.data_ptr(), e1.data_ptr(), ws2.data_ptr(), a1.data_ptr(), a2.data_ptr(), Bs, Cis, Cos, Hs, Wsz, 2, None) == 0
+    torch.cuda.synchronize()
+    assert torch.count_nonzero(e0[:, :, 1::2, :]) == 0 and torch.count_nonzero(e0[:, :, :, 1::2]) == 0 and torch.isfinite(e0).all()
+    refs = torch.einsum("mk,bmhw->bkhw", w2.double(), gys.double())
+    assert float((e0[:, :, ::2, ::2].double() - refs).norm() / refs.norm()) <= 3e-7
+    assert torch.allclose(e1, e0 + a1 + a2, rtol=0, atol=2e-6)
     # shapes outside the split kernels are refused by the _ok queries (the callers then keep the fp32-MFMA kernels)
     assert not L.dc_gemm1x1x3_fwd_ok(24, 512, 256, 6, 20, 1)        # P = 120: pixel runs of 16 would straddle images
-    assert not L.dc_gemm1x1x3_dgrad_ok(2, 256, 512, 80, 256, 2)     # stride-2 data gradient
+    assert L.dc_gemm1x1x3_dgrad_ok(2, 256, 512, 80, 256, 2)         # stride-2 data gradient: the scatter epilogue
     assert not L.dc_gemm1x1x3_fwd_ok(5, 260, 12, 6, 20, 1)
