@@ -278,8 +278,18 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
                     const float2 t = *reinterpret_cast<const float2*>(a.bn_x + o);
                     xv[r][0] = t.x; xv[r][1] = t.y;
                 }
+                if (MODE == 3 && a.addend) {
+                    if constexpr (NT == 4) {
+                        const x3f4 t = *reinterpret_cast<const x3f4*>(a.addend + o);
+                        ad[r][0] = t.x; ad[r][1] = t.y; ad[r][2] = t.z; ad[r][3] = t.w;
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2*>(a.addend + o);
+                        ad[r][0] = t.x; ad[r][1] = t.y;
+                    }
+                } else {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) ad[r][nt] = (MODE == 3 && a.addend) ? a.addend[o + nt] : 0.f;
+                    for (int nt = 0; nt < NT; ++nt) ad[r][nt] = 0.f;
+                }
                 if constexpr (MODE == 3) {
                     // bit l of word w of a 256-element block <-> element 4 l + w (bn_apply_kernel's wave ballots)
                     const int l = (p & 255) >> 2, w0 = p & 3;
@@ -371,6 +381,47 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
         return;
     }
     const bool stats = MODE <= 1 && a.stat_part != nullptr;       // (wave-uniform)
+    if constexpr (EPI) {
+        if (a.bias || a.act != ACT_NONE) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 16 * MT + mt * 16 + kg * 4 + r;
+                    const float bv = (a.bias && m < a.M) ? a.bias[m] : 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = act_fwd(acc[mt][nt][r] + bv, a.act);
+                }
+        }
+        // the other gradient(s) of a residual fork: ALL of this lane's addend values are requested (16-byte loads) before the first is
+        // used -- a load next to its store would wait for itself 4 MT times over (csrc/gemm1x1.hip g1_dgrad_kernel)
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            const float* addp = which == 0 ? a.addend : a.addend2;
+            if (!addp || !nok) continue;
+            float adv[MT][4][NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = min(m0 + wm * 16 * MT + mt * 16 + kg * 4 + r, a.M - 1);
+                    const float* src = addp + ((size_t)b * a.M + m) * P + p;
+                    if constexpr (NT == 4) {
+                        const x3f4 t = *reinterpret_cast<const x3f4*>(src);
+                        adv[mt][r][0] = t.x; adv[mt][r][1] = t.y; adv[mt][r][2] = t.z; adv[mt][r][3] = t.w;
+                    } else {
+                        const float2 t = *reinterpret_cast<const float2*>(src);
+                        adv[mt][r][0] = t.x; adv[mt][r][1] = t.y;
+                    }
+                }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += adv[mt][r][nt];
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -381,15 +432,6 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
             float v[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt][r];
-            if constexpr (EPI) {
-                const float bv = (a.bias && mok) ? a.bias[m] : 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    v[nt] = act_fwd(v[nt] + bv, a.act);
-                    if (a.addend && nok) v[nt] += a.addend[o + nt];
-                    if (a.addend2 && nok) v[nt] += a.addend2[o + nt];
-                }
-            }
             if (nok && mok) {
                 if constexpr (NT == 4) *reinterpret_cast<x3f4*>(a.out + o) = x3f4{v[0], v[1], v[2], v[3]};
                 else *reinterpret_cast<float2*>(a.out + o) = make_float2(v[0], v[1]);

@@ -16,7 +16,9 @@ FAMILIES = [("c3b_conv_kernel", "3x3 convolution on the bf16 matrix cores: forwa
             ("c3b_wgrad_kernel", "3x3 weight gradient on the bf16 matrix cores"), ("c3b_", "bf16 weight packing"),
             ("attn_", "Fusion_v3 AttentionConv forward / backward"),
             ("wino_ps_kernel", "Winograd 3x3 forward / data gradient"), ("wino_wgrad_kernel", "Winograd 3x3 weight gradient"),
-            ("wino_", "Winograd transforms (weights, filter reduce)"), ("g1_", "tiled 1x1 GEMMs (fwd / dgrad / wgrad / reduce)"),
+            ("wino_", "Winograd transforms (weights, filter reduce)"),
+            ("g1x3_", "1x1 GEMMs with split fp32 operands on the bf16 matrix cores (fwd / dgrad / wgrad / prep / slab sum)"),
+            ("g1_", "tiled fp32-MFMA 1x1 GEMMs (fwd / dgrad / wgrad / reduce)"),
             ("stem_", "7x7/2 stem, patch-staged (forward, weight gradient, reduce)"),
             ("cg_", "3x3/2 implicit-GEMM convolutions (forward, data / weight gradient, helpers)"),
             ("slab_reduce16", "fixed-order slab reduce of the split weight gradients"),
@@ -79,7 +81,7 @@ for cfg in ("c2", "c3", "c5", "c5bf16"):
         c = sum(int(r["Calls"]) for r in rs)
         return (sum(float(r["TotalDurationNs"]) for r in rs) / c / 1e3 if c else 0.0), c
     rf = b["roofline"]
-    key = {0: "wino_ps_kernel", 1: "wino_wgrad_kernel", 2: "c3b_conv_kernel", 3: "c3b_wgrad_kernel", 4: "g1_"}
+    key = {0: "wino_ps_kernel", 1: "wino_wgrad_kernel", 2: "c3b_conv_kernel", 3: "c3b_wgrad_kernel", 4: "g1_", 5: "cg_", 6: "stem_", 7: "g1x3_"}
     L.append("\nCross-check of the bench line's `roofline` families (hipEvents inside bench.py) against this trace:\n")
     L.append("| family | rocprofv3 avg us (launches) | bench.py avg us, plain run | bench.py avg us, profiled run | achieved (plain run) |")
     L.append("|---|---:|---:|---:|---|")

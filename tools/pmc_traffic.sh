@@ -17,6 +17,12 @@ def load(d):
         agg[n].append(float(r["Counter_Value"]))
         if any(t in n for t in ("g1_fwd_kernel", "g1_dgrad_kernel", "g1_wgrad_kernel")):
             agg["dc::g1_*"].append(float(r["Counter_Value"]))          # the 1x1 GEMM family of bench.py (mean over all its launches)
+        if any(t in n for t in ("g1x3_kernel", "g1x3_wgrad_kernel")):
+            agg["dc::g1x3_*"].append(float(r["Counter_Value"]))        # the split-operand 1x1 family
+        if any(t in n for t in ("cg_fwd3_kernel", "cg_dgrad3_kernel", "cg_wgrad3_kernel")):
+            agg["dc::cg_*"].append(float(r["Counter_Value"]))
+        if any(t in n for t in ("stem_fwd_kernel", "stem_wgrad_kernel")):
+            agg["dc::stem_*"].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 fe, wr, va = load(sys.argv[1] + "/fetch"), load(sys.argv[1] + "/write"), load(sys.argv[1] + "/valu")
 cal = [k for k in fe if "d2d_fwd" in k][0]
@@ -24,7 +30,7 @@ known_r, known_w = 256.0 * 2**20, 512.0 * 2**20
 kr, kw = known_r / (fe[cal] * 1024.0), known_w / (wr[cal] * 1024.0)
 out = {"calibration": {"kernel": cal, "FETCH_SIZE_KB": fe[cal], "WRITE_SIZE_KB": wr[cal], "read_factor": kr, "write_factor": kw}}
 for k in fe:
-    if any(t in k for t in ("photo_", "identity", "disp_grad", "smooth_fwd", "finalize", "wino_", "c3b_", "g1_", "cg_", "bn_", "pw_", "conv_fold", "conv_gprime")):
+    if any(t in k for t in ("photo_", "identity", "disp_grad", "smooth_fwd", "finalize", "wino_", "c3b_", "g1_", "g1x3_", "cg_", "stem_", "bn_", "pw_", "conv_fold", "conv_gprime")):
         out[k] = {"FETCH_SIZE_KB": fe[k], "WRITE_SIZE_KB": wr.get(k, 0.0),
                   "read_bytes_calibrated": fe[k] * 1024 * kr, "write_bytes_calibrated": wr.get(k, 0.0) * 1024 * kw,
                   "hbm_bytes_calibrated": fe[k] * 1024 * kr + wr.get(k, 0.0) * 1024 * kw, "sq_insts_valu": va.get(k)}
