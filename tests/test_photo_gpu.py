@@ -52,6 +52,9 @@ def test_golden_trainer_level(golden, tag, kw):
     close(losses[4], g[p + "loss"], rtol=1e-3, atol=0)
     for s in range(4):
         close(losses[s], g[p + "loss%d" % s], rtol=1e-3, atol=0)
+        # measured margin (profiles/round6_parity_passrates.txt): with NO absolute floor 97.3-99.9 % of the elements meet the plain
+        # 1e-3 (scale 2 of "auto" 97.3 %, "nossim" 99.9-100 %); the misses are elements near zero of gradient maps that are sums of
+        # mixed-sign SSIM derivatives -- with the 1e-7 floor fewer than 1 % remain
         close_frac(gd[s], g[p + "gdisp%d" % s], rtol=1e-3, atol=1e-7, bad=1e-2, msg="gdisp%d" % s)
         assert rel_l2(gd[s], g[p + "gdisp%d" % s]) < 3e-2
         if not kw.get("disable_automasking"):
@@ -116,6 +119,10 @@ def test_full_size_c2_vs_oracle():
         sel = (ex["argmin"][s] >= 2).cpu()
         assert (sel != oo["identity_selection/%d" % s].bool()).float().mean() < 1e-3
         # each scale-s pixel sums 4^s full-res gradients of mixed sign: allow more outliers there
+        # measured (profiles/round6_parity_passrates.txt, "C2 full size"): plain 1e-3 pass-rates 98.2 / 96.9 / 95.3 / 91.7 % at scales 0-3
+        # against the fp32 oracle, whose OWN distance from fp64 on these tensors is 0.96-1.3e-2 in the norm ("conditioning": the HIP path
+        # 0.75-1.15e-2, i.e. closer to fp64 than the oracle at every scale); the pose gradients -- 12 numbers per frame, each a sum over
+        # 1.5 M pixels -- meet the plain 1e-3 in 15-17 % of their entries and 2.4e-3 in the norm, the fp32 oracle's own 2.3e-3
         close_frac(gd[s], ogd[s], rtol=2e-3, atol=0, atol_rel=2e-3, bad=1e-2 * (s + 1), msg="gdisp%d" % s)
         assert rel_l2(gd[s], ogd[s]) < 2e-2
     for f in range(2):

@@ -136,8 +136,11 @@ def test_all_parameter_gradients_vs_oracle(fusion):
           "; decisions differing from fp64: %d of %d imposed (%.2e)" % (flipped, imposed, flipped / max(imposed, 1)),
           "; 1e-3 pointwise pass-rate per network:", {k: round(pass_rate_1e3(gh[k], g64[k]), 4) for k in g64})
     assert flipped <= 2e-4 * imposed, (flipped, imposed)
+    # Tightened in round 6 from 5x to 2x the fp32 oracle's own distance from fp64: measured (profiles/round6_parity_passrates.txt, the
+    # three front-ends) the HIP path sits at 0.09-0.95 of it -- encoder 1.3e-3 vs 3.0e-3, depth 5.7e-4 vs 1.1e-3, pose encoder 5.0e-4 vs
+    # 5.2e-4 (the worst ratio), fusion 2.1e-4 vs 4.6e-4, gru 6.4e-5 vs 3.0e-4 -- i.e. never further from fp64 than the oracle itself
     for k, (e_hip, e_32) in report.items():
-        assert e_hip <= 5.0 * e_32 + 2e-4, (k, report)
+        assert e_hip <= 2.0 * e_32 + 2e-4, (k, report)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (12, 192, 640)])
