@@ -24,6 +24,7 @@
 #include "dc_common.h"
 #include "conv_bf16.h"
 #include "gemm_tiles.h"
+#include "gemm1x1_x3.h"
 #include "wino.h"
 
 #include <stdlib.h>
@@ -699,6 +700,127 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
     }
 }
 
+// ---- forward on the bf16 matrix cores with split fp32 operands (gemm1x1_x3.hip: three bf16 pieces per operand, six partial products,
+// fp32 accumulation -- fp32 accuracy at 6/16 of the fp32 matrix time).  The fp32 kernel above runs AT the fp32 matrix peak (0.65-0.69 of
+// the nominal rate incl. the K padding): the stem is the one convolution of the step that the matrix pipe bounds outright.
+// Same tile (2 x 64 output pixels x 64 channels) and the same parity-de-interleaved fp32 patch in LDS; the waves split the PIXELS
+// (tile row wn, 32-pixel half wh), so each keeps all 64 channels and a gathered + split B element feeds 4 x 6 matrix instructions.
+// A: the weights' pieces [3][64][Kp] (g1x3_prep_item on the zero-padded weights; reduction permuted inside a chunk of 32 as there),
+// double-buffered in LDS, one ds_read_b128 per (16-channel tile, piece).  B: lane (pixel i, k-group kg) gathers its 8 reduction
+// elements k(kg, e) from the patch through the tap-offset table and splits them in registers.
+constexpr int STX_AST = 40;                       // bf16 per A row in LDS (32 + 8)
+constexpr int STX_APIECE = 64 * STX_AST;
+template <bool FR>
+__global__ __launch_bounds__(256, 2) void stem_fwd_x3_kernel(StemArgs a, const unsigned short* __restrict__ wa) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 sbf8;
+    typedef __attribute__((ext_vector_type(4))) unsigned su4;
+    unsigned short* const As = reinterpret_cast<unsigned short*>(g1_smem);                    // [2][3][64][40] bf16
+    float* const P = g1_smem + (2 * 3 * STX_APIECE) / 2;                                      // [Ci][ST_ROWS][E | O]
+    int* const ktab = reinterpret_cast<int*>(P + a.Ci * ST_ROWS * ST_ROW);                    // [Kp], in the PERMUTED order of the A pieces
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave >> 1, wh = wave & 1;
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int b = lb / per_img, tr = lb - b * per_img, ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    const cgrsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0, (int)a.xbytes, 0x00020000);
+
+    gf4 pv[ST_NVP];
+    stem_patch_load<ST_NVP, FR>(a, xr, b, oy0, ox0, tid, pv);
+    // A staging: 3 pieces x 64 rows x 4 sixteen-byte items per chunk = 768 items, three per thread
+    const unsigned short* asrc[3];
+    int adst[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int idx = tid + j * 256, piece = idx >> 8, rem = idx & 255, row = rem >> 2, ch = rem & 3;
+        asrc[j] = wa + ((size_t)piece * 64 + row) * a.Kp + ch * 8;
+        adst[j] = piece * STX_APIECE + row * STX_AST + ch * 8;
+    }
+    su4 ra[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ra[j] = *reinterpret_cast<const su4*>(asrc[j]);
+    // tap offsets in the order the operand needs them: position 8 kg + e of a chunk <-> k = e < 4 ? 4 kg + e : 16 + 4 kg + e - 4
+    for (int pos = tid; pos < a.Kp; pos += 256) {
+        const int c = pos >> 5, pl = pos & 31, kg = pl >> 3, e = pl & 7;
+        ktab[pos] = stem_koff(c * 32 + (e < 4 ? 4 * kg + e : 16 + 4 * kg + e - 4), a.K);
+    }
+    stem_patch_store<ST_NVP, FR>(a, P, tid, pv, oy0, ox0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<su4*>(As + adst[j]) = ra[j];
+    __syncthreads();
+
+    gf4 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = gf4{0, 0, 0, 0};
+    const int i = lane & 15, kg = lane >> 4;
+    const float* Pl = P + wn * 2 * ST_ROW + wh * 32 + i;   // this lane's pixel (r = wn, c = 32 wh + 16 nt + i), tap offset added per k
+    const int aoff = i * STX_AST + kg * 8;
+    const int nchunk = a.Kp / 32;
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ra[j] = *reinterpret_cast<const su4*>(asrc[j] + (c + 1) * 32);
+        }
+        // B: gather 8 taps per 16-pixel tile, split
+        const int4 k0 = *reinterpret_cast<const int4*>(ktab + c * 32 + kg * 8), k1 = *reinterpret_cast<const int4*>(ktab + c * 32 + kg * 8 + 4);
+        sbf8 bv[2][3];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float* q = Pl + 16 * nt;
+            const float v0 = q[k0.x], v1 = q[k0.y], v2 = q[k0.z], v3 = q[k0.w], v4 = q[k1.x], v5 = q[k1.y], v6 = q[k1.z], v7 = q[k1.w];
+            unsigned p[3][4];
+            x3h_split2(v0, v1, p[0][0], p[1][0], p[2][0]);
+            x3h_split2(v2, v3, p[0][1], p[1][1], p[2][1]);
+            x3h_split2(v4, v5, p[0][2], p[1][2], p[2][2]);
+            x3h_split2(v6, v7, p[0][3], p[1][3], p[2][3]);
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) bv[nt][s3] = __builtin_bit_cast(sbf8, su4{p[s3][0], p[s3][1], p[s3][2], p[s3][3]});
+        }
+        const unsigned short* Ab = As + buf * 3 * STX_APIECE + aoff;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            sbf8 av[3];
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) av[s3] = *reinterpret_cast<const sbf8*>(Ab + s3 * STX_APIECE + mt * 16 * STX_AST);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                gf4 d = acc[mt][nt];
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], bv[nt][0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[nt][1], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[nt][2], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[nt][0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[nt][1], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[nt][0], d, 0, 0, 0);
+                acc[mt][nt] = d;
+            }
+        }
+        if (c + 1 < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<su4*>(As + (buf ^ 1) * 3 * STX_APIECE + adst[j]) = ra[j];
+        }
+        __syncthreads();
+    }
+    const int oy = oy0 + wn;
+    if (oy < a.Ho) {
+        const int P2 = a.Ho * a.Wo;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mt * 16 + kg * 4 + r;
+                float* dst = a.out + ((size_t)b * a.Co + m) * P2 + (size_t)oy * a.Wo + ox0 + wh * 32 + i;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    if (ox0 + wh * 32 + 16 * nt + i < a.Wo) dst[16 * nt] = acc[mt][nt][r];
+            }
+    }
+}
+__global__ __launch_bounds__(256) void stem_x3_prep_kernel(const float* __restrict__ wp, unsigned short* __restrict__ wa, int Kp) {
+    g1x3_prep_item(wp, wa, blockIdx.x * 256 + threadIdx.x, Kp, 0, 64, 64, Kp);       // the zero-padded (64, Kp) weights as a 1x1 "forward" A
+}
+
 // ---- weight gradient: a block walks a contiguous range of tiles and keeps dw[64][Kp] in registers ------------------------
 // 4 waves = (channel half wm) x (column half wn); a wave owns 32 channels x Kp/2 columns = MT 2 x NT (5 or 10) tiles.
 // Reduction = the tile's 128 pixels in octets of 8 along a row: A = gy[co][pixel] (reduction-contiguous image, as the
@@ -896,6 +1018,25 @@ static StemArgs stem_args(int B, int Ci, int Co, int Hi, int Wi) {
     return a;
 }
 static size_t stem_lds_fwd(int Ci, int Kp) { return ((size_t)2 * 64 * (GKC + RP) + (size_t)Ci * ST_ROWS * ST_ROW + Kp) * sizeof(float); }
+static size_t stem_lds_fwd_x3(int Ci, int Kp) { return (size_t)2 * 3 * STX_APIECE * 2 + ((size_t)Ci * ST_ROWS * ST_ROW + Kp) * sizeof(float); }
+// the split-operand forward (dc_set_gemm_split, default on; DC_STEM_X3=0 keeps the fp32-MFMA kernel alone)
+static bool stem_x3_enabled() {
+    static const bool v = [] { const char* e = getenv("DC_STEM_X3"); return !e || atoi(e) != 0; }();
+    return v && dc_get_gemm_split() != 0;
+}
+// pads are in ws (fp32 (64, Kp)); their pieces go behind them
+template <bool FR>
+static int stem_fwd_x3_launch(StemArgs& sa, void* ws, hipStream_t st) {
+    const size_t off = ((size_t)64 * sa.Kp * sizeof(float) + 255) & ~(size_t)255;
+    unsigned short* wa = reinterpret_cast<unsigned short*>((char*)ws + off);
+    hipLaunchKernelGGL(stem_x3_prep_kernel, dim3(ceil_div(64 * (sa.Kp / 4), 256)), dim3(256), 0, st, (const float*)ws, wa, sa.Kp);
+    DC_CHECK_LAUNCH();
+    const size_t lds = stem_lds_fwd_x3(sa.Ci, sa.Kp);
+    static const bool attr = cg_set_lds(stem_fwd_x3_kernel<FR>, stem_lds_fwd_x3(6, 320));
+    if (!attr) return DC_ELAUNCH;
+    hipLaunchKernelGGL(stem_fwd_x3_kernel<FR>, dim3(sa.ntiles, 1), dim3(256), lds, st, sa, (const unsigned short*)wa);
+    return DC_OK;
+}
 static size_t stem_lds_wgrad(int Ci) { return ((size_t)64 * (128 + RP) + (size_t)Ci * ST_ROWS * ST_ROW) * sizeof(float); }
 
 }  // namespace dc
@@ -936,7 +1077,9 @@ extern "C" size_t dc_convs2_fwd_workspace(int B, int Ci, int Co, int Hi, int Wi,
         const int sp = cg_fwd3_plan(B, Ci, Co, Hi, Wi, t);
         if (sp > 1) slabs = (size_t)sp * B * Co * (Hi / 2) * (Wi / 2) * sizeof(float);
     }
-    return std::max(std::max(Kp == K ? (size_t)16 : (size_t)Co * Kp * sizeof(float), b16), slabs);
+    // (7x7 stem: the zero-padded fp32 weights + their three bf16 pieces for the split-operand forward)
+    const size_t wpad = Kp == K ? (size_t)16 : (size_t)Co * Kp * sizeof(float) + (ksize == 7 ? (size_t)Co * Kp * 6 + 512 : 0);
+    return std::max(std::max(wpad, b16), slabs);
 }
 
 extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int Hi, int Wi, int ksize,
@@ -961,7 +1104,12 @@ extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void
         sa.x = x; sa.w = a.w; sa.out = y;
         hipEvent_t pe = conv_prof_begin(6, 2.0 * B * (double)Co * a.K * a.Ho * a.Wo, 2.0 * B * (double)Co * sa.Kp * a.Ho * a.Wo,
                                         4.0 * ((double)B * Ci * Hi * Wi + (double)B * Co * a.Ho * a.Wo + (double)Co * a.K), st);
-        hipLaunchKernelGGL(stem_fwd_kernel<false>, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(Ci, sa.Kp), st, sa);
+        if (stem_x3_enabled() && a.Kp != a.K) {
+            const int rc = stem_fwd_x3_launch<false>(sa, ws, st);
+            if (rc != DC_OK) return rc;
+        } else {
+            hipLaunchKernelGGL(stem_fwd_kernel<false>, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(Ci, sa.Kp), st, sa);
+        }
         conv_prof_end(pe, st);
         DC_CHECK_LAUNCH();
         return DC_OK;
@@ -1104,7 +1252,12 @@ extern "C" int dc_stem_fwd(const float* const* frames, int nf, float mean, float
     const double npix = (double)sa.B * (Hi / 2) * (Wi / 2);
     hipEvent_t pe = conv_prof_begin(6, 2.0 * npix * Co * sa.K, 2.0 * npix * Co * sa.Kp,
                                     4.0 * ((double)sa.B * sa.Ci * Hi * Wi + npix * Co + (double)Co * sa.K), st);
-    hipLaunchKernelGGL(stem_fwd_kernel<true>, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(sa.Ci, sa.Kp), st, sa);
+    if (stem_x3_enabled()) {
+        const int rc = stem_fwd_x3_launch<true>(sa, ws, st);
+        if (rc != DC_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(stem_fwd_kernel<true>, dim3(sa.ntiles, Co / 64), dim3(256), stem_lds_fwd(sa.Ci, sa.Kp), st, sa);
+    }
     conv_prof_end(pe, st);
     DC_CHECK_LAUNCH();
     return DC_OK;

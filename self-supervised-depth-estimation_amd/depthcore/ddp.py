@@ -159,11 +159,11 @@ class GradBuckets:
                 ev[0].record(self.comm)
             self.handles.append(dist.all_reduce(flat, op=op, group=self.pg, async_op=True))
             if ev is not None:
-                if dist.get_backend(self.pg) == "nccl":      # (RCCL enqueues on the current = communication stream)
-                    ev[1].record(self.comm)
-                else:                                        # gloo (rehearsal): the handle completes on the host
-                    self.handles[-1].wait()
-                    ev[1].record(self.comm)
+                # (RCCL runs the collective on its own internal stream; wait() makes the communication stream -- which nothing but
+                # the exchange uses -- wait for it without blocking the host, so the end event brackets the collective; gloo's handle
+                # completes on the host)
+                self.handles[-1].wait()
+                ev[1].record(self.comm)
                 self._tev.append((bi, ev))
         self.launched[bi] = True
         self.launch_order.append(bi)

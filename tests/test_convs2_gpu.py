@@ -178,3 +178,31 @@ def test_conv2d_direct_refuses_what_it_cannot_do():
         ops.conv2d_direct(x, torch.randn(3, 2, 3, 3).cuda(), None, 1, 3)        # padding >= kernel
     with pytest.raises(_lib.DepthcoreError):
         ops.conv2d_direct(x, torch.randn(3, 4, 3, 3).cuda(), None, 1, 1)        # channel mismatch
+
+
+@pytest.mark.parametrize("B,Ci,H,W", [(2, 3, 64, 96), (3, 6, 66, 200), (12, 3, 192, 640), (4, 6, 192, 640)])
+def test_stem_forward_on_split_operands_is_fp32_accurate(B, Ci, H, W):
+    """The stem forward through three bf16 pieces per operand on the bf16 matrix cores (stem_fwd_x3_kernel, dc_set_gemm_split) against
+    the fp32-MFMA kernel: norm-wise error of both against torch's fp64 convolution -- the split path at most 1.25x the fp32 path's
+    (+ 2e-8) -- and the pointwise bound of test_convs2_vs_torch."""
+    from depthcore import ops, _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B * 10 + Ci)
+    x = ((torch.rand(B, Ci, H, W, generator=g) - 0.45) / 0.225).cuda()             # what the network feeds the stem
+    w = (torch.randn(64, Ci, 7, 7, generator=g) * (2.0 / (Ci * 49)) ** 0.5).cuda()
+    ref = F.conv2d(x.double(), w.double(), None, 2, 3)
+    out = {}
+    prev = L.dc_get_gemm_split()
+    try:
+        for mode in (0, 1):
+            L.dc_set_gemm_split(mode)
+            out[mode] = ops.conv_s2(x, w).detach()
+    finally:
+        L.dc_set_gemm_split(prev)
+    e32 = float((out[0].double() - ref).norm() / ref.norm())
+    e3 = float((out[1].double() - ref).norm() / ref.norm())
+    print("stem forward %s: |x3 - f64| / |f64| = %.2e, |f32-MFMA - f64| / |f64| = %.2e" % ((B, Ci, H, W), e3, e32))
+    assert e3 <= 1.25 * e32 + 2e-8, (e3, e32)
+    err = (out[1].double() - ref).abs().max().item()
+    assert err <= 1e-5 * ref.abs().max().item()
+    assert not torch.equal(out[0], out[1])               # (the two kernels really are different arithmetic orders)
