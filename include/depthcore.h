@@ -425,7 +425,11 @@ int dc_conv1x1_wgrad_bn(const float* x, const float* gy, float* dweight, void* w
  * ws = dc_gemm1x1x3_workspace(Ci, Co) bytes, 16-byte aligned (the split weights of the launch; weights registered with the
  * per-step weight cache, dc_wino_cache_*, are split once per step by its refresh instead).  dc_set_gemm_split (default 1; env
  * DC_G1_X3): whether callers that can supply the workspace (depthcore/ops.py, depthcore/bnfold.py) take this path where it
- * applies; 0 keeps the fp32-MFMA kernels (the A/B). */
+ * applies; 0 keeps the fp32-MFMA kernels (the A/B); 3 = 1 + the forward and weight gradient of the 3x3 / 2 trunk convolutions
+ * (dc_convs2_*) on the same kernels with gather loaders -- an experiment: more accurate, slower on most shapes, not the default.
+ * Accumulation: each 32-deep chunk's six products are summed from zero inside the matrix pipe and enter the fp32 accumulator through
+ * ONE round-to-nearest add, with alternating operand signs per chunk -- v_mfma_f32_16x16x32_bf16 truncates its fp32 result toward
+ * -inf (tools/diag_x3_bias.py), which biased long reductions before; now the error against fp64 is 0.3 - 0.5x the fp32-MFMA kernels'. */
 int dc_set_gemm_split(int mode);
 int dc_get_gemm_split(void);
 int dc_gemm1x1x3_fwd_ok(int B, int Ci, int Co, int Hi, int Wi, int stride);

@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_x3_kernel(StemArgs a, const u
     }
 }
 __global__ __launch_bounds__(256) void stem_x3_prep_kernel(const float* __restrict__ wp, unsigned short* __restrict__ wa, int Kp) {
-    g1x3_prep_item(wp, wa, blockIdx.x * 256 + threadIdx.x, Kp, 0, 64, 64, Kp);       // the zero-padded (64, Kp) weights as a 1x1 "forward" A
+    g1x3_prep_item(wp, wa, blockIdx.x * 256 + threadIdx.x, 0, 64, 64, Kp);       // the zero-padded (64, Kp) weights as a 1x1 "forward" A
 }
 
 // ---- weight gradient: a block walks a contiguous range of tiles and keeps dw[64][Kp] in registers ------------------------
@@ -1052,6 +1052,10 @@ static bool cg_ok(int B, int Ci, int Co, int Hi, int Wi, int ks) {
     return true;
 }
 static int cg_kp(int Ci, int ks) { return ceil_div(Ci * ks * ks, GKC) * GKC; }
+// 3 x 3 / 2 forward and weight gradient on the split-operand kernels of gemm1x1_x3.hip: only under dc_set_gemm_split(3) (measured slower
+// than cg_fwd3 / cg_wgrad3 on most step shapes: see g1x3_conv3s2_fwd).  The workspace sizes always cover both paths: the mode may change
+// between the query and the launch.
+static bool cg_x3_enabled() { return (dc_get_gemm_split() & 2) != 0; }
 
 extern "C" int dc_convs2_supported(int B, int Ci, int Co, int Hi, int Wi, int ksize) { return cg_ok(B, Ci, Co, Hi, Wi, ksize) ? 1 : 0; }
 
@@ -1079,7 +1083,8 @@ extern "C" size_t dc_convs2_fwd_workspace(int B, int Ci, int Co, int Hi, int Wi,
     }
     // (7x7 stem: the zero-padded fp32 weights + their three bf16 pieces for the split-operand forward)
     const size_t wpad = Kp == K ? (size_t)16 : (size_t)Co * Kp * sizeof(float) + (ksize == 7 ? (size_t)Co * Kp * 6 + 512 : 0);
-    return std::max(std::max(wpad, b16), slabs);
+    const size_t x3 = ksize == 3 && g1x3_conv3s2_ok(B, Ci, Co, Hi, Wi) ? g1x3_conv3s2_fwd_ws(Ci, Co) : 0;
+    return std::max(std::max(std::max(wpad, b16), slabs), x3);
 }
 
 extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int Hi, int Wi, int ksize,
@@ -1088,6 +1093,7 @@ extern "C" int dc_convs2_fwd(const float* x, const float* weight, float* y, void
     hipStream_t st = (hipStream_t)stream;
     if (ksize == 3 && matrix_precision() == DC_PREC_BF16 && c3b_eligible(Ci, 0, 0, Hi, Wi, 2))      // bf16 matrix cores (conv_bf16.hip)
         return c3b_conv(x, Ci, 0, nullptr, 0, weight, Co, Ci, 0, 0, nullptr, y, ws, B, Hi, Wi, ACT_NONE, PAD_ZERO, 2, st);
+    if (ksize == 3 && cg_x3_enabled() && g1x3_conv3s2_ok(B, Ci, Co, Hi, Wi)) return g1x3_conv3s2_fwd(x, weight, y, ws, B, Ci, Co, Hi, Wi, st);
     CgArgs a{};
     a.x = x; a.out = y; a.B = B; a.Ci = Ci; a.Co = Co; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
     a.K = Ci * ksize * ksize; a.Kp = cg_kp(Ci, ksize);
@@ -1166,7 +1172,8 @@ extern "C" size_t dc_convs2_wgrad_workspace(int B, int Ci, int Co, int Hi, int W
     const int tiles = ceil_div(Co, 64) * ceil_div(K, trip_ok(Ci, ksize) ? 96 : 64);
     const int splits = cg_wsplits(tiles, ceil_div(B * (Hi / 2) * (Wi / 2), GKC));
     const size_t b16 = ksize == 3 ? (size_t)c3b_wgrad_split(B, Hi / 2, Wi / 2, Co, Ci, 2) * Co * K * sizeof(float) : 0;
-    return std::max(splits > 1 ? (size_t)splits * Co * K * sizeof(float) : (size_t)16, b16);
+    const size_t x3 = ksize == 3 && g1x3_conv3s2_wgrad_ok(B, Ci, Co, Hi, Wi) ? g1x3_conv3s2_wgrad_ws(B, Ci, Co, Hi, Wi) : 0;
+    return std::max(std::max(splits > 1 ? (size_t)splits * Co * K * sizeof(float) : (size_t)16, b16), x3);
 }
 
 extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi,
@@ -1178,6 +1185,8 @@ extern "C" int dc_convs2_wgrad(const float* x, const float* gy, float* dweight, 
         const int rc = c3b_wgrad(x, Ci, 0, nullptr, 0, gy, (float*)ws, sp, B, Co, Hi, Wi, PAD_ZERO, 2, st);
         return rc != DC_OK ? rc : conv_wreduce((const float*)ws, nullptr, dweight, nullptr, sp, Co * Ci * 9, 0, st);
     }
+    if (ksize == 3 && cg_x3_enabled() && g1x3_conv3s2_wgrad_ok(B, Ci, Co, Hi, Wi))
+        return g1x3_conv3s2_wgrad(x, gy, dweight, ws, B, Ci, Co, Hi, Wi, st);
     if (stem_ok(Ci, Co, ksize)) {
         StemArgs sa = stem_args(B, Ci, Co, Hi, Wi);
         sa.x = x; sa.gy = gy; sa.out = (float*)ws;

@@ -23,8 +23,10 @@ __device__ __forceinline__ void x3h_split2(float a, float b, unsigned& p0, unsig
 // inside every chunk of 32 -- position 8 kg + e <-> k = e < 4 ? 4 kg + e : 16 + 4 kg + e - 4 (the transposed LDS read of the B
 // operand delivers its rows in that order, gemm1x1_x3.hip).  forward (tr = 0): A[m][k] = w[m][k] (M = Co, K = Ci); data gradient
 // (tr = 1): A[m][k] = w[k][m] (M = Ci, K = Co).  Rows m >= M are zero.
-__device__ __forceinline__ void g1x3_prep_item(const float* __restrict__ w, unsigned short* __restrict__ wa, int idx, int Ci, int tr,
+// (the source's row length is K for tr = 0 -- also a (Co, Ci, 3, 3) weight seen as (Co, 9 Ci) -- and M for tr = 1)
+__device__ __forceinline__ void g1x3_prep_item(const float* __restrict__ w, unsigned short* __restrict__ wa, int idx, int tr,
                                                int M, int Mp, int K) {
+    const int Ci = tr ? M : K;
     const int q = K >> 2;
     if (idx >= Mp * q) return;
     const int m = idx / q, pos4 = (idx - m * q) * 4;
@@ -41,6 +43,14 @@ __device__ __forceinline__ void g1x3_prep_item(const float* __restrict__ w, unsi
         *reinterpret_cast<x3h_u2*>(wa + ((size_t)s * Mp + m) * K + pos4) = x3h_u2{p[s][0], p[s][1]};
 }
 #endif
+
+// the 3 x 3 / 2 trunk convolutions on the split-operand kernels (forward, weight gradient): eligibility, workspace bytes, launches
+bool g1x3_conv3s2_ok(int B, int Ci, int Co, int Hi, int Wi);
+bool g1x3_conv3s2_wgrad_ok(int B, int Ci, int Co, int Hi, int Wi);
+size_t g1x3_conv3s2_fwd_ws(int Ci, int Co);
+size_t g1x3_conv3s2_wgrad_ws(int B, int Ci, int Co, int Hi, int Wi);
+int g1x3_conv3s2_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int Hi, int Wi, hipStream_t st);
+int g1x3_conv3s2_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, hipStream_t st);
 
 // the split weights of (weight, direction) from the per-step weight cache, or nullptr (then the launch prepares them into its workspace)
 const void* wc_lookup_x3(const float* w, int Ci, int Co, int tr, int Mp, int K, hipStream_t st);

@@ -95,9 +95,8 @@ __device__ __forceinline__ float x3_row16_sum(float v) {
 __device__ __forceinline__ void x3_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) { x3h_split2(a, b, p0, p1, p2); }
 
 // ---- weights -> [piece][Mp][K] bf16 (g1x3_prep_item, gemm1x1_x3.h): once per launch, or once per step by the weight cache's refresh
-__global__ __launch_bounds__(256) void g1x3_prep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wa, int Ci, int tr,
-                                                        int M, int Mp, int K) {
-    g1x3_prep_item(w, wa, blockIdx.x * 256 + threadIdx.x, Ci, tr, M, Mp, K);
+__global__ __launch_bounds__(256) void g1x3_prep_kernel(const float* __restrict__ w, unsigned short* __restrict__ wa, int tr, int M, int Mp, int K) {
+    g1x3_prep_item(w, wa, blockIdx.x * 256 + threadIdx.x, tr, M, Mp, K);
 }
 
 // element offset of (b, channel 0, first pixel) of a 4-pixel group of the flattened (b, p) dimension, clamped to the last group
@@ -118,7 +117,57 @@ __device__ __forceinline__ x3f4 x3_load_pix4(const float* p) {
     }
 }
 
+// ---- S = 3: the 3 x 3 / stride 2 / padding 1 convolution as the same GEMM (reference: torchvision BasicBlock / Bottleneck conv with stride 2
+// behind networks/resnet_encoder.py:74-98).  Reduction index k = ci * 9 + ky * 3 + kx -- the weight tensor (Co, Ci, 3, 3) IS the row-major
+// A matrix -- and the B element (k, output pixel (oy, ox)) is x[b, ci, 2 oy - 1 + ky, 2 ox - 1 + kx], zero outside the image.  A 4-pixel group
+// of one output row reads input columns 2 ox0 - 1 + kx + {0, 2, 4, 6}: four dword loads from clamped addresses, masked afterwards (one load
+// shape whatever the tap; only the top row with ky = 0 and the left column with kx = 0 ever fall outside: 2 oy + 1 <= Hi - 1, 2 ox + 1 <= Wi - 1).
+struct X3Grp { long base; int top, left; };          // float offset of x[b, 0, 2 oy - 1, 2 ox0 - 1] (may be negative), border flags
+__device__ __forceinline__ X3Grp x3_group3(int n, int N, int P, int Wo, int C, int Hi, int Wi) {
+    const int nn = min(n, N - 4);
+    const int b = nn / P, p = nn - b * P;
+    const int oy = p / Wo, ox0 = p - oy * Wo;
+    return X3Grp{((long)b * C * Hi + (2 * oy - 1)) * Wi + (2 * ox0 - 1), oy == 0, ox0 == 0};
+}
+__device__ __forceinline__ x3f4 x3_gather3(const float* __restrict__ x, const X3Grp& g, int k, int Hi, int Wi) {
+    const int ci = k / 9, tap = k - 9 * ci, ky = tap / 3, kx = tap - 3 * ky;
+    const long o = g.base + ((long)ci * Hi + ky) * Wi + kx;
+    const bool rok = !(g.top && ky == 0), e0 = rok && !(g.left && kx == 0);
+    const float v0 = x[o > 0 ? o : 0], v1 = x[o + 2 > 0 ? o + 2 : 0], v2 = x[o + 4 > 0 ? o + 4 : 0], v3 = x[o + 6 > 0 ? o + 6 : 0];
+    return x3f4{e0 ? v0 : 0.f, rok ? v1 : 0.f, rok ? v2 : 0.f, rok ? v3 : 0.f};
+}
+
 extern __shared__ unsigned short g1x3_smem[];
+
+// One reduction chunk (32 k) of a 16 x 16 tile: the six partial products, smallest first, summed from ZERO into a chunk total that is then
+// added to the running accumulator by one fp32 add.  Chained through the accumulator itself, every one of the six would round at the
+// accumulator's magnitude (6 roundings of ulp(acc) / 2 per chunk, however small the term); this way the five small terms round at the chunk
+// total's magnitude and the accumulator takes ONE rounding per 32 k -- against one per 4 k in the fp32-MFMA kernels (v_mfma_f32_16x16x4_f32).
+// Same six matrix instructions; the extra cost is four v_fma_f32 per tile and chunk.  (X3_BLOCKED_SUM=0: the chained form, for the A/B.)
+// `sgn`: the matrix instruction does not round its fp32 result to nearest -- measured (tools/diag_x3_bias.py): with operands that are not
+// exact in bf16 the error of a long reduction has a NEGATIVE MEAN of the size of its rms (truncation toward -inf), which grows linearly
+// with the number of chunks (weight gradients: thousands).  So one of the two operands is staged with the sign sgn = +-1 of the chunk's
+// parity and the chunk total enters as sgn * t: odd chunks are truncated upward, even chunks downward, and the bias cancels pairwise.
+#ifndef X3_BLOCKED_SUM
+#define X3_BLOCKED_SUM 1
+#endif
+__device__ __forceinline__ x3f4 x3_chunk(const x3bf8 (&av)[3], const x3bf8 (&bv)[3], x3f4 c, float sgn) {
+#if X3_BLOCKED_SUM
+    x3f4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], bv[0], x3f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#else
+    x3f4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], bv[0], c, 0, 0, 0);
+#endif
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[1], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[2], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], bv[0], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[1], t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], bv[0], t, 0, 0, 0);
+#if X3_BLOCKED_SUM
+    return x3f4{fmaf(t.x, sgn, c.x), fmaf(t.y, sgn, c.y), fmaf(t.z, sgn, c.z), fmaf(t.w, sgn, c.w)};
+#else
+    return t;
+#endif
+}
 
 // MODE 0: plain (EPI: bias + activation + addends); 1: forward with the BatchNorm + ReLU of its input in the loader; 2 / 3: data gradient
 // with the BatchNorm-backward epilogue (ReLU decision re-derived from the raw input / read from the forward's bit mask, + addend).
@@ -154,9 +203,12 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
     // B: reduction row k = tid / 8, pixel run = tid % 8: 4 NT consecutive pixels = lanes' i = 4 (run % 4) .. + 3, all NT tiles
     const int bk = tid >> 3, run = tid & 7;
     const float* bsrc[NG];
+    X3Grp bgrp[S == 3 ? NG : 1];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
-        bsrc[g] = a.x + x3_pix_off(n0 + run * 4 * NT + 4 * g, N, P, a.Wo, a.K, a.Hi, a.Wi, S) + (size_t)bk * plane;
+    for (int g = 0; g < NG; ++g) {
+        if constexpr (S == 3) bgrp[g] = x3_group3(n0 + run * 4 * NT + 4 * g, N, P, a.Wo, a.K / 9, a.Hi, a.Wi);
+        else bsrc[g] = a.x + x3_pix_off(n0 + run * 4 * NT + 4 * g, N, P, a.Wo, a.K, a.Hi, a.Wi, S) + (size_t)bk * plane;
+    }
     // LDS position of pixel NT i + nt of wave column block wn': wn' * 16 NT + nt * 16 + i
     const int bdst = bk * BST + (run >> 2) * 16 * NT + (run & 3) * 4;
 
@@ -170,10 +222,14 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
 #pragma unroll
         for (int j = 0; j < NA; ++j) ra[j] = *reinterpret_cast<const x3u4*>(asrc[j] + c * X3_KC);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) rb[g] = x3_load_pix4<S>(bsrc[g] + (size_t)c * X3_KC * plane);
+        for (int g = 0; g < NG; ++g) {
+            if constexpr (S == 3) rb[g] = x3_gather3(a.x, bgrp[g], c * X3_KC + bk, a.Hi, a.Wi);
+            else rb[g] = x3_load_pix4<S>(bsrc[g] + (size_t)c * X3_KC * plane);
+        }
         if constexpr (MODE == 1) { bsc = a.in_scale[bn_tab + c * X3_KC]; bsh = a.in_shift[bn_tab + c * X3_KC]; }
     };
-    auto commit = [&]() {
+    auto commit = [&](int c) {
+        const float sgn = X3_BLOCKED_SUM && (c & 1) ? -1.f : 1.f;         // (x3_chunk: the chunk's sign rides on the B operand)
 #pragma unroll
         for (int j = 0; j < NA; ++j) *reinterpret_cast<x3u4*>(As + adst[j]) = ra[j];
         // the run's pixel j = NT il + nt (il = 0..3: consecutive lanes i): for a tile nt the four values are consecutive positions
@@ -185,6 +241,7 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
                 const int j = NT * il + nt;
                 v[il] = rb[j >> 2][j & 3];
                 if constexpr (MODE == 1) v[il] = fmaxf(fmaf(v[il], bsc, bsh), 0.f);
+                v[il] *= sgn;
             }
             unsigned p0, p1, p2, q0, q1, q2;
             x3_split2(v[0], v[1], p0, p1, p2);
@@ -204,7 +261,8 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
     // operand addresses (bf16 element offsets)
     const int aoff = (wm * 16 * MT + i16) * X3_AST + kg * 8;                              // + mt * 16 * X3_AST, + piece * APIECE
     const int boff = (4 * kg + (i16 >> 2)) * BST + wn * 16 * NT + 4 * (i16 & 3);          // + nt * 16, + 16 rows for the second half
-    auto compute = [&]() {
+    auto compute = [&](int c) {
+        const float sgn = X3_BLOCKED_SUM && (c & 1) ? -1.f : 1.f;
         x3bf8 b[NT][3];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -224,27 +282,19 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_kernel(G1x3Ar
                 av[s] = *reinterpret_cast<const x3bf8*>(As + s * T::APIECE + aoff + mt * 16 * X3_AST);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                x3f4 c = acc[mt][nt];
-                // smallest terms first
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], b[nt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], b[nt][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[nt][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], b[nt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[nt][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[nt][0], c, 0, 0, 0);
-                acc[mt][nt] = c;
+                acc[mt][nt] = x3_chunk(av, b[nt], acc[mt][nt], sgn);
             }
         }
     };
 
     load(0);
-    commit();
+    commit(0);
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
         if (c + 1 < nch) load(c + 1);
-        compute();
+        compute(c);
         __syncthreads();
-        if (c + 1 < nch) commit();
+        if (c + 1 < nch) commit(c + 1);
         __syncthreads();
     }
 
@@ -467,6 +517,7 @@ struct G1x3WArgs {
 template <int MT, int NT, int S, bool BNIN = false>
 __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_wgrad_kernel(G1x3WArgs a) {
     static_assert(!BNIN || S == 1, "the BatchNorm fold exists at stride 1");
+    // S = 3: the columns of dw are k = ci * 9 + tap of a 3 x 3 / 2 convolution (a.Ci = 9 * input channels), B[k][n] gathered as in the forward
     using T = X3T<MT, NT>;
     constexpr int BPIECE = T::BN * X3_AST;
     unsigned short* const As = g1x3_smem;                     // [3][BM co][40]
@@ -498,19 +549,26 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_wgrad_kernel(
                 wsc[j] = a.in_scale[tab + cch]; wsh[j] = a.in_shift[tab + cch];
             }
         }
-        size_t pix;
+        size_t pix = 0;
         if constexpr (S == 1) {
             pix = p;
-        } else {
+        } else if constexpr (S == 2) {
             const int py = p / a.Wo, px = p - py * a.Wo;
             pix = (size_t)(py * 2) * a.Wi + px * 2;
         }
         const float* ga = a.gy + (size_t)b * a.Co * P + p;
-        const float* xb = a.x + (size_t)b * a.Ci * plane + pix;
 #pragma unroll
         for (int j = 0; j < MT; ++j) ra[j] = *reinterpret_cast<const x3f4*>(ga + arow[j]);
+        if constexpr (S == 3) {
+            const int oy = p / a.Wo, ox0 = p - oy * a.Wo;
+            const X3Grp g{((long)b * (a.Ci / 9) * a.Hi + (2 * oy - 1)) * a.Wi + (2 * ox0 - 1), oy == 0, ox0 == 0};
 #pragma unroll
-        for (int j = 0; j < NT; ++j) rb[j] = x3_load_pix4<S>(xb + brow[j]);
+            for (int j = 0; j < NT; ++j) rb[j] = x3_gather3(a.x, g, min(c0 + row0 + 32 * j, a.Ci - 1), a.Hi, a.Wi);
+        } else {
+            const float* xb = a.x + (size_t)b * a.Ci * plane + pix;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) rb[j] = x3_load_pix4<S>(xb + brow[j]);
+        }
     };
     auto put = [&](unsigned short* base, int piece_stride, int d, x3f4 v) {
         unsigned p0, p1, p2, q0, q1, q2;
@@ -520,9 +578,10 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_wgrad_kernel(
         *reinterpret_cast<x3u2*>(base + piece_stride + d) = x3u2{p1, q1};
         *reinterpret_cast<x3u2*>(base + 2 * piece_stride + d) = x3u2{p2, q2};
     };
-    auto commit = [&]() {
+    auto commit = [&](int ch) {
+        const float sgn = X3_BLOCKED_SUM && (ch & 1) ? -1.f : 1.f;        // (x3_chunk: the chunk's sign rides on the gy operand)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) put(As, T::APIECE, (row0 + 32 * j) * X3_AST + kq * 4, ra[j]);
+        for (int j = 0; j < MT; ++j) put(As, T::APIECE, (row0 + 32 * j) * X3_AST + kq * 4, ra[j] * sgn);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             if constexpr (BNIN)
@@ -537,7 +596,8 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_wgrad_kernel(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = x3f4{0.f, 0.f, 0.f, 0.f};
     const int aoff = (wm * 16 * MT + i16) * X3_AST + kg * 8, boff = (wn * 16 * NT + i16) * X3_AST + kg * 8;
-    auto compute = [&]() {
+    auto compute = [&](int ch) {
+        const float sgn = X3_BLOCKED_SUM && (ch & 1) ? -1.f : 1.f;
         x3bf8 b[NT][3];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -550,14 +610,7 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_wgrad_kernel(
             for (int s = 0; s < 3; ++s) av[s] = *reinterpret_cast<const x3bf8*>(As + s * T::APIECE + aoff + mt * 16 * X3_AST);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                x3f4 c = acc[mt][nt];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], b[nt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], b[nt][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[nt][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], b[nt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[nt][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], b[nt][0], c, 0, 0, 0);
-                acc[mt][nt] = c;
+                acc[mt][nt] = x3_chunk(av, b[nt], acc[mt][nt], sgn);
             }
         }
     };
@@ -565,15 +618,15 @@ __global__ __launch_bounds__(256, (X3T<MT, NT>::PER_CU)) void g1x3_wgrad_kernel(
     const int ch0 = split * per, ch1 = min(ch0 + per, a.chunks);
     if (ch0 < ch1) {
         load(ch0);
-        commit();
+        commit(ch0);
     }
     __syncthreads();
     for (int ch = ch0; ch < ch1; ++ch) {
         const bool more = ch + 1 < ch1;
         if (more) load(ch + 1);
-        compute();
+        compute(ch);
         __syncthreads();
-        if (more) commit();
+        if (more) commit(ch + 1);
         __syncthreads();
     }
     float* slab = a.out + (size_t)split * a.Co * a.Ci;
@@ -652,7 +705,7 @@ static X3Tile x3_pick(int M, int N, int stride) {
 using namespace dc;
 
 extern "C" int dc_set_gemm_split(int mode) {
-    if (mode != 0 && mode != 1) return DC_EINVAL;
+    if (mode != 0 && mode != 1 && mode != 3) return DC_EINVAL;      // (3 = 1 + the 3 x 3 / 2 trunk convolutions: an experiment, see depthcore.h)
     const int prev = g_g1x3;
     g_g1x3 = mode;
     return prev;
@@ -706,9 +759,11 @@ static int g1x3_go(const G1x3Args& a, dim3 grid, int stride, bool epi, int mode,
     static const bool attr = x3_set_lds(g1x3_kernel<MT, NT, 1, false>, T::LDS) && x3_set_lds(g1x3_kernel<MT, NT, 1, true>, T::LDS) &&
                              x3_set_lds(g1x3_kernel<MT, NT, 2, false>, T::LDS) && x3_set_lds(g1x3_kernel<MT, NT, 2, true>, T::LDS) &&
                              x3_set_lds(g1x3_kernel<MT, NT, 1, false, 1>, T::LDS) && x3_set_lds(g1x3_kernel<MT, NT, 1, false, 2>, T::LDS) &&
-                             x3_set_lds(g1x3_kernel<MT, NT, 1, false, 3>, T::LDS) && x3_set_lds(g1x3_kernel<MT, NT, 1, false, 4>, T::LDS);
+                             x3_set_lds(g1x3_kernel<MT, NT, 1, false, 3>, T::LDS) && x3_set_lds(g1x3_kernel<MT, NT, 1, false, 4>, T::LDS) &&
+                             x3_set_lds(g1x3_kernel<MT, NT, 3, false>, T::LDS);
     if (!attr) return DC_ELAUNCH;
-    if (mode == 4) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 1, false, 4>), grid, dim3(256), T::LDS, st, a);
+    if (stride == 3) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 3, false>), grid, dim3(256), T::LDS, st, a);
+    else if (mode == 4) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 1, false, 4>), grid, dim3(256), T::LDS, st, a);
     else if (mode == 1) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 1, false, 1>), grid, dim3(256), T::LDS, st, a);
     else if (mode == 2) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 1, false, 2>), grid, dim3(256), T::LDS, st, a);
     else if (mode == 3) hipLaunchKernelGGL((g1x3_kernel<MT, NT, 1, false, 3>), grid, dim3(256), T::LDS, st, a);
@@ -765,7 +820,7 @@ static int g1x3_launch(const float* src, const float* weight, float* out, void* 
     if (const void* cached = wc_lookup_x3(weight, Ci, Co, tr, a.Mp, K, st)) {
         a.wa = (const unsigned short*)cached;
     } else {
-        hipLaunchKernelGGL(g1x3_prep_kernel, dim3(ceil_div(a.Mp * (K / 4), 256)), dim3(256), 0, st, weight, (unsigned short*)ws, Ci, tr, M, a.Mp, K);
+        hipLaunchKernelGGL(g1x3_prep_kernel, dim3(ceil_div(a.Mp * (K / 4), 256)), dim3(256), 0, st, weight, (unsigned short*)ws, tr, M, a.Mp, K);
         DC_CHECK_LAUNCH();
     }
     const dim3 grid(a.mtiles * a.ntiles);
@@ -830,9 +885,10 @@ template <int MT, int NT>
 static int g1x3_wgo(const G1x3WArgs& a, dim3 grid, int stride, bool bnin, hipStream_t st) {
     using T = X3T<MT, NT>;
     static const bool attr = x3_set_lds(g1x3_wgrad_kernel<MT, NT, 1>, T::LDSW) && x3_set_lds(g1x3_wgrad_kernel<MT, NT, 2>, T::LDSW) &&
-                             x3_set_lds(g1x3_wgrad_kernel<MT, NT, 1, true>, T::LDSW);
+                             x3_set_lds(g1x3_wgrad_kernel<MT, NT, 1, true>, T::LDSW) && x3_set_lds(g1x3_wgrad_kernel<MT, NT, 3>, T::LDSW);
     if (!attr) return DC_ELAUNCH;
-    if (bnin) hipLaunchKernelGGL((g1x3_wgrad_kernel<MT, NT, 1, true>), grid, dim3(256), T::LDSW, st, a);
+    if (stride == 3) hipLaunchKernelGGL((g1x3_wgrad_kernel<MT, NT, 3>), grid, dim3(256), T::LDSW, st, a);
+    else if (bnin) hipLaunchKernelGGL((g1x3_wgrad_kernel<MT, NT, 1, true>), grid, dim3(256), T::LDSW, st, a);
     else if (stride == 1) hipLaunchKernelGGL((g1x3_wgrad_kernel<MT, NT, 1>), grid, dim3(256), T::LDSW, st, a);
     else hipLaunchKernelGGL((g1x3_wgrad_kernel<MT, NT, 2>), grid, dim3(256), T::LDSW, st, a);
     return DC_OK;
@@ -881,3 +937,88 @@ extern "C" int dc_gemm1x1x3_wgrad(const float* x, const float* gy, float* dweigh
 extern "C" int dc_gemm1x1x3_bn_ok(int B, int Ci, int Co, int Hi, int Wi) {
     return dc_gemm1x1x3_fwd_ok(B, Ci, Co, Hi, Wi, 1) && dc_gemm1x1x3_dgrad_ok(B, Ci, Co, Hi, Wi, 1) && dc_gemm1x1x3_wgrad_ok(B, Ci, Co, Hi, Wi, 1);
 }
+
+// ---- the 3 x 3 / stride 2 / padding 1 convolutions of the trunks on the same kernels (S = 3 loaders): forward and weight gradient.  Called by
+// dc_convs2_fwd / dc_convs2_wgrad (convgemm.hip) under dc_set_gemm_split(3) ONLY: more accurate than cg_fwd3 / cg_wgrad3 (about half their
+// error against fp64, tests/test_convs2_gpu.py) but, with four dword gathers per pixel group in the loader, slower on five of the six step
+// shapes (tools/time_convs2.py, MI355X: forward 0.50 - 1.14x, weight gradient 0.74 - 1.25x of the fp32-MFMA kernels' speed; a step: no
+// change) -- so the default (mode 1) keeps the fp32-MFMA kernels for this family.  The data gradient has no split form.
+namespace dc {
+bool g1x3_conv3s2_ok(int B, int Ci, int Co, int Hi, int Wi) {
+    if (!g_g1x3 || B <= 0 || Ci % 32 || Co < 32 || (Hi & 1) || (Wi & 1)) return false;
+    const int Ho = Hi / 2, Wo = Wi / 2;
+    if ((Wo & 3) || (Ho * Wo) % 16) return false;
+    if ((size_t)B * std::max(Ci, Co) * Hi * Wi >= (1ull << 31)) return false;
+    return true;
+}
+size_t g1x3_conv3s2_fwd_ws(int Ci, int Co) { return (size_t)ceil_div(Co, 128) * 128 * 9 * Ci * 6 + 512; }
+int g1x3_conv3s2_fwd(const float* x, const float* weight, float* y, void* ws, int B, int Ci, int Co, int Hi, int Wi, hipStream_t st) {
+    if (((size_t)ws & 15) || ((size_t)x & 15) || ((size_t)y & 15)) return DC_EINVAL;
+    G1x3Args a{};
+    const int M = Co, K = 9 * Ci;
+    a.Mp = ceil_div(M, 128) * 128;
+    a.wa = (unsigned short*)ws; a.x = x; a.out = y; a.act = ACT_NONE;
+    a.B = B; a.M = M; a.K = K; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
+    const int N = B * a.Ho * a.Wo;
+    const X3Tile t = x3_pick(M, N, 2);
+    a.mtiles = ceil_div(M, 32 * t.mt); a.ntiles = ceil_div(N, 32 * t.nt);
+    if (const void* cached = wc_lookup_x3(weight, Ci, Co, 0, a.Mp, K, st)) {
+        a.wa = (const unsigned short*)cached;
+    } else {
+        hipLaunchKernelGGL(g1x3_prep_kernel, dim3(ceil_div(a.Mp * (K / 4), 256)), dim3(256), 0, st, weight, (unsigned short*)ws, 0, M, a.Mp, K);
+        DC_CHECK_LAUNCH();
+    }
+    const dim3 grid(a.mtiles * a.ntiles);
+    hipEvent_t pe = conv_prof_begin(7, 2.0 * (double)N * M * K, 12.0 * (double)grid.x * (32.0 * t.mt) * (32.0 * t.nt) * K,
+                                    4.0 * ((double)B * Ci * Hi * Wi + (double)N * M + (double)M * K), st);
+    int rc;
+    if (t.mt == 4 && t.nt == 4) rc = g1x3_go<4, 4>(a, grid, 3, false, 0, st);
+    else if (t.mt == 2 && t.nt == 4) rc = g1x3_go<2, 4>(a, grid, 3, false, 0, st);
+    else if (t.mt == 4) rc = g1x3_go<4, 2>(a, grid, 3, false, 0, st);
+    else rc = g1x3_go<2, 2>(a, grid, 3, false, 0, st);
+    conv_prof_end(pe, st);
+    if (rc != DC_OK) return rc;
+    DC_CHECK_LAUNCH();
+    return DC_OK;
+}
+static void g1x3_conv3s2_wplan(int B, int Ci, int Co, int Hi, int Wi, X3Tile& t, int& chunks, int& mtiles, int& ntiles, int& splits) {
+    chunks = B * (Hi / 2) * (Wi / 2) / X3_KC;
+    t = x3_wpick(Co, 9 * Ci);
+    mtiles = ceil_div(Co, 32 * t.mt); ntiles = ceil_div(9 * Ci, 32 * t.nt);
+    splits = g1x3_wsplits(mtiles * ntiles, chunks, t);
+}
+size_t g1x3_conv3s2_wgrad_ws(int B, int Ci, int Co, int Hi, int Wi) {
+    X3Tile t; int chunks, mt, nt, splits;
+    g1x3_conv3s2_wplan(B, Ci, Co, Hi, Wi, t, chunks, mt, nt, splits);
+    return splits > 1 ? (size_t)splits * Co * 9 * Ci * sizeof(float) : 16;
+}
+bool g1x3_conv3s2_wgrad_ok(int B, int Ci, int Co, int Hi, int Wi) {
+    return g1x3_conv3s2_ok(B, Ci, Co, Hi, Wi) && ((size_t)B * (Hi / 2) * (Wi / 2)) % 32 == 0;
+}
+int g1x3_conv3s2_wgrad(const float* x, const float* gy, float* dweight, void* ws, int B, int Ci, int Co, int Hi, int Wi, hipStream_t st) {
+    if (((size_t)x & 15) || ((size_t)gy & 15) || ((size_t)ws & 15) || ((size_t)dweight & 15)) return DC_EINVAL;
+    G1x3WArgs a{};
+    a.gy = gy; a.x = x; a.B = B; a.Co = Co; a.Ci = 9 * Ci; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi / 2; a.Wo = Wi / 2;
+    X3Tile t;
+    g1x3_conv3s2_wplan(B, Ci, Co, Hi, Wi, t, a.chunks, a.mtiles, a.ntiles, a.splits);
+    a.out = a.splits > 1 ? (float*)ws : dweight;
+    const dim3 grid(a.mtiles * a.ntiles, a.splits);
+    const double npx = (double)B * a.Ho * a.Wo;
+    hipEvent_t pe = conv_prof_begin(7, 2.0 * npx * Co * 9.0 * Ci, 12.0 * npx * (double)a.mtiles * (32.0 * t.mt) * (double)a.ntiles * (32.0 * t.nt),
+                                    4.0 * ((double)B * Ci * Hi * Wi + npx * Co + 9.0 * Co * Ci), st);
+    int rc;
+    if (t.mt == 4 && t.nt == 4) rc = g1x3_wgo<4, 4>(a, grid, 3, false, st);
+    else if (t.mt == 2 && t.nt == 4) rc = g1x3_wgo<2, 4>(a, grid, 3, false, st);
+    else if (t.mt == 4) rc = g1x3_wgo<4, 2>(a, grid, 3, false, st);
+    else rc = g1x3_wgo<2, 2>(a, grid, 3, false, st);
+    conv_prof_end(pe, st);
+    if (rc != DC_OK) return rc;
+    DC_CHECK_LAUNCH();
+    if (a.splits > 1) {
+        const int n4 = Co * 9 * Ci / 4;
+        hipLaunchKernelGGL(g1x3_slabsum_kernel, dim3(ceil_div(n4, 16)), dim3(256), 0, st, (const x3f4*)ws, (x3f4*)dweight, a.splits, n4);
+        DC_CHECK_LAUNCH();
+    }
+    return DC_OK;
+}
+}  // namespace dc

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const WinoWDe
     const int idx = ((int)blockIdx.x - d.block0) * 256 + threadIdx.x;
     if (d.kind == 1) { c3b_wprep_item(d.w, reinterpret_cast<uint4*>(d.uhat), idx, d.Co, d.Ci, d.dgrad, d.MT, d.Mp, d.Kp); return; }
     if (d.kind == 2) {       // split-operand 1x1 GEMMs: (Mp, Kp) = (padded rows, reduction extent) of this direction
-        g1x3_prep_item(d.w, reinterpret_cast<unsigned short*>(d.uhat), idx, d.Ci, d.dgrad, d.dgrad ? d.Ci : d.Co, d.Mp, d.Kp);
+        g1x3_prep_item(d.w, reinterpret_cast<unsigned short*>(d.uhat), idx, d.dgrad, d.dgrad ? d.Ci : d.Co, d.Mp, d.Kp);
         return;
     }
     if (d.dgrad) wino_weight_one<true>(d.w, d.uhat, idx, d.Co, d.Ci, d.MT, d.Mp, d.Kp, WK);

@@ -128,8 +128,9 @@ def _x3_run(B, Ci, Co, H, W, s, split, bias=False, act=0, seed=0):
 @pytest.mark.parametrize("B,Ci,Co,H,W,s", X3_CASES)
 def test_split_operand_gemms_are_fp32_accurate(B, Ci, Co, H, W, s):
     """The gate of VERDICT round 5 (item 1b): error against an fp64 GEMM no worse than the fp32-MFMA kernels' own.  Norm-wise error of
-    y, dx, dw of both paths against torch's fp64 convolution: the split path may be at most 1.25x the fp32-MFMA path (+ 2e-8), and
-    within the absolute 5e-6-of-the-maximum bound the fp32 kernels are held to above."""
+    y, dx, dw of both paths against torch's fp64 convolution: the split path's must not exceed the fp32-MFMA path's (measured on MI355X
+    with the chunk-blocked, sign-alternating accumulation of x3_chunk: 0.2 - 0.35x for y and dx, 0.4 - 0.8x for dw; the margins are
+    printed under -s), and stays within the absolute 5e-6-of-the-maximum bound the fp32 kernels are held to above."""
     from depthcore import _lib
     L = _lib.lib()
     assert L.dc_gemm1x1x3_fwd_ok(B, Ci, Co, H, W, s) and L.dc_gemm1x1x3_wgrad_ok(B, Ci, Co, H, W, s)
@@ -144,7 +145,7 @@ def test_split_operand_gemms_are_fp32_accurate(B, Ci, Co, H, W, s):
         e32 = float((r32[i].double() - ref).norm() / ref.norm())
         e3 = float((r3[i].double() - ref).norm() / ref.norm())
         report.append((name, e3, e32))
-        assert e3 <= 1.25 * e32 + 2e-8, report
+        assert e3 <= e32 + 1e-9, report
         err = (r3[i].double() - ref).abs().max().item()
         assert err <= 5e-6 * max(ref.abs().max().item(), 1e-6), "%s: %.3e" % (name, err)
     print("split-operand 1x1 %s: (tensor, |x3 - f64| / |f64|, |f32-MFMA - f64| / |f64|) %s" % ((B, Ci, Co, H, W, s), report))

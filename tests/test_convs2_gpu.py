@@ -206,3 +206,43 @@ def test_stem_forward_on_split_operands_is_fp32_accurate(B, Ci, H, W):
     err = (out[1].double() - ref).abs().max().item()
     assert err <= 1e-5 * ref.abs().max().item()
     assert not torch.equal(out[0], out[1])               # (the two kernels really are different arithmetic orders)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(4, 64, 128, 48, 160), (2, 128, 256, 24, 80), (2, 128, 128, 80, 256), (2, 512, 512, 20, 64),
+                                         (2, 64, 96, 16, 24), (12, 256, 512, 12, 40)])
+def test_conv3x3s2_on_split_operands_is_fp32_accurate(B, Ci, Co, H, W):
+    """The 3x3 / 2 forward and weight gradient through the split-operand kernels (g1x3_kernel / g1x3_wgrad_kernel with the S = 3 gather
+    loaders, dc_set_gemm_split(3): an opt-in, slower than the default on most shapes) against the fp32-MFMA kernels (cg_fwd3 / cg_wgrad3):
+    norm-wise error of both against torch's fp64 convolution, the split path at most the fp32 path's (measured: 0.3 - 0.8x); the data
+    gradient is the same kernel in both modes."""
+    from depthcore import ops, _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B * 7 + Ci)
+    x0 = torch.relu(torch.randn(B, Ci, H, W, generator=g)).cuda()                      # post-ReLU activations, as in the trunks
+    w0 = (torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (Ci * 9)) ** 0.5).cuda()
+    gy = torch.randn(B, Co, H // 2, W // 2, generator=g).cuda()
+    xr, wr = x0.double().requires_grad_(True), w0.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 2, 1)
+    yr.backward(gy.double())
+    ref = {"y": yr.detach(), "dw": wr.grad, "dx": xr.grad}
+    out = {}
+    prev = L.dc_get_gemm_split()
+    try:
+        for mode in (0, 3):
+            L.dc_set_gemm_split(mode)
+            x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+            y = ops.conv_s2(x, w)
+            y.backward(gy)
+            out[mode] = {"y": y.detach(), "dw": w.grad, "dx": x.grad}
+    finally:
+        L.dc_set_gemm_split(prev)
+    eligible = (H // 2) * (W // 2) % 16 == 0
+    for name in ("y", "dw"):
+        e32 = float((out[0][name].double() - ref[name]).norm() / ref[name].norm())
+        e3 = float((out[3][name].double() - ref[name]).norm() / ref[name].norm())
+        print("3x3/2 %s %s: |x3 - f64| / |f64| = %.2e, |f32-MFMA - f64| / |f64| = %.2e" % (name, (B, Ci, Co, H, W), e3, e32))
+        assert e3 <= e32 + 1e-9, (name, e3, e32)
+        err = (out[3][name].double() - ref[name]).abs().max().item()
+        assert err <= 1e-5 * ref[name].abs().max().item(), (name, err)
+        assert torch.equal(out[0][name], out[3][name]) == (not eligible)    # (120 output pixels per image at 12 x 40: not a multiple of 16, the shape stays on the fp32 kernels)
+    assert torch.equal(out[0]["dx"], out[3]["dx"])
