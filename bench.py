@@ -54,8 +54,8 @@ FAMILIES = {
     4: ("dc::g1_* (1x1 convolutions as NCHW fp32-MFMA GEMMs: forward, data gradient, weight gradient)", "mfma"),
     5: ("dc::cg_* (3x3 stride-2 convolutions as implicit fp32-MFMA GEMMs: forward, data gradient split by output parity, weight "
         "gradient; main kernels, without the slab sums)", "mfma"),
-    6: ("dc::stem_* (7x7 stride-2 stem, patch-staged fp32-MFMA: forward and weight gradient incl. the input normalisation and "
-        "the pose pairs' concat in the loader)", "mfma"),
+    6: ("dc::stem_* (7x7 stride-2 stem, patch-staged, incl. the input normalisation and the pose pairs' concat in the loader: "
+        "fp32-MFMA weight gradient; forward on bf16x3 split operands by default, counted as the fp32 GEMM it stands for)", "mfma"),
     7: ("dc::g1x3_* (1x1 convolutions as fp32-accurate GEMMs on the bf16 matrix cores: three bf16 pieces per fp32 operand, six "
         "partial products, fp32 accumulation; forward, data gradient, weight gradient)", "mfma_bf16"),
 }

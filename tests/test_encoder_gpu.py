@@ -10,9 +10,10 @@ argmax codes) and the fp64 oracle is evaluated with THOSE decisions imposed (ora
 the recorded window position).  Both sides then evaluate the same smooth function and
 
   * every feature map and every parameter gradient (the gradient of `conv1.weight` sits behind the data gradients of all
-    other layers) must meet the calibrated bound on EVERY input: at most 4x as far from fp64 as torch's own fp32 evaluation
+    other layers) must meet the calibrated bound on EVERY input: at most 2x as far from fp64 as torch's own fp32 evaluation
     of the same function (training-mode BatchNorm on small maps amplifies rounding -- a fixed number would be loose for the
-    stem or flaky for layer4), floor 5e-5;
+    stem or flaky for layer4), floor 2.5e-5 (round 6: halved -- the 24 cases of this file used at most 0.35 of the old
+    max(4x, 5e-5), profiles/round6_parity_passrates.txt; the fraction each case uses is printed);
   * wherever the imposed decision differs from the fp64 oracle's own, the fp64 pre-activation (or the gap between the two
     window entries) must be at rounding level -- i.e. the HIP path only ever "disagrees" on genuine near-ties.  "Rounding
     level" is calibrated per tensor the same way: at most 4x the largest deviation of the oracle's own fp32 evaluation from
@@ -95,7 +96,7 @@ def _one_input(num_layers, groups, nimg, B, H, W, seed):
 
     # (2) with the decisions imposed, everything meets the calibrated bound -- no exceptions
     def bound(e32):
-        return max(4.0 * e32, 5e-5)
+        return max(2.0 * e32, 2.5e-5)
 
     bad, worst, used = [], 0.0, 0.0          # used: the largest fraction of its bound any tensor takes (the gate's measured margin)
     for i in range(5):
@@ -111,7 +112,7 @@ def _one_input(num_layers, groups, nimg, B, H, W, seed):
         if e > bound(e32):
             bad.append((k, e, e32))
     print("resnet%d groups %d seed %d: %d decisions differ from fp64 (worst margin %.1e of rms), worst gradient error %.2e, "
-          "largest fraction of the calibrated bound max(4 x fp32 oracle's own error, 5e-5) used by any tensor: %.2f"
+          "largest fraction of the calibrated bound max(2 x fp32 oracle's own error, 2.5e-5) used by any tensor: %.2f"
           % (num_layers, groups, seed, flips, worst_margin, worst, used))
     assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
 
