@@ -1,7 +1,7 @@
 // Library identity + small shared entry points.
 #include "dc_common.h"
 
-extern "C" const char* dc_version(void) { return "depthcore 0.5.0 (round 5)"; }
+extern "C" const char* dc_version(void) { return "depthcore 0.6.0 (round 6)"; }
 extern "C" const char* dc_arch(void) { return "gfx950"; }
 
 // Every entry point reports a failed launch by reading HIP's per-thread "last error" (DC_CHECK_LAUNCH).  An error raised by
