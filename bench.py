@@ -352,13 +352,17 @@ def run_rank(args):
         front = dict(fusion="v3", frame_ids=[0, -2, -1, 1])
     opt = T.default_options(batch_size=args.batch, height=args.height, width=args.width, num_layers=args.num_layers,
                             nets_dtype=args.nets_dtype,
-                            cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap,
+                            cpu_tiebreak_noise=args.cpu_noise, overlap_streams=not args.no_overlap, step_priority=int(args.step_priority),
                             wino_weight_cache=not args.no_wino_cache, hip_graph=bool(args.graph),
                             wgrad_lanes=int(args.wgrad_lanes), **front)
     if args.bucket_mb > 0:
         opt.bucket_mb = args.bucket_mb
     tr = T.Trainer(opt, device=device, rank=rank, world_size=world)
     tr.set_train()
+    # the training loop -- everything below -- runs on the trainer's step stream (high priority for the depth branch: opt.step_priority);
+    # entered once and left at process exit (the per-loop hand-over of Trainer.on_step_stream)
+    _step_ctx = tr.on_step_stream()
+    _step_ctx.__enter__()
     dist_info = None
     if world > 1:        # who is really in the group: every rank reports (rank, device ordinal, device name)
         mine = (rank, local, torch.cuda.get_device_name(device))
@@ -674,7 +678,9 @@ def run_rank(args):
                        "rgbx_pack_ms_if_done_inside_the_step": round(rgbx_pack_ms, 4) if rgbx_pack_ms is not None else None,
                        "setup_steps": SETUP_STEPS,
                        "step_launch": "one hipGraph replay per step" if graphed else "eager (one launch per kernel)",
-                       "streams": ("depth and pose branches on two HIP streams" if tr.opt.overlap_streams else "one HIP stream")
+                       "streams": (("depth and pose branches on two HIP streams" + ("; the depth branch's is a high-priority stream (opt.step_priority)"
+                                                                                     if tr._main_stream is not None and not graphed else ""))
+                                   if tr.opt.overlap_streams else "one HIP stream")
                                   + ("; weight-gradient kernels on a companion stream of each (opt.wgrad_lanes)" if tr.wgrad_lanes else "")},
             "roofline": dict(dom, **{
                          # HBM bytes per launch from the PMC counters: CITED from the separate `rocprofv3 --pmc` passes kept under
@@ -748,6 +754,7 @@ def main():
                          "loader's batch): the photometric forward then repacks them at every step")
     ap.add_argument("--wgrad-lanes", type=int, default=2, help="weight-gradient kernels on companion streams (opt.wgrad_lanes: 0 off, 1 on, 2 auto)")
     ap.add_argument("--no-overlap", action="store_true", help="pose and depth networks on one stream (A/B of overlap_streams)")
+    ap.add_argument("--step-priority", type=int, default=2, choices=[-1, 0, 2], help="the training loop (depth branch) on a high-priority stream: -1 on, 0 off, 2 auto (opt.step_priority; Trainer.on_step_stream)")
     ap.add_argument("--oversubscribe", action="store_true", help="rehearsal: let ranks share GPUs (use with DC_DIST_BACKEND=gloo)")
     ap.add_argument("--rehearse", action="store_true", help="rehearsal: CPU stand-in step over gloo (launcher / exchange plumbing only)")
     ap.add_argument("--rccl-algo", default=None, help="world > 1: NCCL_ALGO for the gradient exchange (Ring | Tree; RCCL's own choice "

@@ -154,7 +154,7 @@ class WgradLanes:
         key = (dev.index, cur.cuda_stream)
         lane = cls._lanes.get(key)
         if lane is None:
-            lane = cls._lanes[key] = torch.cuda.Stream(dev)
+            lane = cls._lanes[key] = torch.cuda.Stream(dev)       # (normal priority, below the step stream's: Trainer.on_step_stream)
         lane.wait_stream(cur)
         with torch.cuda.stream(lane):
             yield

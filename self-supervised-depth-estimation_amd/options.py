@@ -89,6 +89,7 @@ _REFERENCE = [
 _BUILD = [
     ("fused_loss", int, 1, [0, 1]),              # 1: fused photometric kernels, 0: layer-by-layer kernels
     ("overlap_streams", int, 1, [0, 1]),         # pose and depth networks on two HIP streams
+    ("step_priority", int, 2, [-1, 0, 2]),       # Trainer.on_step_stream(): the training loop (depth branch) on a HIGH-priority stream: -1 on, 0 off, 2 = where it was measured to pay (Trainer)
     ("wgrad_lanes", int, 2, [0, 1, 2]),          # weight-gradient kernels on companion streams of the backward's streams (ops.WgradLanes): 0 off, 1 on, 2 = on for GPU-bound step sizes (Trainer)
     ("bucket_mb", int, 32, None),                # gradient bucket size for the RCCL exchange
     ("cpu_tiebreak_noise", int, 0, [0, 1]),      # 1: the reference's CPU randn + H2D copy (trainer.py:594-595)

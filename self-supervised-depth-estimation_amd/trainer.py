@@ -19,6 +19,7 @@ through the depth encoder + decoder and fused by `networks.Fusion_v3` (BASELINE 
 `opt.len_sequence` frames (dict keys carry the sequence index: ("color", f, s, j), ("K", s, j)), the encoder features of the
 sequence pass through `networks.ConvGRUBlocks_v5`, and the loss runs on the sequence stacked along the batch.
 """
+import contextlib
 import json
 import os
 import types
@@ -167,6 +168,17 @@ class Trainer:
         if lanes == 2:
             lanes = int(self.opt.batch_size * self.opt.height * self.opt.width >= 4 * 192 * 640 and not self.opt.gru)
         self.wgrad_lanes = bool(lanes) and self.device.type == "cuda" and not self.graph_enabled
+        # the loop's stream priority (on_step_stream): 2 = "auto": the GPU-bound step sizes of the lanes' rule, BasicBlock trunks, no
+        # sequence front-end -- C2 -1.4 % (10.98 / 10.95 -> 10.83 / 10.79 ms, alternating runs); measured worse or flat elsewhere:
+        # resnet50 at 320 x 1024 +0.8 % (43.19 / 43.28 -> 43.46 / 43.71), Fusion_v3 +-0.1 %, the host-bound steps (a high-priority
+        # queue's launches cost the host more) ConvGRU 9.0 -> 9.7 ms, batch 1 7.1 -> 7.5 ms
+        prio = int(getattr(self.opt, "step_priority", 0))
+        if prio == 2:
+            prio = -1 if (self.opt.batch_size * self.opt.height * self.opt.width >= 4 * 192 * 640 and not self.opt.gru
+                          and not getattr(self.opt, "fusion", None) and int(self.opt.num_layers) <= 34) else 0
+        # (single process only: with the bucketed exchange the RCCL stream's priority would have to follow the step's, and that
+        # could not be measured on a one-GPU pool -- the world > 1 step stays exactly the one that was rehearsed)
+        self.step_priority = prio if world_size == 1 else 0
         if self.graph_enabled and self.opt.cpu_tiebreak_noise:
             raise ValueError("hip_graph replays cannot include the reference's CPU randn + host-to-device copy (cpu_tiebreak_noise)")
         # reference trainer.py:110-113: one Adam over every trainable tensor.  On the GPU the depthcore kernel (one streaming
@@ -191,6 +203,7 @@ class Trainer:
         self.step = 0
         self.epoch = 0
         self._side_stream = None
+        self._main_stream = None          # the high-priority stream of the eager step (_step_stream)
         use_cache = self.device.type == "cuda" and getattr(self.opt, "wino_weight_cache", True)
         self.wino_cache = WinoWeightCache(self.parameters_to_train) if use_cache else _NoWinoCache()
         if getattr(self.opt, "load_weights_folder", None):       # trainer.py:137-138
@@ -265,7 +278,7 @@ class Trainer:
             # replays each backward op on its forward stream, so the backward overlaps the same way.
             main = torch.cuda.current_stream(self.device)
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(self.device)
+                self._side_stream = torch.cuda.Stream(self.device)      # (normal priority: see on_step_stream)
                 self.buckets.streams = [main, self._side_stream]
             side = self._side_stream
             side.wait_stream(main)
@@ -631,6 +644,38 @@ class Trainer:
 
     # ------------------------------------------------------------------ trainer.py:233-237
     GRAPH_WARMUP = 3      # eager steps before a capture: lazy allocations, LDS attributes, the weight cache's variants
+
+    def _step_stream(self):
+        """The HIGH-priority stream of `on_step_stream()` (eager steps with overlapping branches, self.step_priority = -1), or None."""
+        if (self.device.type != "cuda" or not getattr(self.opt, "overlap_streams", False) or self.graph_enabled
+                or self.step_priority >= 0):
+            return None
+        if self._main_stream is None:
+            self._main_stream = torch.cuda.Stream(self.device, priority=-1)
+        return self._main_stream
+
+    @contextlib.contextmanager
+    def on_step_stream(self):
+        """Run a training LOOP on the trainer's high-priority stream:  `with trainer.on_step_stream(): for batch in loader:
+        trainer.train_step(batch)`.  Inside, the depth branch -- encoder, decoder, loss and their backward, the step's longest
+        dependency chain -- is enqueued at high priority while the pose branch (its side stream) and the weight-gradient lanes stay
+        at normal priority: the command processor hands the chain's workgroups out first and the other two fill what it leaves
+        (same-box A/B at C2, alternating runs: 10.96 / 10.96 / 11.00 -> 10.83 / 10.83 / 10.81 ms; the POSE branch at high priority
+        instead: 11.13).  HIP offers two levels here (torch.cuda.Stream.priority_range() = (0, -1)) and the caller's default stream
+        sits at the lower one, hence a stream of the trainer's own.  The hand-over between the caller's stream and this one is made
+        ONCE, around the loop: made per step (a wait on either side of every train_step) it costs more than the priority gains
+        (10.97-11.06), so train_step() outside this context simply stays on the caller's stream.  No-op (yields at once) on the CPU,
+        with opt.overlap_streams = 0, a captured step (opt.hip_graph), opt.step_priority = 0, or = 2 ("auto") outside the configurations where
+        it was measured to pay (see __init__)."""
+        hp = self._step_stream()
+        if hp is None:
+            yield
+            return
+        cur = torch.cuda.current_stream(self.device)
+        hp.wait_stream(cur)
+        with torch.cuda.stream(hp):
+            yield
+        cur.wait_stream(hp)
 
     def train_step(self, inputs):
         if not self.graph_enabled:

@@ -632,6 +632,41 @@ def test_wgrad_lanes_change_nothing(mode):
     assert not bad, bad[:5]
 
 
+def test_step_stream_priority_changes_nothing():
+    """Trainer.on_step_stream(): the training loop on the trainer's high-priority stream (opt.step_priority; the pose branch's
+    side stream and the weight-gradient lanes stay at normal priority).  Same kernels on the same operands in the same order per
+    stream, only the priority of one stream differs: losses AND every parameter after five steps are bitwise those of the loop
+    on the caller's stream; the context is a no-op with step_priority = 0, hands the caller's stream back, and "auto" (2) picks
+    the stream only for the configurations it was measured on (Trainer.__init__)."""
+    import trainer as T
+    from depthcore.synthetic import synthetic_batch
+
+    def run(prio, n=5):
+        tr = T.Trainer(T.default_options(height=64, width=128, batch_size=2, wgrad_lanes=1, step_priority=prio), device=DEV, seed=5)
+        tr.set_train()
+        cur = torch.cuda.current_stream(DEV)
+        with tr.on_step_stream():
+            inside = torch.cuda.current_stream(DEV)
+            batches = [synthetic_batch(2, 64, 128, torch.device(DEV), seed=s) for s in (2, 3)]
+            losses = [tr.train_step(dict(batches[i % 2]))[1]["loss"].detach() for i in range(n)]
+        assert torch.cuda.current_stream(DEV) == cur
+        losses = [float(l) for l in losses]              # (read on the caller's stream, which waits for the loop's)
+        torch.cuda.synchronize()
+        params = {"%s.%s" % (m, k): v.detach().clone() for m, net in tr.models.items() for k, v in net.named_parameters()}
+        tr.close()
+        return losses, params, inside != cur, inside.priority
+
+    l0, p0, moved0, _ = run(0)
+    l1, p1, moved1, prio1 = run(-1)
+    assert not moved0 and moved1 and prio1 == -1
+    assert l0 == l1, (l0, l1)
+    bad = [k for k in p0 if not torch.equal(p0[k], p1[k])]
+    assert not bad, bad[:5]
+    auto = {kw: T.Trainer(T.default_options(step_priority=2, **dict(kw)), device="cpu").step_priority
+            for kw in ((("batch_size", 12),), (("batch_size", 1),), (("batch_size", 8), ("num_layers", 50), ("height", 320), ("width", 1024)))}
+    assert list(auto.values()) == [-1, 0, 0], auto
+
+
 def test_graph_capture_after_an_unclosed_collected_trainer():
     """The round-3 abort (gpurun_out/r3s): Trainers of FAILED tests were never close()d and sat in reference cycles (exception
     <-> frame); torch.cuda.graph() runs gc.collect() + empty_cache() when it begins a capture, so their weights were freed --
