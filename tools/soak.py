@@ -26,6 +26,8 @@ def main():
     losses = []
     mem0 = None
     trace = []
+    ctx = tr.on_step_stream()          # the loop on the trainer's step stream (high priority where opt.step_priority says so), as bench.py runs it
+    ctx.__enter__()
     for i in range(n):
         _, l = tr.train_step(batches[i % 4])
         if i % 25 == 0 or i == n - 1:
